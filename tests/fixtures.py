@@ -1,0 +1,76 @@
+"""Loading of the golden fixtures (tests/golden/*.npz, produced by tests/golden/make_golden.py from the real
+reference) and regeneration of their inputs/parameters from the stored seeds."""
+import glob
+import json
+import os
+
+import numpy as np
+
+from deepspeech.pytorch_amd import synth
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def fixture_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+class Fixture:
+    def __init__(self, name):
+        self.name = name
+        self.z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        self.meta = json.loads(bytes(self.z["meta_json"]).decode())
+        m = self.meta
+        self.cfg = dict(rnn_type=m["rnn_type"], hidden_size=m["hidden_size"], hidden_layers=m["hidden_layers"],
+                        bidirectional=m["bidirectional"], lookahead_context=m.get("lookahead_context", 20))
+        self.lengths = np.asarray(m["lengths"], dtype=np.int64)
+
+    def batch(self):
+        m = self.meta
+        inputs, targets, pct, tsz = synth.synth_batch(self.lengths, m["data_seed"],
+                                                      chars_per_second=m.get("chars_per_second", 12.0))
+        if "long_target_sample" in m:
+            i = m["long_target_sample"]
+            rs = np.random.RandomState(m["data_seed"] + 999)
+            tsz = tsz.copy()
+            parts, off = [], 0
+            for j, s in enumerate(tsz):
+                if j == i:
+                    parts.append(rs.randint(1, 29, size=int(self.lengths[i])).astype(np.int64))
+                else:
+                    parts.append(targets[off:off + s])
+                off += s
+            tsz[i] = int(self.lengths[i])
+            targets = np.concatenate(parts)
+        return inputs, targets, pct, tsz
+
+    def params(self):
+        m = self.meta
+        P = synth.synth_params({k: tuple(v) for k, v in m["shapes"].items()}, m["param_seed"])
+        g = m.get("bn_gain")
+        if g:
+            for k in ("conv.seq_module.1.weight", "conv.seq_module.4.weight"):
+                P[k] = (P[k] * g).astype(np.float32)
+        return P
+
+    def grad_names(self):
+        return sorted(k.split(".", 1)[1] for k in self.z.files if k.startswith("grad.") or k.startswith("gradsub."))
+
+    def check_grad(self, name, g, rtol, atol_scale=1.0):
+        """Compare gradient `g` (full array) with the stored reference gradient. Returns max abs err / scale."""
+        g = np.asarray(g, dtype=np.float64)
+        if "grad." + name in self.z.files:
+            ref = self.z["grad." + name].astype(np.float64)
+            got = g.reshape(ref.shape)
+        else:
+            ref = self.z["gradsub." + name].astype(np.float64)
+            got = g.reshape(-1)[::self.meta["stride"]]
+            l2 = float(self.z["gradl2." + name])
+            assert abs(np.sqrt((g ** 2).sum()) - l2) <= rtol * max(l2, 1e-3) * 4, (name, "l2 norm")
+        # floor: gradients that are exactly 0 in exact arithmetic (conv bias in front of BatchNorm when nothing
+        # is masked) are pure rounding noise in any implementation
+        scale = max(np.abs(ref).max(), 1e-3) * atol_scale
+        err = np.abs(got - ref).max() / scale
+        assert err <= rtol, "grad %s: max err %.3e of scale %.3e (rel %.3e > %.1e)" % (
+            name, np.abs(got - ref).max(), scale, err, rtol)
+        return err

@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Generate golden vectors from the REAL reference (``/root/reference/deepspeech_pytorch/model.py``, imported
+unmodified through ``ref_harness``) on CPU fp32.  Run in the build container only:
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+
+A fixture stores: the config, the seeds that regenerate inputs/parameters (``deepspeech.pytorch_amd.synth`` with
+numpy's frozen RandomState stream), and the reference's OUTPUTS: training-step loss, logits, output lengths
+(fp32 run = the reference as shipped; plus the same reference code run under ``model.double()`` as the precise
+ground truth), every parameter gradient (from the float64 run; big tensors strided-subsampled + sum + L2 norm;
+``noise.*`` = the fp32 run's own deviation), BatchNorm running stats after the step, eval-mode softmax output,
+greedy transcripts and the hidden-state carry of reference inference.py:86-96.  Nothing here is used by the product path.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+from deepspeech.pytorch_amd import synth  # noqa: E402
+import ref_harness  # noqa: E402
+
+BIG = 50000
+STRIDE = 7
+
+CASES = [
+    dict(name="gru_bi_tiny", rnn_type="gru", hidden_size=32, hidden_layers=2, bidirectional=True,
+         lengths=[61, 50, 37], data_seed=11, param_seed=101),
+    dict(name="lstm_bi_tiny", rnn_type="lstm", hidden_size=32, hidden_layers=2, bidirectional=True,
+         lengths=[58, 58, 41, 22], data_seed=12, param_seed=102),
+    dict(name="rnn_bi_tiny", rnn_type="rnn", hidden_size=32, hidden_layers=2, bidirectional=True,
+         lengths=[47, 33], data_seed=13, param_seed=103),
+    dict(name="gru_uni_la", rnn_type="gru", hidden_size=32, hidden_layers=2, bidirectional=False,
+         lookahead_context=20, lengths=[90, 71, 64], data_seed=14, param_seed=104),
+    dict(name="lstm_uni_la", rnn_type="lstm", hidden_size=48, hidden_layers=3, bidirectional=False,
+         lookahead_context=7, lengths=[66, 40], data_seed=15, param_seed=105),
+    # BN gains large enough that Hardtanh's upper clamp (20) is hit; one sample with more labels than frames
+    # (infeasible -> zero_infinity path, loss and grad contributions are 0, model.py:203)
+    dict(name="gru_bi_clamp_inf", rnn_type="gru", hidden_size=48, hidden_layers=3, bidirectional=True,
+         lengths=[80, 77, 30, 21], data_seed=16, param_seed=106, bn_gain=14.0, chars_per_second=12.0,
+         long_target_sample=3),
+    dict(name="gru_bi_mid", rnn_type="gru", hidden_size=64, hidden_layers=3, bidirectional=True,
+         lengths=[141, 130, 122, 101, 90], data_seed=17, param_seed=107),
+    dict(name="single_sample", rnn_type="lstm", hidden_size=32, hidden_layers=2, bidirectional=True,
+         lengths=[73], data_seed=18, param_seed=108),
+]
+
+
+def make_batch(case):
+    lengths = np.asarray(case["lengths"], dtype=np.int64)
+    inputs, targets, pct, tsz = synth.synth_batch(lengths, case["data_seed"],
+                                                  chars_per_second=case.get("chars_per_second", 12.0))
+    if "long_target_sample" in case:   # make one sample infeasible: more labels than output frames
+        i = case["long_target_sample"]
+        rs = np.random.RandomState(case["data_seed"] + 999)
+        tsz = tsz.copy()
+        parts, off = [], 0
+        for j, s in enumerate(tsz):
+            if j == i:
+                parts.append(rs.randint(1, 29, size=int(lengths[i])).astype(np.int64))  # S = T > T'
+            else:
+                parts.append(targets[off:off + s])
+            off += s
+        tsz[i] = int(lengths[i])
+        targets = np.concatenate(parts)
+    return inputs, targets, pct, tsz
+
+
+def make_params(case, shapes):
+    P = synth.synth_params(shapes, case["param_seed"])
+    g = case.get("bn_gain")
+    if g:
+        for k in ("conv.seq_module.1.weight", "conv.seq_module.4.weight"):
+            P[k] = (P[k] * g).astype(np.float32)
+    return P
+
+
+def fresh_model(ns, case, P, double=False):
+    model = ref_harness.build_reference_model(ns, case["rnn_type"], case["hidden_size"], case["hidden_layers"],
+                                              case["bidirectional"], case.get("lookahead_context", 20))
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in P.items()}, strict=True)
+    return model.double() if double else model
+
+
+def run_train_step(model, inputs, targets, pct, tsz, double):
+    """DeepSpeech.training_step (model.py:241-249) restated only to keep the logits; asserted equal to the
+    reference's own training_step below."""
+    model.train()
+    model.zero_grad()
+    x = torch.from_numpy(inputs)
+    input_sizes = torch.from_numpy(pct.copy()).mul_(int(inputs.shape[3])).int()
+    logits, out_sizes, _ = model(x.double() if double else x, input_sizes)
+    lp = logits.transpose(0, 1).log_softmax(-1)
+    loss = model.criterion(lp, torch.from_numpy(targets), out_sizes, torch.from_numpy(tsz))
+    loss.backward()
+    return loss, logits, out_sizes, input_sizes
+
+
+def main():
+    ns = ref_harness.load_reference()
+    torch.set_num_threads(8)
+    for case in CASES:
+        probe = ref_harness.build_reference_model(ns, case["rnn_type"], case["hidden_size"], case["hidden_layers"],
+                                                  case["bidirectional"], case.get("lookahead_context", 20))
+        shapes = {k: tuple(v.shape) for k, v in probe.state_dict().items()}
+        P = make_params(case, shapes)
+        inputs, targets, pct, tsz = make_batch(case)
+        out = {}
+        # ---- (A) the reference exactly as shipped: fp32 on CPU
+        m32 = fresh_model(ns, case, P)
+        loss32, logits32, out_sizes, input_sizes = run_train_step(m32, inputs, targets, pct, tsz, False)
+        out["loss"] = np.float64(loss32.item())
+        out["logits"] = logits32.detach().numpy()
+        out["output_lengths"] = out_sizes.numpy().astype(np.int32)
+        out["input_sizes"] = input_sizes.numpy().astype(np.int32)
+        for k, b in m32.named_buffers():
+            if k.endswith("running_mean") or k.endswith("running_var"):
+                out["running." + k] = b.detach().numpy().copy()
+        # the reference's own training_step must give the same loss (sanity of the restated step above)
+        chk = fresh_model(ns, case, P)
+        chk.train()
+        l2 = chk.training_step((torch.from_numpy(inputs), torch.from_numpy(targets), torch.from_numpy(pct.copy()),
+                                torch.from_numpy(tsz)), 0)
+        assert abs(l2.item() - loss32.item()) <= 1e-5 * max(1.0, abs(loss32.item())), (l2.item(), loss32.item())
+        # ---- (B) the same reference code run in float64 (model.double()): the precise ground truth.  Gradients
+        # are stored from this run (as float32); "noise.<param>" records how far the fp32 run (A) is from it, i.e.
+        # the reference's own fp32 rounding noise (up to ~1e-3 relative on the conv weight gradients).
+        m64 = fresh_model(ns, case, P, double=True)
+        loss64, logits64, _, _ = run_train_step(m64, inputs, targets, pct, tsz, True)
+        out["loss64"] = np.float64(loss64.item())
+        out["logits64"] = logits64.detach().numpy().astype(np.float32)
+        g32 = {k: p.grad.detach().numpy() for k, p in m32.named_parameters()}
+        for k, p in m64.named_parameters():
+            g = p.grad.detach().numpy()
+            sc = max(np.abs(g).max(), 1e-30)
+            out["noise." + k] = np.float64(np.abs(g32[k].astype(np.float64) - g).max() / sc)
+            if g.size > BIG:
+                out["gradsub." + k] = g.reshape(-1)[::STRIDE].astype(np.float32)
+                out["gradsum." + k] = np.float64(g.sum())
+                out["gradl2." + k] = np.float64(np.sqrt((g ** 2).sum()))
+            else:
+                out["grad." + k] = g.astype(np.float32)
+        # ---- eval forward (fresh weights = the fixture's running stats), softmax probs + transcripts
+        mev = fresh_model(ns, case, P)
+        mev.eval()
+        x = torch.from_numpy(inputs)
+        with torch.no_grad():
+            probs, sizes, hs = mev(x, input_sizes)
+        out["eval_probs"] = probs.numpy()
+        dec = ns.GreedyDecoder(ns.labels)
+        strings, _ = dec.decode(probs, sizes)
+        transcripts = [s[0] for s in strings]
+        # ---- hidden-state carry (inference.py:86-96): batch 1, feed hs back in
+        with torch.no_grad():
+            x1 = x[:1, :, :, :int(case["lengths"][0])]
+            l1 = torch.tensor([int(case["lengths"][0])], dtype=torch.int)
+            _, _, hs1 = mev(x1, l1)
+            probs2, _, hs2 = mev(x1, l1, hs1)
+        out["carry_probs"] = probs2.numpy()
+        if case["rnn_type"] == "lstm":
+            out["carry_h_last"] = hs2[-1][0].numpy()
+            out["carry_c_last"] = hs2[-1][1].numpy()
+        else:
+            out["carry_h_last"] = hs2[-1].numpy()
+        meta = dict(case)
+        meta["transcripts"] = transcripts
+        meta["shapes"] = {k: list(v) for k, v in shapes.items()}
+        meta["torch_version"] = torch.__version__
+        meta["big"] = BIG
+        meta["stride"] = STRIDE
+        out["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        path = os.path.join(HERE, case["name"] + ".npz")
+        np.savez_compressed(path, **out)
+        worst = max(float(out[k]) for k in out if k.startswith("noise."))
+        print("%-20s loss32=%.6f loss64=%.6f T'=%s ref-fp32-noise(max rel grad)=%.1e file=%.0f KB" % (
+            case["name"], loss32.item(), loss64.item(), out["output_lengths"].tolist(), worst,
+            os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__":
+    main()

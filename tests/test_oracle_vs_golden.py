@@ -1,0 +1,80 @@
+"""Pins the numpy oracle (oracle/ds2_oracle.py) against outputs of the real reference model (golden fixtures)."""
+import numpy as np
+import pytest
+
+from fixtures import Fixture, fixture_names
+from oracle import ds2_oracle as O
+
+
+@pytest.mark.parametrize("name", fixture_names())
+def test_train_step_matches_reference(name):
+    """float64 oracle vs (a) the reference code run in float64 -- tight, (b) the reference as shipped (fp32)."""
+    fx = Fixture(name)
+    P = {k: v.astype(np.float64) if v.dtype == np.float32 else v for k, v in fx.params().items()}
+    inputs, targets, pct, tsz = fx.batch()
+    r = O.training_step(P, fx.cfg, inputs.astype(np.float64), targets, pct, tsz, fast_ctc=True)
+    assert np.array_equal(r["output_lengths"], fx.z["output_lengths"])
+    ref64 = float(fx.z["loss64"])
+    assert abs(r["loss"] - ref64) <= 1e-10 * abs(ref64), (r["loss"], ref64)
+    assert np.abs(r["logits"] - fx.z["logits64"]).max() <= 2e-6 * max(1.0, np.abs(fx.z["logits64"]).max())
+    for gname in fx.grad_names():
+        fx.check_grad(gname, r["grads"][gname], rtol=2e-6)     # fixture stores the float64 grads as float32
+    # (b) fp32 reference: its own rounding noise is the only difference
+    ref32 = float(fx.z["loss"])
+    assert abs(r["loss"] - ref32) <= 2e-6 * abs(ref32), (r["loss"], ref32)
+    assert np.abs(r["logits"] - fx.z["logits"]).max() <= 5e-5 * max(1.0, np.abs(fx.z["logits"]).max())
+    for k in fx.z.files:
+        if k.startswith("running."):
+            nm = k.split(".", 1)[1]
+            assert np.allclose(r["running"][nm], fx.z[k], rtol=1e-4, atol=1e-6), nm
+
+
+@pytest.mark.parametrize("name", ["gru_bi_tiny", "gru_bi_clamp_inf"])
+def test_float32_oracle_close_to_float64(name):
+    """The oracle run in float32 (what the cpu_baseline times) stays within the north-star tolerance."""
+    fx = Fixture(name)
+    inputs, targets, pct, tsz = fx.batch()
+    r = O.training_step(fx.params(), fx.cfg, inputs, targets, pct, tsz)
+    assert abs(r["loss"] - float(fx.z["loss64"])) <= 1e-4 * abs(float(fx.z["loss64"]))
+    assert np.abs(r["logits"] - fx.z["logits64"]).max() <= 1e-3
+
+
+@pytest.mark.parametrize("name", ["gru_bi_tiny", "lstm_uni_la"])
+def test_slow_ctc_equals_fast_ctc(name):
+    fx = Fixture(name)
+    inputs, targets, pct, tsz = fx.batch()
+    T, N, C = int(fx.z["output_lengths"].max()), len(fx.lengths), 29
+    rs = np.random.RandomState(5)
+    lp = O.log_softmax(rs.standard_normal((T, N, C)))
+    a = O.ctc_loss_and_grad(lp, targets, fx.z["output_lengths"], tsz)
+    b = O.ctc_loss_and_grad_fast(lp, targets, fx.z["output_lengths"], tsz)
+    assert abs(a[0] - b[0]) < 1e-9 * abs(a[0])
+    assert np.abs(a[2] - b[2]).max() < 1e-9
+
+
+@pytest.mark.parametrize("name", fixture_names())
+def test_eval_forward_and_transcripts(name):
+    fx = Fixture(name)
+    P = {k: v.astype(np.float64) if v.dtype == np.float32 else v for k, v in fx.params().items()}
+    inputs, _, pct, _ = fx.batch()
+    sizes = O.input_sizes_from_percentages(pct, inputs.shape[3])
+    assert np.array_equal(sizes, fx.z["input_sizes"])
+    out, out_lens, hs, _ = O.model_forward(P, fx.cfg, inputs.astype(np.float64), sizes, train=False, keep_cache=False)
+    assert np.abs(out - fx.z["eval_probs"]).max() < 2e-5
+    labels = ["_", "'"] + [chr(ord("A") + i) for i in range(26)] + [" "]
+    assert O.greedy_decode(out, out_lens, labels) == fx.meta["transcripts"]
+    # hidden-state carry (reference inference.py:86-96)
+    t0 = int(fx.lengths[0])
+    x1 = inputs[:1, :, :, :t0].astype(np.float64)
+    _, _, hs1, _ = O.model_forward(P, fx.cfg, x1, np.array([t0]), train=False, keep_cache=False)
+    out2, _, hs2, _ = O.model_forward(P, fx.cfg, x1, np.array([t0]), train=False, hs=hs1, keep_cache=False)
+    assert np.abs(out2 - fx.z["carry_probs"]).max() < 2e-5
+    hl = hs2[-1][0] if fx.cfg["rnn_type"] == "lstm" else hs2[-1]
+    assert np.abs(hl - fx.z["carry_h_last"]).max() < 2e-5
+
+
+def test_seq_lens_formula():
+    # reference model.py:299-310; survey probe: linspace(201,101,8) -> [101,93,86,79,72,65,58,51]
+    ln = np.array([201, 186, 172, 158, 143, 129, 115, 101])
+    assert O.seq_lens(ln).tolist() == [101, 93, 86, 79, 72, 65, 58, 51]
+    assert O.rnn_input_size() == 1312
