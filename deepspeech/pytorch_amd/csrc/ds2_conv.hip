@@ -1,0 +1,419 @@
+// Conv front-end of MaskConv (reference model.py:53-69 over the Sequential at model.py:157-164).
+//
+//   conv1  Conv2d(1,32,(41,11),s=(2,2),p=(20,5))   Cin = 1: no contraction over channels, low arithmetic intensity ->
+//          VALU kernels with the 32 output channels as per-thread accumulators and the weights (fwd) / the output
+//          gradient (wgrad) as wave-uniform scalar operands (s_load + v_fmac with an SGPR source), input patch in LDS.
+//   conv2  Conv2d(32,32,(21,11),s=(2,1),p=(10,5))   implicit GEMM on MFMA 32x32: for every kernel tap a
+//          [32 out] x [32 in] x [32 positions] product; activations are NFTC (channel fastest) so the K operand is a
+//          contiguous 64-byte channel vector of one position; the input patch of a 4-row x 32-position output tile and
+//          the 11 taps of one kernel row are staged in LDS (80-byte position stride = conflict-free ds_read_b128).
+//          dgrad is the SAME kernel run once per output-row parity with the flipped, parity-subsampled weights
+//          (a stride-2 transposed conv is two stride-1 convs); wgrad contracts over positions with the exact-fp32
+//          MFMA 32x32x2 (one element per lane: no K-contiguity requirement on the position axis).
+// Layouts: x (N,1,161,T) f32 as given by the loader; activations NFTC [N][F][T'][32] in storage type T.
+#include "ds2_common.h"
+
+namespace {
+
+constexpr int F0 = 161, F1 = 81, F2 = 41, CH = 32;
+constexpr int K1F = 41, K1T = 11, K2F = 21, K2T = 11;
+
+// ============================================================================================================
+// conv1 forward
+// ============================================================================================================
+constexpr int C1_FB = 4, C1_TB = 64;                       // output tile: 4 freq rows x 64 frames
+constexpr int C1_PR = (C1_FB - 1) * 2 + K1F;               // 47 input rows
+constexpr int C1_PC = (C1_TB - 1) * 2 + K1T;               // 137 input cols
+constexpr int C1_PCP = C1_PC + 1;
+
+__device__ __forceinline__ void conv1_load_patch(float* patch, const float* __restrict__ xn, int T, int f_base, int t_base,
+                                                 int tid, int nthreads) {
+  for (int i = tid; i < C1_PR * C1_PC; i += nthreads) {
+    const int pr = i / C1_PC, pc = i - pr * C1_PC;
+    const int fi = f_base + pr, ti = t_base + pc;
+    float v = 0.f;
+    if (fi >= 0 && fi < F0 && ti >= 0 && ti < T) v = xn[(long)fi * T + ti];
+    patch[pr * C1_PCP + pc] = v;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_conv1_fwd(const float* __restrict__ x, const float* __restrict__ w1k,
+                                                    const float* __restrict__ b1, const int* __restrict__ lens,
+                                                    T* __restrict__ y1, int N, int Tin, int Tp) {
+  __shared__ float patch[C1_PR * C1_PCP];
+  const int tid = threadIdx.x;
+  const int to0 = blockIdx.x * C1_TB, fo0 = blockIdx.y * C1_FB, n = blockIdx.z;
+  conv1_load_patch(patch, x + (long)n * F0 * Tin, Tin, 2 * fo0 - 20, 2 * to0 - 5, tid, 256);
+  __syncthreads();
+  const int r = tid >> 6, c = tid & 63;
+  const int fo = fo0 + r, to = to0 + c;
+  float acc[CH];
+#pragma unroll
+  for (int co = 0; co < CH; ++co) acc[co] = b1[co];
+  const float* prow = patch + (2 * r) * C1_PCP + 2 * c;
+  for (int kf = 0; kf < K1F; ++kf) {
+    const float* wk = w1k + kf * K1T * CH;
+#pragma unroll
+    for (int kt = 0; kt < K1T; ++kt) {
+      const float xv = prow[kf * C1_PCP + kt];
+#pragma unroll
+      for (int co = 0; co < CH; ++co) acc[co] = fmaf(xv, wk[kt * CH + co], acc[co]);
+    }
+  }
+  if (fo < F1 && to < Tp) {
+    const bool live = to < lens[n];
+    T* dst = y1 + (((long)n * F1 + fo) * Tp + to) * CH;
+    constexpr int V = Vec16<T>::N;
+#pragma unroll
+    for (int v = 0; v < CH / V; ++v) {
+      float o[V];
+#pragma unroll
+      for (int i = 0; i < V; ++i) o[i] = live ? acc[v * V + i] : 0.f;
+      Vec16<T>::store(dst + v * V, o);
+    }
+  }
+}
+
+// ============================================================================================================
+// conv1 weight gradient: thread <-> kernel tap, 32 output-channel accumulators, dy as the wave-uniform operand
+// ============================================================================================================
+constexpr int C1W_THREADS = 512;
+constexpr int C1W_MAXBLOCKS = 512;
+
+template <typename T>
+__device__ __forceinline__ void load_dy32(const T* __restrict__ p, float (&d)[CH]);
+template <>
+__device__ __forceinline__ void load_dy32<float>(const float* __restrict__ p, float (&d)[CH]) {
+#pragma unroll
+  for (int i = 0; i < CH; ++i) d[i] = p[i];
+}
+template <>
+__device__ __forceinline__ void load_dy32<bf16_t>(const bf16_t* __restrict__ p, float (&d)[CH]) {
+  const uint32_t* u = reinterpret_cast<const uint32_t*>(p);
+#pragma unroll
+  for (int i = 0; i < CH / 2; ++i) {
+    const uint32_t w = u[i];
+    d[2 * i] = __uint_as_float(w << 16);
+    d[2 * i + 1] = __uint_as_float(w & 0xffff0000u);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(C1W_THREADS) k_conv1_wgrad(const float* __restrict__ x, const T* __restrict__ dy1,
+                                                             float* __restrict__ partial, int N, int Tin, int Tp,
+                                                             int nchunk_t, int nchunk_f) {
+  __shared__ float patch[C1_PR * C1_PCP];
+  const int tid = threadIdx.x;
+  const int tap = tid < K1F * K1T ? tid : 0;
+  const int kf = tap / K1T, kt = tap - kf * K1T;
+  float acc[CH];
+#pragma unroll
+  for (int co = 0; co < CH; ++co) acc[co] = 0.f;
+  const int total = N * nchunk_f * nchunk_t;
+  for (int chunk = blockIdx.x; chunk < total; chunk += gridDim.x) {
+    const int ct = chunk % nchunk_t, cf = (chunk / nchunk_t) % nchunk_f, n = chunk / (nchunk_t * nchunk_f);
+    const int to0 = ct * C1_TB, fo0 = cf * C1_FB;
+    __syncthreads();
+    conv1_load_patch(patch, x + (long)n * F0 * Tin, Tin, 2 * fo0 - 20, 2 * to0 - 5, tid, C1W_THREADS);
+    __syncthreads();
+    const int rmax = min(C1_FB, F1 - fo0), cmax = min(C1_TB, Tp - to0);
+    for (int r = 0; r < rmax; ++r) {
+      const T* dyrow = dy1 + (((long)n * F1 + fo0 + r) * Tp + to0) * CH;
+      const float* prow = patch + (2 * r + kf) * C1_PCP + kt;
+      for (int c = 0; c < cmax; ++c) {
+        float d[CH];
+        load_dy32<T>(dyrow + (long)c * CH, d);   // address depends only on loop counters: scalar loads
+        const float xv = prow[2 * c];
+#pragma unroll
+        for (int co = 0; co < CH; ++co) acc[co] = fmaf(xv, d[co], acc[co]);
+      }
+    }
+  }
+  if (tid < K1F * K1T) {
+    float* dst = partial + ((long)blockIdx.x * (K1F * K1T) + tid) * CH;
+#pragma unroll
+    for (int v = 0; v < CH / 4; ++v)
+      *reinterpret_cast<float4*>(dst + 4 * v) = make_float4(acc[4 * v], acc[4 * v + 1], acc[4 * v + 2], acc[4 * v + 3]);
+  }
+}
+
+// ============================================================================================================
+// conv2 forward / dgrad: MFMA tap-GEMM
+// ============================================================================================================
+constexpr int CT_UB = 4, CT_TB = 32;          // output tile: 4 rows (one per wave) x 32 positions
+constexpr int CT_POSB = 80;                   // LDS bytes per position / per weight row: 64 data + 16 pad
+constexpr int CT_MAXPR = (CT_UB - 1) * 2 + K2F;   // 27
+constexpr int CT_PC = CT_TB + K2T - 1;            // 42
+constexpr int CT_PATCH_BYTES = CT_MAXPR * CT_PC * CT_POSB;       // 90720
+constexpr int CT_WST_BYTES = K2T * CH * CT_POSB;                  // 28160 per kernel row (one pass)
+constexpr int CT_SMEM = CT_PATCH_BYTES + 2 * CT_WST_BYTES;        // 147040
+
+struct ConvTapArgs {
+  const void* X;      // [N][Fin][Tp][32]
+  const void* W;      // [KF*KT][32 m][32 k]
+  const float* bias;  // [32] or null
+  const int* lens;    // [N] or null (time mask on the output)
+  void* Y;            // [N][Fout][Tp][32]
+  int N, Tp, Fin, Fout;
+  int KF, SF, PF;     // kernel rows, input row stride, top padding  (kernel cols = 11, pad 5, col stride 1)
+  int U, OSF, OQ;     // output rows handled: f_out = u*OSF + OQ, u in [0,U)
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256, 1) k_conv_tap(ConvTapArgs a) {
+  constexpr int V = Vec16<T>::N;
+  constexpr int NPASS = (CH * (int)sizeof(T)) / 64;   // bf16: 1 pass of 32 channels; f32: 2 passes of 16 channels
+  constexpr int CPB = 64 / (int)sizeof(T);            // channels per pass
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* patch = smem;
+  unsigned char* wst = smem + CT_PATCH_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lq = lane >> 5;
+  const int to0 = blockIdx.x * CT_TB, u0 = blockIdx.y * CT_UB, n = blockIdx.z;
+  const int PR = (CT_UB - 1) * a.SF + a.KF;
+  const int fi0 = u0 * a.SF - a.PF, ti0 = to0 - 5;
+  const T* Xn = (const T*)a.X + (long)n * a.Fin * a.Tp * CH;
+  const T* Wg = (const T*)a.W;
+
+  ds2_f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  for (int pass = 0; pass < NPASS; ++pass) {
+    const int c0 = pass * CPB;
+    __syncthreads();   // previous pass finished reading patch / wst
+    // ---- stage the input patch: PR x 42 positions x 64 bytes
+    for (int i = tid; i < PR * CT_PC * 4; i += 256) {
+      const int v = i & 3, pos = i >> 2;
+      const int pr = pos / CT_PC, pc = pos - pr * CT_PC;
+      const int fi = fi0 + pr, ti = ti0 + pc;
+      uint4 val = make_uint4(0, 0, 0, 0);
+      if (fi >= 0 && fi < a.Fin && ti >= 0 && ti < a.Tp)
+        val = *reinterpret_cast<const uint4*>(Xn + ((long)fi * a.Tp + ti) * CH + c0 + v * V);
+      *reinterpret_cast<uint4*>(patch + pos * CT_POSB + v * 16) = val;
+    }
+    // ---- weights of kernel row 0 of this pass
+    auto wload = [&](int kf, int buf) {
+      for (int i = tid; i < K2T * CH * 4; i += 256) {
+        const int v = i & 3, row = i >> 2;   // row = kt*32 + m
+        const uint4 val = *reinterpret_cast<const uint4*>(Wg + ((long)(kf * K2T) * CH + row) * CH + c0 + v * V);
+        *reinterpret_cast<uint4*>(wst + buf * CT_WST_BYTES + row * CT_POSB + v * 16) = val;
+      }
+    };
+    wload(0, 0);
+    __syncthreads();
+    for (int kf = 0; kf < a.KF; ++kf) {
+      const int buf = kf & 1;
+      if (kf + 1 < a.KF) wload(kf + 1, buf ^ 1);   // other buffer: last read two iterations ago (barrier in between)
+      const unsigned char* wb = wst + buf * CT_WST_BYTES + li * CT_POSB + lq * 16;
+      const unsigned char* pb = patch + ((wave * a.SF + kf) * CT_PC + li) * CT_POSB + lq * 16;
+#pragma unroll
+      for (int kt = 0; kt < K2T; ++kt) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const uint4 af = *reinterpret_cast<const uint4*>(wb + kt * CH * CT_POSB + c * 32);
+          const uint4 bf = *reinterpret_cast<const uint4*>(pb + kt * CT_POSB + c * 32);
+          Mma<T>::mma32(acc, af, bf);
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: transpose the wave's [32 m][32 pos] tile through LDS, then 64-byte channel-vector stores
+  __syncthreads();
+  float* tile = reinterpret_cast<float*>(smem) + wave * (32 * 33);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) tile[li * 33 + mma32_row(r, lane)] = acc[r];   // tile[pos][m]
+  __syncthreads();
+  const int u = u0 + wave;
+  if (u < a.U) {
+    const int fo = u * a.OSF + a.OQ;
+    const int pos = lane >> 1, half = lane & 1;
+    const int to = to0 + pos;
+    if (to < a.Tp) {
+      const bool live = a.lens ? (to < a.lens[n]) : true;
+      T* dst = (T*)a.Y + (((long)n * a.Fout + fo) * a.Tp + to) * CH + half * 16;
+#pragma unroll
+      for (int v = 0; v < 16 / V; ++v) {
+        float o[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          const int m = half * 16 + v * V + i;
+          float val = tile[pos * 33 + m] + (a.bias ? a.bias[m] : 0.f);
+          o[i] = live ? val : 0.f;
+        }
+        Vec16<T>::store(dst + v * V, o);
+      }
+    }
+  }
+}
+
+// ============================================================================================================
+// conv2 weight gradient: dW[kf][kt][co][ci] = sum_{n,fo,to} dY[n][fo][to][co] * A1[n][2fo-10+kf][to-5+kt][ci]
+// grid (21 kernel rows, S position splits); exact-fp32 MFMA 32x32x2, K = position pairs
+// ============================================================================================================
+constexpr int CW_TB = 128;
+constexpr int CW_SPLITS = 64;
+
+template <typename T>
+__global__ void __launch_bounds__(256, 1) k_conv2_wgrad(const T* __restrict__ dY, const T* __restrict__ A1,
+                                                         float* __restrict__ partial, int N, int Tp) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(CW_TB + (CW_TB + K2T - 1)) * CH * sizeof(float)];
+  T* sdy = reinterpret_cast<T*>(smem);                      // [CW_TB][32]
+  T* sx = sdy + CW_TB * CH;                                 // [CW_TB + 10][32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lq = lane >> 5;
+  const int kf = blockIdx.x, split = blockIdx.y;
+  constexpr int V = Vec16<T>::N;
+  ds2_f32x16 acc[K2T];
+#pragma unroll
+  for (int k = 0; k < K2T; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+
+  const int nrows = N * F2;
+  for (int rr = split; rr < nrows; rr += gridDim.y) {
+    const int n = rr / F2, fo = rr - n * F2;
+    const int fi = 2 * fo - 10 + kf;
+    if (fi < 0 || fi >= F1) continue;   // uniform per block
+    const T* dyrow = dY + ((long)n * F2 + fo) * Tp * CH;
+    const T* xrow = A1 + ((long)n * F1 + fi) * Tp * CH;
+    for (int t0 = 0; t0 < Tp; t0 += CW_TB) {
+      __syncthreads();
+      for (int i = tid; i < CW_TB * (CH / V); i += 256) {
+        const int p = i / (CH / V), v = i - p * (CH / V);
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (t0 + p < Tp) val = *reinterpret_cast<const uint4*>(dyrow + (long)(t0 + p) * CH + v * V);
+        *reinterpret_cast<uint4*>(sdy + p * CH + v * V) = val;
+      }
+      for (int i = tid; i < (CW_TB + K2T - 1) * (CH / V); i += 256) {
+        const int p = i / (CH / V), v = i - p * (CH / V);
+        const int t = t0 - 5 + p;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (t >= 0 && t < Tp) val = *reinterpret_cast<const uint4*>(xrow + (long)t * CH + v * V);
+        *reinterpret_cast<uint4*>(sx + p * CH + v * V) = val;
+      }
+      __syncthreads();
+      const int npairs = (min(CW_TB, Tp - t0) + 1) / 2;   // positions past Tp hold dy = 0
+      for (int p = wave; p < npairs; p += 4) {
+        const float av = ldf(sdy + (2 * p + lq) * CH + li);
+#pragma unroll
+        for (int kt = 0; kt < K2T; ++kt) {
+          const float bv = ldf(sx + (2 * p + lq + kt) * CH + li);
+          acc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[kt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // cross-wave reduction, one tap at a time; red[wave][co][ci]
+  float* red = reinterpret_cast<float*>(smem);
+  float* out = partial + ((long)split * (K2F * K2T) + (long)kf * K2T) * (CH * CH);
+  for (int kt = 0; kt < K2T; ++kt) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave * 1024 + mma32_row(r, lane) * 32 + li] = acc[kt][r];
+    __syncthreads();
+    for (int e = tid; e < 1024; e += 256) out[(long)kt * 1024 + e] = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
+  }
+}
+
+template <typename T>
+int conv_tap_launch(const ConvTapArgs& a, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k_conv_tap<T>, hipFuncAttributeMaxDynamicSharedMemorySize, CT_SMEM);
+    attr = true;
+  }
+  dim3 grid(ds2_cdiv(a.Tp, CT_TB), ds2_cdiv(a.U, CT_UB), a.N);
+  hipLaunchKernelGGL(k_conv_tap<T>, grid, dim3(256), CT_SMEM, st, a);
+  DS2_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ds2_conv1_fwd(int dtype, const float* x, const float* w1k, const float* b1, const int* lens, void* y1, int N, int T,
+                  int Tp, ds2_stream_t st_) {
+  hipStream_t st = (hipStream_t)st_;
+  DS2_REQUIRE(dtype == DS2_F32 || dtype == DS2_BF16, DS2_ERR_DTYPE);
+  DS2_REQUIRE(N > 0 && T > 0 && Tp == (T + 2 * 5 - 10 - 1) / 2 + 1, DS2_ERR_ARG);
+  dim3 grid(ds2_cdiv(Tp, C1_TB), ds2_cdiv(F1, C1_FB), N);
+  if (dtype == DS2_F32)
+    hipLaunchKernelGGL(k_conv1_fwd<float>, grid, dim3(256), 0, st, x, w1k, b1, lens, (float*)y1, N, T, Tp);
+  else
+    hipLaunchKernelGGL(k_conv1_fwd<bf16_t>, grid, dim3(256), 0, st, x, w1k, b1, lens, (bf16_t*)y1, N, T, Tp);
+  DS2_CHECK_LAUNCH();
+  return 0;
+}
+
+static int conv1_wgrad_blocks(int N, int Tp) {
+  long total = (long)N * ds2_cdiv(F1, C1_FB) * ds2_cdiv(Tp, C1_TB);
+  return (int)(total < C1W_MAXBLOCKS ? total : C1W_MAXBLOCKS);
+}
+long ds2_conv1_wgrad_ws_floats(int N, int Tp) {
+  const long P = conv1_wgrad_blocks(N, Tp);
+  return P * (K1F * K1T * CH) + (long)ds2_norm_partials(P) * (K1F * K1T * CH);
+}
+int ds2_conv1_wgrad(int dtype, const float* x, const void* dy1, float* dw1k, int N, int T, int Tp, float* ws,
+                    ds2_stream_t st_) {
+  hipStream_t st = (hipStream_t)st_;
+  DS2_REQUIRE(dtype == DS2_F32 || dtype == DS2_BF16, DS2_ERR_DTYPE);
+  const int P = conv1_wgrad_blocks(N, Tp);
+  const int ncf = ds2_cdiv(F1, C1_FB), nct = ds2_cdiv(Tp, C1_TB);
+  if (dtype == DS2_F32)
+    hipLaunchKernelGGL(k_conv1_wgrad<float>, dim3(P), dim3(C1W_THREADS), 0, st, x, (const float*)dy1, ws, N, T, Tp, nct, ncf);
+  else
+    hipLaunchKernelGGL(k_conv1_wgrad<bf16_t>, dim3(P), dim3(C1W_THREADS), 0, st, x, (const bf16_t*)dy1, ws, N, T, Tp, nct, ncf);
+  DS2_CHECK_LAUNCH();
+  const int C = K1F * K1T * CH;
+  return ds2_colsum(DS2_F32, ws, P, C, C, dw1k, 1.0f, ws + (long)P * C, st_);
+}
+
+int ds2_conv2_fwd(int dtype, const void* a1, const void* w2t, const float* b2, const int* lens, void* y2, int N, int Tp,
+                  ds2_stream_t st_) {
+  hipStream_t st = (hipStream_t)st_;
+  DS2_REQUIRE(dtype == DS2_F32 || dtype == DS2_BF16, DS2_ERR_DTYPE);
+  DS2_REQUIRE(N > 0 && Tp > 0, DS2_ERR_ARG);
+  ConvTapArgs a{a1, w2t, b2, lens, y2, N, Tp, F1, F2, K2F, 2, 10, F2, 1, 0};
+  return dtype == DS2_F32 ? conv_tap_launch<float>(a, st) : conv_tap_launch<bf16_t>(a, st);
+}
+
+// da1[n][f][t][ci] = sum_{co,kf,kt} w2[co][ci][kf][kt] * dy2[n][(f+10-kf)/2][t+5-kt][co]   (only even f+10-kf)
+// f = 2u+q: kf = q + 2m ->  input row u + 5 - m, i.e. a stride-1 correlation with the flipped taps m' = M_q-1-m
+// (M_0 = 11, M_1 = 10), top padding M_q - 6, and kt' = 10 - kt with padding 5.
+//   w2d_q [M_q*11][32 ci][32 co] = w2[co][ci][q + 2*(M_q-1-m')][10 - kt']        (prepared by the binding)
+int ds2_conv2_dgrad(int dtype, const void* dy2, const void* w2d_even, const void* w2d_odd, void* da1, int N, int Tp,
+                    ds2_stream_t st_) {
+  hipStream_t st = (hipStream_t)st_;
+  DS2_REQUIRE(dtype == DS2_F32 || dtype == DS2_BF16, DS2_ERR_DTYPE);
+  DS2_REQUIRE(N > 0 && Tp > 0, DS2_ERR_ARG);
+  ConvTapArgs e{dy2, w2d_even, nullptr, nullptr, da1, N, Tp, F2, F1, 11, 1, 5, 41, 2, 0};
+  ConvTapArgs o{dy2, w2d_odd, nullptr, nullptr, da1, N, Tp, F2, F1, 10, 1, 4, 40, 2, 1};
+  int rc = dtype == DS2_F32 ? conv_tap_launch<float>(e, st) : conv_tap_launch<bf16_t>(e, st);
+  if (rc) return rc;
+  return dtype == DS2_F32 ? conv_tap_launch<float>(o, st) : conv_tap_launch<bf16_t>(o, st);
+}
+
+long ds2_conv2_wgrad_ws_floats(int N, int Tp) {
+  (void)N; (void)Tp;
+  const long C = (long)K2F * K2T * CH * CH;
+  return (long)CW_SPLITS * C + (long)ds2_norm_partials(CW_SPLITS) * C;
+}
+int ds2_conv2_wgrad(int dtype, const void* dy2, const void* a1, float* dw2t, int N, int Tp, float* ws, ds2_stream_t st_) {
+  hipStream_t st = (hipStream_t)st_;
+  DS2_REQUIRE(dtype == DS2_F32 || dtype == DS2_BF16, DS2_ERR_DTYPE);
+  dim3 grid(K2F, CW_SPLITS);
+  if (dtype == DS2_F32)
+    hipLaunchKernelGGL(k_conv2_wgrad<float>, grid, dim3(256), 0, st, (const float*)dy2, (const float*)a1, ws, N, Tp);
+  else
+    hipLaunchKernelGGL(k_conv2_wgrad<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dy2, (const bf16_t*)a1, ws, N, Tp);
+  DS2_CHECK_LAUNCH();
+  const int C = K2F * K2T * CH * CH;
+  return ds2_colsum(DS2_F32, ws, CW_SPLITS, C, C, dw2t, 1.0f, ws + (long)CW_SPLITS * C, st_);
+}
+
+}  // extern "C"

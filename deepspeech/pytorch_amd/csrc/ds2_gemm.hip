@@ -1,0 +1,185 @@
+// NT GEMM on MFMA:  C[M][N] = sum_k A[m][k] * B[n][k]  (+ bias[n])        (both operands K-contiguous)
+//
+// Used for every dense contraction of the path that is not inside the recurrence:
+//   i2h   gi = X * W_ih^T + b_ih            (reference model.py:97-99, torch GRU/LSTM input projection)
+//   dgrad dX = dGI * W_ih   (B = W_ih^T)    wgrad dW = dG^T * X (operands pre-transposed)     head model.py:197
+// Tile: 128x128 per 256-thread workgroup, K-tile = 128 bytes per row (64 bf16 / 32 f32), 4 waves as 2x2, each wave a
+// 64x64 sub-tile = 2x2 MFMA 32x32 accumulators (64 fp32 regs).  Global -> registers -> LDS (row stride 144 B: the 16-B
+// pad makes the 16-lane ds_read_b128 groups hit 16 distinct 16-B slots), double-buffered LDS, one barrier per K-tile,
+// next tile's global loads in flight during the MFMAs.  bf16: v_mfma_f32_32x32x16_bf16; f32: v_mfma_f32_32x32x2_f32
+// (exact fp32, used by the 1e-3 parity mode).  Roofline: MFMA (2.5 PF bf16 / 157 TF f32); algorithmic flops 2*M*N*K.
+#include "ds2_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128;
+constexpr int KTB = 128;             // bytes of K per row per LDS stage
+constexpr int ROWB = KTB + 16;       // padded LDS row stride in bytes
+constexpr int STAGE_BYTES = (BM + BN) * ROWB;
+
+struct GemmArgs {
+  const void* A;
+  const void* B;
+  void* C;
+  const float* bias;
+  int M, N, K;
+  long lda, ldb, ldc;
+  long sA, sB, sC, sBias;  // batch strides (elements)
+  int splitk;              // >1: K is split over blockIdx.z % splitk and results are atomically added (f32 C only)
+  int out_is_f32;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256, 2) k_gemm_nt(GemmArgs g) {
+  constexpr int V = Vec16<T>::N;              // elements per 16 bytes
+  constexpr int KT = KTB / (int)sizeof(T);    // elements of K per stage
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int batch = blockIdx.z, ks = 0;
+  if (g.splitk > 1) {
+    ks = blockIdx.z % g.splitk;
+    batch = blockIdx.z / g.splitk;
+  }
+  const T* A = (const T*)g.A + (long)batch * g.sA;
+  const T* B = (const T*)g.B + (long)batch * g.sB;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+  // K range of this block
+  int nkt_total = (g.K + KT - 1) / KT;
+  int kt_begin = 0, kt_end = nkt_total;
+  if (g.splitk > 1) {
+    int per = (nkt_total + g.splitk - 1) / g.splitk;
+    kt_begin = ks * per;
+    kt_end = min(nkt_total, kt_begin + per);
+  }
+
+  ds2_f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  uint4 ra[4], rb[4];
+  auto gload = [&](int kt) {
+    const int k0 = kt * KT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int v = tid + i * 256;
+      int row = v >> 3, kc = v & 7;
+      int k = k0 + kc * V;
+      uint4 z = make_uint4(0, 0, 0, 0);
+      ra[i] = (m0 + row < g.M && k < g.K) ? *reinterpret_cast<const uint4*>(A + (long)(m0 + row) * g.lda + k) : z;
+      rb[i] = (n0 + row < g.N && k < g.K) ? *reinterpret_cast<const uint4*>(B + (long)(n0 + row) * g.ldb + k) : z;
+    }
+  };
+  auto swrite = [&](int stage) {
+    unsigned char* sa = smem + stage * STAGE_BYTES;
+    unsigned char* sb = sa + BM * ROWB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int v = tid + i * 256;
+      int row = v >> 3, kc = v & 7;
+      *reinterpret_cast<uint4*>(sa + row * ROWB + kc * 16) = ra[i];
+      *reinterpret_cast<uint4*>(sb + row * ROWB + kc * 16) = rb[i];
+    }
+  };
+
+  if (kt_begin < kt_end) {
+    gload(kt_begin);
+    swrite(0);
+  }
+  __syncthreads();
+  const int li = lane & 31, lq = lane >> 5;
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int stage = (kt - kt_begin) & 1;
+    const bool more = kt + 1 < kt_end;
+    if (more) gload(kt + 1);
+    const unsigned char* sa = smem + stage * STAGE_BYTES + (wm * 64 + li) * ROWB + lq * 16;
+    const unsigned char* sb = smem + stage * STAGE_BYTES + BM * ROWB + (wn * 64 + li) * ROWB + lq * 16;
+#pragma unroll
+    for (int c = 0; c < KTB / 32; ++c) {
+      uint4 a0 = *reinterpret_cast<const uint4*>(sa + c * 32);
+      uint4 a1 = *reinterpret_cast<const uint4*>(sa + 32 * ROWB + c * 32);
+      uint4 b0 = *reinterpret_cast<const uint4*>(sb + c * 32);
+      uint4 b1 = *reinterpret_cast<const uint4*>(sb + 32 * ROWB + c * 32);
+      Mma<T>::mma32(acc[0][0], a0, b0);
+      Mma<T>::mma32(acc[0][1], a0, b1);
+      Mma<T>::mma32(acc[1][0], a1, b0);
+      Mma<T>::mma32(acc[1][1], a1, b1);
+    }
+    if (more) swrite(stage ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue
+  const float* bias = g.bias ? g.bias + (long)batch * g.sBias : nullptr;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + li;
+      if (col >= g.N) continue;
+      const float bv = (bias && ks == 0) ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + mma32_row(r, lane);
+        if (row >= g.M) continue;
+        const float v = acc[i][j][r] + bv;
+        const long off = (long)batch * g.sC + (long)row * g.ldc + col;
+        if (g.out_is_f32) {
+          float* cp = (float*)g.C + off;
+          if (g.splitk > 1)
+            atomicAdd(cp, v);
+          else
+            *cp = v;
+        } else {
+          stf((T*)g.C + off, v);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// C (f32 if out_f32 else `dtype`) [M][ldc] = A[M][lda] * B[N][ldb]^T (+bias[N]); batched over `batch` with element strides.
+// K, lda, ldb must be multiples of 16 bytes / sizeof(T); A/B 16-byte aligned.  splitk>1 requires out_f32 and a
+// zero-initialised C (results are atomically accumulated).
+int ds2_gemm_nt(int dtype, const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long lda, long ldb,
+                long ldc, int out_f32, int batch, long strideA, long strideB, long strideC, long strideBias, int splitk,
+                ds2_stream_t st_) {
+  hipStream_t st = (hipStream_t)st_;
+  DS2_REQUIRE(dtype == DS2_F32 || dtype == DS2_BF16, DS2_ERR_DTYPE);
+  const int V = dtype == DS2_F32 ? 4 : 8;
+  DS2_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0 && splitk >= 1, DS2_ERR_ARG);
+  DS2_REQUIRE(K % V == 0 && lda % V == 0 && ldb % V == 0 && strideA % V == 0 && strideB % V == 0, DS2_ERR_ALIGN);
+  DS2_REQUIRE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)B) & 15) == 0, DS2_ERR_ALIGN);
+  DS2_REQUIRE(splitk == 1 || out_f32, DS2_ERR_ARG);
+  GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, strideA, strideB, strideC, strideBias, splitk, out_f32 || dtype == DS2_F32};
+  dim3 grid(ds2_cdiv(N, BN), ds2_cdiv(M, BM), batch * splitk), blk(256);
+  const size_t shm = 2 * STAGE_BYTES;
+  if (dtype == DS2_F32) {
+    static bool attr_f = false;
+    if (!attr_f) {
+      hipFuncSetAttribute((const void*)k_gemm_nt<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      attr_f = true;
+    }
+    hipLaunchKernelGGL(k_gemm_nt<float>, grid, blk, shm, st, g);
+  } else {
+    static bool attr_b = false;
+    if (!attr_b) {
+      hipFuncSetAttribute((const void*)k_gemm_nt<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      attr_b = true;
+    }
+    hipLaunchKernelGGL(k_gemm_nt<bf16_t>, grid, blk, shm, st, g);
+  }
+  DS2_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

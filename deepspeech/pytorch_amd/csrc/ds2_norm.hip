@@ -1,0 +1,424 @@
+// BatchNorm family (reference model.py:159,162 BatchNorm2d; model.py:28-33,86,196 SequenceWise BatchNorm1d).
+//
+// Everything is a "column norm" over a row-major matrix X[R][ld] with C channels in the fastest dimension:
+//   * conv activations live in NFTC layout  -> R = N*F*T', C = 32, row = (n*F + f)*T' + t
+//   * sequence activations are (T'*N) x H   -> R = T'*N,   C = H
+// Statistics include every row (also the zero rows the time mask / padding produced), exactly like the reference.
+// HBM-bound streaming kernels: 16-byte loads per lane, fp32 accumulation, deterministic two-stage reduction
+// (per-block partials -> fp64 finalize).  Algorithmic bytes: read X once for stats, read X + write Y for apply.
+#include "ds2_common.h"
+
+namespace {
+
+constexpr int NORM_RY = 8;     // rows per block iteration (threadIdx.y)
+constexpr int NORM_CX = 32;    // 16-byte column chunks per block (threadIdx.x)
+
+// maps a row of a conv activation (NFTC) to (n, t) for the time mask
+struct RowMap {
+  int F, Tp;  // F == 0 -> no mapping (sequence matrix)
+  __device__ __forceinline__ void nt(long row, int& n, int& t) const {
+    t = (int)(row % Tp);
+    n = (int)(row / ((long)F * Tp));
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// column sums / sums of squares -> partial[blockIdx.y][C]
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, bool SQ>
+__global__ void __launch_bounds__(NORM_RY* NORM_CX) k_colstats(const T* __restrict__ X, long R, int C, long ld,
+                                                                float* __restrict__ psum, float* __restrict__ psq) {
+  constexpr int V = Vec16<T>::N;
+  __shared__ float red[NORM_RY][NORM_CX * V + 1];
+  const int cx = blockIdx.x * NORM_CX + threadIdx.x;
+  const bool ok = (long)cx * V < C;
+  float s[V], q[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) s[i] = q[i] = 0.f;
+  if (ok) {
+    for (long r = (long)blockIdx.y * NORM_RY + threadIdx.y; r < R; r += (long)gridDim.y * NORM_RY) {
+      float v[V];
+      Vec16<T>::load(X + r * ld + (long)cx * V, v);
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        s[i] += v[i];
+        if (SQ) q[i] += v[i] * v[i];
+      }
+    }
+  }
+  for (int pass = 0; pass < (SQ ? 2 : 1); ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < V; ++i) red[threadIdx.y][threadIdx.x * V + i] = pass ? q[i] : s[i];
+    __syncthreads();
+    if (threadIdx.y == 0 && ok) {
+      float* dst = (pass ? psq : psum) + (long)blockIdx.y * C + (long)cx * V;
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        float a = 0.f;
+#pragma unroll
+        for (int y = 0; y < NORM_RY; ++y) a += red[y][threadIdx.x * V + i];
+        dst[i] = a;
+      }
+    }
+  }
+}
+
+// partial[P][C] -> out[c] = sum_p (fp64 accumulate)
+__global__ void k_colsum_finalize(const float* __restrict__ psum, int P, int C, float* __restrict__ out, float scale) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0;
+  for (int p = 0; p < P; ++p) a += (double)psum[(long)p * C + c];
+  out[c] = (float)(a * (double)scale);
+}
+
+// training-mode statistics -> mean, rstd, scale = gamma*rstd, shift = beta - mean*scale; running stats update
+// (momentum, UNBIASED variance for running_var -- torch semantics), num_batches_tracked += 1.
+__global__ void k_bn_finalize(const float* __restrict__ psum, const float* __restrict__ psq, int P, int C, double count,
+                              const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                              float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
+                              long long* __restrict__ num_batches_tracked, float* __restrict__ mean_out,
+                              float* __restrict__ rstd_out, float* __restrict__ scale_out, float* __restrict__ shift_out) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int p = 0; p < P; ++p) {
+    s += (double)psum[(long)p * C + c];
+    q += (double)psq[(long)p * C + c];
+  }
+  double mean = s / count;
+  double var = q / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  double rstd = 1.0 / sqrt(var + (double)eps);
+  mean_out[c] = (float)mean;
+  rstd_out[c] = (float)rstd;
+  float sc = (float)((double)gamma[c] * rstd);
+  scale_out[c] = sc;
+  shift_out[c] = (float)((double)beta[c] - mean * (double)gamma[c] * rstd);
+  if (running_mean) {
+    double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
+    running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+    running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unb);
+  }
+}
+
+// eval-mode: scale/shift from the running statistics
+__global__ void k_bn_eval_coeffs(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                 const float* __restrict__ running_mean, const float* __restrict__ running_var, float eps,
+                                 float* __restrict__ scale_out, float* __restrict__ shift_out) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double rstd = 1.0 / sqrt((double)running_var[c] + (double)eps);
+  scale_out[c] = (float)((double)gamma[c] * rstd);
+  shift_out[c] = (float)((double)beta[c] - (double)running_mean[c] * (double)gamma[c] * rstd);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// apply:  y = x*scale + shift   [CONV: then Hardtanh(0,20) and the time mask (model.py:61-68,160,163)]
+// SEQ_OUT: additionally the output is written in sequence layout X0[(t*N + n)][f*32 + c] (the collapse+transpose of
+// model.py:219-221 fused into the store; the internal feature order f*32+c is undone on the weight side).
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, bool CONV, bool SEQ_OUT>
+__global__ void __launch_bounds__(256) k_bn_apply(const T* __restrict__ X, T* __restrict__ Y, long R, int C, long ldx,
+                                                   long ldy, const float* __restrict__ scale,
+                                                   const float* __restrict__ shift, RowMap rm,
+                                                   const int* __restrict__ lens, int N) {
+  constexpr int V = Vec16<T>::N;
+  const int chunks = C / V;
+  const long total = R * chunks;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    long r = e / chunks;
+    int c0 = (int)(e % chunks) * V;
+    float v[V];
+    bool live = true;
+    int n = 0, t = 0;
+    if (CONV) {
+      rm.nt(r, n, t);
+      live = t < lens[n];
+    }
+    if (live) {
+      Vec16<T>::load(X + r * ldx + c0, v);
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        float y = v[i] * scale[c0 + i] + shift[c0 + i];
+        if (CONV) y = fminf(fmaxf(y, 0.f), 20.f);
+        v[i] = y;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < V; ++i) v[i] = 0.f;
+    }
+    if (SEQ_OUT) {
+      int f = (int)((r / rm.Tp) % rm.F);
+      Vec16<T>::store(Y + ((long)t * N + n) * ldy + (long)f * C + c0, v);
+    } else {
+      Vec16<T>::store(Y + r * ldy + c0, v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// backward.  g = upstream gradient, gated for the conv case by Hardtanh' (0 < x*scale+shift < 20, strict, like
+// torch hardtanh_backward) and by the time mask.  SEQ_IN: upstream gradient is read from the sequence layout.
+//   reduce : sum_r g, sum_r g*xhat            (xhat = (x-mean)*rstd)
+//   apply  : dx = scale * (g - c1 - xhat*c2)  [* mask]   with c1 = sum g / M, c2 = sum g*xhat / M
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, bool CONV, bool SEQ_IN>
+__device__ __forceinline__ bool load_gated(const T* __restrict__ G, const T* __restrict__ X, long r, int c0, int C,
+                                           long ldg, long ldx, const float* __restrict__ scale,
+                                           const float* __restrict__ shift, const float* __restrict__ mean,
+                                           const float* __restrict__ rstd, const RowMap& rm, const int* __restrict__ lens,
+                                           int N, float (&g)[Vec16<T>::N], float (&xh)[Vec16<T>::N]) {
+  constexpr int V = Vec16<T>::N;
+  int n = 0, t = 0;
+  if (CONV) {
+    rm.nt(r, n, t);
+    if (t >= lens[n]) return false;
+  }
+  float x[V];
+  Vec16<T>::load(X + r * ldx + c0, x);
+  if (SEQ_IN) {
+    int f = (int)((r / rm.Tp) % rm.F);
+    Vec16<T>::load(G + ((long)t * N + n) * ldg + (long)f * C + c0, g);
+  } else {
+    Vec16<T>::load(G + r * ldg + c0, g);
+  }
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    if (CONV) {
+      float y = x[i] * scale[c0 + i] + shift[c0 + i];
+      if (!(y > 0.f && y < 20.f)) g[i] = 0.f;
+    }
+    xh[i] = (x[i] - mean[c0 + i]) * rstd[c0 + i];
+  }
+  return true;
+}
+
+template <typename T, bool CONV, bool SEQ_IN>
+__global__ void __launch_bounds__(NORM_RY* NORM_CX)
+    k_bn_bwd_reduce(const T* __restrict__ G, const T* __restrict__ X, long R, int C, long ldg, long ldx,
+                    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+                    const float* __restrict__ rstd, RowMap rm, const int* __restrict__ lens, int N,
+                    float* __restrict__ psum_g, float* __restrict__ psum_gx) {
+  constexpr int V = Vec16<T>::N;
+  __shared__ float red[NORM_RY][NORM_CX * V + 1];
+  const int cx = blockIdx.x * NORM_CX + threadIdx.x;
+  const bool ok = (long)cx * V < C;
+  float s[V], q[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) s[i] = q[i] = 0.f;
+  if (ok) {
+    for (long r = (long)blockIdx.y * NORM_RY + threadIdx.y; r < R; r += (long)gridDim.y * NORM_RY) {
+      float g[V], xh[V];
+      if (load_gated<T, CONV, SEQ_IN>(G, X, r, cx * V, C, ldg, ldx, scale, shift, mean, rstd, rm, lens, N, g, xh)) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          s[i] += g[i];
+          q[i] += g[i] * xh[i];
+        }
+      }
+    }
+  }
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < V; ++i) red[threadIdx.y][threadIdx.x * V + i] = pass ? q[i] : s[i];
+    __syncthreads();
+    if (threadIdx.y == 0 && ok) {
+      float* dst = (pass ? psum_gx : psum_g) + (long)blockIdx.y * C + (long)cx * V;
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        float a = 0.f;
+#pragma unroll
+        for (int y = 0; y < NORM_RY; ++y) a += red[y][threadIdx.x * V + i];
+        dst[i] = a;
+      }
+    }
+  }
+}
+
+__global__ void k_bn_bwd_finalize(const float* __restrict__ psum_g, const float* __restrict__ psum_gx, int P, int C,
+                                  double count, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                  float* __restrict__ c1, float* __restrict__ c2) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int p = 0; p < P; ++p) {
+    s += (double)psum_g[(long)p * C + c];
+    q += (double)psum_gx[(long)p * C + c];
+  }
+  dbeta[c] = (float)s;
+  dgamma[c] = (float)q;
+  c1[c] = (float)(s / count);
+  c2[c] = (float)(q / count);
+}
+
+template <typename T, bool CONV, bool SEQ_IN>
+__global__ void __launch_bounds__(256)
+    k_bn_bwd_apply(const T* __restrict__ G, const T* __restrict__ X, T* __restrict__ DX, long R, int C, long ldg, long ldx,
+                   long lddx, const float* __restrict__ scale, const float* __restrict__ shift,
+                   const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ c1,
+                   const float* __restrict__ c2, RowMap rm, const int* __restrict__ lens, int N) {
+  constexpr int V = Vec16<T>::N;
+  const int chunks = C / V;
+  const long total = R * chunks;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    long r = e / chunks;
+    int c0 = (int)(e % chunks) * V;
+    float g[V], xh[V], o[V];
+    if (load_gated<T, CONV, SEQ_IN>(G, X, r, c0, C, ldg, ldx, scale, shift, mean, rstd, rm, lens, N, g, xh)) {
+#pragma unroll
+      for (int i = 0; i < V; ++i) o[i] = scale[c0 + i] * (g[i] - c1[c0 + i] - xh[i] * c2[c0 + i]);
+    } else {
+      // masked position: the mask that follows the conv (model.py:61-68) zeroes this gradient
+#pragma unroll
+      for (int i = 0; i < V; ++i) o[i] = 0.f;
+    }
+    Vec16<T>::store(DX + r * lddx + c0, o);
+  }
+}
+
+inline int norm_grid_y(long R) {
+  long gy = (R + NORM_RY - 1) / NORM_RY;
+  if (gy > 256) gy = 256;
+  if (gy < 1) gy = 1;
+  return (int)gy;
+}
+
+template <typename T>
+int colstats_impl(const void* X, long R, int C, long ld, float* psum, float* psq, int* P_out, hipStream_t st) {
+  constexpr int V = Vec16<T>::N;
+  DS2_REQUIRE(C % V == 0 && ld % V == 0, DS2_ERR_ALIGN);
+  dim3 blk(NORM_CX, NORM_RY);
+  dim3 grd(ds2_cdiv(C / V, NORM_CX), norm_grid_y(R));
+  if (psq)
+    hipLaunchKernelGGL((k_colstats<T, true>), grd, blk, 0, st, (const T*)X, R, C, ld, psum, psq);
+  else
+    hipLaunchKernelGGL((k_colstats<T, false>), grd, blk, 0, st, (const T*)X, R, C, ld, psum, psq);
+  *P_out = grd.y;
+  DS2_CHECK_LAUNCH();
+  return 0;
+}
+
+inline int apply_grid(long total) {
+  long g = (total + 255) / 256;
+  if (g > 256 * 8) g = 256 * 8;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ds2_norm_partials(long R) { return norm_grid_y(R); }
+
+int ds2_colsum(int dtype, const void* X, long R, int C, long ld, float* out, float scale, float* ws, ds2_stream_t st_) {
+  hipStream_t st = (hipStream_t)st_;
+  int P = 0, rc;
+  if (dtype == DS2_F32)
+    rc = colstats_impl<float>(X, R, C, ld, ws, nullptr, &P, st);
+  else
+    rc = colstats_impl<bf16_t>(X, R, C, ld, ws, nullptr, &P, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_colsum_finalize, dim3(ds2_cdiv(C, 256)), dim3(256), 0, st, ws, P, C, out, scale);
+  DS2_CHECK_LAUNCH();
+  return 0;
+}
+
+// mode: 0 = sequence matrix (BatchNorm1d), 1 = conv activation in NFTC (hardtanh + time mask),
+//       2 = conv activation, output/upstream-gradient in sequence layout (the last conv BN feeding the RNN stack)
+int ds2_bn_fwd(int dtype, int mode, int training, const void* X, void* Y, long R, int C, long ldx, long ldy, int F, int Tp,
+               int N, const int* lens, const float* gamma, const float* beta, float* running_mean, float* running_var,
+               long long* num_batches_tracked, float eps, float momentum, float* save_mean, float* save_rstd,
+               float* save_scale, float* save_shift, float* ws, ds2_stream_t st_) {
+  hipStream_t st = (hipStream_t)st_;
+  DS2_REQUIRE(dtype == DS2_F32 || dtype == DS2_BF16, DS2_ERR_DTYPE);
+  DS2_REQUIRE(mode >= 0 && mode <= 2, DS2_ERR_ARG);
+  int rc, P = 0;
+  if (training) {
+    float* psum = ws;
+    float* psq = ws + (long)norm_grid_y(R) * C;
+    rc = dtype == DS2_F32 ? colstats_impl<float>(X, R, C, ldx, psum, psq, &P, st)
+                          : colstats_impl<bf16_t>(X, R, C, ldx, psum, psq, &P, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_bn_finalize, dim3(ds2_cdiv(C, 128)), dim3(128), 0, st, psum, psq, P, C, (double)R, gamma, beta,
+                       eps, momentum, running_mean, running_var, num_batches_tracked, save_mean, save_rstd, save_scale,
+                       save_shift);
+  } else {
+    hipLaunchKernelGGL(k_bn_eval_coeffs, dim3(ds2_cdiv(C, 128)), dim3(128), 0, st, C, gamma, beta, running_mean,
+                       running_var, eps, save_scale, save_shift);
+  }
+  DS2_CHECK_LAUNCH();
+  RowMap rm{F, Tp};
+  const int V = dtype == DS2_F32 ? 4 : 8;
+  DS2_REQUIRE(C % V == 0 && ldx % V == 0 && ldy % V == 0, DS2_ERR_ALIGN);
+  dim3 g(apply_grid(R * (C / V))), b(256);
+#define LAUNCH_APPLY(TT)                                                                                              \
+  if (mode == 0)                                                                                                      \
+    hipLaunchKernelGGL((k_bn_apply<TT, false, false>), g, b, 0, st, (const TT*)X, (TT*)Y, R, C, ldx, ldy, save_scale,  \
+                       save_shift, rm, lens, N);                                                                      \
+  else if (mode == 1)                                                                                                 \
+    hipLaunchKernelGGL((k_bn_apply<TT, true, false>), g, b, 0, st, (const TT*)X, (TT*)Y, R, C, ldx, ldy, save_scale,   \
+                       save_shift, rm, lens, N);                                                                      \
+  else                                                                                                                \
+    hipLaunchKernelGGL((k_bn_apply<TT, true, true>), g, b, 0, st, (const TT*)X, (TT*)Y, R, C, ldx, ldy, save_scale,    \
+                       save_shift, rm, lens, N);
+  if (dtype == DS2_F32) {
+    LAUNCH_APPLY(float)
+  } else {
+    LAUNCH_APPLY(bf16_t)
+  }
+#undef LAUNCH_APPLY
+  DS2_CHECK_LAUNCH();
+  return 0;
+}
+
+int ds2_bn_bwd(int dtype, int mode, const void* G, const void* X, void* DX, long R, int C, long ldg, long ldx, long lddx,
+               int F, int Tp, int N, const int* lens, const float* save_mean, const float* save_rstd,
+               const float* save_scale, const float* save_shift, float* dgamma, float* dbeta, float* ws, ds2_stream_t st_) {
+  hipStream_t st = (hipStream_t)st_;
+  DS2_REQUIRE(dtype == DS2_F32 || dtype == DS2_BF16, DS2_ERR_DTYPE);
+  DS2_REQUIRE(mode >= 0 && mode <= 2, DS2_ERR_ARG);
+  const int V = dtype == DS2_F32 ? 4 : 8;
+  DS2_REQUIRE(C % V == 0 && ldx % V == 0 && ldg % V == 0 && lddx % V == 0, DS2_ERR_ALIGN);
+  RowMap rm{F, Tp};
+  const int P = norm_grid_y(R);
+  float* ps = ws;
+  float* pq = ws + (long)P * C;
+  float* c1 = pq + (long)P * C;
+  float* c2 = c1 + C;
+  dim3 blk(NORM_CX, NORM_RY), grd(ds2_cdiv(C / V, NORM_CX), P);
+#define LAUNCH_RED(TT, CV, SI)                                                                                          \
+  hipLaunchKernelGGL((k_bn_bwd_reduce<TT, CV, SI>), grd, blk, 0, st, (const TT*)G, (const TT*)X, R, C, ldg, ldx,          \
+                     save_scale, save_shift, save_mean, save_rstd, rm, lens, N, ps, pq)
+#define LAUNCH_APP(TT, CV, SI)                                                                                          \
+  hipLaunchKernelGGL((k_bn_bwd_apply<TT, CV, SI>), dim3(apply_grid(R*(C / V))), dim3(256), 0, st, (const TT*)G,           \
+                     (const TT*)X, (TT*)DX, R, C, ldg, ldx, lddx, save_scale, save_shift, save_mean, save_rstd, c1, c2, \
+                     rm, lens, N)
+#define BOTH(WHICH)                                        \
+  if (dtype == DS2_F32) {                                  \
+    if (mode == 0) WHICH(float, false, false);             \
+    else if (mode == 1) WHICH(float, true, false);         \
+    else WHICH(float, true, true);                         \
+  } else {                                                 \
+    if (mode == 0) WHICH(bf16_t, false, false);            \
+    else if (mode == 1) WHICH(bf16_t, true, false);        \
+    else WHICH(bf16_t, true, true);                        \
+  }
+  BOTH(LAUNCH_RED)
+  DS2_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(ds2_cdiv(C, 128)), dim3(128), 0, st, ps, pq, P, C, (double)R, dgamma, dbeta,
+                     c1, c2);
+  DS2_CHECK_LAUNCH();
+  BOTH(LAUNCH_APP)
+  DS2_CHECK_LAUNCH();
+#undef BOTH
+#undef LAUNCH_RED
+#undef LAUNCH_APP
+  return 0;
+}
+
+}  // extern "C"

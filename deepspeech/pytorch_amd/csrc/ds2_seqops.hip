@@ -1,0 +1,251 @@
+// Small sequence ops: direction sum (model.py:101), 2-D transpose (operand re-layout for the wgrad GEMMs), Lookahead
+// (model.py:105-135 + Hardtanh model.py:189-193), inference softmax (model.py:72-77).  All HBM-bound streaming kernels.
+#include "ds2_common.h"
+
+namespace {
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_add2(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, long nvec) {
+  constexpr int V = Vec16<T>::N;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    float x[V], y[V];
+    Vec16<T>::load(a + i * V, x);
+    Vec16<T>::load(b + i * V, y);
+#pragma unroll
+    for (int k = 0; k < V; ++k) x[k] += y[k];
+    Vec16<T>::store(o + i * V, x);
+  }
+}
+
+// dst[c][r] = src[r][c]; tile 64x64 through LDS (row stride padded by one 4-byte word -> conflict-free column reads)
+template <typename E>   // E = storage element (uint16_t or float)
+__global__ void __launch_bounds__(256) k_transpose(const E* __restrict__ src, E* __restrict__ dst, long R, int C, long lds_,
+                                                    long ldd) {
+  constexpr int V = 16 / (int)sizeof(E);
+  constexpr int PADE = 4 / (int)sizeof(E) > 0 ? 4 / (int)sizeof(E) : 1;
+  __shared__ E tile[64][64 + PADE];
+  const long r0 = (long)blockIdx.y * 64;
+  const int c0 = blockIdx.x * 64;
+  for (int i = threadIdx.x; i < 64 * (64 / V); i += 256) {
+    const int rr = i / (64 / V), cv = i % (64 / V);
+    const long r = r0 + rr;
+    const int c = c0 + cv * V;
+    alignas(16) E tmp[V];
+    if (r < R && c < C) {
+      *reinterpret_cast<uint4*>(tmp) = *reinterpret_cast<const uint4*>(src + r * lds_ + c);
+    } else {
+#pragma unroll
+      for (int k = 0; k < V; ++k) tmp[k] = (E)0;
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) tile[rr][cv * V + k] = tmp[k];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * (64 / V); i += 256) {
+    const int cc = i / (64 / V), rv = i % (64 / V);
+    const int c = c0 + cc;
+    const long r = r0 + rv * V;
+    if (c < C && r < ldd) {   // ldd % V == 0: rows r in [R, ldd) are written as zeros (tile is zero there)
+      alignas(16) E tmp[V];
+#pragma unroll
+      for (int k = 0; k < V; ++k) tmp[k] = tile[rv * V + k][cc];
+      *reinterpret_cast<uint4*>(dst + (long)c * ldd + r) = *reinterpret_cast<uint4*>(tmp);
+    }
+  }
+}
+
+// Lookahead forward: y[t][n][h] = hardtanh( sum_k w[h][k] * x[t+k][n][h] ), x[t>=Tp] = 0   (model.py:125-130)
+template <typename T>
+__global__ void __launch_bounds__(256) k_lookahead_fwd(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y,
+                                                        T* __restrict__ pre, int Tp, int N, int H, int ctx) {
+  constexpr int V = Vec16<T>::N;
+  const int hv = H / V;
+  const long total = (long)Tp * N * hv;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int h0 = (int)(e % hv) * V;
+    const long tn = e / hv;
+    const int t = (int)(tn / N);
+    float acc[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) acc[i] = 0.f;
+    for (int k = 0; k < ctx && t + k < Tp; ++k) {
+      float xv[V];
+      Vec16<T>::load(x + (tn + (long)k * N) * H + h0, xv);
+#pragma unroll
+      for (int i = 0; i < V; ++i) acc[i] = fmaf(w[(long)(h0 + i) * ctx + k], xv[i], acc[i]);
+    }
+    if (pre) Vec16<T>::store(pre + tn * H + h0, acc);   // pre-activation, kept for Hardtanh' in backward
+#pragma unroll
+    for (int i = 0; i < V; ++i) acc[i] = fminf(fmaxf(acc[i], 0.f), 20.f);
+    Vec16<T>::store(y + tn * H + h0, acc);
+  }
+}
+
+// backward wrt x: g = dy * [0 < pre < 20];  dx[t] = sum_k w[h][k] * g[t-k]
+template <typename T>
+__global__ void __launch_bounds__(256) k_lookahead_bwd_x(const T* __restrict__ dy, const T* __restrict__ pre,
+                                                          const float* __restrict__ w, T* __restrict__ dx, int Tp, int N, int H,
+                                                          int ctx) {
+  constexpr int V = Vec16<T>::N;
+  const int hv = H / V;
+  const long total = (long)Tp * N * hv;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int h0 = (int)(e % hv) * V;
+    const long tn = e / hv;
+    const int t = (int)(tn / N);
+    float acc[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) acc[i] = 0.f;
+    for (int k = 0; k < ctx && t - k >= 0; ++k) {
+      float g[V], p[V];
+      const long off = (tn - (long)k * N) * H + h0;
+      Vec16<T>::load(dy + off, g);
+      Vec16<T>::load(pre + off, p);
+#pragma unroll
+      for (int i = 0; i < V; ++i)
+        if (p[i] > 0.f && p[i] < 20.f) acc[i] = fmaf(w[(long)(h0 + i) * ctx + k], g[i], acc[i]);
+    }
+    Vec16<T>::store(dx + tn * H + h0, acc);
+  }
+}
+
+// backward wrt w: dw[h][k] = sum_{t,n} g[t][n][h] * x[t+k][n][h]; partial over row blocks -> ws[P][H*ctx]
+constexpr int LA_ROWS = 256;  // (t,n) rows per block
+template <typename T>
+__global__ void __launch_bounds__(256) k_lookahead_bwd_w(const T* __restrict__ dy, const T* __restrict__ pre,
+                                                          const T* __restrict__ x, float* __restrict__ partial, int Tp, int N,
+                                                          int H, int ctx) {
+  const int h = blockIdx.x * 256 + threadIdx.x;
+  if (h >= H) return;
+  const long rows = (long)Tp * N;
+  const long r0 = (long)blockIdx.y * LA_ROWS, r1 = min(rows, r0 + LA_ROWS);
+  float acc[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) acc[k] = 0.f;
+  for (long r = r0; r < r1; ++r) {
+    const float p = ldf(pre + r * H + h);
+    if (!(p > 0.f && p < 20.f)) continue;
+    const float g = ldf(dy + r * H + h);
+    const int t = (int)(r / N);
+#pragma unroll
+    for (int k = 0; k < 32; ++k)
+      if (k < ctx && t + k < Tp) acc[k] = fmaf(g, ldf(x + (r + (long)k * N) * H + h), acc[k]);
+  }
+  float* dst = partial + (long)blockIdx.y * H * ctx + (long)h * ctx;
+  for (int k = 0; k < ctx; ++k) dst[k] = acc[k];
+}
+
+__global__ void __launch_bounds__(256) k_softmax_rows(const float* __restrict__ in, float* __restrict__ out, long rows, int C,
+                                                       long ldi, long ldo) {
+  for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (long)gridDim.x * blockDim.x) {
+    const float* x = in + r * ldi;
+    float m = -INFINITY;
+    for (int c = 0; c < C; ++c) m = fmaxf(m, x[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(x[c] - m);
+    const float inv = 1.f / s;
+    for (int c = 0; c < C; ++c) out[r * ldo + c] = expf(x[c] - m) * inv;
+  }
+}
+
+inline int ew_grid(long n) {
+  long g = (n + 255) / 256;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ds2_version(void) { return 100; }
+
+const char* ds2_error_string(int code) {
+  switch (code) {
+    case DS2_OK: return "ok";
+    case DS2_ERR_DTYPE: return "ds2hip: unknown dtype";
+    case DS2_ERR_ARG: return "ds2hip: bad argument (dimension / null pointer / unsupported combination)";
+    case DS2_ERR_ALIGN: return "ds2hip: pointer or leading dimension violates the 16-byte alignment contract";
+    default: return hipGetErrorString((hipError_t)code);
+  }
+}
+
+int ds2_add2(int dtype, const void* a, const void* b, void* out, long n, ds2_stream_t st_) {
+  hipStream_t st = (hipStream_t)st_;
+  DS2_REQUIRE(dtype == DS2_F32 || dtype == DS2_BF16, DS2_ERR_DTYPE);
+  const int V = dtype == DS2_F32 ? 4 : 8;
+  DS2_REQUIRE(n % V == 0, DS2_ERR_ALIGN);
+  if (dtype == DS2_F32)
+    hipLaunchKernelGGL(k_add2<float>, dim3(ew_grid(n / V)), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)out, n / V);
+  else
+    hipLaunchKernelGGL(k_add2<bf16_t>, dim3(ew_grid(n / V)), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n / V);
+  DS2_CHECK_LAUNCH();
+  return 0;
+}
+
+int ds2_transpose(int dtype, const void* src, void* dst, long R, int C, long lds_, long ldd, ds2_stream_t st_) {
+  hipStream_t st = (hipStream_t)st_;
+  DS2_REQUIRE(dtype == DS2_F32 || dtype == DS2_BF16, DS2_ERR_DTYPE);
+  const int V = dtype == DS2_F32 ? 4 : 8;
+  DS2_REQUIRE(C % V == 0 && lds_ % V == 0 && ldd % V == 0 && ldd >= R, DS2_ERR_ALIGN);
+  dim3 grid(ds2_cdiv(C, 64), ds2_cdiv(ldd, 64));
+  if (dtype == DS2_F32)
+    hipLaunchKernelGGL(k_transpose<float>, grid, dim3(256), 0, st, (const float*)src, (float*)dst, R, C, lds_, ldd);
+  else
+    hipLaunchKernelGGL(k_transpose<uint16_t>, grid, dim3(256), 0, st, (const uint16_t*)src, (uint16_t*)dst, R, C, lds_, ldd);
+  DS2_CHECK_LAUNCH();
+  return 0;
+}
+
+// y = hardtanh(lookahead(x)); `pre` (same shape, may be null in eval) keeps the pre-activation for backward
+int ds2_lookahead_fwd(int dtype, const void* x, const float* w, void* y, void* pre, int Tp, int N, int H, int ctx,
+                      ds2_stream_t st_) {
+  hipStream_t st = (hipStream_t)st_;
+  DS2_REQUIRE(dtype == DS2_F32 || dtype == DS2_BF16, DS2_ERR_DTYPE);
+  const int V = dtype == DS2_F32 ? 4 : 8;
+  DS2_REQUIRE(H % V == 0 && ctx > 0, DS2_ERR_ARG);
+  const long total = (long)Tp * N * (H / V);
+  if (dtype == DS2_F32)
+    hipLaunchKernelGGL(k_lookahead_fwd<float>, dim3(ew_grid(total)), dim3(256), 0, st, (const float*)x, w, (float*)y, (float*)pre, Tp, N, H, ctx);
+  else
+    hipLaunchKernelGGL(k_lookahead_fwd<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, st, (const bf16_t*)x, w, (bf16_t*)y, (bf16_t*)pre, Tp, N, H, ctx);
+  DS2_CHECK_LAUNCH();
+  return 0;
+}
+
+static int la_row_blocks(int Tp, int N) { return ds2_cdiv((long)Tp * N, LA_ROWS); }
+long ds2_lookahead_ws_floats(int Tp, int N, int H, int ctx) {
+  const long P = la_row_blocks(Tp, N);
+  return P * H * ctx + (long)ds2_norm_partials(P) * H * ctx;
+}
+int ds2_lookahead_bwd(int dtype, const void* x, const float* w, const void* pre, const void* dy, void* dx, float* dw, int Tp,
+                      int N, int H, int ctx, float* ws, ds2_stream_t st_) {
+  hipStream_t st = (hipStream_t)st_;
+  DS2_REQUIRE(dtype == DS2_F32 || dtype == DS2_BF16, DS2_ERR_DTYPE);
+  const int V = dtype == DS2_F32 ? 4 : 8;
+  DS2_REQUIRE(H % V == 0 && ctx > 0 && ctx <= 32 && (H * ctx) % 4 == 0, DS2_ERR_ARG);
+  const long total = (long)Tp * N * (H / V);
+  const int P = la_row_blocks(Tp, N);
+  dim3 gw(ds2_cdiv(H, 256), P);
+  if (dtype == DS2_F32) {
+    hipLaunchKernelGGL(k_lookahead_bwd_x<float>, dim3(ew_grid(total)), dim3(256), 0, st, (const float*)dy, (const float*)pre, w, (float*)dx, Tp, N, H, ctx);
+    hipLaunchKernelGGL(k_lookahead_bwd_w<float>, gw, dim3(256), 0, st, (const float*)dy, (const float*)pre, (const float*)x, ws, Tp, N, H, ctx);
+  } else {
+    hipLaunchKernelGGL(k_lookahead_bwd_x<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)pre, w, (bf16_t*)dx, Tp, N, H, ctx);
+    hipLaunchKernelGGL(k_lookahead_bwd_w<bf16_t>, gw, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)pre, (const bf16_t*)x, ws, Tp, N, H, ctx);
+  }
+  DS2_CHECK_LAUNCH();
+  const int C = H * ctx;
+  return ds2_colsum(DS2_F32, ws, P, C, C, dw, 1.0f, ws + (long)P * C, st_);
+}
+
+int ds2_softmax_rows(const float* logits, float* probs, long rows, int C, long ld_in, long ld_out, ds2_stream_t st_) {
+  hipStream_t st = (hipStream_t)st_;
+  DS2_REQUIRE(rows > 0 && C > 0, DS2_ERR_ARG);
+  hipLaunchKernelGGL(k_softmax_rows, dim3(ew_grid(rows)), dim3(256), 0, st, logits, probs, rows, C, ld_in, ld_out);
+  DS2_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

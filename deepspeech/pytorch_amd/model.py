@@ -1,0 +1,541 @@
+"""Drop-in replacement for ``deepspeech_pytorch.model.DeepSpeech`` (reference model.py:138-310) whose forward /
+training step run on the hand-written gfx950 kernels of libds2hip.so.
+
+Boundary kept identical to the reference:
+  * constructor ``DeepSpeech(labels, model_cfg, precision, optim_cfg, spect_cfg)`` (model.py:139-145)
+  * ``forward(x (N,1,161,T), lengths, hs=None) -> (out (N,T',C), output_lengths int32 CPU, new_hs)`` (model.py:214-239);
+    logits in train mode, softmax probabilities in eval mode (model.py:72-77)
+  * ``training_step`` (sum-reduced CTC, model.py:241-249), ``validation_step``, ``configure_optimizers``, ``get_seq_lens``
+  * parameter / buffer names and shapes == the reference ``state_dict`` (checkpoints load both ways, strict=True)
+The module tree below exists only to own the parameters under the reference names; none of the torch layers is ever
+called.  Kernel-friendly re-layouts of the weights (bf16 copies, transposes, tap-major conv kernels) live in a cache
+keyed on the parameters' version counters, never in the state.
+
+There is no CPU / torch-op fallback: CPU tensors or a missing libds2hip.so raise.
+"""
+import math
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import Ds2HipError
+
+try:  # the Lightning / OmegaConf stack is optional here (absent from the build image); the reference needs it
+    import pytorch_lightning as pl
+    _Base = pl.LightningModule
+except Exception:  # pragma: no cover - exercised in the build image
+    pl = None
+
+    class _Base(nn.Module):
+        """Minimal stand-in for pl.LightningModule (save_hyperparameters / log / device) when Lightning is absent."""
+
+        def save_hyperparameters(self, *a, **k):
+            pass
+
+        def log(self, *a, **k):
+            pass
+
+        @property
+        def device(self):
+            return next(self.parameters()).device
+
+try:
+    from omegaconf import OmegaConf
+
+    def _cfg_type_name(cfg):
+        t = OmegaConf.get_type(cfg)
+        return getattr(t, "__name__", str(t))
+except Exception:  # pragma: no cover
+    def _cfg_type_name(cfg):
+        return type(cfg).__name__
+
+from .configs import AdamConfig, BiDirectionalConfig, SGDConfig, SpectConfig, UniDirectionalConfig, rnn_kind  # noqa: E402
+
+N_FREQ_CONV2 = 41
+RNN_INPUT = 32 * N_FREQ_CONV2  # 1312, model.py:166-169
+
+
+# ==================================================================================================================
+# parameter containers (reference names; never called)
+# ==================================================================================================================
+class SequenceWise(nn.Module):  # model.py:18-39 (container only)
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+
+class MaskConv(nn.Module):  # model.py:42-69 (container only)
+    def __init__(self, seq_module):
+        super().__init__()
+        self.seq_module = seq_module
+
+
+class _RNNParams(nn.Module):
+    """Owns weight_ih_l0 / weight_hh_l0 / bias_ih_l0 / bias_hh_l0 [+ _reverse] exactly like torch.nn.RNNBase
+    (same creation order and the same U(-1/sqrt(H), 1/sqrt(H)) init, so identical seeds give identical weights)."""
+
+    def __init__(self, kind, input_size, hidden_size, bidirectional):
+        super().__init__()
+        g = ops.GATES[kind]
+        for suf in [""] + (["_reverse"] if bidirectional else []):
+            self.register_parameter("weight_ih_l0" + suf, nn.Parameter(torch.empty(g * hidden_size, input_size)))
+            self.register_parameter("weight_hh_l0" + suf, nn.Parameter(torch.empty(g * hidden_size, hidden_size)))
+            self.register_parameter("bias_ih_l0" + suf, nn.Parameter(torch.empty(g * hidden_size)))
+            self.register_parameter("bias_hh_l0" + suf, nn.Parameter(torch.empty(g * hidden_size)))
+        stdv = 1.0 / math.sqrt(hidden_size) if hidden_size > 0 else 0
+        for w in self.parameters():
+            nn.init.uniform_(w, -stdv, stdv)
+
+
+class BatchRNN(nn.Module):  # model.py:80-102 (container only)
+    def __init__(self, input_size, hidden_size, kind, bidirectional=False, batch_norm=True):
+        super().__init__()
+        self.input_size, self.hidden_size, self.bidirectional, self.kind = input_size, hidden_size, bidirectional, kind
+        self.batch_norm = SequenceWise(nn.BatchNorm1d(input_size)) if batch_norm else None
+        self.rnn = _RNNParams(kind, input_size, hidden_size, bidirectional)
+        self.num_directions = 2 if bidirectional else 1
+
+
+class Lookahead(nn.Module):  # model.py:105-135 (container only)
+    def __init__(self, n_features, context):
+        super().__init__()
+        assert context > 0
+        self.context, self.n_features = context, n_features
+        self.conv = nn.Conv1d(n_features, n_features, kernel_size=context, stride=1, groups=n_features, padding=0, bias=False)
+
+
+# ==================================================================================================================
+# weight cache: kernel layouts derived from the fp32 parameters, rebuilt when a parameter's version changes
+# ==================================================================================================================
+class _WeightCache:
+    def __init__(self):
+        self._store = {}
+
+    def get(self, key, params, builder):
+        ver = tuple((p._version, p.data_ptr()) for p in params)
+        hit = self._store.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        with torch.no_grad():
+            val = builder()
+        self._store[key] = (ver, val)
+        return val
+
+    def clear(self):
+        self._store.clear()
+
+
+def _perm_cols_to_internal(w):
+    """rnns.0 weight_ih columns: reference feature c*41+f -> internal f*32+c."""
+    g = w.shape[0]
+    return w.reshape(g, 32, N_FREQ_CONV2).permute(0, 2, 1).reshape(g, RNN_INPUT)
+
+
+def _perm_cols_to_reference(w):
+    g = w.shape[0]
+    return w.reshape(g, N_FREQ_CONV2, 32).permute(0, 2, 1).reshape(g, RNN_INPUT)
+
+
+# ==================================================================================================================
+# autograd stages
+# ==================================================================================================================
+class _ConvStackFn(torch.autograd.Function):
+    """MaskConv over conv1-BN-Hardtanh-conv2-BN-Hardtanh (model.py:157-164, 53-69) + collapse/transpose (219-221).
+    Output: X0 [(t*N+n)][1312] in the internal feature order f*32+c."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, g1, be1, w2, b2, g2, be2, mod, lens_dev, Tp, dtype, training):
+        N, T = x.shape[0], x.shape[3]
+        c = mod._cache
+        bn1, bn2 = mod.conv.seq_module[1], mod.conv.seq_module[4]
+        w1k = c.get("w1k", [w1], lambda: w1.detach().reshape(32, 451).t().contiguous())
+        w2t = c.get(("w2t", dtype), [w2], lambda: w2.detach().permute(2, 3, 0, 1).contiguous().to(dtype))
+        x = x.contiguous().float()
+        y1 = ops.conv1_fwd(x, w1k, b1.detach(), lens_dev, Tp, dtype)
+        R1 = N * 81 * Tp
+        a1 = torch.empty_like(y1)
+        sv1 = ops.bn_fwd(y1, 1, training, g1.detach(), be1.detach(), bn1.running_mean, bn1.running_var,
+                         bn1.num_batches_tracked, R1, 32, 32, a1, 32, F=81, Tp=Tp, N=N, lens=lens_dev, eps=bn1.eps,
+                         momentum=bn1.momentum)
+        y2 = ops.conv2_fwd(a1, w2t, b2.detach(), lens_dev)
+        R2 = N * 41 * Tp
+        x0 = torch.empty((Tp * N, RNN_INPUT), dtype=dtype, device=x.device)
+        sv2 = ops.bn_fwd(y2, 2, training, g2.detach(), be2.detach(), bn2.running_mean, bn2.running_var,
+                         bn2.num_batches_tracked, R2, 32, 32, x0, RNN_INPUT, F=41, Tp=Tp, N=N, lens=lens_dev, eps=bn2.eps,
+                         momentum=bn2.momentum)
+        ctx.mod, ctx.dims, ctx.sv = mod, (N, T, Tp, dtype), (sv1, sv2)
+        ctx.save_for_backward(x, y1, a1, y2, lens_dev, w2)
+        return x0
+
+    @staticmethod
+    def backward(ctx, dx0):
+        x, y1, a1, y2, lens_dev, w2 = ctx.saved_tensors
+        N, T, Tp, dtype = ctx.dims
+        sv1, sv2 = ctx.sv
+        c = ctx.mod._cache
+        dx0 = dx0.contiguous().to(dtype)
+        R1, R2 = N * 81 * Tp, N * 41 * Tp
+        dy2 = torch.empty_like(y2)
+        dg2, dbe2 = ops.bn_bwd(dx0, y2, dy2, 2, sv2, R2, 32, RNN_INPUT, 32, 32, F=41, Tp=Tp, N=N, lens=lens_dev)
+        db2 = ops.colsum(dy2.view(R2, 32))
+        dw2t = ops.conv2_wgrad(dy2, a1)
+        dw2 = dw2t.view(21, 11, 32, 32).permute(2, 3, 0, 1).contiguous()
+        w2d = c.get(("w2d", dtype), [w2], lambda: [
+            w2.detach()[:, :, q::2, :].flip(2, 3).permute(2, 3, 1, 0).contiguous().to(dtype) for q in (0, 1)])
+        da1 = ops.conv2_dgrad(dy2, w2d[0], w2d[1])
+        dy1 = torch.empty_like(y1)
+        dg1, dbe1 = ops.bn_bwd(da1, y1, dy1, 1, sv1, R1, 32, 32, 32, 32, F=81, Tp=Tp, N=N, lens=lens_dev)
+        db1 = ops.colsum(dy1.view(R1, 32))
+        dw1k = ops.conv1_wgrad(x, dy1, Tp)
+        dw1 = dw1k.t().reshape(32, 1, 41, 11).contiguous()
+        return (None, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, None, None, None, None, None)
+
+
+class _RnnLayerFn(torch.autograd.Function):
+    """BatchRNN.forward (model.py:94-102): [SequenceWise BatchNorm1d] -> packed bi/uni GRU/LSTM/RNN -> direction sum."""
+
+    @staticmethod
+    def forward(ctx, X, bn_w, bn_b, mod, layer_idx, lens_dev, N, Tp, dtype, training, h0, c0, *wts):
+        layer = mod.rnns[layer_idx]
+        kind, H, D = layer.kind, layer.hidden_size, layer.num_directions
+        G = ops.GATES[kind]
+        I = layer.input_size
+        c = mod._cache
+        first = layer_idx == 0
+        wih = [wts[4 * d + 0] for d in range(D)]
+        whh = [wts[4 * d + 1] for d in range(D)]
+        bih = [wts[4 * d + 2] for d in range(D)]
+        bhh = [wts[4 * d + 3] for d in range(D)]
+
+        def build_ih():
+            w = torch.cat([p.detach() for p in wih], 0)
+            if first:
+                w = _perm_cols_to_internal(w)
+            return w.to(dtype).contiguous()
+        Wih = c.get(("wih", layer_idx, dtype), wih, build_ih)
+        Whh = c.get(("whh", layer_idx, dtype), whh, lambda: torch.stack([p.detach() for p in whh], 0).to(dtype).contiguous())
+        Bih = c.get(("bih", layer_idx), bih, lambda: torch.cat([p.detach() for p in bih], 0).contiguous())
+        Bhh = c.get(("bhh", layer_idx), bhh, lambda: torch.stack([p.detach() for p in bhh], 0).contiguous())
+        R = Tp * N
+        sv = None
+        Xh = X
+        if layer.batch_norm is not None:
+            bn = layer.batch_norm.module
+            Xh = torch.empty_like(X)
+            sv = ops.bn_fwd(X, 0, training, bn_w.detach(), bn_b.detach(), bn.running_mean, bn.running_var,
+                            bn.num_batches_tracked, R, I, I, Xh, I, eps=bn.eps, momentum=bn.momentum)
+        GI = ops.gemm_nt(Xh, Wih, bias=Bih)                                  # [R][D*G*H]
+        hext, Sv, hn, cn = ops.rnn_fwd(kind, GI, Whh, Bhh, lens_dev, D, N, H, Tp, h0=h0, c0=c0)
+        del GI
+        if D == 2:
+            out = ops.add2(hext[0, 1:Tp + 1].reshape(R, H), hext[1, 1:Tp + 1].reshape(R, H))
+        else:
+            out = hext[0, 1:Tp + 1].reshape(R, H).clone()
+        ctx.mod, ctx.layer_idx, ctx.dims, ctx.sv = mod, layer_idx, (N, Tp, dtype, kind, H, D, G, I), sv
+        ctx.has_bn = layer.batch_norm is not None
+        ctx.had_state = h0 is not None
+        ctx.save_for_backward(X, Xh if ctx.has_bn else None, hext, Sv, lens_dev, *whh, *wih)
+        ctx.mark_non_differentiable(hn)
+        if cn is not None:
+            ctx.mark_non_differentiable(cn)
+            return out, hn, cn
+        return out, hn
+
+    @staticmethod
+    def backward(ctx, dout, *unused):
+        N, Tp, dtype, kind, H, D, G, I = ctx.dims
+        if ctx.had_state:
+            raise Ds2HipError("backward through a forward that was given initial hidden states (hs) is not supported")
+        saved = ctx.saved_tensors
+        X, Xh, hext, Sv, lens_dev = saved[:5]
+        whh, wih = saved[5:5 + D], saved[5 + D:5 + 2 * D]
+        if Xh is None:
+            Xh = X
+        c = ctx.mod._cache
+        li = ctx.layer_idx
+        first = li == 0
+        R, GH = Tp * N, G * H
+        WhhT = c.get(("whhT", li, dtype), list(whh),
+                     lambda: torch.stack([p.detach().t() for p in whh], 0).to(dtype).contiguous())      # [D][H][G*H]
+
+        def build_ihT():
+            w = torch.cat([p.detach() for p in wih], 0)
+            if first:
+                w = _perm_cols_to_internal(w)
+            return w.t().to(dtype).contiguous()                                                         # [I][D*G*H]
+        WihT = c.get(("wihT", li, dtype), list(wih), build_ihT)
+        dout = dout.contiguous().to(dtype)
+        dGI, dGH = ops.rnn_bwd(kind, dout, WhhT, hext, Sv, lens_dev, D, N, H, Tp)
+        # ---- parameter gradients: contraction over the T'*N rows -> transposed operands for the NT GEMM
+        dGI_T = ops.transpose(dGI)                                  # [D*G*H][ldT]
+        Xh_T = ops.transpose(Xh)                                    # [I][ldT]
+        ldT = dGI_T.shape[1]
+        dWih = ops.gemm_nt(dGI_T, Xh_T, out_dtype=torch.float32)    # [D*G*H][I]
+        del Xh_T
+        if first:
+            dWih = torch.cat([_perm_cols_to_reference(dWih[d * GH:(d + 1) * GH]) for d in range(D)], 0)
+        dBih = ops.colsum(dGI)
+        grads_w = []
+        for d in range(D):
+            # h_{t-1} of the forward direction is slot t of the guarded buffer, h_{t+1} of the reverse direction slot t+2
+            hprev = hext[d, 0:Tp] if d == 0 else hext[d, 2:Tp + 2]
+            Hp_T = ops.transpose(hprev.reshape(R, H))               # [H][ldT]
+            if kind == "gru":
+                dGH_T = ops.transpose(dGH[d].reshape(R, GH))        # [G*H][ldT]
+                dBhh = ops.colsum(dGH[d].reshape(R, GH))
+            else:
+                dGH_T = dGI_T[d * GH:(d + 1) * GH]
+                dBhh = dBih[d * GH:(d + 1) * GH]
+            dWhh = ops.gemm_nt(dGH_T, Hp_T, out_dtype=torch.float32, M=GH, N=H, K=ldT, lda=ldT, ldb=ldT)
+            grads_w += [dWih[d * GH:(d + 1) * GH].contiguous(), dWhh, dBih[d * GH:(d + 1) * GH].contiguous(),
+                        dBhh.contiguous()]
+        del dGI_T
+        dXh = ops.gemm_nt(dGI, WihT)                                # [R][I]
+        dbn_w = dbn_b = None
+        if ctx.has_bn:
+            dX = torch.empty_like(dXh)
+            dbn_w, dbn_b = ops.bn_bwd(dXh, X, dX, 0, ctx.sv, R, I, I, I, I)
+        else:
+            dX = dXh
+        return (dX, dbn_w, dbn_b, None, None, None, None, None, None, None, None, None, *grads_w)
+
+
+class _LookaheadFn(torch.autograd.Function):
+    """Lookahead + Hardtanh (model.py:105-135, 189-193), uni-directional models."""
+
+    @staticmethod
+    def forward(ctx, X, w, N, Tp):
+        H, ctxlen = w.shape[0], w.shape[2]
+        wf = w.detach().reshape(H, ctxlen).contiguous()
+        y, pre = ops.lookahead_fwd(X, wf, Tp, N, H)
+        ctx.dims = (N, Tp, H, ctxlen)
+        ctx.save_for_backward(X, wf, pre)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        X, wf, pre = ctx.saved_tensors
+        N, Tp, H, ctxlen = ctx.dims
+        dx, dw = ops.lookahead_bwd(X, wf, pre, dy.contiguous().to(X.dtype), Tp, N, H)
+        return dx, dw.reshape(H, 1, ctxlen), None, None
+
+
+class _HeadFn(torch.autograd.Function):
+    """fc = SequenceWise(BatchNorm1d(H) -> Linear(H, C, bias=False)) (model.py:195-201).  Output: fp32 logits [T'*N][32]
+    (C = 29 valid columns, the rest zero) -- the padded leading dimension is what the CTC kernel and the GEMMs want."""
+
+    @staticmethod
+    def forward(ctx, X, bn_w, bn_b, wfc, mod, N, Tp, dtype, training):
+        bn = mod.fc[0].module[0]
+        H, Cc = wfc.shape[1], wfc.shape[0]
+        R = Tp * N
+        c = mod._cache
+        Xh = torch.empty_like(X)
+        sv = ops.bn_fwd(X, 0, training, bn_w.detach(), bn_b.detach(), bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                        R, H, H, Xh, H, eps=bn.eps, momentum=bn.momentum)
+        Wp = c.get(("wfc", dtype), [wfc], lambda: torch.cat(
+            [wfc.detach(), torch.zeros(32 - Cc, H, device=wfc.device)], 0).to(dtype).contiguous())          # [32][H]
+        logits = ops.gemm_nt(Xh, Wp, out_dtype=torch.float32)                                                # [R][32]
+        ctx.mod, ctx.dims, ctx.sv = mod, (N, Tp, dtype, H, Cc), sv
+        ctx.save_for_backward(X, Xh, wfc)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        X, Xh, wfc = ctx.saved_tensors
+        N, Tp, dtype, H, Cc = ctx.dims
+        R = Tp * N
+        c = ctx.mod._cache
+        dl = dlogits.contiguous().to(dtype)                                                                  # [R][32]
+        WpT = c.get(("wfcT", dtype), [wfc], lambda: torch.cat(
+            [wfc.detach(), torch.zeros(32 - Cc, H, device=wfc.device)], 0).t().to(dtype).contiguous())       # [H][32]
+        dXh = ops.gemm_nt(dl, WpT)                                                                           # [R][H]
+        dl_T, Xh_T = ops.transpose(dl), ops.transpose(Xh)
+        dW = ops.gemm_nt(dl_T, Xh_T, out_dtype=torch.float32, splitk=max(1, min(32, R // 2048)))             # [32][H]
+        dX = torch.empty_like(dXh)
+        dg, db = ops.bn_bwd(dXh, X, dX, 0, ctx.sv, R, H, H, H, H)
+        return dX, dg, db, dW[:Cc].contiguous(), None, None, None, None, None
+
+
+class _CtcFn(torch.autograd.Function):
+    """log_softmax + CTCLoss(blank, 'sum', zero_infinity=True) (model.py:246,203,248); gradient computed in the same
+    launch as the loss and scaled by the upstream gradient in backward."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, out_lens_dev, target_sizes, N, Tp, Cc, blank):
+        dev = logits.device
+        tsz = target_sizes.to(torch.int64).cpu()
+        offs = torch.zeros(N, dtype=torch.int64)
+        if N > 1:
+            offs[1:] = torch.cumsum(tsz, 0)[:-1]
+        max_tl = int(tsz.max().item()) if N > 0 else 0
+        loss, nll, dl = ops.ctc_loss_grad(logits, targets.to(dev, torch.int32), offs.to(dev, torch.int32), out_lens_dev,
+                                          tsz.to(dev, torch.int32), Tp, N, Cc, blank, max_tl)
+        ctx.save_for_backward(dl)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g, None, None, None, None, None, None, None
+
+
+# ==================================================================================================================
+# the model
+# ==================================================================================================================
+class DeepSpeech(_Base):
+    def __init__(self, labels: List, model_cfg, precision, optim_cfg, spect_cfg):
+        super().__init__()
+        self.save_hyperparameters()
+        self.model_cfg = model_cfg
+        self.precision = precision
+        self.optim_cfg = optim_cfg
+        self.spect_cfg = spect_cfg
+        self.bidirectional = _cfg_type_name(model_cfg) == "BiDirectionalConfig"   # model.py:152
+        self.labels = labels
+        num_classes = len(self.labels)
+        kind = rnn_kind(model_cfg.rnn_type)
+        H, L = int(model_cfg.hidden_size), int(model_cfg.hidden_layers)
+        if H % 16 != 0:
+            raise ValueError("the gfx950 recurrent kernels tile the hidden units by 16: hidden_size %d %% 16 != 0" % H)
+        if num_classes > 32:
+            raise ValueError("the fused CTC kernel supports at most 32 output classes, got %d" % num_classes)
+
+        self.conv = MaskConv(nn.Sequential(
+            nn.Conv2d(1, 32, kernel_size=(41, 11), stride=(2, 2), padding=(20, 5)),
+            nn.BatchNorm2d(32),
+            nn.Hardtanh(0, 20, inplace=True),
+            nn.Conv2d(32, 32, kernel_size=(21, 11), stride=(2, 1), padding=(10, 5)),
+            nn.BatchNorm2d(32),
+            nn.Hardtanh(0, 20, inplace=True)
+        ))
+        rnn_input_size = int(math.floor((self.spect_cfg.sample_rate * self.spect_cfg.window_size) / 2) + 1)
+        rnn_input_size = int(math.floor(rnn_input_size + 2 * 20 - 41) / 2 + 1)
+        rnn_input_size = int(math.floor(rnn_input_size + 2 * 10 - 21) / 2 + 1)
+        rnn_input_size *= 32
+        if rnn_input_size != RNN_INPUT:
+            raise ValueError("the conv kernels are specialised for 161 frequency bins (16 kHz, 20 ms window)")
+        self.rnns = nn.Sequential(
+            BatchRNN(rnn_input_size, H, kind, bidirectional=self.bidirectional, batch_norm=False),
+            *(BatchRNN(H, H, kind, bidirectional=self.bidirectional) for _ in range(L - 1))
+        )
+        self.lookahead = nn.Sequential(
+            Lookahead(H, context=model_cfg.lookahead_context),
+            nn.Hardtanh(0, 20, inplace=True)
+        ) if not self.bidirectional else None
+        fully_connected = nn.Sequential(nn.BatchNorm1d(H), nn.Linear(H, num_classes, bias=False))
+        self.fc = nn.Sequential(SequenceWise(fully_connected))
+        self.blank_index = self.labels.index('_')      # model.py:203
+        self._cache = _WeightCache()
+        self._kind = kind
+
+    # ---- precision policy -------------------------------------------------------------------------------------
+    def compute_dtype(self):
+        """bf16 storage/MFMA operands under autocast or when constructed with a 16-bit precision; fp32 otherwise
+        (the 1e-3 parity mode).  Parameters, statistics, gate math, CTC and parameter gradients are always fp32."""
+        if torch.is_autocast_enabled():
+            return torch.bfloat16
+        if str(self.precision) in ("16", "bf16", "16-mixed", "bf16-mixed"):
+            return torch.bfloat16
+        return torch.float32
+
+    # ---- forward ------------------------------------------------------------------------------------------------
+    def _logits(self, x, lengths, hs=None):
+        if not x.is_cuda:
+            raise Ds2HipError("DeepSpeech (gfx950) needs its input on a HIP device; there is no CPU fallback")
+        dtype = self.compute_dtype()
+        lengths = lengths.cpu().int()                      # model.py:215
+        output_lengths = self.get_seq_lens(lengths)        # model.py:216
+        N, T = x.shape[0], x.shape[3]
+        Tp = (T + 2 * 5 - 10 - 1) // 2 + 1
+        dev = x.device
+        lens_dev = output_lengths.to(dev, torch.int32, non_blocking=True)
+        training = self.training
+        sm = self.conv.seq_module
+        with torch.autocast("cuda", enabled=False):
+            X = _ConvStackFn.apply(x, sm[0].weight, sm[0].bias, sm[1].weight, sm[1].bias, sm[3].weight, sm[3].bias,
+                                   sm[4].weight, sm[4].bias, self, lens_dev, Tp, dtype, training)
+            if hs is None:
+                hs = [None] * len(self.rnns)
+            new_hs = []
+            for i, layer in enumerate(self.rnns):
+                h0 = c0 = None
+                if hs[i] is not None:
+                    if self._kind == "lstm":
+                        h0, c0 = hs[i][0].float().contiguous(), hs[i][1].float().contiguous()
+                    else:
+                        h0 = hs[i].float().contiguous()
+                p = layer.rnn
+                wts = []
+                for suf in [""] + (["_reverse"] if self.bidirectional else []):
+                    wts += [getattr(p, "weight_ih_l0" + suf), getattr(p, "weight_hh_l0" + suf),
+                            getattr(p, "bias_ih_l0" + suf), getattr(p, "bias_hh_l0" + suf)]
+                bn = layer.batch_norm.module if layer.batch_norm is not None else None
+                res = _RnnLayerFn.apply(X, bn.weight if bn else None, bn.bias if bn else None, self, i, lens_dev, N, Tp,
+                                        dtype, training, h0, c0, *wts)
+                X = res[0]
+                new_hs.append((res[1], res[2]) if self._kind == "lstm" else res[1])
+            if not self.bidirectional:
+                X = _LookaheadFn.apply(X, self.lookahead[0].conv.weight, N, Tp)
+            fcm = self.fc[0].module
+            logits = _HeadFn.apply(X, fcm[0].weight, fcm[0].bias, fcm[1].weight, self, N, Tp, dtype, training)
+        return logits, output_lengths, new_hs, lens_dev, N, Tp
+
+    def forward(self, x, lengths, hs=None):
+        logits, output_lengths, new_hs, _, N, Tp = self._logits(x, lengths, hs)
+        Cc = len(self.labels)
+        if self.training:
+            out = logits.view(Tp, N, 32)[:, :, :Cc].transpose(0, 1)        # (N, T', C) view, model.py:236
+        else:
+            out = ops.softmax_rows(logits, Cc).view(Tp, N, Cc).transpose(0, 1)   # model.py:238, 72-77
+        return out, output_lengths, new_hs
+
+    def training_step(self, batch, batch_idx):
+        inputs, targets, input_percentages, target_sizes = batch
+        input_sizes = input_percentages.mul_(int(inputs.size(3))).int()       # model.py:243
+        logits, output_sizes, _, lens_dev, N, Tp = self._logits(inputs, input_sizes)
+        return _CtcFn.apply(logits, targets, lens_dev, target_sizes, N, Tp, len(self.labels), self.blank_index)
+
+    def validation_step(self, batch, batch_idx):
+        # model.py:251-271: forward in eval mode + greedy decode + WER/CER.  The decoder / metric objects are the
+        # reference's own (out of the hot-path scope); attach them with `attach_evaluation(decoder, wer, cer)`.
+        inputs, targets, input_percentages, target_sizes = batch
+        input_sizes = input_percentages.mul_(int(inputs.size(3))).int()
+        inputs = inputs.to(self.device)
+        out, output_sizes, hs = self(inputs, input_sizes)
+        dec = getattr(self, "evaluation_decoder", None)
+        if dec is None:
+            return out, output_sizes
+        decoded_output, _ = dec.decode(out, output_sizes)
+        for metric, name in ((getattr(self, "wer", None), "wer"), (getattr(self, "cer", None), "cer")):
+            if metric is not None:
+                metric(preds=out, preds_sizes=output_sizes, targets=targets, target_sizes=target_sizes)
+                self.log(name, metric.compute(), prog_bar=True, on_epoch=True)
+        return decoded_output
+
+    def attach_evaluation(self, decoder, wer=None, cer=None):
+        self.evaluation_decoder, self.wer, self.cer = decoder, wer, cer
+
+    def configure_optimizers(self):  # model.py:273-297
+        name = _cfg_type_name(self.optim_cfg)
+        if name == "SGDConfig":
+            optimizer = torch.optim.SGD(params=self.parameters(), lr=self.optim_cfg.learning_rate,
+                                        momentum=self.optim_cfg.momentum, nesterov=True,
+                                        weight_decay=self.optim_cfg.weight_decay)
+        elif name == "AdamConfig":
+            optimizer = torch.optim.AdamW(params=self.parameters(), lr=self.optim_cfg.learning_rate,
+                                          betas=tuple(self.optim_cfg.betas), eps=self.optim_cfg.eps,
+                                          weight_decay=self.optim_cfg.weight_decay)
+        else:
+            raise ValueError("Optimizer has not been specified correctly.")
+        scheduler = torch.optim.lr_scheduler.ExponentialLR(optimizer=optimizer, gamma=self.optim_cfg.learning_anneal)
+        return [optimizer], [scheduler]
+
+    def get_seq_lens(self, input_length):  # model.py:299-310
+        seq_len = input_length
+        for m in self.conv.modules():
+            if type(m) == nn.modules.conv.Conv2d:
+                seq_len = ((seq_len + 2 * m.padding[1] - m.dilation[1] * (m.kernel_size[1] - 1) - 1) // m.stride[1] + 1)
+        return seq_len.int()

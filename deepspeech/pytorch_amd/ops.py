@@ -1,0 +1,220 @@
+"""Torch-tensor wrappers around the C ABI (include/ds2hip.h).  torch is used here only as the owner of device
+memory and streams; every computation is a ds2hip kernel.  All tensors must be CUDA(HIP) tensors -- there is no CPU
+path (a CPU tensor raises)."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import F32, BF16, call, query
+
+CELLS = {"gru": _lib.CELL_GRU, "lstm": _lib.CELL_LSTM, "rnn": _lib.CELL_RNN_TANH}
+GATES = {"gru": 3, "lstm": 4, "rnn": 1}
+SAVED_PLANES = {"gru": 4, "lstm": 5, "rnn": 0}
+
+
+def dt(t):
+    d = t if isinstance(t, torch.dtype) else t.dtype
+    if d == torch.float32:
+        return F32
+    if d == torch.bfloat16:
+        return BF16
+    raise TypeError("ds2hip supports float32 and bfloat16 activations, got %s" % d)
+
+
+def vecw(dtype):
+    return 4 if dtype == torch.float32 else 8
+
+
+def P(t):
+    """device pointer of a tensor (None -> NULL); refuses CPU tensors: the HIP path is the only path."""
+    if t is None:
+        return C.c_void_p(0)
+    if not t.is_cuda:
+        raise _lib.Ds2HipError("ds2hip ops need CUDA(HIP) tensors; got a %s tensor -- there is no CPU fallback" % t.device)
+    return C.c_void_p(t.data_ptr())
+
+
+def S():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def rup(x, m):
+    return (x + m - 1) // m * m
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def gemm_nt(A, B, bias=None, out_dtype=None, M=None, N=None, K=None, lda=None, ldb=None, out=None, ldc=None, splitk=1,
+            batch=1, sA=0, sB=0, sC=0, sBias=0):
+    """C[M][N] = A[M][K] * B[N][K]^T (+bias).  A, B: 2-D row-major tensors (or explicit M/N/K/ld for views)."""
+    M = A.shape[-2] if M is None else M
+    N = B.shape[-2] if N is None else N
+    K = A.shape[-1] if K is None else K
+    lda = A.stride(-2) if lda is None else lda
+    ldb = B.stride(-2) if ldb is None else ldb
+    out_dtype = out_dtype or A.dtype
+    if out is None:
+        shape = (batch, M, N) if batch > 1 else (M, N)
+        out = (torch.zeros if splitk > 1 else torch.empty)(shape, dtype=out_dtype, device=A.device)
+        ldc = N
+        sC = M * N
+    out_f32 = 1 if out.dtype == torch.float32 else 0
+    call("ds2_gemm_nt", dt(A), P(A), P(B), P(out), P(bias), M, N, K, lda, ldb, ldc, out_f32, batch, sA, sB, sC, sBias, splitk, S())
+    return out
+
+
+def colsum(X, R=None, Cc=None, ld=None, scale=1.0):
+    R = X.shape[0] if R is None else R
+    Cc = X.shape[1] if Cc is None else Cc
+    ld = X.stride(0) if ld is None else ld
+    out = torch.empty(Cc, dtype=torch.float32, device=X.device)
+    ws = torch.empty(query("ds2_norm_partials", R) * Cc, dtype=torch.float32, device=X.device)
+    call("ds2_colsum", dt(X), P(X), R, Cc, ld, P(out), float(scale), P(ws), S())
+    return out
+
+
+def transpose(X, R=None, Cc=None, lds=None):
+    """dst[C][ldd] = X[R][C]^T with ldd = roundup(R, 8) and zero fill of the pad columns."""
+    R = X.shape[0] if R is None else R
+    Cc = X.shape[1] if Cc is None else Cc
+    lds = X.stride(0) if lds is None else lds
+    ldd = rup(R, 8)
+    out = torch.empty((Cc, ldd), dtype=X.dtype, device=X.device)
+    call("ds2_transpose", dt(X), P(X), P(out), R, Cc, lds, ldd, S())
+    return out
+
+
+def add2(a, b):
+    out = torch.empty_like(a)
+    call("ds2_add2", dt(a), P(a), P(b), P(out), a.numel(), S())
+    return out
+
+
+class BnSaved:
+    __slots__ = ("mean", "rstd", "scale", "shift")
+
+    def __init__(self, Cc, device):
+        buf = torch.empty((4, Cc), dtype=torch.float32, device=device)
+        self.mean, self.rstd, self.scale, self.shift = buf[0], buf[1], buf[2], buf[3]
+
+
+def bn_fwd(X, mode, training, gamma, beta, rmean, rvar, nbt, R, Cc, ldx, Y, ldy, F=0, Tp=0, N=0, lens=None, eps=1e-5,
+           momentum=0.1):
+    sv = BnSaved(Cc, X.device)
+    ws = torch.empty(2 * query("ds2_norm_partials", R) * Cc, dtype=torch.float32, device=X.device)
+    call("ds2_bn_fwd", dt(X), mode, 1 if training else 0, P(X), P(Y), R, Cc, ldx, ldy, F, Tp, N, P(lens), P(gamma), P(beta),
+         P(rmean), P(rvar), P(nbt) if training else C.c_void_p(0), float(eps), float(momentum), P(sv.mean), P(sv.rstd),
+         P(sv.scale), P(sv.shift), P(ws), S())
+    return sv
+
+
+def bn_bwd(G, X, DX, mode, sv, R, Cc, ldg, ldx, lddx, F=0, Tp=0, N=0, lens=None):
+    dgamma = torch.empty(Cc, dtype=torch.float32, device=X.device)
+    dbeta = torch.empty(Cc, dtype=torch.float32, device=X.device)
+    ws = torch.empty((2 * query("ds2_norm_partials", R) + 2) * Cc, dtype=torch.float32, device=X.device)
+    call("ds2_bn_bwd", dt(X), mode, P(G), P(X), P(DX), R, Cc, ldg, ldx, lddx, F, Tp, N, P(lens), P(sv.mean), P(sv.rstd),
+         P(sv.scale), P(sv.shift), P(dgamma), P(dbeta), P(ws), S())
+    return dgamma, dbeta
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def conv1_fwd(x, w1k, b1, lens, Tp, dtype):
+    N, _, F, T = x.shape
+    y1 = torch.empty((N, 81, Tp, 32), dtype=dtype, device=x.device)
+    call("ds2_conv1_fwd", dt(dtype), P(x), P(w1k), P(b1), P(lens), P(y1), N, T, Tp, S())
+    return y1
+
+
+def conv1_wgrad(x, dy1, Tp):
+    N, _, F, T = x.shape
+    dw = torch.empty((451, 32), dtype=torch.float32, device=x.device)
+    ws = torch.empty(query("ds2_conv1_wgrad_ws_floats", N, Tp), dtype=torch.float32, device=x.device)
+    call("ds2_conv1_wgrad", dt(dy1), P(x), P(dy1), P(dw), N, T, Tp, P(ws), S())
+    return dw
+
+
+def conv2_fwd(a1, w2t, b2, lens):
+    N, _, Tp, _ = a1.shape
+    y2 = torch.empty((N, 41, Tp, 32), dtype=a1.dtype, device=a1.device)
+    call("ds2_conv2_fwd", dt(a1), P(a1), P(w2t), P(b2), P(lens), P(y2), N, Tp, S())
+    return y2
+
+
+def conv2_dgrad(dy2, w2d_even, w2d_odd):
+    N, _, Tp, _ = dy2.shape
+    da1 = torch.empty((N, 81, Tp, 32), dtype=dy2.dtype, device=dy2.device)
+    call("ds2_conv2_dgrad", dt(dy2), P(dy2), P(w2d_even), P(w2d_odd), P(da1), N, Tp, S())
+    return da1
+
+
+def conv2_wgrad(dy2, a1):
+    N, _, Tp, _ = dy2.shape
+    dw = torch.empty((231, 32, 32), dtype=torch.float32, device=dy2.device)
+    ws = torch.empty(query("ds2_conv2_wgrad_ws_floats", N, Tp), dtype=torch.float32, device=dy2.device)
+    call("ds2_conv2_wgrad", dt(dy2), P(dy2), P(a1), P(dw), N, Tp, P(ws), S())
+    return dw
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def rnn_fwd(kind, GI, Whh, bhh, lens, D, N, H, Tp, h0=None, c0=None, save=True):
+    """Returns (HseqExt [D][Tp+2][N][H] with zero guard slots, S, hn [D,N,H] f32, cn or None)."""
+    dev, dtype = GI.device, GI.dtype
+    hext = torch.empty((D, Tp + 2, N, H), dtype=dtype, device=dev)
+    hext[:, 0].zero_()
+    hext[:, Tp + 1].zero_()
+    ns = SAVED_PLANES[kind]
+    Sv = torch.empty((D, Tp, N, max(ns, 1) * H) if ns else (1,), dtype=dtype, device=dev)
+    hn = torch.empty((D, N, H), dtype=torch.float32, device=dev)
+    cn = torch.empty((D, N, H), dtype=torch.float32, device=dev) if kind == "lstm" else None
+    state = torch.empty(query("ds2_rnn_state_bytes", D, N, H), dtype=torch.uint8, device=dev)
+    call("ds2_rnn_fwd", dt(dtype), CELLS[kind], D, N, H, Tp, P(lens), P(GI), P(Whh), P(bhh), P(h0), P(c0),
+         P(hext[:, 1]), (Tp + 2) * N * H, P(Sv), P(hn), P(cn), P(state), S())
+    return hext, Sv, hn, cn
+
+
+def rnn_bwd(kind, dOut, WhhT, hext, Sv, lens, D, N, H, Tp):
+    dev, dtype = dOut.device, dOut.dtype
+    G = GATES[kind]
+    dGI = torch.empty((Tp * N, D * G * H), dtype=dtype, device=dev)
+    dGH = torch.empty((D, Tp, N, G * H), dtype=dtype, device=dev) if kind == "gru" else None
+    state = torch.empty(query("ds2_rnn_state_bytes", D, N, H), dtype=torch.uint8, device=dev)
+    call("ds2_rnn_bwd", dt(dtype), CELLS[kind], D, N, H, Tp, P(lens), P(dOut), P(WhhT), P(hext[:, 1]), (Tp + 2) * N * H,
+         P(Sv), P(dGI), P(dGH), P(state), S())
+    return dGI, dGH
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def lookahead_fwd(x, w, Tp, N, H, save=True):
+    y = torch.empty_like(x)
+    pre = torch.empty_like(x) if save else None
+    call("ds2_lookahead_fwd", dt(x), P(x), P(w), P(y), P(pre), Tp, N, H, w.shape[1], S())
+    return y, pre
+
+
+def lookahead_bwd(x, w, pre, dy, Tp, N, H):
+    ctx = w.shape[1]
+    dx = torch.empty_like(x)
+    dw = torch.empty((H, ctx), dtype=torch.float32, device=x.device)
+    ws = torch.empty(query("ds2_lookahead_ws_floats", Tp, N, H, ctx), dtype=torch.float32, device=x.device)
+    call("ds2_lookahead_bwd", dt(x), P(x), P(w), P(pre), P(dy), P(dx), P(dw), Tp, N, H, ctx, P(ws), S())
+    return dx, dw
+
+
+def softmax_rows(logits, Cc):
+    rows = logits.shape[0]
+    out = torch.empty((rows, Cc), dtype=torch.float32, device=logits.device)
+    call("ds2_softmax_rows", P(logits), P(out), rows, Cc, logits.stride(0), Cc, S())
+    return out
+
+
+def ctc_loss_grad(logits, targets_i32, target_offsets, input_lengths, target_lengths, Tp, N, Cc, blank, max_target_len,
+                  ldg=32):
+    """logits [Tp*N][ld] f32.  Returns (loss_sum [1], nll [N], dlogits [Tp*N][ldg] f32 with unit upstream gradient)."""
+    dev = logits.device
+    nll = torch.empty(N, dtype=torch.float32, device=dev)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    dlogits = torch.empty((Tp * N, ldg), dtype=torch.float32, device=dev)
+    ws = torch.empty(query("ds2_ctc_ws_floats", Tp, N, Cc, max_target_len), dtype=torch.float32, device=dev)
+    call("ds2_ctc_loss_grad", P(logits), logits.stride(0), P(targets_i32), P(target_offsets), P(input_lengths),
+         P(target_lengths), Tp, N, Cc, blank, max_target_len, 1.0, P(nll), P(loss), P(dlogits), ldg, P(ws), S())
+    return loss, nll, dlogits

@@ -1,0 +1,135 @@
+/* ds2hip.h -- C ABI of libds2hip.so: MI355X (gfx950) kernels for the DeepSpeech2 train-step hot path.
+ *
+ * The reference (SeanNaren/deepspeech.pytorch) is pure Python and has NO FFI/plugin interface: its boundary for this
+ * path is the Python class deepspeech_pytorch.model.DeepSpeech (model.py:138-310).  This header is the C-ABI seam
+ * placed directly beneath that class: one entry per stage of DeepSpeech.forward / training_step, each citing the
+ * reference lines it replaces.  A maintainer binds it with ctypes; the shipped binding is
+ * deepspeech/pytorch_amd/_lib.py and the drop-in class is deepspeech/pytorch_amd/model.py.
+ *
+ * Conventions
+ *  - Every pointer is a DEVICE pointer unless named *_host.  The library never allocates or frees device memory and
+ *    never synchronises: the caller owns all buffers (torch's caching allocator) and passes the stream (a hipStream_t) to launch
+ *    on (torch.cuda.current_stream().cuda_stream).  Re-entrant, no thread-local state (backward runs on autograd's
+ *    worker thread).
+ *  - Return value: 0 = ok; >0 = hipError_t of a failed launch; DS2_ERR_* (>= 1000) = argument errors.
+ *  - dtype selects the activation STORAGE type (and the MFMA operand type): DS2_F32 or DS2_BF16 (raw uint16 bits).
+ *    Accumulation, statistics, gate math, CTC and all parameter gradients are fp32.
+ *  - "T" below means the storage type selected by dtype.
+ *  - Activation layouts (internal to this library; only the class boundary must match the reference):
+ *      conv activations   NFTC : [N][F][T'][32]   (channel fastest)                 reference: NCHW (N,32,F,T')
+ *      sequence matrices  rows = t*N + n, features fastest: [T'*N][ld]              reference: (T',N,H)
+ *      conv->RNN features are ordered f*32+c (reference model.py:219-221 orders c*41+f; the binding permutes the
+ *      columns of rnns.0 weight_ih accordingly, parameters themselves keep the reference layout).
+ */
+#ifndef DS2HIP_H
+#define DS2HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* a hipStream_t, passed as a plain pointer so that the header needs no HIP headers */
+typedef void* ds2_stream_t;
+
+enum { DS2_F32 = 0, DS2_BF16 = 1 };
+enum { DS2_CELL_GRU = 0, DS2_CELL_LSTM = 1, DS2_CELL_RNN_TANH = 2 };
+enum {
+  DS2_OK = 0,
+  DS2_ERR_DTYPE = 1001, /* unknown dtype */
+  DS2_ERR_ARG = 1002,   /* bad dimension / null pointer / unsupported combination */
+  DS2_ERR_ALIGN = 1003  /* pointer or leading dimension not 16-byte aligned / not a multiple of the vector width */
+};
+
+int ds2_version(void);
+const char* ds2_error_string(int code);
+
+/* ---- dense contraction (MFMA): C[M][ldc] = A[M][lda] * B[N][ldb]^T (+ bias[N]) -------------------------------------
+ * Replaces the GEMMs inside torch's GRU/LSTM input projection (model.py:97-99), nn.Linear of the head (model.py:197)
+ * and their autograd backward.  out_f32 != 0 -> C is float regardless of dtype.  splitk > 1: C must be zeroed, f32. */
+int ds2_gemm_nt(int dtype, const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long lda, long ldb,
+                long ldc, int out_f32, int batch, long strideA, long strideB, long strideC, long strideBias, int splitk,
+                ds2_stream_t stream);
+
+/* ---- BatchNorm (model.py:159,162 BatchNorm2d in NFTC; model.py:28-33,86,196 SequenceWise BatchNorm1d) ---------------
+ * mode 0: sequence matrix X[R][ldx], C features.   mode 1: conv activation NFTC (R = N*F*Tp rows, C = 32): output also
+ * gets Hardtanh(0,20) (model.py:160,163) and the MaskConv time mask (model.py:61-68; t >= lens[n] -> 0).
+ * mode 2: like 1 but Y (fwd) / G (bwd) are in sequence layout [(t*N+n)][f*32+c] (fuses model.py:219-221).
+ * training != 0: batch statistics over ALL rows (biased variance), running stats updated with `momentum` (unbiased
+ * variance), num_batches_tracked += 1.  save_* (C floats each) are kept for backward.  ws: 2*ds2_norm_partials(R)*C floats.*/
+int ds2_norm_partials(long R);
+int ds2_bn_fwd(int dtype, int mode, int training, const void* X, void* Y, long R, int C, long ldx, long ldy, int F, int Tp,
+               int N, const int* lens, const float* gamma, const float* beta, float* running_mean, float* running_var,
+               long long* num_batches_tracked, float eps, float momentum, float* save_mean, float* save_rstd,
+               float* save_scale, float* save_shift, float* ws, ds2_stream_t stream);
+/* G = upstream gradient (gated by Hardtanh' and the mask in modes 1/2), X = the forward input of the BN.
+ * ws: (2*ds2_norm_partials(R) + 2) * C floats. */
+int ds2_bn_bwd(int dtype, int mode, const void* G, const void* X, void* DX, long R, int C, long ldg, long ldx, long lddx,
+               int F, int Tp, int N, const int* lens, const float* save_mean, const float* save_rstd,
+               const float* save_scale, const float* save_shift, float* dgamma, float* dbeta, float* ws,
+               ds2_stream_t stream);
+/* out[c] = scale * sum_r X[r][c]  (bias gradients; ws: ds2_norm_partials(R)*C floats) */
+int ds2_colsum(int dtype, const void* X, long R, int C, long ld, float* out, float scale, float* ws, ds2_stream_t stream);
+
+/* ---- conv front-end (MaskConv over model.py:157-164) ------------------------------------------------------------------
+ * conv1: Conv2d(1,32,(41,11),stride (2,2),pad (20,5)) on x (N,1,161,T) f32 -> y1 NFTC [N][81][Tp][32] (T), bias added,
+ *        time mask applied.  w1k = weight re-laid as [41*11][32] f32 (tap-major, out-channel fastest).
+ * conv2: Conv2d(32,32,(21,11),stride (2,1),pad (10,5)) on a1 NFTC [N][81][Tp][32] -> y2 NFTC [N][41][Tp][32];
+ *        w2t = weight re-laid as [21*11][32 out][32 in] (T).
+ * dgrad: da1 = conv2^T(dy2) with w2d = the two stride-parity sub-kernels, layout documented in _lib.py/prep. */
+int ds2_conv1_fwd(int dtype, const float* x, const float* w1k, const float* b1, const int* lens, void* y1, int N, int T,
+                  int Tp, ds2_stream_t stream);
+/* dw1k [451][32] f32 = sum over positions of dy1 (NFTC, T) x input taps.  ws: ds2_conv1_wgrad_ws_floats(N,Tp) floats. */
+long ds2_conv1_wgrad_ws_floats(int N, int Tp);
+int ds2_conv1_wgrad(int dtype, const float* x, const void* dy1, float* dw1k, int N, int T, int Tp, float* ws,
+                    ds2_stream_t stream);
+int ds2_conv2_fwd(int dtype, const void* a1, const void* w2t, const float* b2, const int* lens, void* y2, int N, int Tp,
+                  ds2_stream_t stream);
+int ds2_conv2_dgrad(int dtype, const void* dy2, const void* w2d_even, const void* w2d_odd, void* da1, int N, int Tp,
+                    ds2_stream_t stream);
+/* dw2t [231][32 out][32 in] f32.  ws: ds2_conv2_wgrad_ws_floats(N,Tp) floats. */
+long ds2_conv2_wgrad_ws_floats(int N, int Tp);
+int ds2_conv2_wgrad(int dtype, const void* dy2, const void* a1, float* dw2t, int N, int Tp, float* ws, ds2_stream_t stream);
+
+/* ---- recurrent sweeps (BatchRNN, model.py:94-102; nn.GRU / nn.LSTM / nn.RNN(tanh), enums.py:17-21) ---------------------
+ * See csrc/ds2_rnn.hip for the buffer shapes.  H % 16 == 0. */
+int ds2_rnn_gates(int cell);
+int ds2_rnn_saved_planes(int cell);
+long ds2_rnn_state_bytes(int D, int N, int H);
+int ds2_rnn_fwd(int dtype, int cell, int D, int N, int H, int Tp, const int* lens, const void* GI, const void* Whh,
+                const float* bhh, const float* h0, const float* c0, void* Hseq, long hseq_dstride, void* S, float* hn, float* cn,
+                void* state, ds2_stream_t stream);
+int ds2_rnn_bwd(int dtype, int cell, int D, int N, int H, int Tp, const int* lens, const void* dOut, const void* WhhT,
+                const void* Hseq, long hseq_dstride, const void* S, void* dGI, void* dGH, void* state, ds2_stream_t stream);
+
+/* ---- small sequence ops ---------------------------------------------------------------------------------------------------
+ * add2: out = a + b (direction sum, model.py:101).  transpose: dst[C][ldd] = src[R][lds]^T, zero-filling r in [R, ldd).
+ * lookahead (model.py:105-135, uni-directional models): y[t] = hardtanh(sum_k w[h][k] * x[t+k]), x/y [Tp*N][H] (T),
+ * w [H][ctx] f32, ctx <= 32; `pre` keeps the pre-Hardtanh value for backward (may be null in eval).
+ * bwd: dx and dw (dw via ws of ds2_lookahead_ws_floats). */
+int ds2_add2(int dtype, const void* a, const void* b, void* out, long n, ds2_stream_t stream);
+int ds2_transpose(int dtype, const void* src, void* dst, long R, int C, long lds, long ldd, ds2_stream_t stream);
+int ds2_lookahead_fwd(int dtype, const void* x, const float* w, void* y, void* pre, int Tp, int N, int H, int ctx,
+                      ds2_stream_t stream);
+long ds2_lookahead_ws_floats(int Tp, int N, int H, int ctx);
+int ds2_lookahead_bwd(int dtype, const void* x, const float* w, const void* pre, const void* dy, void* dx, float* dw, int Tp,
+                      int N, int H, int ctx, float* ws, ds2_stream_t stream);
+/* probs = softmax(logits) row-wise (InferenceBatchSoftmax, model.py:72-77), f32 [rows][C] */
+int ds2_softmax_rows(const float* logits, float* probs, long rows, int C, long ld_in, long ld_out, ds2_stream_t stream);
+
+/* ---- log_softmax + CTC loss + gradient (model.py:246,203,248) -----------------------------------------------------------
+ * logits [Tp*N][ldl] f32 (row = t*N+n, C classes), targets int32 concatenated with target_offsets[N] (start of each
+ * sample's labels), input_lengths/target_lengths int32 [N].  blank index `blank`; reduction 'sum'; zero_infinity: an
+ * infeasible sample contributes loss 0 and gradient 0.  Outputs: nll [N] f32 (per-sample), loss_sum [1] f32,
+ * dlogits [Tp*N][ldg] f32 = grad_scale * d(loss_sum)/d(logits) (log_softmax backward fused; zero rows for t >= length;
+ * columns >= C are zero-filled up to ldg).  ws: ds2_ctc_ws_floats(...) floats.  max_target_len: max over target_lengths. */
+long ds2_ctc_ws_floats(int Tp, int N, int C, int max_target_len);
+int ds2_ctc_loss_grad(const float* logits, long ldl, const int* targets, const int* target_offsets, const int* input_lengths,
+                      const int* target_lengths, int Tp, int N, int C, int blank, int max_target_len, float grad_scale,
+                      float* nll, float* loss_sum, float* dlogits, long ldg, float* ws, ds2_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DS2HIP_H */

@@ -1,0 +1,390 @@
+"""GPU parity tests, kernel by kernel: every C-ABI entry of libds2hip.so against the numpy oracle on seeded inputs.
+fp32 storage: tight tolerances (the 1e-3 north-star bar with margin).  bf16 storage: the oracle is fed bf16-rounded
+inputs; tolerance is bf16 rounding of the stored outputs (2^-8 relative) plus accumulation noise."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ds2_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def ops():
+    from deepspeech.pytorch_amd import ops as _ops
+    return _ops
+
+
+def cu(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV).to(dtype).contiguous()
+
+
+def rnd(a, dtype):
+    """what the device sees after storing `a` in `dtype` (numpy float64 in, float64 out)"""
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dtype).to(torch.float64).numpy()
+
+
+def np64(t):
+    return t.detach().to(torch.float64).cpu().numpy()
+
+
+def relerr(got, ref):
+    return np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)
+
+
+DTYPES = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 2e-5, torch.bfloat16: 1.2e-2}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(200, 77, 96), (128, 128, 64), (257, 300, 1312), (29, 64, 40), (1000, 29, 64)])
+def test_gemm_nt(dtype, M, N, K):
+    rs = np.random.RandomState(M + N + K)
+    A, B, bias = rs.standard_normal((M, K)), rs.standard_normal((N, K)), rs.standard_normal(N)
+    ref = rnd(A, dtype) @ rnd(B, dtype).T + bias
+    o = ops()
+    got = o.gemm_nt(cu(A, dtype), cu(B, dtype), bias=cu(bias), out_dtype=torch.float32)
+    assert relerr(np64(got), ref) < (1e-5 if dtype == torch.float32 else 1e-4)   # fp32 accumulate, fp32 out
+    got_t = o.gemm_nt(cu(A, dtype), cu(B, dtype), bias=cu(bias))
+    assert relerr(np64(got_t), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_nt_transposed_operands_and_splitk(dtype):
+    """A asymmetric, non-square: catches row/col swaps of the MFMA C layout (cdna guide: always test asymmetric)."""
+    rs = np.random.RandomState(3)
+    M, N, K = 96, 160, 1000
+    A, B = rs.standard_normal((M, K)), rs.standard_normal((N, K)) * np.arange(1, N + 1)[:, None] / N
+    ref = rnd(A, dtype) @ rnd(B, dtype).T
+    o = ops()
+    got = o.gemm_nt(cu(A, dtype), cu(B, dtype), out_dtype=torch.float32, splitk=4)
+    assert relerr(np64(got), ref) < 1e-4
+    # batched
+    Ab, Bb = rs.standard_normal((3, 40, 64)), rs.standard_normal((3, 50, 64))
+    refb = np.einsum("bmk,bnk->bmn", rnd(Ab, dtype), rnd(Bb, dtype))
+    gotb = o.gemm_nt(cu(Ab, dtype), cu(Bb, dtype), out_dtype=torch.float32, batch=3, sA=40 * 64, sB=50 * 64)
+    assert relerr(np64(gotb), refb) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_transpose_colsum_add(dtype):
+    rs = np.random.RandomState(4)
+    o = ops()
+    for R, Cc in [(93, 96), (64, 64), (300, 1312), (7, 8)]:
+        X = rs.standard_normal((R, Cc))
+        t = o.transpose(cu(X, dtype))
+        assert t.shape == (Cc, (R + 7) // 8 * 8)
+        got = np64(t)
+        assert np.array_equal(got[:, :R], rnd(X, dtype).T)
+        assert np.all(got[:, R:] == 0)
+        cs = o.colsum(cu(X, dtype))
+        assert relerr(np64(cs), rnd(X, dtype).sum(0)) < 1e-5
+    a, b = rs.standard_normal(4096), rs.standard_normal(4096)
+    s = o.add2(cu(a, dtype), cu(b, dtype))
+    assert relerr(np64(s), rnd(a, dtype) + rnd(b, dtype)) < TOL[dtype]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def nftc(a):   # (N,C,F,T) -> [N][F][T][C]
+    return np.ascontiguousarray(a.transpose(0, 2, 3, 1))
+
+
+def nchw(a):
+    return np.ascontiguousarray(a.transpose(0, 3, 1, 2))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_bn_sequence(dtype):
+    rs = np.random.RandomState(5)
+    R, Cc = 93, 64
+    X = rs.standard_normal((R, Cc)) * 2 + 0.5
+    X[80:] = 0   # zero pad rows take part in the statistics
+    gamma, beta = rs.uniform(0.5, 1.5, Cc), rs.uniform(-0.2, 0.2, Cc)
+    rm, rv = rs.uniform(-0.1, 0.1, Cc), rs.uniform(0.5, 1.5, Cc)
+    Xr = rnd(X, dtype)
+    yref, cache = O.bn_train_fwd(Xr, gamma, beta, (0,))
+    rm2, rv2 = O.bn_running_update(rm, rv, cache)
+    o = ops()
+    Xd, Y = cu(X, dtype), torch.empty((R, Cc), dtype=dtype, device=DEV)
+    rmd, rvd, nbt = cu(rm), cu(rv), torch.zeros(1, dtype=torch.int64, device=DEV)
+    sv = o.bn_fwd(Xd, 0, True, cu(gamma), cu(beta), rmd, rvd, nbt, R, Cc, Cc, Y, Cc)
+    assert relerr(np64(Y), yref) < TOL[dtype]
+    assert relerr(np64(rmd), rm2) < 1e-5 and relerr(np64(rvd), rv2) < 1e-5 and int(nbt.item()) == 1
+    G = rs.standard_normal((R, Cc))
+    dxref, dgref, dbref = O.bn_train_bwd(rnd(G, dtype), gamma, cache)
+    DX = torch.empty((R, Cc), dtype=dtype, device=DEV)
+    dg, db = o.bn_bwd(cu(G, dtype), Xd, DX, 0, sv, R, Cc, Cc, Cc, Cc)
+    assert relerr(np64(DX), dxref) < TOL[dtype]
+    assert relerr(np64(dg), dgref) < 1e-4 and relerr(np64(db), dbref) < 1e-4
+    # eval mode uses the running statistics
+    Y2 = torch.empty((R, Cc), dtype=dtype, device=DEV)
+    o.bn_fwd(Xd, 0, False, cu(gamma), cu(beta), cu(rm), cu(rv), None, R, Cc, Cc, Y2, Cc)
+    assert relerr(np64(Y2), O.bn_eval_fwd(Xr, gamma, beta, rm, rv, 1)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("seq_out", [False, True])
+def test_bn_conv_modes(dtype, seq_out):
+    """BatchNorm2d + Hardtanh + time mask on an NFTC activation (modes 1/2), forward and backward."""
+    rs = np.random.RandomState(6)
+    N, F, Tp, Cc = 3, 5, 19, 32
+    lens = np.array([19, 12, 7], dtype=np.int32)
+    x = rs.standard_normal((N, Cc, F, Tp)) * 3
+    m = O.time_mask(x.shape, lens)
+    x[m] = 0
+    gamma, beta = rs.uniform(3.0, 9.0, Cc), rs.uniform(-0.2, 4.0, Cc)   # large gain: both clamp sides are hit
+    xr = nchw(rnd(nftc(x), dtype))
+    z, cache = O.bn_train_fwd(xr, gamma, beta, (0, 2, 3))
+    z[m] = 0
+    a = O.hardtanh_fwd(z)
+    a[m] = 0
+    assert (z >= 20).any() and (z <= 0).any()
+    o = ops()
+    R = N * F * Tp
+    Xd = cu(nftc(x), dtype).view(R, Cc)
+    lens_d = torch.from_numpy(lens).to(DEV)
+    rmd, rvd, nbt = cu(np.zeros(Cc)), cu(np.ones(Cc)), torch.zeros(1, dtype=torch.int64, device=DEV)
+    if seq_out:
+        Y = torch.full((Tp * N, F * Cc), 7.0, dtype=dtype, device=DEV)
+        sv = o.bn_fwd(Xd, 2, True, cu(gamma), cu(beta), rmd, rvd, nbt, R, Cc, Cc, Y, F * Cc, F=F, Tp=Tp, N=N, lens=lens_d)
+        ref = a.transpose(3, 0, 2, 1).reshape(Tp * N, F * Cc)   # [(t,n)][f*32+c]
+    else:
+        Y = torch.full((R, Cc), 7.0, dtype=dtype, device=DEV)
+        sv = o.bn_fwd(Xd, 1, True, cu(gamma), cu(beta), rmd, rvd, nbt, R, Cc, Cc, Y, Cc, F=F, Tp=Tp, N=N, lens=lens_d)
+        ref = nftc(a).reshape(R, Cc)
+    assert np.abs(np64(Y) - ref).max() < TOL[dtype] * 20
+    # backward
+    g = rs.standard_normal(x.shape)
+    d = rnd(g, dtype).copy()
+    d[m] = 0
+    d = O.hardtanh_bwd(z, d)
+    d[m] = 0
+    dx, dgam, dbet = O.bn_train_bwd(d, gamma, cache)
+    dx[m] = 0
+    DX = torch.empty((R, Cc), dtype=dtype, device=DEV)
+    if seq_out:
+        Gd = cu(g.transpose(3, 0, 2, 1).reshape(Tp * N, F * Cc), dtype)
+        dg, db = o.bn_bwd(Gd, Xd, DX, 2, sv, R, Cc, F * Cc, Cc, Cc, F=F, Tp=Tp, N=N, lens=lens_d)
+    else:
+        Gd = cu(nftc(g).reshape(R, Cc), dtype)
+        dg, db = o.bn_bwd(Gd, Xd, DX, 1, sv, R, Cc, Cc, Cc, Cc, F=F, Tp=Tp, N=N, lens=lens_d)
+    # elements whose BN output sits within rounding distance of a clamp edge may legitimately flip in bf16
+    tol = TOL[dtype] * (1 if dtype == torch.float32 else 8)
+    assert relerr(np64(DX), nftc(dx).reshape(R, Cc)) < tol
+    assert relerr(np64(dg), dgam) < tol and relerr(np64(db), dbet) < tol
+
+
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,T", [(2, 37), (3, 150)])
+def test_conv1_fwd_and_wgrad(dtype, N, T):
+    rs = np.random.RandomState(7 + T)
+    x = rs.standard_normal((N, 1, 161, T))
+    w, b = rs.uniform(-0.05, 0.05, (32, 1, 41, 11)), rs.uniform(-0.1, 0.1, 32)
+    lens_in = np.array([T, max(T - 9, 1), max(T // 2, 1)][:N])
+    lens = O.seq_lens(lens_in)
+    Tp = int(O.seq_lens(np.array([T]))[0])
+    y = O.conv2d_fwd(x.astype(np.float32).astype(np.float64), w.astype(np.float32).astype(np.float64),
+                     b.astype(np.float32).astype(np.float64), (2, 2), (20, 5))
+    m = O.time_mask(y.shape, lens)
+    y[m] = 0
+    o = ops()
+    xd, lens_d = cu(x), torch.from_numpy(lens).to(DEV)
+    w1k = cu(w.reshape(32, 451).T)
+    y1 = o.conv1_fwd(xd, w1k, cu(b), lens_d, Tp, dtype)
+    assert relerr(np64(y1), nftc(y)) < TOL[dtype]
+    # weight gradient: dy masked like the real pipeline
+    dy = rs.standard_normal(y.shape)
+    dy[m] = 0
+    dyr = nchw(rnd(nftc(dy), dtype))
+    _, dw, _ = O.conv2d_bwd(x.astype(np.float32).astype(np.float64), w, dyr, (2, 2), (20, 5), need_dx=False)
+    got = o.conv1_wgrad(xd, cu(nftc(dy), dtype), Tp)
+    assert relerr(np64(got), dw.reshape(32, 451).T) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,Tp", [(2, 19), (3, 75)])
+def test_conv2_fwd_dgrad_wgrad(dtype, N, Tp):
+    rs = np.random.RandomState(8 + Tp)
+    a1 = np.maximum(rs.standard_normal((N, 32, 81, Tp)), 0)
+    lens = np.array([Tp, max(Tp - 5, 1), max(Tp // 3, 1)][:N], dtype=np.int32)
+    a1[O.time_mask(a1.shape, lens)] = 0
+    w, b = rs.uniform(-0.02, 0.02, (32, 32, 21, 11)), rs.uniform(-0.1, 0.1, 32)
+    a1r, wr = nchw(rnd(nftc(a1), dtype)), rnd(w, dtype)
+    y = O.conv2d_fwd(a1r, wr, b.astype(np.float32).astype(np.float64), (2, 1), (10, 5))
+    m = O.time_mask(y.shape, lens)
+    y[m] = 0
+    o = ops()
+    lens_d = torch.from_numpy(lens).to(DEV)
+    a1d = cu(nftc(a1), dtype)
+    w2t = cu(w.transpose(2, 3, 0, 1), dtype)            # [kf][kt][co][ci]
+    y2 = o.conv2_fwd(a1d, w2t, cu(b), lens_d)
+    assert relerr(np64(y2), nftc(y)) < TOL[dtype]
+    # backward
+    dy = rs.standard_normal(y.shape)
+    dy[m] = 0
+    dyr = nchw(rnd(nftc(dy), dtype))
+    dx, dw, _ = O.conv2d_bwd(a1r, wr, dyr, (2, 1), (10, 5))
+    wt = torch.from_numpy(w)
+    w2d = [wt[:, :, q::2, :].flip(2, 3).permute(2, 3, 1, 0).contiguous().to(DEV).to(dtype) for q in (0, 1)]
+    dyd = cu(nftc(dy), dtype)
+    da1 = o.conv2_dgrad(dyd, w2d[0], w2d[1])
+    assert relerr(np64(da1), nftc(dx)) < TOL[dtype]
+    # wgrad contracts bf16-exact products in fp32: compare against the oracle on the rounded operands
+    dw2 = o.conv2_wgrad(dyd, a1d)
+    assert relerr(np64(dw2).reshape(21, 11, 32, 32), dw.transpose(2, 3, 0, 1)) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("kind", ["gru", "lstm", "rnn"])
+@pytest.mark.parametrize("D,N,H,Tp", [(2, 3, 32, 13), (1, 20, 48, 9), (2, 37, 32, 7)])
+def test_rnn_sweeps(dtype, kind, D, N, H, Tp):
+    rs = np.random.RandomState(D * 100 + N + H + Tp)
+    G = O.GATES[kind]
+    I = 24
+    lens = np.sort(rs.randint(1, Tp + 1, size=N))[::-1].copy()
+    lens[0] = Tp
+    x = rs.standard_normal((Tp, N, I))
+    for i, ln in enumerate(lens):
+        x[ln:, i] = 0
+    Wih = rs.uniform(-0.3, 0.3, (D, G * H, I))
+    Whh = rs.uniform(-0.3, 0.3, (D, G * H, H))
+    bih, bhh = rs.uniform(-0.2, 0.2, (D, G * H)), rs.uniform(-0.2, 0.2, (D, G * H))
+    Whh_r = rnd(Whh, dtype)
+    o = ops()
+    # the input projection is part of the GEMM tests; feed the sweeps the oracle's projection
+    GI = np.stack([x.reshape(Tp * N, I) @ Wih[d].T + bih[d] for d in range(D)], axis=1).reshape(Tp * N, D * G * H)
+    GI_r = rnd(GI, dtype)
+    outs, caches, hns, cns = [], [], [], []
+    for d in range(D):
+        # oracle with W_ih = identity on the pre-computed (rounded) projection
+        out, hn, cn, cache = O.rnn_dir_fwd(kind, GI_r.reshape(Tp, N, D, G * H)[:, :, d], lens, np.eye(G * H), Whh_r[d],
+                                           np.zeros(G * H), bhh[d], reverse=(d == 1))
+        outs.append(out), caches.append(cache), hns.append(hn), cns.append(cn)
+    lens_d = torch.from_numpy(lens.astype(np.int32)).to(DEV)
+    hext, Sv, hn_d, cn_d = o.rnn_fwd(kind, cu(GI, dtype), cu(Whh, dtype), cu(bhh), lens_d, D, N, H, Tp)
+    got = np64(hext[:, 1:Tp + 1])
+    tol = TOL[dtype] * (1 if dtype == torch.float32 else 4)
+    for d in range(D):
+        assert np.abs(got[d] - outs[d]).max() < tol, (kind, d)
+        assert np.abs(np64(hn_d[d]) - hns[d]).max() < tol
+        if kind == "lstm":
+            assert np.abs(np64(cn_d[d]) - cns[d]).max() < tol * 2
+    assert np.all(np64(hext[:, 0]) == 0) and np.all(np64(hext[:, Tp + 1]) == 0)
+    # ---- BPTT
+    dout = rs.standard_normal((Tp, N, H))
+    dout_r = rnd(dout, dtype)
+    WhhT = cu(Whh.transpose(0, 2, 1), dtype)
+    dGI, dGH = o.rnn_bwd(kind, cu(dout, dtype), WhhT, hext, Sv, lens_d, D, N, H, Tp)
+    dgi = np64(dGI).reshape(Tp, N, D, G * H)
+    for d in range(D):
+        dx, dwi, dwh, dbi, dbh = O.rnn_dir_bwd(caches[d], dout_r, np.eye(G * H), Whh_r[d])
+        # with W_ih = I the oracle's dx IS d loss / d GI
+        scale = max(np.abs(dx).max(), 1e-6)
+        assert np.abs(dgi[:, :, d] - dx).max() / scale < tol * (1 if dtype == torch.float32 else 3), (kind, d)
+        if kind == "gru":
+            assert relerr(np64(dGH[d]).reshape(Tp * N, G * H).sum(0), dbh) < tol * 4
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_rnn_initial_state(dtype):
+    """hidden-state carry of reference inference.py:86-96: h0/c0 given, batch 1."""
+    rs = np.random.RandomState(11)
+    D, N, H, Tp, kind = 2, 1, 32, 6, "lstm"
+    G = 4
+    GI = rs.standard_normal((Tp * N, D * G * H))
+    Whh, bhh = rs.uniform(-0.3, 0.3, (D, G * H, H)), rs.uniform(-0.2, 0.2, (D, G * H))
+    h0, c0 = rs.standard_normal((D, N, H)), rs.standard_normal((D, N, H))
+    lens = np.array([Tp])
+    o = ops()
+    hext, _, hn, cn = o.rnn_fwd(kind, cu(GI, dtype), cu(Whh, dtype), cu(bhh), torch.from_numpy(lens.astype(np.int32)).to(DEV),
+                                D, N, H, Tp, h0=cu(h0), c0=cu(c0))
+    for d in range(D):
+        out, h, c, _ = O.rnn_dir_fwd(kind, rnd(GI, dtype).reshape(Tp, N, D, G * H)[:, :, d], lens, np.eye(G * H),
+                                     rnd(Whh, dtype)[d], np.zeros(G * H), bhh[d], reverse=(d == 1), h0=h0[d], c0=c0[d])
+        tol = TOL[dtype] * (1 if dtype == torch.float32 else 4)
+        assert np.abs(np64(hext[d, 1:Tp + 1]) - out).max() < tol
+        assert np.abs(np64(hn[d]) - h).max() < tol and np.abs(np64(cn[d]) - c).max() < tol * 2
+
+
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("ctx", [20, 7])
+def test_lookahead(dtype, ctx):
+    rs = np.random.RandomState(12)
+    Tp, N, H = 33, 3, 48
+    x = rs.standard_normal((Tp, N, H)) * 3
+    w = rs.uniform(-0.6, 0.9, (H, 1, ctx))
+    xr = rnd(x, dtype)
+    pre = O.lookahead_fwd(xr, w)
+    y = O.hardtanh_fwd(pre)
+    o = ops()
+    xd, wd = cu(x.reshape(Tp * N, H), dtype), cu(w.reshape(H, ctx))
+    yd, pred = o.lookahead_fwd(xd, wd, Tp, N, H)
+    assert np.abs(np64(yd).reshape(Tp, N, H) - y).max() < TOL[dtype] * 30
+    dy = rs.standard_normal((Tp, N, H))
+    g = O.hardtanh_bwd(rnd(pre, dtype), rnd(dy, dtype))
+    dx, dw = O.lookahead_bwd(xr, w, g)
+    dxd, dwd = o.lookahead_bwd(xd, wd, pred, cu(dy.reshape(Tp * N, H), dtype), Tp, N, H)
+    tol = TOL[dtype] * (1 if dtype == torch.float32 else 6)
+    assert relerr(np64(dxd).reshape(Tp, N, H), dx) < tol
+    assert relerr(np64(dwd), dw.reshape(H, ctx)) < tol
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def _ctc_case(N, Tp, lens, tlens, seed, Cc=29, scale=2.0):
+    rs = np.random.RandomState(seed)
+    logits = rs.standard_normal((Tp, N, Cc)) * scale
+    targets = rs.randint(1, Cc, size=int(np.sum(tlens)))
+    # force some repeated labels (the s-2 skip rule)
+    if len(targets) > 3:
+        targets[1] = targets[0]
+        targets[-1] = targets[-2]
+    return logits, targets
+
+
+@pytest.mark.parametrize("N,Tp,lens,tlens", [
+    (3, 31, [31, 25, 19], [7, 6, 4]),
+    (4, 40, [40, 39, 15, 11], [9, 9, 3, 21]),      # last sample infeasible (S > T'): zero_infinity
+    (1, 12, [12], [12]),                            # S == T' (feasible only without repeats)
+    (2, 300, [300, 150], [140, 1]),                 # more states than threads (2S+1 = 281 > 256)
+    (2, 9, [9, 5], [0, 2]),                         # empty target
+])
+def test_ctc_loss_and_grad(N, Tp, lens, tlens):
+    logits, targets = _ctc_case(N, Tp, lens, tlens, seed=Tp + N)
+    lp = O.log_softmax(logits)
+    loss_ref, nll_ref, dlp = O.ctc_loss_and_grad(lp, targets, lens, tlens)
+    dlogits_ref = dlp - np.exp(lp) * dlp.sum(-1, keepdims=True)
+    o = ops()
+    ld = 32
+    lg = torch.zeros((Tp * N, ld), dtype=torch.float32, device=DEV)
+    lg[:, :29] = cu(logits.reshape(Tp * N, 29))
+    offs = np.concatenate([[0], np.cumsum(tlens)[:-1]]).astype(np.int32)
+    loss, nll, dl = o.ctc_loss_grad(lg, torch.from_numpy(targets.astype(np.int32)).to(DEV), torch.from_numpy(offs).to(DEV),
+                                    torch.from_numpy(np.asarray(lens, np.int32)).to(DEV),
+                                    torch.from_numpy(np.asarray(tlens, np.int32)).to(DEV), Tp, N, 29, 0, int(max(tlens)))
+    assert np.allclose(np64(nll), nll_ref, rtol=2e-5, atol=1e-4), (np64(nll), nll_ref)
+    assert abs(float(loss.item()) - loss_ref) <= 2e-5 * max(1.0, abs(loss_ref))
+    got = np64(dl).reshape(Tp, N, ld)
+    assert np.abs(got[:, :, :29] - dlogits_ref).max() < 2e-5
+    assert np.all(got[:, :, 29:] == 0)
+
+
+def test_softmax_rows():
+    rs = np.random.RandomState(13)
+    x = rs.standard_normal((77, 29)) * 4
+    e = np.exp(x - x.max(-1, keepdims=True))
+    ref = e / e.sum(-1, keepdims=True)
+    lg = torch.zeros((77, 32), dtype=torch.float32, device=DEV)
+    lg[:, :29] = cu(x)
+    assert np.abs(np64(ops().softmax_rows(lg, 29)) - ref).max() < 1e-6
+
+
+def test_cpu_tensor_is_refused():
+    from deepspeech.pytorch_amd import _lib
+    with pytest.raises(_lib.Ds2HipError):
+        ops().add2(torch.zeros(8), torch.zeros(8))

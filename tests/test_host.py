@@ -1,0 +1,110 @@
+"""CPU-side checks (run with -m "not gpu"): the C-ABI library builds, loads and exports every symbol that
+include/ds2hip.h declares; the drop-in class has the reference's constructor surface, state_dict keys/shapes and
+length arithmetic; the product path refuses CPU tensors (no fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from fixtures import Fixture, fixture_names
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from deepspeech.pytorch_amd import build, _lib
+    build.build(verbose=False)
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from deepspeech.pytorch_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "ds2hip.h")).read()
+    declared = set(re.findall(r"\b(ds2_[a-z0-9_]+)\s*\(", hdr))
+    declared.discard("ds2_stream_t")
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), "libds2hip.so does not export %s" % name
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert lib.ds2_version() >= 100
+    assert b"alignment" in lib.ds2_error_string(1003)
+    # pure size queries are host-only and safe without a GPU
+    assert lib.ds2_rnn_gates(0) == 3 and lib.ds2_rnn_gates(1) == 4 and lib.ds2_rnn_gates(2) == 1
+    assert lib.ds2_rnn_state_bytes(2, 32, 1024) == 2 * 32 * 1024 * 24
+    assert lib.ds2_norm_partials(10) == 2 and lib.ds2_norm_partials(10 ** 7) == 256
+    assert lib.ds2_ctc_ws_floats(751, 32, 29, 180) == 32 * 751 * 32 + 32 * 751 * 361
+
+
+def build_model(fx):
+    from deepspeech.pytorch_amd import configs
+    from deepspeech.pytorch_amd.model import DeepSpeech
+    c = fx.cfg
+    rt = getattr(configs.RNNType, c["rnn_type"])
+    if c["bidirectional"]:
+        mc = configs.BiDirectionalConfig(rnn_type=rt, hidden_size=c["hidden_size"], hidden_layers=c["hidden_layers"])
+    else:
+        mc = configs.UniDirectionalConfig(rnn_type=rt, hidden_size=c["hidden_size"], hidden_layers=c["hidden_layers"],
+                                          lookahead_context=c["lookahead_context"])
+    return DeepSpeech(labels=configs.LABELS, model_cfg=mc, precision=32, optim_cfg=configs.AdamConfig(),
+                      spect_cfg=configs.SpectConfig())
+
+
+@pytest.mark.parametrize("name", fixture_names())
+def test_state_dict_matches_reference_keys_and_shapes(name):
+    fx = Fixture(name)
+    m = build_model(fx)
+    sd = m.state_dict()
+    ref_shapes = {k: tuple(v) for k, v in fx.meta["shapes"].items()}
+    assert list(sd.keys()) == list(ref_shapes.keys()) or set(sd.keys()) == set(ref_shapes.keys())
+    for k, v in sd.items():
+        assert tuple(v.shape) == ref_shapes[k], k
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in fx.params().items()}, strict=True)
+    assert m.bidirectional == fx.cfg["bidirectional"]
+    assert (m.lookahead is None) == fx.cfg["bidirectional"]
+
+
+def test_seq_lens_and_optimizers():
+    fx = Fixture("gru_bi_tiny")
+    m = build_model(fx)
+    ln = torch.tensor([201, 186, 172, 158, 143, 129, 115, 101])
+    assert m.get_seq_lens(ln).tolist() == [101, 93, 86, 79, 72, 65, 58, 51]
+    (opt,), (sched,) = m.configure_optimizers()
+    assert isinstance(opt, torch.optim.AdamW) and opt.defaults["lr"] == 1.5e-4 and opt.defaults["weight_decay"] == 1e-5
+    from deepspeech.pytorch_amd import configs
+    m.optim_cfg = configs.SGDConfig()
+    (opt,), _ = m.configure_optimizers()
+    assert isinstance(opt, torch.optim.SGD) and opt.defaults["nesterov"] and opt.defaults["momentum"] == 0.9
+
+
+def test_same_seed_same_init_as_reference_layout():
+    """parameter creation order and init distributions follow torch's modules: same seed -> same tensors twice."""
+    fx = Fixture("lstm_bi_tiny")
+    torch.manual_seed(0)
+    a = build_model(fx).state_dict()
+    torch.manual_seed(0)
+    b = build_model(fx).state_dict()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    h = fx.cfg["hidden_size"]
+    w = a["rnns.0.rnn.weight_hh_l0"]
+    assert float(w.abs().max()) <= 1.0 / np.sqrt(h) + 1e-7
+
+
+def test_no_cpu_fallback(lib):
+    from deepspeech.pytorch_amd._lib import Ds2HipError
+    fx = Fixture("gru_bi_tiny")
+    m = build_model(fx)
+    inputs, _, pct, _ = fx.batch()
+    with pytest.raises(Ds2HipError):
+        m(torch.from_numpy(inputs), torch.from_numpy(fx.z["input_sizes"].copy()))
+
+
+def test_product_path_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "deepspeech", "pytorch_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src.replace("CPU oracle", "").replace("the oracle", ""), fn
