@@ -1,0 +1,281 @@
+#!/usr/bin/env python
+"""bench.py -- training-step throughput of the MI355X-native DeepSpeech2 hot path.
+
+    python bench.py [--gpus N --steps K --warmup W]                       # 1 GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W                            # N GPUs, one rank per GPU over RCCL
+
+Metric (BASELINE.json / SURVEY.md section 8d): audio-seconds/sec of one training step
+    zero_grad -> training_step (forward + CTC) -> backward [-> gradient all-reduce] -> clip_grad_norm_(400) -> AdamW.step
+on the LibriSpeech-shaped configuration cfg3: 5 x BiGRU hidden=1024, batch 32 clips/GPU of 12-15 s, bf16 activations /
+MFMA operands with fp32 master weights, statistics, gate math and CTC; synthetic 16 kHz log-spectrograms already
+resident in HBM when the timed region starts; weak scaling (32 clips per GPU).  Audio seconds = true (unpadded) frames
+x 10 ms.  One JSON line is printed by rank 0; it also carries
+
+  "roofline":     the dominant kernel (the per-time-step recurrent kernel k_rnn_step_*): algorithmic FLOPs per launch /
+                  average launch duration measured live with HIP events on the launch stream, against the dense bf16
+                  MFMA peak (2.5 PFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md);
+  "cpu_baseline": oracle/ds2_torch_port.py (the same torch calls the reference makes) timed on the host cores of this
+                  box on a bounded sample of the same model (rank 0, N=1 only).  A reported baseline, not the target.
+
+`--stock` instead times stock PyTorch-ROCm (oracle/ds2_torch_port.py on the GPU under bf16 autocast: MIOpen conv / BN /
+RNN + ATen CTC) on the same batch: the denominator of the north star's ">= 3x over stock PyTorch-ROCm".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # dense MFMA peaks, MI355X_MICROARCH.md chip table
+CONFIGS = {
+    # name: (rnn_type, H, L, bidirectional, N per GPU, Tmin, Tmax, dtype)
+    "cfg3": ("gru", 1024, 5, True, 32, 1201, 1501, "bf16"),      # LibriSpeech-shaped (the headline configuration)
+    "cfg2": ("gru", 800, 5, True, 8, 101, 201, "f32"),           # AN4-shaped, fp32 parity mode
+    "cfg5a": ("lstm", 1280, 7, True, 64, 501, 1501, "bf16"),
+    "cfg5b": ("lstm", 1280, 7, False, 64, 501, 1501, "bf16"),
+}
+GATES = {"gru": 3, "lstm": 4, "rnn": 1}
+
+
+def build_batch(cfg_name, rank, device):
+    from deepspeech.pytorch_amd import synth
+    kind, H, L, bi, N, tmin, tmax, dtype = CONFIGS[cfg_name]
+    cfg_id = {"cfg2": 2, "cfg3": 3, "cfg5a": 5, "cfg5b": 6}[cfg_name]
+    lengths = synth.synth_lengths(N, tmin, tmax, seed=cfg_id * 1000 + rank, linear=(cfg_name == "cfg2"))
+    inputs, targets, pct, tsz = synth.synth_batch(lengths, seed=cfg_id * 1000 + rank)
+    batch = (torch.from_numpy(inputs).to(device), torch.from_numpy(targets), torch.from_numpy(pct), torch.from_numpy(tsz))
+    return lengths, batch
+
+
+def out_frames(lengths):
+    """Output frames per sample after the conv stack (reference model.py:299-310), incl. the float32 percentage round
+    trip of model.py:243."""
+    lengths = np.asarray(lengths, dtype=np.int64)
+    tmax = int(lengths.max())
+    rt = ((lengths / float(tmax)).astype(np.float32) * np.float32(tmax)).astype(np.int32).astype(np.int64)
+    return (rt + 2 * 5 - 10 - 1) // 2 + 1
+
+
+def train_flops(cfg_name, lengths):
+    kind, H, L, bi, N, tmin, tmax, dtype = CONFIGS[cfg_name]
+    D, G = (2 if bi else 1), GATES[kind]
+    frames = int(out_frames(lengths).sum())
+    macs = 32 * 81 * 41 * 11 + 32 * 41 * 21 * 11 * 32 + D * G * H * 1312 + (L - 1) * D * G * H * H + L * D * G * H * H + 29 * H
+    if not bi:
+        macs += H * 20
+    return 3 * 2.0 * macs * frames
+
+
+class StepModule(torch.nn.Module):
+    """forward(batch) = training_step(batch): lets torch DDP (RCCL) hook the backward of the drop-in class exactly the
+    way Lightning's DDP strategy wraps a LightningModule."""
+
+    def __init__(self, model):
+        super().__init__()
+        self.model = model
+
+    def forward(self, inputs, targets, pct, tsz):
+        return self.model.training_step((inputs, targets, pct, tsz), 0)
+
+
+def run_native(args, rank, world, device):
+    from deepspeech.pytorch_amd import configs, ops
+    from deepspeech.pytorch_amd.model import DeepSpeech
+    kind, H, L, bi, N, tmin, tmax, dtype = CONFIGS[args.config]
+    torch.manual_seed(0)
+    rt = getattr(configs.RNNType, kind)
+    mc = configs.BiDirectionalConfig(rnn_type=rt, hidden_size=H, hidden_layers=L) if bi else \
+        configs.UniDirectionalConfig(rnn_type=rt, hidden_size=H, hidden_layers=L, lookahead_context=20)
+    model = DeepSpeech(configs.LABELS, mc, "bf16" if dtype == "bf16" else 32, configs.AdamConfig(), configs.SpectConfig()).to(device)
+    model.train()
+    lengths, batch = build_batch(args.config, rank, device)
+    opt = model.configure_optimizers()[0][0]
+    step_mod = StepModule(model)
+    if world > 1:
+        step_mod = torch.nn.parallel.DistributedDataParallel(step_mod, device_ids=[device.index], broadcast_buffers=False,
+                                                             bucket_cap_mb=64, gradient_as_bucket_view=True)
+    params = [p for p in model.parameters()]
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = step_mod(batch[0], batch[1], batch[2].clone(), batch[3])
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 400.0)
+        opt.step()
+        return loss
+
+    first_loss = None
+    for i in range(args.warmup):
+        l = step()
+        if i == 0:
+            first_loss = float(l.detach().item())
+    if first_loss is None:
+        first_loss = float("nan")
+    ops.SWEEP_EVENTS = []
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    events, ops.SWEEP_EVENTS = ops.SWEEP_EVENTS, None
+    last_loss = float(last.detach().item())
+
+    # ---- roofline of the dominant kernel: the per-time-step recurrent kernel (one launch per time step and sweep)
+    launches = sum(e[1] for e in events)
+    sweep_ms = sum(e[2].elapsed_time(e[3]) for e in events)
+    D, G = (2 if bi else 1), GATES[kind]
+    frames = int(out_frames(lengths).sum())
+    # algorithmic flops of one sweep = 2 * (valid frames) * D * G*H*H ; per launch = that / T'
+    flops_per_sweep = 2.0 * frames * D * G * H * H
+    n_sweeps = max(1, len(events))
+    avg_launch_s = (sweep_ms / 1e3) / max(1, launches)
+    tp = int(out_frames(lengths).max())
+    achieved = (flops_per_sweep / tp) / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
+    peak = PEAK_TFLOPS[dtype]
+    roofline = {"bound": "mfma", "kernel": "k_rnn_step_fwd/bwd (one launch per time step)", "achieved": round(achieved, 3),
+                "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 6), "traffic": None,
+                "avg_launch_us": round(avg_launch_s * 1e6, 3), "launches_per_step": launches // max(1, args.steps),
+                "sweep_ms_per_step": round(sweep_ms / max(1, args.steps), 3),
+                "whole_step_frac_of_mfma_roofline": None}
+    return lengths, dt, first_loss, last_loss, roofline
+
+
+def run_stock(args, rank, world, device):
+    """Stock PyTorch-ROCm on the same batch (bf16 autocast for cfg3, as the reference's precision=16 does)."""
+    from oracle import ds2_torch_port as TP
+    kind, H, L, bi, N, tmin, tmax, dtype = CONFIGS[args.config]
+    cfg = dict(rnn_type=kind, hidden_size=H, hidden_layers=L, bidirectional=bi, lookahead_context=20)
+    port = TP.Port(cfg, TP.random_state(cfg, 0), device)
+    lengths, batch = build_batch(args.config, rank, device)
+    opt = port.make_optimizer()
+    ac = torch.bfloat16 if dtype == "bf16" else None
+    first = None
+    for i in range(args.warmup):
+        l = port.train_step(batch, opt, ac)
+        if i == 0:
+            first = float(l.detach().item())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = port.train_step(batch, opt, ac)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return lengths, dt, first if first is not None else float("nan"), float(last.detach().item()), None
+
+
+def cpu_baseline(args):
+    """oracle/ds2_torch_port.py on the host cores: same model, bounded sample (a few short clips), fp32."""
+    from deepspeech.pytorch_amd import synth
+    from oracle import ds2_torch_port as TP
+    kind, H, L, bi, N, tmin, tmax, dtype = CONFIGS[args.config]
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = dict(rnn_type=kind, hidden_size=H, hidden_layers=L, bidirectional=bi, lookahead_context=20)
+    port = TP.Port(cfg, TP.random_state(cfg, 0), "cpu")
+    n, t = args.cpu_clips, args.cpu_frames
+    lengths = synth.synth_lengths(n, max(101, t - 100), t, seed=77)
+    inputs, targets, pct, tsz = synth.synth_batch(lengths, seed=77)
+    batch = (torch.from_numpy(inputs), torch.from_numpy(targets), torch.from_numpy(pct), torch.from_numpy(tsz))
+    opt = port.make_optimizer()
+    port.train_step(batch, opt)          # warm-up
+    times = []
+    t_all = time.perf_counter()
+    while len(times) < 2 or (time.perf_counter() - t_all < 12.0 and len(times) < 8):
+        t0 = time.perf_counter()
+        port.train_step(batch, opt)
+        times.append(time.perf_counter() - t0)
+    best = min(times)
+    secs = synth.audio_seconds(lengths)
+    return {"value": round(secs / best, 3), "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
+            "sample": "oracle/ds2_torch_port.py (the reference's torch op sequence) fp32, same model (%s H=%d L=%d %s), %d clips of "
+                      "%.2f-%.2f s, best of %d steps (%.2f s/step), torch %s, %d threads" % (
+                          kind, H, L, "bi" if bi else "uni", n, lengths.min() * 0.01, lengths.max() * 0.01, len(times), best,
+                          torch.__version__, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
+    ap.add_argument("--stock", action="store_true", help="time stock PyTorch-ROCm instead of the native path")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-clips", type=int, default=4)
+    ap.add_argument("--cpu-frames", type=int, default=301)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU path for the product)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+
+    runner = run_stock if args.stock else run_native
+    lengths, dt, first_loss, last_loss, roofline = runner(args, rank, world, device)
+
+    from deepspeech.pytorch_amd import synth
+    secs_local = synth.audio_seconds(lengths)
+    tt = torch.tensor([dt, secs_local], dtype=torch.float64, device=device)
+    if world > 1:
+        tmax = tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = tt.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt_max, secs_total = float(tmax[0]), float(tsum[1])
+    else:
+        dt_max, secs_total = dt, secs_local
+    kind, H, L, bi, N, tmin, tmax_, dtype = CONFIGS[args.config]
+    value = secs_total * args.steps / dt_max
+    ms_per_step = dt_max / args.steps * 1e3
+    if roofline is not None:
+        # whole-step view: algorithmic train FLOPs over valid frames / step time / MFMA peak
+        roofline["whole_step_frac_of_mfma_roofline"] = round(train_flops(args.config, lengths) / (ms_per_step / 1e3) / 1e12 /
+                                                             PEAK_TFLOPS[dtype], 6)
+    out = {
+        "metric": "audio-seconds/sec (train step)", "value": round(value, 2), "unit": "audio-seconds/sec", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+        "impl": "stock-pytorch-rocm" if args.stock else "ds2hip",
+        "config": {"workload": "%s: %dx %s%s hidden=%d, %d clips/GPU of %.1f-%.1f s, train step incl. clip_grad_norm(400)+AdamW" % (
+            args.config, L, "Bi" if bi else "Uni", kind.upper(), H, N, tmin * 0.01, tmax_ * 0.01),
+            "global_batch": N * world, "frames_max": int(tmax_), "parallelism": "dp%d" % world,
+            "audio_seconds_per_step": round(secs_total, 2)},
+        "ctc_loss_first_step": first_loss, "ctc_loss_last_step": last_loss,
+    }
+    if roofline is not None:
+        out["roofline"] = roofline
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.stock:
+        out["cpu_baseline"] = cpu_baseline(args)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

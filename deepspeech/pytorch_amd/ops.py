@@ -43,6 +43,29 @@ def rup(x, m):
     return (x + m - 1) // m * m
 
 
+# Optional measurement hook (bench.py): when set to a list, every recurrent sweep appends
+# (tag, n_launches, start_event, end_event) recorded on the stream the kernels are launched on.
+SWEEP_EVENTS = None
+
+
+class _sweep_timer:
+    def __init__(self, tag, launches):
+        self.tag, self.launches = tag, launches
+
+    def __enter__(self):
+        if SWEEP_EVENTS is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if SWEEP_EVENTS is not None:
+            self.e1.record()
+            SWEEP_EVENTS.append((self.tag, self.launches, self.e0, self.e1))
+        return False
+
+
 # ---------------------------------------------------------------------------------------------------------------
 def gemm_nt(A, B, bias=None, out_dtype=None, M=None, N=None, K=None, lda=None, ldb=None, out=None, ldc=None, splitk=1,
             batch=1, sA=0, sB=0, sC=0, sBias=0):
@@ -167,8 +190,9 @@ def rnn_fwd(kind, GI, Whh, bhh, lens, D, N, H, Tp, h0=None, c0=None, save=True):
     hn = torch.empty((D, N, H), dtype=torch.float32, device=dev)
     cn = torch.empty((D, N, H), dtype=torch.float32, device=dev) if kind == "lstm" else None
     state = torch.empty(query("ds2_rnn_state_bytes", D, N, H), dtype=torch.uint8, device=dev)
-    call("ds2_rnn_fwd", dt(dtype), CELLS[kind], D, N, H, Tp, P(lens), P(GI), P(Whh), P(bhh), P(h0), P(c0),
-         P(hext[:, 1]), (Tp + 2) * N * H, P(Sv), P(hn), P(cn), P(state), S())
+    with _sweep_timer("rnn_fwd", Tp):
+        call("ds2_rnn_fwd", dt(dtype), CELLS[kind], D, N, H, Tp, P(lens), P(GI), P(Whh), P(bhh), P(h0), P(c0),
+             P(hext[:, 1]), (Tp + 2) * N * H, P(Sv), P(hn), P(cn), P(state), S())
     return hext, Sv, hn, cn
 
 
@@ -178,8 +202,9 @@ def rnn_bwd(kind, dOut, WhhT, hext, Sv, lens, D, N, H, Tp):
     dGI = torch.empty((Tp * N, D * G * H), dtype=dtype, device=dev)
     dGH = torch.empty((D, Tp, N, G * H), dtype=dtype, device=dev) if kind == "gru" else None
     state = torch.empty(query("ds2_rnn_state_bytes", D, N, H), dtype=torch.uint8, device=dev)
-    call("ds2_rnn_bwd", dt(dtype), CELLS[kind], D, N, H, Tp, P(lens), P(dOut), P(WhhT), P(hext[:, 1]), (Tp + 2) * N * H,
-         P(Sv), P(dGI), P(dGH), P(state), S())
+    with _sweep_timer("rnn_bwd", Tp):
+        call("ds2_rnn_bwd", dt(dtype), CELLS[kind], D, N, H, Tp, P(lens), P(dOut), P(WhhT), P(hext[:, 1]), (Tp + 2) * N * H,
+             P(Sv), P(dGI), P(dGH), P(state), S())
     return dGI, dGH
 
 

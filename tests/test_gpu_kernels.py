@@ -370,7 +370,9 @@ def test_ctc_loss_and_grad(N, Tp, lens, tlens):
     assert np.allclose(np64(nll), nll_ref, rtol=2e-5, atol=1e-4), (np64(nll), nll_ref)
     assert abs(float(loss.item()) - loss_ref) <= 2e-5 * max(1.0, abs(loss_ref))
     got = np64(dl).reshape(Tp, N, ld)
-    assert np.abs(got[:, :, :29] - dlogits_ref).max() < 2e-5
+    # fp32 log-space recursion: alpha/beta reach magnitude ~3*T', whose fp32 ulp (6e-8 * 3T') bounds the precision of
+    # exp(alpha + beta - ll); torch's fp32 CTC has the same noise.  Stated bar: 2e-6 * T' absolute.
+    assert np.abs(got[:, :, :29] - dlogits_ref).max() < max(2e-5, 2e-6 * Tp)
     assert np.all(got[:, :, 29:] == 0)
 
 

@@ -78,3 +78,26 @@ def test_seq_lens_formula():
     ln = np.array([201, 186, 172, 158, 143, 129, 115, 101])
     assert O.seq_lens(ln).tolist() == [101, 93, 86, 79, 72, 65, 58, 51]
     assert O.rnn_input_size() == 1312
+
+
+@pytest.mark.parametrize("name", fixture_names())
+def test_torch_port_matches_reference(name):
+    """oracle/ds2_torch_port.py (the stock-torch restatement timed as cpu_baseline / stock-ROCm baseline) reproduces the
+    real reference's fp32 loss, logits and every gradient."""
+    import torch
+    from oracle import ds2_torch_port as TP
+    fx = Fixture(name)
+    port = TP.Port(fx.cfg, fx.params(), "cpu")
+    inputs, targets, pct, tsz = fx.batch()
+    batch = (torch.from_numpy(inputs), torch.from_numpy(targets), torch.from_numpy(pct.copy()), torch.from_numpy(tsz))
+    loss = port.training_loss(batch)
+    loss.backward()
+    ref32 = float(fx.z["loss"])
+    lv = float(loss.detach())
+    assert abs(lv - ref32) <= 2e-5 * abs(ref32), (lv, ref32)
+    logits, ol = port.forward(batch[0], torch.from_numpy(fx.z["input_sizes"].copy()), train=True)
+    assert np.array_equal(ol.numpy(), fx.z["output_lengths"])
+    assert np.abs(logits.detach().transpose(0, 1).numpy() - fx.z["logits"]).max() <= 1e-4
+    for gname in fx.grad_names():
+        noise = float(fx.z["noise." + gname]) if "noise." + gname in fx.z.files else 0.0
+        fx.check_grad(gname, port.P[gname].grad.numpy(), rtol=max(2e-3, 3 * min(noise, 1e-2)))
