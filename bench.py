@@ -114,12 +114,15 @@ def run_native(args, rank, world, device):
         return loss
 
     first_loss = None
+    log("model + batch ready; warm-up")
     for i in range(args.warmup):
         l = step()
         if i == 0:
             first_loss = float(l.detach().item())
+            log("first step done, loss %.4f" % first_loss)
     if first_loss is None:
         first_loss = float("nan")
+    log("timed region")
     ops.SWEEP_EVENTS = []
     torch.cuda.synchronize()
     if world > 1:
@@ -134,6 +137,7 @@ def run_native(args, rank, world, device):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     events, ops.SWEEP_EVENTS = ops.SWEEP_EVENTS, None
+    log("timed region done: %.1f ms/step" % (dt / args.steps * 1e3))
     last_loss = float(last.detach().item())
 
     # ---- roofline of the dominant kernel: the per-time-step recurrent kernel (one launch per time step and sweep)
@@ -179,12 +183,48 @@ def run_stock(args, rank, world, device):
     return lengths, dt, first if first is not None else float("nan"), float(last.detach().item()), None
 
 
+def usable_cores():
+    """Cores this process may actually use: affinity mask and cgroup CPU quota (os.cpu_count() reports the host's)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
+def log(msg):
+    print("[bench %.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
+def cpu_baseline_subprocess(args):
+    """Runs the CPU leg in a child process under a hard time limit so that it can never stall the GPU bench."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--config", args.config,
+           "--cpu-clips", str(args.cpu_clips), "--cpu-frames", str(args.cpu_frames)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_timeout)
+        for line in r.stdout.splitlines()[::-1]:
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"value": None, "unit": "audio-seconds/sec", "cores": usable_cores(), "kind": "port",
+                "sample": "cpu leg failed: " + (r.stderr.strip().splitlines() or ["?"])[-1][:200]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "audio-seconds/sec", "cores": usable_cores(), "kind": "port",
+                "sample": "cpu leg exceeded its %d s limit" % args.cpu_timeout}
+
+
 def cpu_baseline(args):
     """oracle/ds2_torch_port.py on the host cores: same model, bounded sample (a few short clips), fp32."""
     from deepspeech.pytorch_amd import synth
     from oracle import ds2_torch_port as TP
     kind, H, L, bi, N, tmin, tmax, dtype = CONFIGS[args.config]
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     cfg = dict(rnn_type=kind, hidden_size=H, hidden_layers=L, bidirectional=bi, lookahead_context=20)
     port = TP.Port(cfg, TP.random_state(cfg, 0), "cpu")
@@ -219,7 +259,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=4)
     ap.add_argument("--cpu-frames", type=int, default=301)
+    ap.add_argument("--cpu-timeout", type=int, default=150)
+    ap.add_argument("--cpu-baseline-only", action="store_true")
     args = ap.parse_args()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args)))
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -235,6 +280,7 @@ def main():
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
     runner = run_stock if args.stock else run_native
+    log("start %s on %d rank(s), config %s" % ("stock" if args.stock else "native", world, args.config))
     lengths, dt, first_loss, last_loss, roofline = runner(args, rank, world, device)
 
     from deepspeech.pytorch_amd import synth
@@ -269,7 +315,8 @@ def main():
     if roofline is not None:
         out["roofline"] = roofline
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.stock:
-        out["cpu_baseline"] = cpu_baseline(args)
+        log("cpu baseline leg (subprocess, <= %d s)" % args.cpu_timeout)
+        out["cpu_baseline"] = cpu_baseline_subprocess(args)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
