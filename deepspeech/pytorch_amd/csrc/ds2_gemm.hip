@@ -62,41 +62,63 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  uint4 ra[4], rb[4];
-  auto gload = [&](int kt) {
-    const int k0 = kt * KT;
+  // Staging registers: 4 x 16 B of A and of B per thread and K-tile.  Loads are UNCONDITIONAL so that all eight stay in
+  // flight together (a predicated load compiles to a branch + s_waitcnt vmcnt(0) per load and serialises the pipeline):
+  // row addresses are clamped into the matrix (rows >= M / N just repeat the last row; their results are never stored)
+  // and the K tail is zeroed with a bit mask.
+  uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+  uint32_t kmask = 0;   // K-tail mask of the tile currently held in the staging registers (applied at LDS-write time)
+  const int ld_row = tid >> 3, ld_kc = (tid & 7) * V;
+  const T* a_row[4];
+  const T* b_row[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int v = tid + i * 256;
-      int row = v >> 3, kc = v & 7;
-      int k = k0 + kc * V;
-      uint4 z = make_uint4(0, 0, 0, 0);
-      ra[i] = (m0 + row < g.M && k < g.K) ? *reinterpret_cast<const uint4*>(A + (long)(m0 + row) * g.lda + k) : z;
-      rb[i] = (n0 + row < g.N && k < g.K) ? *reinterpret_cast<const uint4*>(B + (long)(n0 + row) * g.ldb + k) : z;
-    }
-  };
-  auto swrite = [&](int stage) {
-    unsigned char* sa = smem + stage * STAGE_BYTES;
-    unsigned char* sb = sa + BM * ROWB;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int v = tid + i * 256;
-      int row = v >> 3, kc = v & 7;
-      *reinterpret_cast<uint4*>(sa + row * ROWB + kc * 16) = ra[i];
-      *reinterpret_cast<uint4*>(sb + row * ROWB + kc * 16) = rb[i];
-    }
-  };
+  for (int i = 0; i < 4; ++i) {
+    const int row = ld_row + i * 32;
+    a_row[i] = A + (long)min(m0 + row, g.M - 1) * g.lda;
+    b_row[i] = B + (long)min(n0 + row, g.N - 1) * g.ldb;
+  }
+#define DS2_MASK4(r, m) r.x &= m; r.y &= m; r.z &= m; r.w &= m;
+#define DS2_GLOAD(kt)                                                              \
+  {                                                                                \
+    const int k_ = (kt) * KT + ld_kc;                                              \
+    const bool kok_ = k_ < g.K;                                                    \
+    const int kc_ = kok_ ? k_ : 0;                                                 \
+    ra0 = *reinterpret_cast<const uint4*>(a_row[0] + kc_);                         \
+    ra1 = *reinterpret_cast<const uint4*>(a_row[1] + kc_);                         \
+    ra2 = *reinterpret_cast<const uint4*>(a_row[2] + kc_);                         \
+    ra3 = *reinterpret_cast<const uint4*>(a_row[3] + kc_);                         \
+    rb0 = *reinterpret_cast<const uint4*>(b_row[0] + kc_);                         \
+    rb1 = *reinterpret_cast<const uint4*>(b_row[1] + kc_);                         \
+    rb2 = *reinterpret_cast<const uint4*>(b_row[2] + kc_);                         \
+    rb3 = *reinterpret_cast<const uint4*>(b_row[3] + kc_);                         \
+    kmask = kok_ ? 0xffffffffu : 0u;                                               \
+  }
+#define DS2_SWRITE(stage)                                                          \
+  {                                                                                \
+    unsigned char* sa_ = smem + (stage) * STAGE_BYTES + ld_row * ROWB + (tid & 7) * 16; \
+    unsigned char* sb_ = sa_ + BM * ROWB;                                          \
+    DS2_MASK4(ra0, kmask) DS2_MASK4(ra1, kmask) DS2_MASK4(ra2, kmask) DS2_MASK4(ra3, kmask) \
+    DS2_MASK4(rb0, kmask) DS2_MASK4(rb1, kmask) DS2_MASK4(rb2, kmask) DS2_MASK4(rb3, kmask) \
+    *reinterpret_cast<uint4*>(sa_) = ra0;                                          \
+    *reinterpret_cast<uint4*>(sa_ + 32 * ROWB) = ra1;                              \
+    *reinterpret_cast<uint4*>(sa_ + 64 * ROWB) = ra2;                              \
+    *reinterpret_cast<uint4*>(sa_ + 96 * ROWB) = ra3;                              \
+    *reinterpret_cast<uint4*>(sb_) = rb0;                                          \
+    *reinterpret_cast<uint4*>(sb_ + 32 * ROWB) = rb1;                              \
+    *reinterpret_cast<uint4*>(sb_ + 64 * ROWB) = rb2;                              \
+    *reinterpret_cast<uint4*>(sb_ + 96 * ROWB) = rb3;                              \
+  }
 
   if (kt_begin < kt_end) {
-    gload(kt_begin);
-    swrite(0);
+    DS2_GLOAD(kt_begin);
+    DS2_SWRITE(0);
   }
   __syncthreads();
   const int li = lane & 31, lq = lane >> 5;
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const int stage = (kt - kt_begin) & 1;
     const bool more = kt + 1 < kt_end;
-    if (more) gload(kt + 1);
+    if (more) DS2_GLOAD(kt + 1);
     const unsigned char* sa = smem + stage * STAGE_BYTES + (wm * 64 + li) * ROWB + lq * 16;
     const unsigned char* sb = smem + stage * STAGE_BYTES + BM * ROWB + (wn * 64 + li) * ROWB + lq * 16;
 #pragma unroll
@@ -110,7 +132,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt(GemmArgs g) {
       Mma<T>::mma32(acc[1][0], a1, b0);
       Mma<T>::mma32(acc[1][1], a1, b1);
     }
-    if (more) swrite(stage ^ 1);
+    if (more) DS2_SWRITE(stage ^ 1);
     __syncthreads();
   }
 

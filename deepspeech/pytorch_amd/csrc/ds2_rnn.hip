@@ -62,24 +62,48 @@ __device__ __forceinline__ void skinny_gemm(ds2_f32x4 (&acc)[MT][NT], const T* a
                                             const T* const (&b_rows)[NT], long ldb, int K, int wave, int lane) {
   constexpr int V = Vec16<T>::N;
   constexpr int KC = Mma<T>::K16;  // elements of K per chunk (64 bytes per row)
+  constexpr int U = 4;             // chunks whose loads are in flight together
   const int li = lane & 15, lq = lane >> 4;
   const int nch = (K + KC - 1) / KC;
-  const uint4 z = make_uint4(0, 0, 0, 0);
-  for (int c = wave; c < nch; c += 4) {
-    const int k = c * KC + lq * V;
-    const bool kok = k < K;
-    uint4 a[MT], b[NT];
+  // All loads are unconditional (a predicated 16-byte load compiles to branch + s_waitcnt vmcnt(0), i.e. one L2 round
+  // trip per load, serialised): rows >= nrows re-read the last valid row (their results are never used), the K tail is
+  // clamped to k = 0 and zeroed with a bit mask on both operands.
+  const T* a_ptr[MT];
+  const T* b_ptr[NT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const int row = m * 16 + li;
-      a[m] = (kok && row < nrows) ? *reinterpret_cast<const uint4*>(a_base + (long)row * lda + k) : z;
+  for (int m = 0; m < MT; ++m) a_ptr[m] = a_base + (long)min(m * 16 + li, nrows - 1) * lda + lq * V;
+#pragma unroll
+  for (int n = 0; n < NT; ++n) b_ptr[n] = b_rows[n] + (long)li * ldb + lq * V;
+  for (int c0 = wave; c0 < nch; c0 += 4 * U) {
+    uint4 a[U][MT], b[U][NT];
+    uint32_t msk[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + 4 * u;
+      const int k = c * KC + lq * V;
+      const bool kok = (c < nch) && (k < K);
+      const int kk = kok ? c * KC : 0;
+      msk[u] = kok ? 0xffffffffu : 0u;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a[u][m] = *reinterpret_cast<const uint4*>(a_ptr[m] + kk);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) b[u][n] = *reinterpret_cast<const uint4*>(b_ptr[n] + kk);
     }
 #pragma unroll
-    for (int n = 0; n < NT; ++n) b[n] = kok ? *reinterpret_cast<const uint4*>(b_rows[n] + (long)li * ldb + k) : z;
+    for (int u = 0; u < U; ++u) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+      for (int m = 0; m < MT; ++m) {
+        a[u][m].x &= msk[u]; a[u][m].y &= msk[u]; a[u][m].z &= msk[u]; a[u][m].w &= msk[u];
+      }
 #pragma unroll
-      for (int n = 0; n < NT; ++n) Mma<T>::mma16(acc[m][n], a[m], b[n]);
+      for (int n = 0; n < NT; ++n) {
+        b[u][n].x &= msk[u]; b[u][n].y &= msk[u]; b[u][n].z &= msk[u]; b[u][n].w &= msk[u];
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) Mma<T>::mma16(acc[m][n], a[u][m], b[u][n]);
+    }
   }
 }
 
