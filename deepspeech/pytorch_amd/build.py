@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libds2hip.so")
-SOURCES = ["ds2_norm.hip", "ds2_gemm.hip", "ds2_rnn.hip", "ds2_conv.hip", "ds2_ctc.hip", "ds2_seqops.hip"]
+SOURCES = ["ds2_norm.hip", "ds2_gemm.hip", "ds2_rnn.hip", "ds2_rnn_persist.hip", "ds2_conv.hip", "ds2_ctc.hip", "ds2_seqops.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-pass-failed"]
 

@@ -1,0 +1,580 @@
+// Persistent recurrent sweeps (forward and BPTT) of BatchRNN (reference model.py:94-102) for bf16 storage:
+// ONE launch per layer and sweep, all T' dependent time steps inside the kernel, W_hh resident in registers.
+//
+// Why: the recurrence is 2*L*T' dependent steps per training step (7 510 for the LibriSpeech configuration); a kernel
+// boundary per step costs >= 10 us in practice (ds2_rnn.hip: launch gap + cold dependent-load chain + W_hh re-streamed
+// from L2), the arithmetic of one step is < 0.5 us of MFMA time.  Here the chip is cut into 8 independent GROUPS of 32
+// workgroups (one workgroup per CU; group = blockIdx % 8, which the dispatcher places on one XCD -- a speed
+// assumption only).  A group owns one direction and a slice of the minibatch (samples are independent, so groups never
+// talk to each other); inside a group, workgroup p owns hidden units [p*U, (p+1)*U) of every gate and keeps its slice
+// of W_hh (G*U rows x H, 192 KiB for GRU-1024) in VGPRs as ready-made MFMA B fragments for the whole sweep.
+// Per time step a workgroup
+//   1. gathers the group's h_{t-1} (samples x H, bf16) from the exchange buffer -- 8-byte {tag = step, 2 x bf16}
+//      granules written write-through (sc1) by their producers and polled with sc1 loads: the data is the flag, no fence,
+//      no barrier (MI355X guide section 6 G16, recipe R2).  Wave w gathers exactly the K-quarter it multiplies, straight
+//      into MFMA A-fragment registers (no LDS staging);
+//   2. multiplies it with its resident W slice (v_mfma_f32_16x16x32_bf16, samples are the M rows), K split over the 4
+//      waves, partial sums to LDS (double-buffered by step parity: one barrier per step);
+//   3. 2 hidden units per thread: adds the hoisted input projection (prefetched at the top of the step), gate math in
+//      fp32 with the fp32 carried state in a register, packed-sequence masking, stores (h_t, saved gates), and publishes
+//      its two new h values as one granule.
+// The BPTT kernel has the same skeleton with W_hh^T resident (U rows x G*H), exchanging the gate gradients.
+//
+// Placement independence: any assignment of workgroups to CUs/XCDs is correct as long as all 256 workgroups are
+// co-resident (grid == CU count, 1 wave per SIMD by register use); every spin is bounded and a timed-out workgroup
+// raises *err, poisons its outputs with NaN and stops waiting, so the launch always terminates.
+// Roofline: MFMA-shaped work (2*samples*G*H*H flops per step and direction) but latency-bound by construction; the
+// measured quantity is us per time step (bench.py roofline object).
+#include "ds2_common.h"
+
+namespace {
+
+typedef unsigned long long u64;
+
+enum { CELL_GRU = 0, CELL_LSTM = 1, CELL_RNN = 2 };
+constexpr int NGROUPS = 8;
+constexpr int MAXS = 16;                 // samples per group (MFMA M tile)
+constexpr unsigned SPIN_LIMIT = 4000000; // ~ seconds; then give up loudly
+constexpr unsigned TAG_INIT = 0x40000000u;
+
+template <int CELL>
+struct CellInfo;
+template <>
+struct CellInfo<CELL_GRU> {
+  static constexpr int G = 3, NS = 4;
+};
+template <>
+struct CellInfo<CELL_LSTM> {
+  static constexpr int G = 4, NS = 5;
+};
+template <>
+struct CellInfo<CELL_RNN> {
+  static constexpr int G = 1, NS = 0;
+};
+
+struct PArgs {
+  int N, Tp, D, gpd;        // gpd = groups per direction (NGROUPS / D)
+  const int* lens;          // [N]
+  const bf16_t* W;          // fwd: W_hh [D][G*H][H]        bwd: W_hh^T [D][H][G*H]
+  const float* bhh;         // [D][G*H]
+  const bf16_t* GI;         // fwd: input projection [Tp*N][D*G*H]
+  bf16_t* Hseq;             // h_t of direction d at Hseq + d*hseq_dstride + (t*N+n)*H (guard slots at t=-1 and t=Tp are zero)
+  long hseq_dstride;
+  bf16_t* S;                // saved planes [D][Tp][N][NS*H]
+  const float* h0;          // [D][N][H] or null
+  const float* c0;
+  float* hn;                // [D][N][H] or null
+  float* cn;
+  const bf16_t* dOut;       // bwd: [Tp][N][H]
+  bf16_t* dGI;              // bwd: [Tp*N][D*G*H]
+  bf16_t* dGH;              // bwd, GRU only: [D][Tp][N][3H]
+  u64* xbuf;                // [NGROUPS][2][MAXS][X/2] granules, zeroed before the launch
+  int* err;                 // device word, set to 1 on a spin time-out
+};
+
+__device__ __forceinline__ u64 g_load(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void g_store(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+}
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// Gathers this wave's K-quarter of the exchanged vector (granules tagged `epoch`) and multiplies it with the resident
+// fragments: acc[tile] += A(samples x K-quarter) * w[tile](16 rows x K-quarter)^T.  `src` = the lane's first granule
+// (sample row and the lane group's 8-k sub-block already applied); consecutive k-steps are 16 granules apart.
+template <int TILES, int KS>
+__device__ __forceinline__ void gather_mma(ds2_f32x4 (&acc)[TILES], const uint4 (&w)[TILES][KS], const u64* src, bool need,
+                                           unsigned epoch, int* err, bool& dead) {
+  // k-steps gathered per poll round (<= 32 granules in flight per lane): the largest divisor of KS that is <= 8
+  constexpr int CH = KS % 8 == 0 ? 8 : KS % 6 == 0 ? 6 : KS % 4 == 0 ? 4 : KS % 3 == 0 ? 3 : KS % 2 == 0 ? 2 : 1;
+  static_assert(KS % CH == 0, "k-steps per wave must be a multiple of the poll chunk");
+#pragma unroll
+  for (int c = 0; c < KS / CH; ++c) {
+    u64 v[CH][4];
+    unsigned spins = 0;
+    for (;;) {
+      bool bad = false;
+      if (need) {
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[k][q] = g_load(src + 16 * (c * CH + k) + q);
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bad |= (unsigned)(v[k][q] >> 32) != epoch;
+      }
+      if (!__any(bad) || dead) break;
+      if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+        dead = true;
+        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      uint4 a = make_uint4(0, 0, 0, 0);
+      if (need) a = make_uint4((uint32_t)v[k][0], (uint32_t)v[k][1], (uint32_t)v[k][2], (uint32_t)v[k][3]);
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) Mma<bf16_t>::mma16(acc[t], a, w[t][c * CH + k]);
+    }
+  }
+}
+
+template <int TILES>
+__device__ __forceinline__ void store_partials(float* part, const ds2_f32x4 (&acc)[TILES], int wave, int lane) {
+#pragma unroll
+  for (int t = 0; t < TILES; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[((wave * TILES + t) * 16 + mma16_row(r, lane)) * 16 + (lane & 15)] = acc[t][r];
+}
+// sum over the 4 waves of the two adjacent columns (col, col+1) of row `row` of tile `t`
+template <int TILES>
+__device__ __forceinline__ float2 load_partials(const float* part, int t, int row, int col) {
+  float2 s = make_float2(0.f, 0.f);
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const float2 v = *reinterpret_cast<const float2*>(part + ((w * TILES + t) * 16 + row) * 16 + col);
+    s.x += v.x;
+    s.y += v.y;
+  }
+  return s;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// forward sweep
+// ------------------------------------------------------------------------------------------------------------------
+template <int CELL, int H, int P>
+__global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd(PArgs a) {
+  constexpr int G = CellInfo<CELL>::G, NS = CellInfo<CELL>::NS;
+  constexpr int U = H / P;                 // hidden units owned by a workgroup
+  constexpr int TILES = G * U / 16;        // 16-row MFMA tiles of the resident W slice
+  constexpr int KS = H / 128;              // k-steps (of 32) per wave: K quarter = H/4
+  constexpr int X2 = H / 2;                // granules per sample
+  static_assert(U % 16 == 0 && H % 128 == 0, "unsupported hidden size for the persistent kernel");
+  __shared__ __attribute__((aligned(16))) float part[2][4 * TILES * 256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = blockIdx.x % NGROUPS, p = blockIdx.x / NGROUPS;
+  const int d = grp / a.gpd, slice = grp % a.gpd;
+  const int N = a.N, Tp = a.Tp;
+  const int Ns = (N - slice + a.gpd - 1) / a.gpd;          // samples n = slice + gpd*i, i < Ns
+  const int li = lane & 15, lq = lane >> 4;
+  constexpr long GH = (long)G * H;
+  const long ldgi = (long)a.D * GH;
+
+  // ---- resident W fragments: tile t row li = local row r = 16 t + li -> gate r / U, unit p*U + r % U
+  uint4 w[TILES][KS];
+  {
+    const bf16_t* Wd = a.W + (long)d * GH * H;
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+      const int r = 16 * t + li;
+      const bf16_t* row = Wd + ((long)(r / U) * H + p * U + (r % U)) * H + wave * (H / 4) + lq * 8;
+#pragma unroll
+      for (int k = 0; k < KS; ++k) w[t][k] = *reinterpret_cast<const uint4*>(row + 32 * k);
+    }
+  }
+  u64* xg = a.xbuf + (long)grp * 2 * MAXS * X2;
+  const bool need = li < Ns;
+  const u64* src_base = xg + (long)li * X2 + (wave * (H / 4) + lq * 8) / 2;
+
+  // ---- gate-phase identity: thread -> (sample i, unit pair)
+  constexpr int UP = U / 2;
+  const int gi_i = tid / UP, up = tid % UP;
+  const bool gate_thread = gi_i < Ns;        // Ns <= 16 and U/2 * 16 <= 256
+  const int n = slice + a.gpd * gi_i;
+  const int j = p * U + 2 * up;              // first of the two hidden units of this thread
+  int len = 0;
+  float hprev0 = 0.f, hprev1 = 0.f, cprev0 = 0.f, cprev1 = 0.f;
+  float bh[G][2];
+#pragma unroll
+  for (int g = 0; g < G; ++g) bh[g][0] = bh[g][1] = 0.f;
+  if (gate_thread) {
+    len = a.lens[n];
+    const long so = ((long)d * N + n) * H + j;
+    if (a.h0) {
+      hprev0 = a.h0[so];
+      hprev1 = a.h0[so + 1];
+    }
+    if (CELL == CELL_LSTM && a.c0) {
+      cprev0 = a.c0[so];
+      cprev1 = a.c0[so + 1];
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      bh[g][0] = a.bhh[(long)d * GH + (long)g * H + j];
+      bh[g][1] = a.bhh[(long)d * GH + (long)g * H + j + 1];
+    }
+    if (a.h0)   // initial state as "step -1": parity 1, tag TAG_INIT
+      g_store(xg + (long)(1 * MAXS + gi_i) * X2 + j / 2, ((u64)TAG_INIT << 32) | pack_bf16x2(hprev0, hprev1));
+  }
+  bool dead = false;
+
+  for (int s = 0; s < Tp; ++s) {
+    const int t = d == 0 ? s : Tp - 1 - s;
+    const int par = s & 1;
+    // prefetch the hoisted input projection of this step
+    uint32_t gi[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) gi[g] = 0;
+    if (gate_thread) {
+      const bf16_t* gp = a.GI + ((long)t * N + n) * ldgi + (long)d * GH + j;
+#pragma unroll
+      for (int g = 0; g < G; ++g) gi[g] = *reinterpret_cast<const uint32_t*>(gp + (long)g * H);
+    }
+    ds2_f32x4 acc[TILES];
+#pragma unroll
+    for (int tt = 0; tt < TILES; ++tt) acc[tt] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
+    if (s > 0 || a.h0)
+      gather_mma<TILES, KS>(acc, w, src_base + (long)((par ^ 1) * MAXS) * X2, need, s > 0 ? (unsigned)s : TAG_INIT, a.err, dead);
+    store_partials<TILES>(part[par], acc, wave, lane);
+    __syncthreads();
+    if (gate_thread) {
+      const bool act = t < len;
+      float hn0 = 0.f, hn1 = 0.f;     // emitted h_t (0 when inactive)
+      bf16_t* sv = NS ? a.S + (((long)d * Tp + t) * N + n) * (long)(NS ? NS : 1) * H + j : nullptr;
+      float2 gh[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const int r = g * U + 2 * up;
+        gh[g] = load_partials<TILES>(part[par], r / 16, gi_i, r % 16);
+      }
+      if (CELL == CELL_GRU) {
+        float r0 = 0.f, r1 = 0.f, z0 = 0.f, z1 = 0.f, n0 = 0.f, n1 = 0.f, q0 = 0.f, q1 = 0.f;
+        if (act) {
+          q0 = gh[2].x + bh[2][0];
+          q1 = gh[2].y + bh[2][1];
+          r0 = sigmoid_acc(bf_lo(gi[0]) + gh[0].x + bh[0][0]);
+          r1 = sigmoid_acc(bf_hi(gi[0]) + gh[0].y + bh[0][1]);
+          z0 = sigmoid_acc(bf_lo(gi[1]) + gh[1].x + bh[1][0]);
+          z1 = sigmoid_acc(bf_hi(gi[1]) + gh[1].y + bh[1][1]);
+          n0 = tanhf_(bf_lo(gi[2]) + r0 * q0);
+          n1 = tanhf_(bf_hi(gi[2]) + r1 * q1);
+          hn0 = (1.f - z0) * n0 + z0 * hprev0;
+          hn1 = (1.f - z1) * n1 + z1 * hprev1;
+          hprev0 = hn0;
+          hprev1 = hn1;
+        }
+        *reinterpret_cast<uint32_t*>(sv) = pack_bf16x2(r0, r1);
+        *reinterpret_cast<uint32_t*>(sv + H) = pack_bf16x2(z0, z1);
+        *reinterpret_cast<uint32_t*>(sv + 2 * H) = pack_bf16x2(n0, n1);
+        *reinterpret_cast<uint32_t*>(sv + 3 * H) = pack_bf16x2(q0, q1);
+      } else if (CELL == CELL_LSTM) {
+        float i0 = 0.f, i1 = 0.f, f0 = 0.f, f1 = 0.f, g0 = 0.f, g1 = 0.f, o0 = 0.f, o1 = 0.f, c0 = 0.f, c1 = 0.f;
+        if (act) {
+          i0 = sigmoid_acc(bf_lo(gi[0]) + gh[0].x + bh[0][0]);
+          i1 = sigmoid_acc(bf_hi(gi[0]) + gh[0].y + bh[0][1]);
+          f0 = sigmoid_acc(bf_lo(gi[1]) + gh[1].x + bh[1][0]);
+          f1 = sigmoid_acc(bf_hi(gi[1]) + gh[1].y + bh[1][1]);
+          g0 = tanhf_(bf_lo(gi[2]) + gh[2].x + bh[2][0]);
+          g1 = tanhf_(bf_hi(gi[2]) + gh[2].y + bh[2][1]);
+          o0 = sigmoid_acc(bf_lo(gi[3 % G]) + gh[3 % G].x + bh[3 % G][0]);
+          o1 = sigmoid_acc(bf_hi(gi[3 % G]) + gh[3 % G].y + bh[3 % G][1]);
+          c0 = f0 * cprev0 + i0 * g0;
+          c1 = f1 * cprev1 + i1 * g1;
+          hn0 = o0 * tanhf_(c0);
+          hn1 = o1 * tanhf_(c1);
+          cprev0 = c0;
+          cprev1 = c1;
+          hprev0 = hn0;
+          hprev1 = hn1;
+        }
+        *reinterpret_cast<uint32_t*>(sv) = pack_bf16x2(i0, i1);
+        *reinterpret_cast<uint32_t*>(sv + H) = pack_bf16x2(f0, f1);
+        *reinterpret_cast<uint32_t*>(sv + 2 * H) = pack_bf16x2(g0, g1);
+        *reinterpret_cast<uint32_t*>(sv + 3 * H) = pack_bf16x2(o0, o1);
+        *reinterpret_cast<uint32_t*>(sv + 4 * H) = pack_bf16x2(c0, c1);
+      } else {
+        if (act) {
+          hn0 = tanhf_(bf_lo(gi[0]) + gh[0].x + bh[0][0]);
+          hn1 = tanhf_(bf_hi(gi[0]) + gh[0].y + bh[0][1]);
+          hprev0 = hn0;
+          hprev1 = hn1;
+        }
+      }
+      if (dead) hn0 = hn1 = hprev0 = hprev1 = __uint_as_float(0x7fc00000u);   // fail loudly downstream
+      *reinterpret_cast<uint32_t*>(a.Hseq + (long)d * a.hseq_dstride + ((long)t * N + n) * H + j) = pack_bf16x2(hn0, hn1);
+      // publish the carried state (inactive samples republish their unchanged state)
+      g_store(xg + (long)(par * MAXS + gi_i) * X2 + j / 2, ((u64)(unsigned)(s + 1) << 32) | pack_bf16x2(hprev0, hprev1));
+    }
+  }
+  if (gate_thread) {
+    const long so = ((long)d * N + n) * H + j;
+    if (a.hn) {
+      a.hn[so] = hprev0;
+      a.hn[so + 1] = hprev1;
+    }
+    if (CELL == CELL_LSTM && a.cn) {
+      a.cn[so] = cprev0;
+      a.cn[so + 1] = cprev1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// BPTT sweep.  dh_t = dOut[t] + carry (elementwise part of dh from the step processed before) + dgh_{t'} * W_hh.
+// ------------------------------------------------------------------------------------------------------------------
+template <int CELL, int H, int P>
+__global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd(PArgs a) {
+  constexpr int G = CellInfo<CELL>::G, NS = CellInfo<CELL>::NS;
+  constexpr int U = H / P;
+  constexpr int TILES = U / 16;            // rows of W_hh^T owned: the U output units
+  constexpr int KS = G * H / 128;          // K = G*H split over 4 waves, 32 per k-step
+  constexpr int X2 = G * H / 2;
+  static_assert(U % 16 == 0 && (G * H) % 128 == 0, "unsupported hidden size for the persistent kernel");
+  __shared__ __attribute__((aligned(16))) float part[2][4 * TILES * 256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = blockIdx.x % NGROUPS, p = blockIdx.x / NGROUPS;
+  const int d = grp / a.gpd, slice = grp % a.gpd;
+  const int N = a.N, Tp = a.Tp;
+  const int Ns = (N - slice + a.gpd - 1) / a.gpd;
+  const int li = lane & 15, lq = lane >> 4;
+  constexpr long GH = (long)G * H;
+  const long ldgi = (long)a.D * GH;
+
+  uint4 w[TILES][KS];
+  {
+    const bf16_t* WT = a.W + (long)d * H * GH;
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+      const bf16_t* row = WT + (long)(p * U + 16 * t + li) * GH + wave * (GH / 4) + lq * 8;
+#pragma unroll
+      for (int k = 0; k < KS; ++k) w[t][k] = *reinterpret_cast<const uint4*>(row + 32 * k);
+    }
+  }
+  u64* xg = a.xbuf + (long)grp * 2 * MAXS * X2;
+  const bool need = li < Ns;
+  const u64* src_base = xg + (long)li * X2 + (wave * (int)(GH / 4) + lq * 8) / 2;
+
+  constexpr int UP = U / 2;
+  const int gi_i = tid / UP, up = tid % UP;
+  const bool gate_thread = gi_i < Ns;
+  const int n = slice + a.gpd * gi_i;
+  const int j = p * U + 2 * up;
+  int len = 0;
+  if (gate_thread) len = a.lens[n];
+  float car0 = 0.f, car1 = 0.f, dc0 = 0.f, dc1 = 0.f;   // carried dh (elementwise part) and dc
+  bool dead = false;
+  constexpr long NSH = (long)(NS ? NS : 1) * H;
+
+  for (int s = 0; s < Tp; ++s) {
+    const int t = d == 0 ? Tp - 1 - s : s;
+    const int par = s & 1;
+    // ---- prefetch everything the gate phase needs
+    uint32_t dout = 0, sp[NS ? NS : 1], hp = 0, cp = 0;
+#pragma unroll
+    for (int q = 0; q < (NS ? NS : 1); ++q) sp[q] = 0;
+    const int tprev = d == 0 ? t - 1 : t + 1;            // previous step in FORWARD order of this direction
+    if (gate_thread) {
+      dout = *reinterpret_cast<const uint32_t*>(a.dOut + ((long)t * N + n) * H + j);
+      const long seq = ((long)d * Tp + t) * N + n;
+      if (NS) {
+        const bf16_t* sv = a.S + seq * NSH + j;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) sp[q] = *reinterpret_cast<const uint32_t*>(sv + (long)q * H);
+      }
+      // h_{prev}: guard slots / inactive frames hold zeros, so the read is unconditional (tprev in [-1, Tp])
+      hp = *reinterpret_cast<const uint32_t*>(a.Hseq + (long)d * a.hseq_dstride + ((long)tprev * N + n) * H + j);
+      if (CELL == CELL_LSTM) {
+        const bool has_prev = d == 0 ? (t > 0) : (t + 1 < len);
+        if (has_prev) cp = *reinterpret_cast<const uint32_t*>(a.S + (((long)d * Tp + tprev) * N + n) * NSH + 4 * H + j);
+      }
+      if (CELL == CELL_RNN) hp = *reinterpret_cast<const uint32_t*>(a.Hseq + (long)d * a.hseq_dstride + ((long)t * N + n) * H + j);
+    }
+    ds2_f32x4 acc[TILES];
+#pragma unroll
+    for (int tt = 0; tt < TILES; ++tt) acc[tt] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
+    if (s > 0) gather_mma<TILES, KS>(acc, w, src_base + (long)((par ^ 1) * MAXS) * X2, need, (unsigned)s, a.err, dead);
+    store_partials<TILES>(part[par], acc, wave, lane);
+    __syncthreads();
+    if (gate_thread) {
+      const bool act = t < len;
+      const float2 mp = load_partials<TILES>(part[par], (2 * up) / 16, gi_i, (2 * up) % 16);
+      const float din0 = car0 + mp.x, din1 = car1 + mp.y;
+      bf16_t* dgi = a.dGI + ((long)t * N + n) * ldgi + (long)d * GH + j;
+      u64* xo = xg + (long)(par * MAXS + gi_i) * X2 + j / 2;
+      const u64 tag = (u64)(unsigned)(s + 1) << 32;
+      if (CELL == CELL_GRU) {
+        float dr0 = 0.f, dr1 = 0.f, dz0 = 0.f, dz1 = 0.f, dn0 = 0.f, dn1 = 0.f, dq0 = 0.f, dq1 = 0.f;
+        car0 = din0;
+        car1 = din1;
+        if (act) {
+          const float r0 = bf_lo(sp[0]), r1 = bf_hi(sp[0]), z0 = bf_lo(sp[1 % (NS ? NS : 1)]), z1 = bf_hi(sp[1 % (NS ? NS : 1)]);
+          const float n0 = bf_lo(sp[2 % (NS ? NS : 1)]), n1 = bf_hi(sp[2 % (NS ? NS : 1)]);
+          const float q0 = bf_lo(sp[3 % (NS ? NS : 1)]), q1 = bf_hi(sp[3 % (NS ? NS : 1)]);
+          const float dh0 = bf_lo(dout) + din0, dh1 = bf_hi(dout) + din1;
+          dn0 = dh0 * (1.f - z0) * (1.f - n0 * n0);
+          dn1 = dh1 * (1.f - z1) * (1.f - n1 * n1);
+          dz0 = dh0 * (bf_lo(hp) - n0) * z0 * (1.f - z0);
+          dz1 = dh1 * (bf_hi(hp) - n1) * z1 * (1.f - z1);
+          dr0 = dn0 * q0 * r0 * (1.f - r0);
+          dr1 = dn1 * q1 * r1 * (1.f - r1);
+          dq0 = dn0 * r0;
+          dq1 = dn1 * r1;
+          car0 = dh0 * z0;
+          car1 = dh1 * z1;
+        }
+        if (dead) dr0 = dr1 = __uint_as_float(0x7fc00000u);
+        const uint32_t pr = pack_bf16x2(dr0, dr1), pz = pack_bf16x2(dz0, dz1), pn = pack_bf16x2(dn0, dn1), pq = pack_bf16x2(dq0, dq1);
+        *reinterpret_cast<uint32_t*>(dgi) = pr;
+        *reinterpret_cast<uint32_t*>(dgi + H) = pz;
+        *reinterpret_cast<uint32_t*>(dgi + 2 * H) = pn;
+        bf16_t* dgh = a.dGH + (((long)d * Tp + t) * N + n) * GH + j;
+        *reinterpret_cast<uint32_t*>(dgh) = pr;
+        *reinterpret_cast<uint32_t*>(dgh + H) = pz;
+        *reinterpret_cast<uint32_t*>(dgh + 2 * H) = pq;
+        g_store(xo, tag | pr);
+        g_store(xo + H / 2, tag | pz);
+        g_store(xo + H, tag | pq);
+      } else if (CELL == CELL_LSTM) {
+        float di0 = 0.f, di1 = 0.f, df0 = 0.f, df1 = 0.f, dg0 = 0.f, dg1 = 0.f, do0 = 0.f, do1 = 0.f;
+        car0 = din0;
+        car1 = din1;
+        if (act) {
+          constexpr int M = NS ? NS : 1;
+          const float i0 = bf_lo(sp[0]), i1 = bf_hi(sp[0]), f0 = bf_lo(sp[1 % M]), f1 = bf_hi(sp[1 % M]);
+          const float g0 = bf_lo(sp[2 % M]), g1 = bf_hi(sp[2 % M]), o0 = bf_lo(sp[3 % M]), o1 = bf_hi(sp[3 % M]);
+          const float tc0 = tanhf_(bf_lo(sp[4 % M])), tc1 = tanhf_(bf_hi(sp[4 % M]));
+          const float dh0 = bf_lo(dout) + din0, dh1 = bf_hi(dout) + din1;
+          const float dcn0 = dc0 + dh0 * o0 * (1.f - tc0 * tc0), dcn1 = dc1 + dh1 * o1 * (1.f - tc1 * tc1);
+          di0 = dcn0 * g0 * i0 * (1.f - i0);
+          di1 = dcn1 * g1 * i1 * (1.f - i1);
+          df0 = dcn0 * bf_lo(cp) * f0 * (1.f - f0);
+          df1 = dcn1 * bf_hi(cp) * f1 * (1.f - f1);
+          dg0 = dcn0 * i0 * (1.f - g0 * g0);
+          dg1 = dcn1 * i1 * (1.f - g1 * g1);
+          do0 = dh0 * tc0 * o0 * (1.f - o0);
+          do1 = dh1 * tc1 * o1 * (1.f - o1);
+          car0 = car1 = 0.f;
+          dc0 = dcn0 * f0;
+          dc1 = dcn1 * f1;
+        }
+        if (dead) di0 = di1 = __uint_as_float(0x7fc00000u);
+        const uint32_t pi = pack_bf16x2(di0, di1), pf = pack_bf16x2(df0, df1), pg = pack_bf16x2(dg0, dg1), po = pack_bf16x2(do0, do1);
+        *reinterpret_cast<uint32_t*>(dgi) = pi;
+        *reinterpret_cast<uint32_t*>(dgi + H) = pf;
+        *reinterpret_cast<uint32_t*>(dgi + 2 * H) = pg;
+        *reinterpret_cast<uint32_t*>(dgi + 3 * H) = po;
+        g_store(xo, tag | pi);
+        g_store(xo + H / 2, tag | pf);
+        g_store(xo + H, tag | pg);
+        g_store(xo + 3 * (H / 2), tag | po);
+      } else {
+        float dg0 = 0.f, dg1 = 0.f;
+        car0 = din0;
+        car1 = din1;
+        if (act) {
+          const float h0v = bf_lo(hp), h1v = bf_hi(hp);
+          dg0 = (bf_lo(dout) + din0) * (1.f - h0v * h0v);
+          dg1 = (bf_hi(dout) + din1) * (1.f - h1v * h1v);
+          car0 = car1 = 0.f;
+        }
+        if (dead) dg0 = dg1 = __uint_as_float(0x7fc00000u);
+        const uint32_t pg = pack_bf16x2(dg0, dg1);
+        *reinterpret_cast<uint32_t*>(dgi) = pg;
+        g_store(xo, tag | pg);
+      }
+    }
+  }
+}
+
+int cu_count() {
+  static int n = -1;
+  if (n < 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) n = v;
+    else n = 0;
+  }
+  return n;
+}
+
+template <int CELL, int H, int P>
+int launch(bool bwd, const PArgs& a, hipStream_t st) {
+  if (bwd)
+    hipLaunchKernelGGL((k_rnn_persist_bwd<CELL, H, P>), dim3(NGROUPS * P), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((k_rnn_persist_fwd<CELL, H, P>), dim3(NGROUPS * P), dim3(256), 0, st, a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+int dispatch(bool bwd, int cell, int H, const PArgs& a, hipStream_t st) {
+  if (H == 1024) {
+    switch (cell) {
+      case CELL_GRU: return launch<CELL_GRU, 1024, 32>(bwd, a, st);
+      case CELL_LSTM: return launch<CELL_LSTM, 1024, 32>(bwd, a, st);
+      case CELL_RNN: return launch<CELL_RNN, 1024, 32>(bwd, a, st);
+    }
+  }
+  if (H == 512) {
+    switch (cell) {
+      case CELL_GRU: return launch<CELL_GRU, 512, 32>(bwd, a, st);
+      case CELL_LSTM: return launch<CELL_LSTM, 512, 32>(bwd, a, st);
+      case CELL_RNN: return launch<CELL_RNN, 512, 32>(bwd, a, st);
+    }
+  }
+  return DS2_ERR_ARG;
+}
+
+long xbuf_bytes(int cell, int H, bool bwd) {
+  const int G = cell == CELL_GRU ? 3 : cell == CELL_LSTM ? 4 : 1;
+  const long X2 = (bwd ? (long)G * H : (long)H) / 2;
+  return (long)NGROUPS * 2 * MAXS * X2 * 8;
+}
+
+}  // namespace
+
+extern "C" {
+
+// 1 if the persistent kernels cover this problem on the current device (bf16 storage only): H in {512, 1024}, the
+// device has exactly 256 CUs (one workgroup per CU, all co-resident), and a direction's share of the minibatch fits
+// the 16-row MFMA tile of each of its 8/D groups.
+int ds2_rnn_persist_supported(int dtype, int cell, int D, int N, int H) {
+  if (dtype != DS2_BF16 || (cell != CELL_GRU && cell != CELL_LSTM && cell != CELL_RNN)) return 0;
+  if (H != 1024 && H != 512) return 0;
+  if (D != 1 && D != 2) return 0;
+  const int gpd = NGROUPS / D;
+  if (N < 1 || (N + gpd - 1) / gpd > MAXS) return 0;
+  return cu_count() == 256 ? 1 : 0;
+}
+
+// bytes of the exchange buffer (max of the forward and backward sweep needs) + 64 for the error word
+long ds2_rnn_persist_ws_bytes(int cell, int H) { return xbuf_bytes(cell, H, true) + 64; }
+
+// Same contract as ds2_rnn_fwd (ds2_rnn.hip) for dtype bf16; ws = ds2_rnn_persist_ws_bytes() bytes (zeroed here).
+// err: one device int, set to 1 if a workgroup gave up waiting (outputs are then NaN-poisoned).
+int ds2_rnn_persist_fwd(int cell, int D, int N, int H, int Tp, const int* lens, const void* GI, const void* Whh,
+                        const float* bhh, const float* h0, const float* c0, void* Hseq, long hseq_dstride, void* S, float* hn,
+                        float* cn, void* ws, int* err, ds2_stream_t st_) {
+  hipStream_t st = (hipStream_t)st_;
+  DS2_REQUIRE(ds2_rnn_persist_supported(DS2_BF16, cell, D, N, H), DS2_ERR_ARG);
+  DS2_REQUIRE(Tp > 0 && Tp < (int)TAG_INIT && ws && err, DS2_ERR_ARG);
+  hipError_t e = hipMemsetAsync(ws, 0, xbuf_bytes(cell, H, false), st);
+  if (e != hipSuccess) return (int)e;
+  PArgs a{};
+  a.N = N; a.Tp = Tp; a.D = D; a.gpd = NGROUPS / D; a.lens = lens; a.W = (const bf16_t*)Whh; a.bhh = bhh;
+  a.GI = (const bf16_t*)GI; a.Hseq = (bf16_t*)Hseq; a.hseq_dstride = hseq_dstride; a.S = (bf16_t*)S; a.h0 = h0; a.c0 = c0;
+  a.hn = hn; a.cn = cn; a.xbuf = (u64*)ws; a.err = err;
+  return dispatch(false, cell, H, a, st);
+}
+
+// Same contract as ds2_rnn_bwd for dtype bf16 (zero initial state).
+int ds2_rnn_persist_bwd(int cell, int D, int N, int H, int Tp, const int* lens, const void* dOut, const void* WhhT,
+                        const void* Hseq, long hseq_dstride, const void* S, void* dGI, void* dGH, void* ws, int* err,
+                        ds2_stream_t st_) {
+  hipStream_t st = (hipStream_t)st_;
+  DS2_REQUIRE(ds2_rnn_persist_supported(DS2_BF16, cell, D, N, H), DS2_ERR_ARG);
+  DS2_REQUIRE(Tp > 0 && Tp < (int)TAG_INIT && ws && err, DS2_ERR_ARG);
+  DS2_REQUIRE(cell != CELL_GRU || dGH != nullptr, DS2_ERR_ARG);
+  hipError_t e = hipMemsetAsync(ws, 0, xbuf_bytes(cell, H, true), st);
+  if (e != hipSuccess) return (int)e;
+  PArgs a{};
+  a.N = N; a.Tp = Tp; a.D = D; a.gpd = NGROUPS / D; a.lens = lens; a.W = (const bf16_t*)WhhT;
+  a.Hseq = (bf16_t*)Hseq; a.hseq_dstride = hseq_dstride; a.S = (bf16_t*)S; a.dOut = (const bf16_t*)dOut;
+  a.dGI = (bf16_t*)dGI; a.dGH = (bf16_t*)dGH; a.xbuf = (u64*)ws; a.err = err;
+  return dispatch(true, cell, H, a, st);
+}
+
+}  // extern "C"

@@ -179,6 +179,32 @@ def conv2_wgrad(dy2, a1):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+_PERSIST_ERR = {}
+
+
+def _persist_err(dev):
+    """One int32 word per device that the persistent recurrent kernels raise when a workgroup times out."""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    t = _PERSIST_ERR.get(key)
+    if t is None:
+        t = _PERSIST_ERR[key] = torch.zeros(16, dtype=torch.int32, device=dev)
+    return t
+
+
+def check_persistent_kernels():
+    """Synchronises and raises if any persistent recurrent kernel launched so far gave up waiting for its peers."""
+    for key, t in _PERSIST_ERR.items():
+        if int(t[0].item()) != 0:
+            raise _lib.Ds2HipError("a persistent recurrent kernel timed out on device %d (outputs were NaN-poisoned)" % key)
+
+
+def use_persistent(kind, dtype, D, N, H):
+    import os
+    if os.environ.get("DS2_RNN_PERSIST", "1") == "0" or dtype != torch.bfloat16:
+        return False
+    return bool(query("ds2_rnn_persist_supported", BF16, CELLS[kind], D, N, H))
+
+
 def rnn_fwd(kind, GI, Whh, bhh, lens, D, N, H, Tp, h0=None, c0=None, save=True):
     """Returns (HseqExt [D][Tp+2][N][H] with zero guard slots, S, hn [D,N,H] f32, cn or None)."""
     dev, dtype = GI.device, GI.dtype
@@ -189,6 +215,12 @@ def rnn_fwd(kind, GI, Whh, bhh, lens, D, N, H, Tp, h0=None, c0=None, save=True):
     Sv = torch.empty((D, Tp, N, max(ns, 1) * H) if ns else (1,), dtype=dtype, device=dev)
     hn = torch.empty((D, N, H), dtype=torch.float32, device=dev)
     cn = torch.empty((D, N, H), dtype=torch.float32, device=dev) if kind == "lstm" else None
+    if use_persistent(kind, dtype, D, N, H):
+        ws = torch.empty(query("ds2_rnn_persist_ws_bytes", CELLS[kind], H), dtype=torch.uint8, device=dev)
+        with _sweep_timer("rnn_fwd_persistent", Tp):
+            call("ds2_rnn_persist_fwd", CELLS[kind], D, N, H, Tp, P(lens), P(GI), P(Whh), P(bhh), P(h0), P(c0),
+                 P(hext[:, 1]), (Tp + 2) * N * H, P(Sv), P(hn), P(cn), P(ws), P(_persist_err(dev)), S())
+        return hext, Sv, hn, cn
     state = torch.empty(query("ds2_rnn_state_bytes", D, N, H), dtype=torch.uint8, device=dev)
     with _sweep_timer("rnn_fwd", Tp):
         call("ds2_rnn_fwd", dt(dtype), CELLS[kind], D, N, H, Tp, P(lens), P(GI), P(Whh), P(bhh), P(h0), P(c0),
@@ -201,6 +233,12 @@ def rnn_bwd(kind, dOut, WhhT, hext, Sv, lens, D, N, H, Tp):
     G = GATES[kind]
     dGI = torch.empty((Tp * N, D * G * H), dtype=dtype, device=dev)
     dGH = torch.empty((D, Tp, N, G * H), dtype=dtype, device=dev) if kind == "gru" else None
+    if use_persistent(kind, dtype, D, N, H):
+        ws = torch.empty(query("ds2_rnn_persist_ws_bytes", CELLS[kind], H), dtype=torch.uint8, device=dev)
+        with _sweep_timer("rnn_bwd_persistent", Tp):
+            call("ds2_rnn_persist_bwd", CELLS[kind], D, N, H, Tp, P(lens), P(dOut), P(WhhT), P(hext[:, 1]), (Tp + 2) * N * H,
+                 P(Sv), P(dGI), P(dGH), P(ws), P(_persist_err(dev)), S())
+        return dGI, dGH
     state = torch.empty(query("ds2_rnn_state_bytes", D, N, H), dtype=torch.uint8, device=dev)
     with _sweep_timer("rnn_bwd", Tp):
         call("ds2_rnn_bwd", dt(dtype), CELLS[kind], D, N, H, Tp, P(lens), P(dOut), P(WhhT), P(hext[:, 1]), (Tp + 2) * N * H,

@@ -103,6 +103,19 @@ int ds2_rnn_fwd(int dtype, int cell, int D, int N, int H, int Tp, const int* len
 int ds2_rnn_bwd(int dtype, int cell, int D, int N, int H, int Tp, const int* lens, const void* dOut, const void* WhhT,
                 const void* Hseq, long hseq_dstride, const void* S, void* dGI, void* dGH, void* state, ds2_stream_t stream);
 
+/* Persistent variant (csrc/ds2_rnn_persist.hip): one launch per sweep, all time steps inside the kernel, W_hh resident in
+ * registers, h exchanged between the workgroups of a group through tagged 8-byte granules.  bf16 storage only; same
+ * buffer contract as ds2_rnn_fwd / ds2_rnn_bwd.  ws: ds2_rnn_persist_ws_bytes() bytes of scratch; err: one device int that
+ * the kernel sets to 1 if a workgroup gave up waiting for its peers (its outputs are then NaN). */
+int ds2_rnn_persist_supported(int dtype, int cell, int D, int N, int H);
+long ds2_rnn_persist_ws_bytes(int cell, int H);
+int ds2_rnn_persist_fwd(int cell, int D, int N, int H, int Tp, const int* lens, const void* GI, const void* Whh,
+                        const float* bhh, const float* h0, const float* c0, void* Hseq, long hseq_dstride, void* S, float* hn,
+                        float* cn, void* ws, int* err, ds2_stream_t stream);
+int ds2_rnn_persist_bwd(int cell, int D, int N, int H, int Tp, const int* lens, const void* dOut, const void* WhhT,
+                        const void* Hseq, long hseq_dstride, const void* S, void* dGI, void* dGH, void* ws, int* err,
+                        ds2_stream_t stream);
+
 /* ---- small sequence ops ---------------------------------------------------------------------------------------------------
  * add2: out = a + b (direction sum, model.py:101).  transpose: dst[C][ldd] = src[R][lds]^T, zero-filling r in [R, ldd).
  * lookahead (model.py:105-135, uni-directional models): y[t] = hardtanh(sum_k w[h][k] * x[t+k]), x/y [Tp*N][H] (T),

@@ -243,6 +243,30 @@ def test_conv2_fwd_dgrad_wgrad(dtype, N, Tp):
 @pytest.mark.parametrize("kind", ["gru", "lstm", "rnn"])
 @pytest.mark.parametrize("D,N,H,Tp", [(2, 3, 32, 13), (1, 20, 48, 9), (2, 37, 32, 7)])
 def test_rnn_sweeps(dtype, kind, D, N, H, Tp):
+    _rnn_sweep_case(dtype, kind, D, N, H, Tp, 0.3)
+
+
+@pytest.mark.parametrize("kind,D,N,H,Tp", [("gru", 2, 11, 512, 21), ("gru", 1, 32, 512, 12), ("gru", 2, 32, 1024, 9),
+                                           ("lstm", 2, 13, 512, 14), ("lstm", 1, 5, 1024, 6), ("rnn", 2, 9, 512, 11),
+                                           ("gru", 2, 1, 512, 7), ("gru", 2, 64, 512, 5)])
+def test_rnn_persistent_sweeps(kind, D, N, H, Tp):
+    """The persistent recurrent kernels (one launch per sweep, W_hh resident in registers, tagged-granule exchange) against
+    the oracle, and against the per-time-step kernels on the same inputs."""
+    o = ops()
+    assert o.use_persistent(kind, torch.bfloat16, D, N, H), "persistent path not selected on this device"
+    res_p = _rnn_sweep_case(torch.bfloat16, kind, D, N, H, Tp, 1.0 / np.sqrt(H))
+    o.check_persistent_kernels()
+    import os
+    os.environ["DS2_RNN_PERSIST"] = "0"
+    try:
+        res_s = _rnn_sweep_case(torch.bfloat16, kind, D, N, H, Tp, 1.0 / np.sqrt(H))
+    finally:
+        os.environ.pop("DS2_RNN_PERSIST")
+    for a, b in zip(res_p, res_s):   # same bf16 operands; only the fp32 summation order differs
+        assert np.abs(a - b).max() <= 2e-2 * max(1.0, np.abs(b).max()), np.abs(a - b).max()
+
+
+def _rnn_sweep_case(dtype, kind, D, N, H, Tp, wscale):
     rs = np.random.RandomState(D * 100 + N + H + Tp)
     G = O.GATES[kind]
     I = 24
@@ -252,7 +276,7 @@ def test_rnn_sweeps(dtype, kind, D, N, H, Tp):
     for i, ln in enumerate(lens):
         x[ln:, i] = 0
     Wih = rs.uniform(-0.3, 0.3, (D, G * H, I))
-    Whh = rs.uniform(-0.3, 0.3, (D, G * H, H))
+    Whh = rs.uniform(-wscale, wscale, (D, G * H, H))
     bih, bhh = rs.uniform(-0.2, 0.2, (D, G * H)), rs.uniform(-0.2, 0.2, (D, G * H))
     Whh_r = rnd(Whh, dtype)
     o = ops()
@@ -288,6 +312,34 @@ def test_rnn_sweeps(dtype, kind, D, N, H, Tp):
         assert np.abs(dgi[:, :, d] - dx).max() / scale < tol * (1 if dtype == torch.float32 else 3), (kind, d)
         if kind == "gru":
             assert relerr(np64(dGH[d]).reshape(Tp * N, G * H).sum(0), dbh) < tol * 4
+    return got, np64(hn_d), dgi
+
+
+def test_rnn_persistent_initial_state():
+    """h0/c0 carry (reference inference.py:86-96) through the persistent forward kernel, batch 1 and batch 3."""
+    rs = np.random.RandomState(12)
+    for kind, D, N, H, Tp in (("lstm", 2, 1, 512, 6), ("gru", 1, 3, 512, 5)):
+        G = O.GATES[kind]
+        GI = rs.standard_normal((Tp * N, D * G * H))
+        Whh, bhh = rs.uniform(-0.05, 0.05, (D, G * H, H)), rs.uniform(-0.2, 0.2, (D, G * H))
+        h0, c0 = rs.standard_normal((D, N, H)), rs.standard_normal((D, N, H))
+        lens = np.array([Tp] + [max(1, Tp - 2)] * (N - 1), dtype=np.int32)
+        dt_ = torch.bfloat16
+        GI_r, Whh_r = rnd(GI, dt_), rnd(Whh, dt_)
+        o = ops()
+        assert o.use_persistent(kind, dt_, D, N, H)
+        hext, Sv, hn, cn = o.rnn_fwd(kind, cu(GI, dt_), cu(Whh, dt_), cu(bhh), torch.from_numpy(lens).to(DEV), D, N, H, Tp,
+                                     h0=cu(h0), c0=cu(c0) if kind == "lstm" else None)
+        o.check_persistent_kernels()
+        for d in range(D):
+            # the kernel feeds the bf16-rounded state to the MFMA and keeps the fp32 state for the elementwise carry
+            out, hn_ref, cn_ref, _ = O.rnn_dir_fwd(kind, GI_r.reshape(Tp, N, D, G * H)[:, :, d], lens, np.eye(G * H), Whh_r[d],
+                                                   np.zeros(G * H), bhh[d], reverse=(d == 1), h0=h0[d],
+                                                   c0=c0[d] if kind == "lstm" else None)
+            assert np.abs(np64(hext[d, 1:Tp + 1]) - out).max() < 4e-2
+            assert np.abs(np64(hn[d]) - hn_ref).max() < 4e-2
+            if kind == "lstm":
+                assert np.abs(np64(cn[d]) - cn_ref).max() < 6e-2
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
