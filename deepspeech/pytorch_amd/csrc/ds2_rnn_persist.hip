@@ -25,6 +25,8 @@
 // raises *err, poisons its outputs with NaN and stops waiting, so the launch always terminates.
 // Roofline: MFMA-shaped work (2*samples*G*H*H flops per step and direction) but latency-bound by construction; the
 // measured quantity is us per time step (bench.py roofline object).
+#include <stdlib.h>
+
 #include "ds2_common.h"
 
 namespace {
@@ -70,40 +72,104 @@ struct PArgs {
   bf16_t* dGH;              // bwd, GRU only: [D][Tp][N][3H]
   u64* xbuf;                // [NGROUPS][2][MAXS][X/2] granules, zeroed before the launch
   int* err;                 // device word, set to 1 on a spin time-out
+  unsigned long long* dbg;  // [NGROUPS][8] cycle counters of workgroup 0 of each group (tools/probe_rnn_persist.py)
+  int dbgmask;              // profiling only: 1 skip GI/dOut/S prefetch loads, 2 skip output stores, 4 skip MFMA, 8 skip gather, 16 skip publish
+  u64* xcc;                 // [NGROUPS][32] start-up exchange of the workgroups' XCC ids, zeroed before the launch
 };
 
 __device__ __forceinline__ u64 g_load(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void g_store(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Publish one granule.  `local` (all workgroups of the group verified to sit on ONE XCD, see group_is_xcd_local): a plain
+// 8-byte store, which stays in that XCD's L2 where the peers' sc1 (L1-bypassing) loads find it at L2 latency.  Otherwise the
+// write-through (sc1) form that is visible chip-wide but drops the line from L2, so every reader pays a fabric round trip.
+__device__ __forceinline__ void publish(u64* p, u64 v, bool local) {
+  if (local)
+    __builtin_nontemporal_store(v, p);   // lowers to a plain-policy `nt` store: line stays in this XCD's L2, no wait inserted
+  else
+    g_store(p, v);
+}
+
+// Start-up handshake (placement-independent sc1 protocol): every workgroup publishes its XCC id, waits for the 31 peers of
+// its group and returns true iff all 32 ids are equal.  Every member evaluates the same 32 words, so the group agrees.
+__device__ __forceinline__ bool group_is_xcd_local(u64* slots /* this group's [32] */, int p, int tid, int* err, bool& dead) {
+  __shared__ int s_local;
+  if (tid < 64) {
+    const unsigned my = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf;   // HW_REG_XCC_ID[3:0]
+    if (tid == 0) g_store(slots + p, (0x5ca1ab1eull << 32) | my);
+    bool same = true;
+    unsigned spins = 0;
+    for (;;) {
+      u64 v = 0;
+      if (tid < 32) v = g_load(slots + tid);
+      const bool bad = tid < 32 && (unsigned)(v >> 32) != 0x5ca1ab1eu;
+      if (!__any(bad)) {
+        same = !(tid < 32) || ((unsigned)v == my);
+        break;
+      }
+      if (++spins > SPIN_LIMIT) {
+        dead = true;
+        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        same = false;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    const bool all_same = __all(same);
+    if (tid == 0) s_local = all_same ? 1 : 0;
+  }
+  __syncthreads();
+  return s_local != 0;
+}
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
 }
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
+// fast gate math for the bf16 path: v_exp_f32 / v_rcp_f32 (1 ulp) instead of the full-precision expf + IEEE division of
+// the fp32 parity kernels -- the gate phase runs on one wave per SIMD, where every VALU instruction is exposed latency.
+__device__ __forceinline__ float fsigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float ftanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+
+__device__ __forceinline__ uint32_t ror8(uint32_t v) {   // lane i <- lane i^8 within each row of 16 lanes
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xf, 0xf, true);
+}
+
+constexpr int chunk_ksteps(int KS, int SPLIT) {
+  return SPLIT == 2 ? (KS <= 24 ? KS : KS / 2) : (KS <= 12 ? KS : (KS % 12 == 0 ? 12 : 8));
+}
+
 // Gathers this wave's K-quarter of the exchanged vector (granules tagged `epoch`) and multiplies it with the resident
-// fragments: acc[tile] += A(samples x K-quarter) * w[tile](16 rows x K-quarter)^T.  `src` = the lane's first granule
-// (sample row and the lane group's 8-k sub-block already applied); consecutive k-steps are 16 granules apart.
-template <int TILES, int KS>
-__device__ __forceinline__ void gather_mma(ds2_f32x4 (&acc)[TILES], const uint4 (&w)[TILES][KS], const u64* src, bool need,
-                                           unsigned epoch, int* err, bool& dead) {
-  // k-steps gathered per poll round (<= 32 granules in flight per lane): the largest divisor of KS that is <= 8
-  constexpr int CH = KS % 8 == 0 ? 8 : KS % 6 == 0 ? 6 : KS % 4 == 0 ? 4 : KS % 3 == 0 ? 3 : KS % 2 == 0 ? 2 : 1;
-  static_assert(KS % CH == 0, "k-steps per wave must be a multiple of the poll chunk");
+// fragments: acc[tile] += A(samples x K-quarter) * w[tile](16 rows x K-quarter)^T.
+// Loads are 16-byte sc1 buffer loads (2 granules each: the sweep is priced per load INSTRUCTION, not per byte).  With
+// SPLIT == 2 (at most 8 samples in the group) the otherwise idle upper 8 lanes of every 16-lane row fetch the second
+// half of each chunk's k-steps for sample (lane & 7) and hand it over with a DPP row rotate: half the loads per lane.
+// A rows >= the sample count may hold anything: they only feed D rows that nobody reads.
+// voff = byte offset (within the group's buffer) of the lane's 4 granules of k-step 0; k-steps are 128 bytes apart.
+template <int TILES, int KS, int SPLIT>
+__device__ __forceinline__ void gather_mma(ds2_f32x4 (&acc)[TILES], const uint4 (&w)[TILES][KS], __amdgpu_buffer_rsrc_t rsrc,
+                                           int voff, int half, bool need, unsigned epoch, int* err, bool& dead,
+                                           unsigned& rounds, bool do_mma) {
+  constexpr int CH = chunk_ksteps(KS, SPLIT);
+  constexpr int PER = CH / SPLIT;   // k-steps a lane loads per chunk
+  static_assert(KS % CH == 0 && CH % SPLIT == 0, "k-steps per wave must tile into poll chunks");
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 #pragma unroll
   for (int c = 0; c < KS / CH; ++c) {
-    u64 v[CH][4];
+    u32x4 v[PER][2];
     unsigned spins = 0;
     for (;;) {
       bool bad = false;
       if (need) {
 #pragma unroll
-        for (int k = 0; k < CH; ++k)
+        for (int i = 0; i < PER; ++i)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[k][q] = g_load(src + 16 * (c * CH + k) + q);
+          for (int q = 0; q < 2; ++q)
+            v[i][q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + (c * CH + half * PER + i) * 128 + q * 16, 0, 16 /* sc1 */);
 #pragma unroll
-        for (int k = 0; k < CH; ++k)
+        for (int i = 0; i < PER; ++i)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) bad |= (unsigned)(v[k][q] >> 32) != epoch;
+          for (int q = 0; q < 2; ++q) bad |= (v[i][q][1] != epoch) | (v[i][q][3] != epoch);
       }
       if (!__any(bad) || dead) break;
       if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
@@ -112,13 +178,17 @@ __device__ __forceinline__ void gather_mma(ds2_f32x4 (&acc)[TILES], const uint4 
         break;
       }
       __builtin_amdgcn_s_sleep(1);
+      ++rounds;
     }
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
+      const int i = k % PER;
       uint4 a = make_uint4(0, 0, 0, 0);
-      if (need) a = make_uint4((uint32_t)v[k][0], (uint32_t)v[k][1], (uint32_t)v[k][2], (uint32_t)v[k][3]);
+      if (need) a = make_uint4(v[i][0][0], v[i][0][2], v[i][1][0], v[i][1][2]);
+      if (SPLIT == 2 && k >= PER) a = make_uint4(ror8(a.x), ror8(a.y), ror8(a.z), ror8(a.w));
 #pragma unroll
-      for (int t = 0; t < TILES; ++t) Mma<bf16_t>::mma16(acc[t], a, w[t][c * CH + k]);
+      for (int t = 0; t < TILES; ++t)
+        if (do_mma) Mma<bf16_t>::mma16(acc[t], a, w[t][c * CH + k]);
     }
   }
 }
@@ -146,7 +216,7 @@ __device__ __forceinline__ float2 load_partials(const float* part, int t, int ro
 // ------------------------------------------------------------------------------------------------------------------
 // forward sweep
 // ------------------------------------------------------------------------------------------------------------------
-template <int CELL, int H, int P>
+template <int CELL, int H, int P, int SPLIT>
 __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd(PArgs a) {
   constexpr int G = CellInfo<CELL>::G, NS = CellInfo<CELL>::NS;
   constexpr int U = H / P;                 // hidden units owned by a workgroup
@@ -177,13 +247,18 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd(PArgs a) {
     }
   }
   u64* xg = a.xbuf + (long)grp * 2 * MAXS * X2;
-  const bool need = li < Ns;
-  const u64* src_base = xg + (long)li * X2 + (wave * (H / 4) + lq * 8) / 2;
+  const int srow = SPLIT == 2 ? (li & 7) : li, half = SPLIT == 2 ? (li >> 3) : 0;
+  const bool need = srow < Ns;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, 2 * MAXS * X2 * 8, 0x00020000);
+  const int voff0 = (srow * X2 + (wave * (H / 4) + lq * 8) / 2) * 8;
 
   // ---- gate-phase identity: thread -> (sample i, unit pair)
   constexpr int UP = U / 2;
-  const int gi_i = tid / UP, up = tid % UP;
-  const bool gate_thread = gi_i < Ns;        // Ns <= 16 and U/2 * 16 <= 256
+  // gate threads are the LAST Ns*UP threads: with <= 8 samples they fill waves 2-3, so that waves 0-1 never issue
+  // stores (vmcnt retires in order: a wave's gather would otherwise wait for its own previous publish to be acknowledged)
+  const int gtid = tid - (256 - Ns * UP);
+  const int gi_i = gtid >= 0 ? gtid / UP : MAXS, up = gtid >= 0 ? gtid % UP : 0;
+  const bool gate_thread = gtid >= 0;
   const int n = slice + a.gpd * gi_i;
   const int j = p * U + 2 * up;              // first of the two hidden units of this thread
   int len = 0;
@@ -207,19 +282,23 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd(PArgs a) {
       bh[g][0] = a.bhh[(long)d * GH + (long)g * H + j];
       bh[g][1] = a.bhh[(long)d * GH + (long)g * H + j + 1];
     }
-    if (a.h0)   // initial state as "step -1": parity 1, tag TAG_INIT
-      g_store(xg + (long)(1 * MAXS + gi_i) * X2 + j / 2, ((u64)TAG_INIT << 32) | pack_bf16x2(hprev0, hprev1));
   }
   bool dead = false;
+  const bool local = group_is_xcd_local(a.xcc + grp * 32, p, tid, a.err, dead);
+  if (gate_thread && a.h0)   // initial state as "step -1": parity 1, tag TAG_INIT
+    publish(xg + (long)(1 * MAXS + gi_i) * X2 + j / 2, ((u64)TAG_INIT << 32) | pack_bf16x2(hprev0, hprev1), local);
+  unsigned rounds = 0;
+  unsigned long long c_gather = 0, c_mma = 0, c_bar = 0, c_gate = 0;
 
   for (int s = 0; s < Tp; ++s) {
+    const unsigned long long t0 = __builtin_readcyclecounter();
     const int t = d == 0 ? s : Tp - 1 - s;
     const int par = s & 1;
     // prefetch the hoisted input projection of this step
     uint32_t gi[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) gi[g] = 0;
-    if (gate_thread) {
+    if (gate_thread && !(a.dbgmask & 1)) {
       const bf16_t* gp = a.GI + ((long)t * N + n) * ldgi + (long)d * GH + j;
 #pragma unroll
       for (int g = 0; g < G; ++g) gi[g] = *reinterpret_cast<const uint32_t*>(gp + (long)g * H);
@@ -227,13 +306,17 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd(PArgs a) {
     ds2_f32x4 acc[TILES];
 #pragma unroll
     for (int tt = 0; tt < TILES; ++tt) acc[tt] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
-    if (s > 0 || a.h0)
-      gather_mma<TILES, KS>(acc, w, src_base + (long)((par ^ 1) * MAXS) * X2, need, s > 0 ? (unsigned)s : TAG_INIT, a.err, dead);
+    if ((s > 0 || a.h0) && !(a.dbgmask & 8))
+      gather_mma<TILES, KS, SPLIT>(acc, w, rsrc, voff0 + (par ^ 1) * MAXS * X2 * 8, half, need, s > 0 ? (unsigned)s : TAG_INIT, a.err,
+                                   dead, rounds, !(a.dbgmask & 4));
+    const unsigned long long t1 = __builtin_readcyclecounter();
     store_partials<TILES>(part[par], acc, wave, lane);
     __syncthreads();
+    const unsigned long long t2 = __builtin_readcyclecounter();
     if (gate_thread) {
       const bool act = t < len;
       float hn0 = 0.f, hn1 = 0.f;     // emitted h_t (0 when inactive)
+      const bool st_on = !(a.dbgmask & 2);
       bf16_t* sv = NS ? a.S + (((long)d * Tp + t) * N + n) * (long)(NS ? NS : 1) * H + j : nullptr;
       float2 gh[G];
 #pragma unroll
@@ -246,60 +329,72 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd(PArgs a) {
         if (act) {
           q0 = gh[2].x + bh[2][0];
           q1 = gh[2].y + bh[2][1];
-          r0 = sigmoid_acc(bf_lo(gi[0]) + gh[0].x + bh[0][0]);
-          r1 = sigmoid_acc(bf_hi(gi[0]) + gh[0].y + bh[0][1]);
-          z0 = sigmoid_acc(bf_lo(gi[1]) + gh[1].x + bh[1][0]);
-          z1 = sigmoid_acc(bf_hi(gi[1]) + gh[1].y + bh[1][1]);
-          n0 = tanhf_(bf_lo(gi[2]) + r0 * q0);
-          n1 = tanhf_(bf_hi(gi[2]) + r1 * q1);
+          r0 = fsigmoid(bf_lo(gi[0]) + gh[0].x + bh[0][0]);
+          r1 = fsigmoid(bf_hi(gi[0]) + gh[0].y + bh[0][1]);
+          z0 = fsigmoid(bf_lo(gi[1]) + gh[1].x + bh[1][0]);
+          z1 = fsigmoid(bf_hi(gi[1]) + gh[1].y + bh[1][1]);
+          n0 = ftanh(bf_lo(gi[2]) + r0 * q0);
+          n1 = ftanh(bf_hi(gi[2]) + r1 * q1);
           hn0 = (1.f - z0) * n0 + z0 * hprev0;
           hn1 = (1.f - z1) * n1 + z1 * hprev1;
           hprev0 = hn0;
           hprev1 = hn1;
         }
-        *reinterpret_cast<uint32_t*>(sv) = pack_bf16x2(r0, r1);
-        *reinterpret_cast<uint32_t*>(sv + H) = pack_bf16x2(z0, z1);
-        *reinterpret_cast<uint32_t*>(sv + 2 * H) = pack_bf16x2(n0, n1);
-        *reinterpret_cast<uint32_t*>(sv + 3 * H) = pack_bf16x2(q0, q1);
+        if (st_on) *reinterpret_cast<uint32_t*>(sv) = pack_bf16x2(r0, r1);
+        if (st_on) *reinterpret_cast<uint32_t*>(sv + H) = pack_bf16x2(z0, z1);
+        if (st_on) *reinterpret_cast<uint32_t*>(sv + 2 * H) = pack_bf16x2(n0, n1);
+        if (st_on) *reinterpret_cast<uint32_t*>(sv + 3 * H) = pack_bf16x2(q0, q1);
       } else if (CELL == CELL_LSTM) {
         float i0 = 0.f, i1 = 0.f, f0 = 0.f, f1 = 0.f, g0 = 0.f, g1 = 0.f, o0 = 0.f, o1 = 0.f, c0 = 0.f, c1 = 0.f;
         if (act) {
-          i0 = sigmoid_acc(bf_lo(gi[0]) + gh[0].x + bh[0][0]);
-          i1 = sigmoid_acc(bf_hi(gi[0]) + gh[0].y + bh[0][1]);
-          f0 = sigmoid_acc(bf_lo(gi[1]) + gh[1].x + bh[1][0]);
-          f1 = sigmoid_acc(bf_hi(gi[1]) + gh[1].y + bh[1][1]);
-          g0 = tanhf_(bf_lo(gi[2]) + gh[2].x + bh[2][0]);
-          g1 = tanhf_(bf_hi(gi[2]) + gh[2].y + bh[2][1]);
-          o0 = sigmoid_acc(bf_lo(gi[3 % G]) + gh[3 % G].x + bh[3 % G][0]);
-          o1 = sigmoid_acc(bf_hi(gi[3 % G]) + gh[3 % G].y + bh[3 % G][1]);
+          i0 = fsigmoid(bf_lo(gi[0]) + gh[0].x + bh[0][0]);
+          i1 = fsigmoid(bf_hi(gi[0]) + gh[0].y + bh[0][1]);
+          f0 = fsigmoid(bf_lo(gi[1]) + gh[1].x + bh[1][0]);
+          f1 = fsigmoid(bf_hi(gi[1]) + gh[1].y + bh[1][1]);
+          g0 = ftanh(bf_lo(gi[2]) + gh[2].x + bh[2][0]);
+          g1 = ftanh(bf_hi(gi[2]) + gh[2].y + bh[2][1]);
+          o0 = fsigmoid(bf_lo(gi[3 % G]) + gh[3 % G].x + bh[3 % G][0]);
+          o1 = fsigmoid(bf_hi(gi[3 % G]) + gh[3 % G].y + bh[3 % G][1]);
           c0 = f0 * cprev0 + i0 * g0;
           c1 = f1 * cprev1 + i1 * g1;
-          hn0 = o0 * tanhf_(c0);
-          hn1 = o1 * tanhf_(c1);
+          hn0 = o0 * ftanh(c0);
+          hn1 = o1 * ftanh(c1);
           cprev0 = c0;
           cprev1 = c1;
           hprev0 = hn0;
           hprev1 = hn1;
         }
-        *reinterpret_cast<uint32_t*>(sv) = pack_bf16x2(i0, i1);
-        *reinterpret_cast<uint32_t*>(sv + H) = pack_bf16x2(f0, f1);
-        *reinterpret_cast<uint32_t*>(sv + 2 * H) = pack_bf16x2(g0, g1);
-        *reinterpret_cast<uint32_t*>(sv + 3 * H) = pack_bf16x2(o0, o1);
-        *reinterpret_cast<uint32_t*>(sv + 4 * H) = pack_bf16x2(c0, c1);
+        if (st_on) *reinterpret_cast<uint32_t*>(sv) = pack_bf16x2(i0, i1);
+        if (st_on) *reinterpret_cast<uint32_t*>(sv + H) = pack_bf16x2(f0, f1);
+        if (st_on) *reinterpret_cast<uint32_t*>(sv + 2 * H) = pack_bf16x2(g0, g1);
+        if (st_on) *reinterpret_cast<uint32_t*>(sv + 3 * H) = pack_bf16x2(o0, o1);
+        if (st_on) *reinterpret_cast<uint32_t*>(sv + 4 * H) = pack_bf16x2(c0, c1);
       } else {
         if (act) {
-          hn0 = tanhf_(bf_lo(gi[0]) + gh[0].x + bh[0][0]);
-          hn1 = tanhf_(bf_hi(gi[0]) + gh[0].y + bh[0][1]);
+          hn0 = ftanh(bf_lo(gi[0]) + gh[0].x + bh[0][0]);
+          hn1 = ftanh(bf_hi(gi[0]) + gh[0].y + bh[0][1]);
           hprev0 = hn0;
           hprev1 = hn1;
         }
       }
       if (dead) hn0 = hn1 = hprev0 = hprev1 = __uint_as_float(0x7fc00000u);   // fail loudly downstream
-      *reinterpret_cast<uint32_t*>(a.Hseq + (long)d * a.hseq_dstride + ((long)t * N + n) * H + j) = pack_bf16x2(hn0, hn1);
+      if (st_on) *reinterpret_cast<uint32_t*>(a.Hseq + (long)d * a.hseq_dstride + ((long)t * N + n) * H + j) = pack_bf16x2(hn0, hn1);
       // publish the carried state (inactive samples republish their unchanged state)
-      g_store(xg + (long)(par * MAXS + gi_i) * X2 + j / 2, ((u64)(unsigned)(s + 1) << 32) | pack_bf16x2(hprev0, hprev1));
+      publish(xg + (long)(par * MAXS + gi_i) * X2 + j / 2, ((u64)(unsigned)(s + 1) << 32) | pack_bf16x2(hprev0, hprev1), local);
     }
+    const unsigned long long t3 = __builtin_readcyclecounter();
+    c_gather += t1 - t0;
+    c_bar += t2 - t1;
+    c_gate += t3 - t2;
   }
+  if (a.dbg && p == 0 && (tid == 0 || tid == 255)) {
+    const int o = grp * 8 + (tid == 0 ? 0 : 4);
+    a.dbg[o + 0] = c_gather;
+    a.dbg[o + 1] = c_bar;
+    a.dbg[o + 2] = c_gate;
+    a.dbg[o + 3] = rounds;
+  }
+  (void)c_mma;
   if (gate_thread) {
     const long so = ((long)d * N + n) * H + j;
     if (a.hn) {
@@ -316,7 +411,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd(PArgs a) {
 // ------------------------------------------------------------------------------------------------------------------
 // BPTT sweep.  dh_t = dOut[t] + carry (elementwise part of dh from the step processed before) + dgh_{t'} * W_hh.
 // ------------------------------------------------------------------------------------------------------------------
-template <int CELL, int H, int P>
+template <int CELL, int H, int P, int SPLIT>
 __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd(PArgs a) {
   constexpr int G = CellInfo<CELL>::G, NS = CellInfo<CELL>::NS;
   constexpr int U = H / P;
@@ -345,21 +440,30 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd(PArgs a) {
     }
   }
   u64* xg = a.xbuf + (long)grp * 2 * MAXS * X2;
-  const bool need = li < Ns;
-  const u64* src_base = xg + (long)li * X2 + (wave * (int)(GH / 4) + lq * 8) / 2;
+  const int srow = SPLIT == 2 ? (li & 7) : li, half = SPLIT == 2 ? (li >> 3) : 0;
+  const bool need = srow < Ns;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, 2 * MAXS * X2 * 8, 0x00020000);
+  const int voff0 = (srow * X2 + (wave * (int)(GH / 4) + lq * 8) / 2) * 8;
 
   constexpr int UP = U / 2;
-  const int gi_i = tid / UP, up = tid % UP;
-  const bool gate_thread = gi_i < Ns;
+  // gate threads are the LAST Ns*UP threads: with <= 8 samples they fill waves 2-3, so that waves 0-1 never issue
+  // stores (vmcnt retires in order: a wave's gather would otherwise wait for its own previous publish to be acknowledged)
+  const int gtid = tid - (256 - Ns * UP);
+  const int gi_i = gtid >= 0 ? gtid / UP : MAXS, up = gtid >= 0 ? gtid % UP : 0;
+  const bool gate_thread = gtid >= 0;
   const int n = slice + a.gpd * gi_i;
   const int j = p * U + 2 * up;
   int len = 0;
   if (gate_thread) len = a.lens[n];
   float car0 = 0.f, car1 = 0.f, dc0 = 0.f, dc1 = 0.f;   // carried dh (elementwise part) and dc
   bool dead = false;
+  const bool local = group_is_xcd_local(a.xcc + grp * 32, p, tid, a.err, dead);
+  unsigned rounds = 0;
+  unsigned long long c_gather = 0, c_bar = 0, c_gate = 0;
   constexpr long NSH = (long)(NS ? NS : 1) * H;
 
   for (int s = 0; s < Tp; ++s) {
+    const unsigned long long t0 = __builtin_readcyclecounter();
     const int t = d == 0 ? Tp - 1 - s : s;
     const int par = s & 1;
     // ---- prefetch everything the gate phase needs
@@ -367,7 +471,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd(PArgs a) {
 #pragma unroll
     for (int q = 0; q < (NS ? NS : 1); ++q) sp[q] = 0;
     const int tprev = d == 0 ? t - 1 : t + 1;            // previous step in FORWARD order of this direction
-    if (gate_thread) {
+    if (gate_thread && !(a.dbgmask & 1)) {
       dout = *reinterpret_cast<const uint32_t*>(a.dOut + ((long)t * N + n) * H + j);
       const long seq = ((long)d * Tp + t) * N + n;
       if (NS) {
@@ -386,9 +490,11 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd(PArgs a) {
     ds2_f32x4 acc[TILES];
 #pragma unroll
     for (int tt = 0; tt < TILES; ++tt) acc[tt] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
-    if (s > 0) gather_mma<TILES, KS>(acc, w, src_base + (long)((par ^ 1) * MAXS) * X2, need, (unsigned)s, a.err, dead);
+    if (s > 0 && !(a.dbgmask & 8)) gather_mma<TILES, KS, SPLIT>(acc, w, rsrc, voff0 + (par ^ 1) * MAXS * X2 * 8, half, need, (unsigned)s, a.err, dead, rounds, !(a.dbgmask & 4));
+    const unsigned long long t1 = __builtin_readcyclecounter();
     store_partials<TILES>(part[par], acc, wave, lane);
     __syncthreads();
+    const unsigned long long t2 = __builtin_readcyclecounter();
     if (gate_thread) {
       const bool act = t < len;
       const float2 mp = load_partials<TILES>(part[par], (2 * up) / 16, gi_i, (2 * up) % 16);
@@ -396,6 +502,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd(PArgs a) {
       bf16_t* dgi = a.dGI + ((long)t * N + n) * ldgi + (long)d * GH + j;
       u64* xo = xg + (long)(par * MAXS + gi_i) * X2 + j / 2;
       const u64 tag = (u64)(unsigned)(s + 1) << 32;
+      const bool st_on = !(a.dbgmask & 2);
       if (CELL == CELL_GRU) {
         float dr0 = 0.f, dr1 = 0.f, dz0 = 0.f, dz1 = 0.f, dn0 = 0.f, dn1 = 0.f, dq0 = 0.f, dq1 = 0.f;
         car0 = din0;
@@ -418,16 +525,16 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd(PArgs a) {
         }
         if (dead) dr0 = dr1 = __uint_as_float(0x7fc00000u);
         const uint32_t pr = pack_bf16x2(dr0, dr1), pz = pack_bf16x2(dz0, dz1), pn = pack_bf16x2(dn0, dn1), pq = pack_bf16x2(dq0, dq1);
-        *reinterpret_cast<uint32_t*>(dgi) = pr;
-        *reinterpret_cast<uint32_t*>(dgi + H) = pz;
-        *reinterpret_cast<uint32_t*>(dgi + 2 * H) = pn;
+        if (st_on) *reinterpret_cast<uint32_t*>(dgi) = pr;
+        if (st_on) *reinterpret_cast<uint32_t*>(dgi + H) = pz;
+        if (st_on) *reinterpret_cast<uint32_t*>(dgi + 2 * H) = pn;
         bf16_t* dgh = a.dGH + (((long)d * Tp + t) * N + n) * GH + j;
-        *reinterpret_cast<uint32_t*>(dgh) = pr;
-        *reinterpret_cast<uint32_t*>(dgh + H) = pz;
-        *reinterpret_cast<uint32_t*>(dgh + 2 * H) = pq;
-        g_store(xo, tag | pr);
-        g_store(xo + H / 2, tag | pz);
-        g_store(xo + H, tag | pq);
+        if (st_on) *reinterpret_cast<uint32_t*>(dgh) = pr;
+        if (st_on) *reinterpret_cast<uint32_t*>(dgh + H) = pz;
+        if (st_on) *reinterpret_cast<uint32_t*>(dgh + 2 * H) = pq;
+        publish(xo, tag | pr, local);
+        publish(xo + H / 2, tag | pz, local);
+        publish(xo + H, tag | pq, local);
       } else if (CELL == CELL_LSTM) {
         float di0 = 0.f, di1 = 0.f, df0 = 0.f, df1 = 0.f, dg0 = 0.f, dg1 = 0.f, do0 = 0.f, do1 = 0.f;
         car0 = din0;
@@ -436,7 +543,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd(PArgs a) {
           constexpr int M = NS ? NS : 1;
           const float i0 = bf_lo(sp[0]), i1 = bf_hi(sp[0]), f0 = bf_lo(sp[1 % M]), f1 = bf_hi(sp[1 % M]);
           const float g0 = bf_lo(sp[2 % M]), g1 = bf_hi(sp[2 % M]), o0 = bf_lo(sp[3 % M]), o1 = bf_hi(sp[3 % M]);
-          const float tc0 = tanhf_(bf_lo(sp[4 % M])), tc1 = tanhf_(bf_hi(sp[4 % M]));
+          const float tc0 = ftanh(bf_lo(sp[4 % M])), tc1 = ftanh(bf_hi(sp[4 % M]));
           const float dh0 = bf_lo(dout) + din0, dh1 = bf_hi(dout) + din1;
           const float dcn0 = dc0 + dh0 * o0 * (1.f - tc0 * tc0), dcn1 = dc1 + dh1 * o1 * (1.f - tc1 * tc1);
           di0 = dcn0 * g0 * i0 * (1.f - i0);
@@ -453,14 +560,14 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd(PArgs a) {
         }
         if (dead) di0 = di1 = __uint_as_float(0x7fc00000u);
         const uint32_t pi = pack_bf16x2(di0, di1), pf = pack_bf16x2(df0, df1), pg = pack_bf16x2(dg0, dg1), po = pack_bf16x2(do0, do1);
-        *reinterpret_cast<uint32_t*>(dgi) = pi;
-        *reinterpret_cast<uint32_t*>(dgi + H) = pf;
-        *reinterpret_cast<uint32_t*>(dgi + 2 * H) = pg;
-        *reinterpret_cast<uint32_t*>(dgi + 3 * H) = po;
-        g_store(xo, tag | pi);
-        g_store(xo + H / 2, tag | pf);
-        g_store(xo + H, tag | pg);
-        g_store(xo + 3 * (H / 2), tag | po);
+        if (st_on) *reinterpret_cast<uint32_t*>(dgi) = pi;
+        if (st_on) *reinterpret_cast<uint32_t*>(dgi + H) = pf;
+        if (st_on) *reinterpret_cast<uint32_t*>(dgi + 2 * H) = pg;
+        if (st_on) *reinterpret_cast<uint32_t*>(dgi + 3 * H) = po;
+        publish(xo, tag | pi, local);
+        publish(xo + H / 2, tag | pf, local);
+        publish(xo + H, tag | pg, local);
+        publish(xo + 3 * (H / 2), tag | po, local);
       } else {
         float dg0 = 0.f, dg1 = 0.f;
         car0 = din0;
@@ -473,10 +580,21 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd(PArgs a) {
         }
         if (dead) dg0 = dg1 = __uint_as_float(0x7fc00000u);
         const uint32_t pg = pack_bf16x2(dg0, dg1);
-        *reinterpret_cast<uint32_t*>(dgi) = pg;
-        g_store(xo, tag | pg);
+        if (st_on) *reinterpret_cast<uint32_t*>(dgi) = pg;
+        publish(xo, tag | pg, local);
       }
     }
+    const unsigned long long t3 = __builtin_readcyclecounter();
+    c_gather += t1 - t0;
+    c_bar += t2 - t1;
+    c_gate += t3 - t2;
+  }
+  if (a.dbg && p == 0 && (tid == 0 || tid == 255)) {
+    const int o = grp * 8 + (tid == 0 ? 0 : 4);
+    a.dbg[o + 0] = c_gather;
+    a.dbg[o + 1] = c_bar;
+    a.dbg[o + 2] = c_gate;
+    a.dbg[o + 3] = rounds;
   }
 }
 
@@ -492,10 +610,18 @@ int cu_count() {
 
 template <int CELL, int H, int P>
 int launch(bool bwd, const PArgs& a, hipStream_t st) {
-  if (bwd)
-    hipLaunchKernelGGL((k_rnn_persist_bwd<CELL, H, P>), dim3(NGROUPS * P), dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL((k_rnn_persist_fwd<CELL, H, P>), dim3(NGROUPS * P), dim3(256), 0, st, a);
+  const bool split = (a.N + a.gpd - 1) / a.gpd <= 8;   // <= 8 samples per group: lane pairs share the gather
+  if (bwd) {
+    if (split)
+      hipLaunchKernelGGL((k_rnn_persist_bwd<CELL, H, P, 2>), dim3(NGROUPS * P), dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((k_rnn_persist_bwd<CELL, H, P, 1>), dim3(NGROUPS * P), dim3(256), 0, st, a);
+  } else {
+    if (split)
+      hipLaunchKernelGGL((k_rnn_persist_fwd<CELL, H, P, 2>), dim3(NGROUPS * P), dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((k_rnn_persist_fwd<CELL, H, P, 1>), dim3(NGROUPS * P), dim3(256), 0, st, a);
+  }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
@@ -517,6 +643,8 @@ int dispatch(bool bwd, int cell, int H, const PArgs& a, hipStream_t st) {
   }
   return DS2_ERR_ARG;
 }
+
+constexpr long AUX_BYTES = 4096;   // [0,1024) cycle counters, [1024,3072) XCC-id handshake slots; exchange buffer follows
 
 long xbuf_bytes(int cell, int H, bool bwd) {
   const int G = cell == CELL_GRU ? 3 : cell == CELL_LSTM ? 4 : 1;
@@ -541,7 +669,7 @@ int ds2_rnn_persist_supported(int dtype, int cell, int D, int N, int H) {
 }
 
 // bytes of the exchange buffer (max of the forward and backward sweep needs) + 64 for the error word
-long ds2_rnn_persist_ws_bytes(int cell, int H) { return xbuf_bytes(cell, H, true) + 64; }
+long ds2_rnn_persist_ws_bytes(int cell, int H) { return AUX_BYTES + xbuf_bytes(cell, H, true); }
 
 // Same contract as ds2_rnn_fwd (ds2_rnn.hip) for dtype bf16; ws = ds2_rnn_persist_ws_bytes() bytes (zeroed here).
 // err: one device int, set to 1 if a workgroup gave up waiting (outputs are then NaN-poisoned).
@@ -551,12 +679,14 @@ int ds2_rnn_persist_fwd(int cell, int D, int N, int H, int Tp, const int* lens, 
   hipStream_t st = (hipStream_t)st_;
   DS2_REQUIRE(ds2_rnn_persist_supported(DS2_BF16, cell, D, N, H), DS2_ERR_ARG);
   DS2_REQUIRE(Tp > 0 && Tp < (int)TAG_INIT && ws && err, DS2_ERR_ARG);
-  hipError_t e = hipMemsetAsync(ws, 0, xbuf_bytes(cell, H, false), st);
+  hipError_t e = hipMemsetAsync(ws, 0, AUX_BYTES + xbuf_bytes(cell, H, false), st);
   if (e != hipSuccess) return (int)e;
   PArgs a{};
   a.N = N; a.Tp = Tp; a.D = D; a.gpd = NGROUPS / D; a.lens = lens; a.W = (const bf16_t*)Whh; a.bhh = bhh;
   a.GI = (const bf16_t*)GI; a.Hseq = (bf16_t*)Hseq; a.hseq_dstride = hseq_dstride; a.S = (bf16_t*)S; a.h0 = h0; a.c0 = c0;
-  a.hn = hn; a.cn = cn; a.xbuf = (u64*)ws; a.err = err;
+  a.hn = hn; a.cn = cn; a.xbuf = (u64*)((char*)ws + AUX_BYTES); a.err = err;
+  a.dbg = (unsigned long long*)ws; a.xcc = (u64*)((char*)ws + 1024);
+  { const char* e_ = getenv("DS2_PERSIST_DBG"); a.dbgmask = e_ ? atoi(e_) : 0; }
   return dispatch(false, cell, H, a, st);
 }
 
@@ -568,12 +698,14 @@ int ds2_rnn_persist_bwd(int cell, int D, int N, int H, int Tp, const int* lens, 
   DS2_REQUIRE(ds2_rnn_persist_supported(DS2_BF16, cell, D, N, H), DS2_ERR_ARG);
   DS2_REQUIRE(Tp > 0 && Tp < (int)TAG_INIT && ws && err, DS2_ERR_ARG);
   DS2_REQUIRE(cell != CELL_GRU || dGH != nullptr, DS2_ERR_ARG);
-  hipError_t e = hipMemsetAsync(ws, 0, xbuf_bytes(cell, H, true), st);
+  hipError_t e = hipMemsetAsync(ws, 0, AUX_BYTES + xbuf_bytes(cell, H, true), st);
   if (e != hipSuccess) return (int)e;
   PArgs a{};
   a.N = N; a.Tp = Tp; a.D = D; a.gpd = NGROUPS / D; a.lens = lens; a.W = (const bf16_t*)WhhT;
   a.Hseq = (bf16_t*)Hseq; a.hseq_dstride = hseq_dstride; a.S = (bf16_t*)S; a.dOut = (const bf16_t*)dOut;
-  a.dGI = (bf16_t*)dGI; a.dGH = (bf16_t*)dGH; a.xbuf = (u64*)ws; a.err = err;
+  a.dGI = (bf16_t*)dGI; a.dGH = (bf16_t*)dGH; a.xbuf = (u64*)((char*)ws + AUX_BYTES); a.err = err;
+  a.dbg = (unsigned long long*)ws; a.xcc = (u64*)((char*)ws + 1024);
+  { const char* e_ = getenv("DS2_PERSIST_DBG"); a.dbgmask = e_ ? atoi(e_) : 0; }
   return dispatch(true, cell, H, a, st);
 }
 

@@ -180,6 +180,7 @@ def conv2_wgrad(dy2, a1):
 
 # ---------------------------------------------------------------------------------------------------------------
 _PERSIST_ERR = {}
+LAST_PERSIST_WS = None   # the most recent persistent sweep's scratch (its tail holds the kernel's cycle counters)
 
 
 def _persist_err(dev):
@@ -217,6 +218,8 @@ def rnn_fwd(kind, GI, Whh, bhh, lens, D, N, H, Tp, h0=None, c0=None, save=True):
     cn = torch.empty((D, N, H), dtype=torch.float32, device=dev) if kind == "lstm" else None
     if use_persistent(kind, dtype, D, N, H):
         ws = torch.empty(query("ds2_rnn_persist_ws_bytes", CELLS[kind], H), dtype=torch.uint8, device=dev)
+        global LAST_PERSIST_WS
+        LAST_PERSIST_WS = ws
         with _sweep_timer("rnn_fwd_persistent", Tp):
             call("ds2_rnn_persist_fwd", CELLS[kind], D, N, H, Tp, P(lens), P(GI), P(Whh), P(bhh), P(h0), P(c0),
                  P(hext[:, 1]), (Tp + 2) * N * H, P(Sv), P(hn), P(cn), P(ws), P(_persist_err(dev)), S())
@@ -235,6 +238,8 @@ def rnn_bwd(kind, dOut, WhhT, hext, Sv, lens, D, N, H, Tp):
     dGH = torch.empty((D, Tp, N, G * H), dtype=dtype, device=dev) if kind == "gru" else None
     if use_persistent(kind, dtype, D, N, H):
         ws = torch.empty(query("ds2_rnn_persist_ws_bytes", CELLS[kind], H), dtype=torch.uint8, device=dev)
+        global LAST_PERSIST_WS
+        LAST_PERSIST_WS = ws
         with _sweep_timer("rnn_bwd_persistent", Tp):
             call("ds2_rnn_persist_bwd", CELLS[kind], D, N, H, Tp, P(lens), P(dOut), P(WhhT), P(hext[:, 1]), (Tp + 2) * N * H,
                  P(Sv), P(dGI), P(dGH), P(ws), P(_persist_err(dev)), S())
