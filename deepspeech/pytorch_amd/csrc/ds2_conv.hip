@@ -319,6 +319,151 @@ __global__ void __launch_bounds__(256, 1) k_conv2_wgrad(const T* __restrict__ dY
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// bf16 variant on the bf16 MFMA (16x the rate of the exact-fp32 form above; the operands ARE bf16 in this mode, so the
+// products are exact and only the fp32 summation order differs).  The contraction runs over POSITIONS, which are the
+// slow axis of the NFTC activations, so both operand tiles are transposed on their way into LDS: a thread loads the same
+// 8 channels of two neighbouring positions (2 x 16 B), pairs them up in registers and writes 8 dwords into a
+// channel-major image  sdy[co][t] / sx[ci][t]  (row strides 272 B / 304 B: conflict-free ds_read_b128 over 16 rows).
+// A fragment = dY^T (rows co, 8 consecutive positions per lane: one aligned ds_read_b128); B fragment of tap kt = the
+// same 8 positions shifted by kt-5: three aligned 16-byte reads per k-step cover all 11 shifts, v_alignbyte picks the
+// window.  Per 128-position tile: 8 k-steps x 11 taps of v_mfma_f32_32x32x16_bf16, k-steps split over the 4 waves; the
+// next tile's global loads are issued before the MFMAs of the current one.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int CWB_DY_LD = 136;          // bf16 per channel row of the dY^T tile (128 positions + pad)
+constexpr int CWB_X_POS = 144;          // staged X positions: t0-8 .. t0+135
+constexpr int CWB_X_LD = 152;
+
+__device__ __forceinline__ uint32_t cw_pair_lo(uint32_t a, uint32_t b) { return (a & 0xffffu) | (b << 16); }      // even channel of (t, t+1)
+__device__ __forceinline__ uint32_t cw_pair_hi(uint32_t a, uint32_t b) { return (a >> 16) | (b & 0xffff0000u); }  // odd channel
+
+template <int S>   // window of 8 bf16 starting at element S (0..7) of the 16-element concatenation lo|hi
+__device__ __forceinline__ uint4 cw_window(const uint4& lo, const uint4& hi) {
+  const uint32_t d[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  constexpr int o = S / 2;
+  if (S % 2 == 0) return make_uint4(d[o], d[o + 1], d[o + 2], d[o + 3]);
+  return make_uint4(__builtin_amdgcn_alignbyte(d[o + 1], d[o], 2), __builtin_amdgcn_alignbyte(d[o + 2], d[o + 1], 2),
+                    __builtin_amdgcn_alignbyte(d[o + 3], d[o + 2], 2), __builtin_amdgcn_alignbyte(d[o + 4], d[o + 3], 2));
+}
+
+template <int KT>
+__device__ __forceinline__ void cw_tap(ds2_f32x16 (&acc)[K2T], const uint4& a, const uint4& q0, const uint4& q1, const uint4& q2) {
+  constexpr int e = KT + 3;   // element offset of tap KT inside the three staged 8-element chunks
+  const uint4 b = e < 8 ? cw_window<e % 8>(q0, q1) : cw_window<e % 8>(q1, q2);
+  Mma<bf16_t>::mma32(acc[KT], a, b);
+}
+
+__global__ void __launch_bounds__(256, 1) k_conv2_wgrad_bf16(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ A1,
+                                                              float* __restrict__ partial, int N, int Tp) {
+  constexpr int TILE_BYTES = CH * (CWB_DY_LD + CWB_X_LD) * 2;   // 8704 + 9728
+  __shared__ __attribute__((aligned(16))) unsigned char smem[TILE_BYTES > 4 * 1024 * 4 ? TILE_BYTES : 4 * 1024 * 4];   // reused by the reduction
+  uint16_t* sdy = reinterpret_cast<uint16_t*>(smem);
+  uint16_t* sx = sdy + CH * CWB_DY_LD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lq = lane >> 5;
+  const int kf = blockIdx.x, split = blockIdx.y;
+  ds2_f32x16 acc[K2T];
+#pragma unroll
+  for (int k = 0; k < K2T; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+
+  // rows (n, fo) whose input row fi = 2 fo - 10 + kf exists
+  const int fo_lo = kf >= 10 ? 0 : (10 - kf + 1) / 2;
+  const int fo_hi = min(F2 - 1, (F1 - 1 + 10 - kf) / 2);
+  const int nvalid = fo_hi - fo_lo + 1;
+  const int ntiles = (Tp + CW_TB - 1) / CW_TB;
+  const long nwork = (long)N * nvalid * ntiles;
+
+  // staging identity: dY item = (position pair tid % 64, channel group tid / 64); X items tid and tid + 256 (< 288)
+  const int dy_pp = tid & 63, dy_v = tid >> 6;
+  const int x_pp0 = tid % 72, x_v0 = tid / 72;              // tid < 256 -> v0 in 0..3 (tid 216..255 -> v0 = 3)
+  const int x_pp1 = (tid + 256) % 72, x_v1 = (tid + 256) / 72;
+  const bool x_has1 = tid + 256 < 72 * 4;
+  uint4 g[6];
+  uint32_t gm[6];   // masks (all ones / zero) for out-of-range positions
+
+  auto issue = [&](long wk) {
+    const int r = (int)(wk / ntiles), t0 = (int)(wk % ntiles) * CW_TB;
+    const int n = r / nvalid, fo = fo_lo + r % nvalid, fi = 2 * fo - 10 + kf;
+    const bf16_t* dyrow = dY + ((long)n * F2 + fo) * Tp * CH;
+    const bf16_t* xrow = A1 + ((long)n * F1 + fi) * Tp * CH;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int t = t0 + 2 * dy_pp + h;
+      gm[h] = t < Tp ? 0xffffffffu : 0u;
+      g[h] = *reinterpret_cast<const uint4*>(dyrow + (long)min(t, Tp - 1) * CH + dy_v * 8);
+      const int tx = t0 - 8 + 2 * x_pp0 + h;
+      gm[2 + h] = (tx >= 0 && tx < Tp) ? 0xffffffffu : 0u;
+      g[2 + h] = *reinterpret_cast<const uint4*>(xrow + (long)min(max(tx, 0), Tp - 1) * CH + x_v0 * 8);
+      const int ty = t0 - 8 + 2 * x_pp1 + h;
+      gm[4 + h] = (x_has1 && ty >= 0 && ty < Tp) ? 0xffffffffu : 0u;
+      g[4 + h] = *reinterpret_cast<const uint4*>(xrow + (long)min(max(ty, 0), Tp - 1) * CH + (x_has1 ? x_v1 : 0) * 8);
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      g[i].x &= gm[i]; g[i].y &= gm[i]; g[i].z &= gm[i]; g[i].w &= gm[i];
+    }
+    {
+      uint32_t* row = reinterpret_cast<uint32_t*>(sdy + (dy_v * 8) * CWB_DY_LD + 2 * dy_pp);
+      constexpr int LD = CWB_DY_LD / 2;
+      row[0 * LD] = cw_pair_lo(g[0].x, g[1].x); row[1 * LD] = cw_pair_hi(g[0].x, g[1].x);
+      row[2 * LD] = cw_pair_lo(g[0].y, g[1].y); row[3 * LD] = cw_pair_hi(g[0].y, g[1].y);
+      row[4 * LD] = cw_pair_lo(g[0].z, g[1].z); row[5 * LD] = cw_pair_hi(g[0].z, g[1].z);
+      row[6 * LD] = cw_pair_lo(g[0].w, g[1].w); row[7 * LD] = cw_pair_hi(g[0].w, g[1].w);
+    }
+    constexpr int LX = CWB_X_LD / 2;
+    {
+      uint32_t* row = reinterpret_cast<uint32_t*>(sx + (x_v0 * 8) * CWB_X_LD + 2 * x_pp0);
+      row[0 * LX] = cw_pair_lo(g[2].x, g[3].x); row[1 * LX] = cw_pair_hi(g[2].x, g[3].x);
+      row[2 * LX] = cw_pair_lo(g[2].y, g[3].y); row[3 * LX] = cw_pair_hi(g[2].y, g[3].y);
+      row[4 * LX] = cw_pair_lo(g[2].z, g[3].z); row[5 * LX] = cw_pair_hi(g[2].z, g[3].z);
+      row[6 * LX] = cw_pair_lo(g[2].w, g[3].w); row[7 * LX] = cw_pair_hi(g[2].w, g[3].w);
+    }
+    if (x_has1) {
+      uint32_t* row = reinterpret_cast<uint32_t*>(sx + (x_v1 * 8) * CWB_X_LD + 2 * x_pp1);
+      row[0 * LX] = cw_pair_lo(g[4].x, g[5].x); row[1 * LX] = cw_pair_hi(g[4].x, g[5].x);
+      row[2 * LX] = cw_pair_lo(g[4].y, g[5].y); row[3 * LX] = cw_pair_hi(g[4].y, g[5].y);
+      row[4 * LX] = cw_pair_lo(g[4].z, g[5].z); row[5 * LX] = cw_pair_hi(g[4].z, g[5].z);
+      row[6 * LX] = cw_pair_lo(g[4].w, g[5].w); row[7 * LX] = cw_pair_hi(g[4].w, g[5].w);
+    }
+  };
+
+  long wk = split;
+  if (wk < nwork) issue(wk);
+  for (; wk < nwork; wk += gridDim.y) {
+    __syncthreads();            // previous tile's fragment reads are done
+    stage();
+    __syncthreads();
+    const long nxt = wk + gridDim.y;
+    if (nxt < nwork) issue(nxt);   // in flight during the MFMAs below
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int ks = wave + 4 * kk;
+      const uint4 a = *reinterpret_cast<const uint4*>(sdy + li * CWB_DY_LD + 16 * ks + 8 * lq);
+      const uint16_t* xb = sx + li * CWB_X_LD + (2 * ks + lq) * 8;
+      const uint4 q0 = *reinterpret_cast<const uint4*>(xb);
+      const uint4 q1 = *reinterpret_cast<const uint4*>(xb + 8);
+      const uint4 q2 = *reinterpret_cast<const uint4*>(xb + 16);
+      cw_tap<0>(acc, a, q0, q1, q2); cw_tap<1>(acc, a, q0, q1, q2); cw_tap<2>(acc, a, q0, q1, q2);
+      cw_tap<3>(acc, a, q0, q1, q2); cw_tap<4>(acc, a, q0, q1, q2); cw_tap<5>(acc, a, q0, q1, q2);
+      cw_tap<6>(acc, a, q0, q1, q2); cw_tap<7>(acc, a, q0, q1, q2); cw_tap<8>(acc, a, q0, q1, q2);
+      cw_tap<9>(acc, a, q0, q1, q2); cw_tap<10>(acc, a, q0, q1, q2);
+    }
+  }
+  float* red = reinterpret_cast<float*>(smem);
+  float* out = partial + ((long)split * (K2F * K2T) + (long)kf * K2T) * (CH * CH);
+  for (int kt = 0; kt < K2T; ++kt) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave * 1024 + mma32_row(r, lane) * 32 + li] = acc[kt][r];
+    __syncthreads();
+    for (int e = tid; e < 1024; e += 256) out[(long)kt * 1024 + e] = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
+  }
+}
+
 template <typename T>
 int conv_tap_launch(const ConvTapArgs& a, hipStream_t st) {
   static bool attr = false;
@@ -410,7 +555,7 @@ int ds2_conv2_wgrad(int dtype, const void* dy2, const void* a1, float* dw2t, int
   if (dtype == DS2_F32)
     hipLaunchKernelGGL(k_conv2_wgrad<float>, grid, dim3(256), 0, st, (const float*)dy2, (const float*)a1, ws, N, Tp);
   else
-    hipLaunchKernelGGL(k_conv2_wgrad<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dy2, (const bf16_t*)a1, ws, N, Tp);
+    hipLaunchKernelGGL(k_conv2_wgrad_bf16, grid, dim3(256), 0, st, (const bf16_t*)dy2, (const bf16_t*)a1, ws, N, Tp);
   DS2_CHECK_LAUNCH();
   const int C = K2F * K2T * CH * CH;
   return ds2_colsum(DS2_F32, ws, CW_SPLITS, C, C, dw2t, 1.0f, ws + (long)CW_SPLITS * C, st_);

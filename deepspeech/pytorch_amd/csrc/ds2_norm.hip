@@ -64,13 +64,44 @@ __global__ void __launch_bounds__(NORM_RY* NORM_CX) k_colstats(const T* __restri
   }
 }
 
-// partial[P][C] -> out[c] = sum_p (fp64 accumulate)
-__global__ void k_colsum_finalize(const float* __restrict__ psum, int P, int C, float* __restrict__ out, float scale) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double a = 0.0;
-  for (int p = 0; p < P; ++p) a += (double)psum[(long)p * C + c];
-  out[c] = (float)(a * (double)scale);
+// Column sums of the per-block partials, partial[P][C], accumulated in fp64.  A finalize block is 32 columns x 8 slices of
+// P: every thread keeps its loads independent (a single thread walking P = 256 partials is 256 dependent L2 round trips,
+// ~60 us for a kernel that moves a few KB), the 8 slices meet in LDS.  Returns the sums to the threads with py == 0.
+constexpr int FIN_COLS = 32, FIN_SLICES = 8;
+template <int NA>
+__device__ __forceinline__ void finalize_sums(const float* const (&arr)[NA], int P, int C, int c, int py, double (&tot)[NA]) {
+  __shared__ double sh[NA][FIN_SLICES][FIN_COLS];
+  double acc[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) acc[a] = 0.0;
+  if (c < C) {
+#pragma unroll 8
+    for (int p = py; p < P; p += FIN_SLICES) {
+#pragma unroll
+      for (int a = 0; a < NA; ++a) acc[a] += (double)arr[a][(long)p * C + c];
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < NA; ++a) sh[a][py][threadIdx.x & (FIN_COLS - 1)] = acc[a];
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < NA; ++a) {
+    double t = 0.0;
+    if (py == 0) {
+#pragma unroll
+      for (int q = 0; q < FIN_SLICES; ++q) t += sh[a][q][threadIdx.x & (FIN_COLS - 1)];
+    }
+    tot[a] = t;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_colsum_finalize(const float* __restrict__ psum, int P, int C, float* __restrict__ out,
+                                                          float scale) {
+  const int c = blockIdx.x * FIN_COLS + (threadIdx.x & (FIN_COLS - 1)), py = threadIdx.x / FIN_COLS;
+  const float* const arr[1] = {psum};
+  double tot[1];
+  finalize_sums<1>(arr, P, C, c, py, tot);
+  if (py == 0 && c < C) out[c] = (float)(tot[0] * (double)scale);
 }
 
 // training-mode statistics -> mean, rstd, scale = gamma*rstd, shift = beta - mean*scale; running stats update
@@ -80,14 +111,13 @@ __global__ void k_bn_finalize(const float* __restrict__ psum, const float* __res
                               float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
                               long long* __restrict__ num_batches_tracked, float* __restrict__ mean_out,
                               float* __restrict__ rstd_out, float* __restrict__ scale_out, float* __restrict__ shift_out) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int p = 0; p < P; ++p) {
-    s += (double)psum[(long)p * C + c];
-    q += (double)psq[(long)p * C + c];
-  }
+  const int c = blockIdx.x * FIN_COLS + (threadIdx.x & (FIN_COLS - 1)), py = threadIdx.x / FIN_COLS;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += 1;
+  const float* const arr[2] = {psum, psq};
+  double tot[2];
+  finalize_sums<2>(arr, P, C, c, py, tot);
+  if (py != 0 || c >= C) return;
+  const double s = tot[0], q = tot[1];
   double mean = s / count;
   double var = q / count - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -242,13 +272,12 @@ __global__ void __launch_bounds__(NORM_RY* NORM_CX)
 __global__ void k_bn_bwd_finalize(const float* __restrict__ psum_g, const float* __restrict__ psum_gx, int P, int C,
                                   double count, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                   float* __restrict__ c1, float* __restrict__ c2) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int p = 0; p < P; ++p) {
-    s += (double)psum_g[(long)p * C + c];
-    q += (double)psum_gx[(long)p * C + c];
-  }
+  const int c = blockIdx.x * FIN_COLS + (threadIdx.x & (FIN_COLS - 1)), py = threadIdx.x / FIN_COLS;
+  const float* const arr[2] = {psum_g, psum_gx};
+  double tot[2];
+  finalize_sums<2>(arr, P, C, c, py, tot);
+  if (py != 0 || c >= C) return;
+  const double s = tot[0], q = tot[1];
   dbeta[c] = (float)s;
   dgamma[c] = (float)q;
   c1[c] = (float)(s / count);
@@ -323,7 +352,7 @@ int ds2_colsum(int dtype, const void* X, long R, int C, long ld, float* out, flo
   else
     rc = colstats_impl<bf16_t>(X, R, C, ld, ws, nullptr, &P, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_colsum_finalize, dim3(ds2_cdiv(C, 256)), dim3(256), 0, st, ws, P, C, out, scale);
+  hipLaunchKernelGGL(k_colsum_finalize, dim3(ds2_cdiv(C, FIN_COLS)), dim3(256), 0, st, ws, P, C, out, scale);
   DS2_CHECK_LAUNCH();
   return 0;
 }
@@ -344,7 +373,7 @@ int ds2_bn_fwd(int dtype, int mode, int training, const void* X, void* Y, long R
     rc = dtype == DS2_F32 ? colstats_impl<float>(X, R, C, ldx, psum, psq, &P, st)
                           : colstats_impl<bf16_t>(X, R, C, ldx, psum, psq, &P, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_bn_finalize, dim3(ds2_cdiv(C, 128)), dim3(128), 0, st, psum, psq, P, C, (double)R, gamma, beta,
+    hipLaunchKernelGGL(k_bn_finalize, dim3(ds2_cdiv(C, FIN_COLS)), dim3(256), 0, st, psum, psq, P, C, (double)R, gamma, beta,
                        eps, momentum, running_mean, running_var, num_batches_tracked, save_mean, save_rstd, save_scale,
                        save_shift);
   } else {
@@ -410,7 +439,7 @@ int ds2_bn_bwd(int dtype, int mode, const void* G, const void* X, void* DX, long
   }
   BOTH(LAUNCH_RED)
   DS2_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(ds2_cdiv(C, 128)), dim3(128), 0, st, ps, pq, P, C, (double)R, dgamma, dbeta,
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(ds2_cdiv(C, FIN_COLS)), dim3(256), 0, st, ps, pq, P, C, (double)R, dgamma, dbeta,
                      c1, c2);
   DS2_CHECK_LAUNCH();
   BOTH(LAUNCH_APP)

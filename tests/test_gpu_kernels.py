@@ -206,7 +206,7 @@ def test_conv1_fwd_and_wgrad(dtype, N, T):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("N,Tp", [(2, 19), (3, 75)])
+@pytest.mark.parametrize("N,Tp", [(2, 19), (3, 75), (2, 300)])
 def test_conv2_fwd_dgrad_wgrad(dtype, N, Tp):
     rs = np.random.RandomState(8 + Tp)
     a1 = np.maximum(rs.standard_normal((N, 32, 81, Tp)), 0)
