@@ -8,6 +8,8 @@
 // pad makes the 16-lane ds_read_b128 groups hit 16 distinct 16-B slots), double-buffered LDS, one barrier per K-tile,
 // next tile's global loads in flight during the MFMAs.  bf16: v_mfma_f32_32x32x16_bf16; f32: v_mfma_f32_32x32x2_f32
 // (exact fp32, used by the 1e-3 parity mode).  Roofline: MFMA (2.5 PF bf16 / 157 TF f32); algorithmic flops 2*M*N*K.
+#include <stdlib.h>
+
 #include "ds2_common.h"
 
 namespace {
@@ -165,6 +167,132 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt(GemmArgs g) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// bf16 fast path: the same 128x128x64 tile, staged with direct global -> LDS DMA (global_load_lds_dwordx4): no staging
+// VGPRs, no ds_write pass.  The DMA writes lane-linear (wave-uniform base + lane*16 B), so an LDS row is the plain 128-byte
+// K-slice of a matrix row; the bank-conflict fix is an XOR swizzle applied to the per-lane SOURCE address and to the
+// fragment read address (both sides or neither, guide rule 21): 16-byte chunk c of tile row r lives in slot
+// c ^ ((r >> 1) & 7) -- the 16 rows of every ds_read_b128 lane group then hit 16 distinct slots of the 256-byte bank row.
+// Two LDS stages; iteration kt: wait for stage kt (vmcnt(0) + barrier), issue the DMA of tile kt+1, MFMA on tile kt.
+// Requires K % 64 == 0 and 16-byte aligned rows (the binding pads K); rows past M / N re-read the last row.
+// Workgroup ids are remapped so that each XCD (own L2) works on a contiguous band of the tile grid.
+// ------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+__global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16_glds(GemmArgs g) {
+  constexpr int KT = 64;                         // elements of K per stage (128 bytes per row)
+  constexpr int ROW = 128;                       // LDS bytes per tile row
+  constexpr int STAGE = (BM + BN) * ROW;         // 32 KiB
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // XCD-aware remap of the (x, y) tile id (bijective for any grid size)
+  const int gx = gridDim.x, nblk = gridDim.x * gridDim.y;
+  int id = blockIdx.y * gx + blockIdx.x;
+  {
+    const int q = nblk / 8, r = nblk % 8, xcd = id % 8, k = id / 8;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int bx = id % gx, by = id / gx;
+  int batch = blockIdx.z, ks = 0;
+  if (g.splitk > 1) {
+    ks = blockIdx.z % g.splitk;
+    batch = blockIdx.z / g.splitk;
+  }
+  const bf16_t* A = (const bf16_t*)g.A + (long)batch * g.sA;
+  const bf16_t* B = (const bf16_t*)g.B + (long)batch * g.sB;
+  const int m0 = by * BM, n0 = bx * BN;
+  const int nkt_total = g.K / KT;
+  int kt_begin = 0, kt_end = nkt_total;
+  if (g.splitk > 1) {
+    const int per = (nkt_total + g.splitk - 1) / g.splitk;
+    kt_begin = ks * per;
+    kt_end = min(nkt_total, kt_begin + per);
+  }
+
+  ds2_f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // DMA identity: wave w stages tile rows [32w, 32w+32) of A and of B, 8 rows (1 KiB) per instruction
+  const int r_in = lane >> 3, slot = lane & 7;
+  const bf16_t* a_src[4];
+  const bf16_t* b_src[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = wave * 32 + j * 8 + r_in;
+    const int chunk = slot ^ ((r >> 1) & 7);
+    a_src[j] = A + (long)min(m0 + r, g.M - 1) * g.lda + chunk * 8;
+    b_src[j] = B + (long)min(n0 + r, g.N - 1) * g.ldb + chunk * 8;
+  }
+  auto dma = [&](int stage, int kt) {
+    unsigned char* sa = smem + stage * STAGE + wave * 32 * ROW;
+    unsigned char* sb = sa + BM * ROW;
+    const int k0 = kt * KT;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(a_src[j] + k0), (lds_ptr_t)(sa + j * 8 * ROW), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(b_src[j] + k0), (lds_ptr_t)(sb + j * 8 * ROW), 16, 0, 0);
+    }
+  };
+
+  const int li = lane & 31, lq = lane >> 5;
+  const int key = (li >> 1) & 7;                 // rows wm*64 + i*32 + li: the swizzle key depends on li only
+  if (kt_begin < kt_end) dma(0, kt_begin);
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int stage = (kt - kt_begin) & 1;
+    __syncthreads();                              // (the compiler drains the DMA queue -- vmcnt(0) -- ahead of the barrier)
+    if (kt + 1 < kt_end) dma(stage ^ 1, kt + 1);
+    const unsigned char* sa = smem + stage * STAGE + (wm * 64 + li) * ROW;
+    const unsigned char* sb = smem + stage * STAGE + BM * ROW + (wn * 64 + li) * ROW;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {                 // k-step of 16 elements = chunks 2c (lq = 0) and 2c+1 (lq = 1)
+      const int off = ((2 * c + lq) ^ key) * 16;
+      const uint4 a0 = *reinterpret_cast<const uint4*>(sa + off);
+      const uint4 a1 = *reinterpret_cast<const uint4*>(sa + 32 * ROW + off);
+      const uint4 b0 = *reinterpret_cast<const uint4*>(sb + off);
+      const uint4 b1 = *reinterpret_cast<const uint4*>(sb + 32 * ROW + off);
+      Mma<bf16_t>::mma32(acc[0][0], a0, b0);
+      Mma<bf16_t>::mma32(acc[0][1], a0, b1);
+      Mma<bf16_t>::mma32(acc[1][0], a1, b0);
+      Mma<bf16_t>::mma32(acc[1][1], a1, b1);
+    }
+  }
+
+  const float* bias = g.bias ? g.bias + (long)batch * g.sBias : nullptr;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + li;
+      if (col >= g.N) continue;
+      const float bv = (bias && ks == 0) ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + mma32_row(r, lane);
+        if (row >= g.M) continue;
+        const float v = acc[i][j][r] + bv;
+        const long off = (long)batch * g.sC + (long)row * g.ldc + col;
+        if (g.out_is_f32) {
+          float* cp = (float*)g.C + off;
+          if (g.splitk > 1)
+            atomicAdd(cp, v);
+          else
+            *cp = v;
+        } else {
+          stf((bf16_t*)g.C + off, v);
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -192,6 +320,15 @@ int ds2_gemm_nt(int dtype, const void* A, const void* B, void* C, const float* b
       attr_f = true;
     }
     hipLaunchKernelGGL(k_gemm_nt<float>, grid, blk, shm, st, g);
+  } else if (K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && getenv("DS2_GEMM_NO_GLDS") == nullptr) {
+    static bool attr_g = false;
+    const size_t shm_g = 2 * (BM + BN) * 128;
+    if (!attr_g) {
+      (void)hipFuncSetAttribute((const void*)k_gemm_nt_bf16_glds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_g);
+      attr_g = true;
+    }
+    g.out_is_f32 = out_f32;
+    hipLaunchKernelGGL(k_gemm_nt_bf16_glds, grid, blk, shm_g, st, g);
   } else {
     static bool attr_b = false;
     if (!attr_b) {

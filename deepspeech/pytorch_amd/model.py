@@ -55,6 +55,7 @@ from .configs import AdamConfig, BiDirectionalConfig, SGDConfig, SpectConfig, Un
 
 N_FREQ_CONV2 = 41
 RNN_INPUT = 32 * N_FREQ_CONV2  # 1312, model.py:166-169
+RNN_INPUT_LD = 1344            # leading dimension of the conv-stack output: 1312 rounded up to the GEMM K-tile (64); pad = 0
 
 
 # ==================================================================================================================
@@ -128,14 +129,16 @@ class _WeightCache:
 
 
 def _perm_cols_to_internal(w):
-    """rnns.0 weight_ih columns: reference feature c*41+f -> internal f*32+c."""
+    """rnns.0 weight_ih columns: reference feature c*41+f -> internal f*32+c, zero-padded to RNN_INPUT_LD columns."""
     g = w.shape[0]
-    return w.reshape(g, 32, N_FREQ_CONV2).permute(0, 2, 1).reshape(g, RNN_INPUT)
+    out = w.new_zeros((g, RNN_INPUT_LD))
+    out[:, :RNN_INPUT] = w.reshape(g, 32, N_FREQ_CONV2).permute(0, 2, 1).reshape(g, RNN_INPUT)
+    return out
 
 
 def _perm_cols_to_reference(w):
     g = w.shape[0]
-    return w.reshape(g, N_FREQ_CONV2, 32).permute(0, 2, 1).reshape(g, RNN_INPUT)
+    return w[:, :RNN_INPUT].reshape(g, N_FREQ_CONV2, 32).permute(0, 2, 1).reshape(g, RNN_INPUT)
 
 
 # ==================================================================================================================
@@ -143,7 +146,7 @@ def _perm_cols_to_reference(w):
 # ==================================================================================================================
 class _ConvStackFn(torch.autograd.Function):
     """MaskConv over conv1-BN-Hardtanh-conv2-BN-Hardtanh (model.py:157-164, 53-69) + collapse/transpose (219-221).
-    Output: X0 [(t*N+n)][1312] in the internal feature order f*32+c."""
+    Output: X0 [(t*N+n)][1344]: 1312 features in the internal order f*32+c + 32 zero pad columns (GEMM K-tile)."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, g1, be1, w2, b2, g2, be2, mod, lens_dev, Tp, dtype, training):
@@ -161,9 +164,10 @@ class _ConvStackFn(torch.autograd.Function):
                          momentum=bn1.momentum)
         y2 = ops.conv2_fwd(a1, w2t, b2.detach(), lens_dev)
         R2 = N * 41 * Tp
-        x0 = torch.empty((Tp * N, RNN_INPUT), dtype=dtype, device=x.device)
+        x0 = torch.empty((Tp * N, RNN_INPUT_LD), dtype=dtype, device=x.device)
+        x0[:, RNN_INPUT:].zero_()
         sv2 = ops.bn_fwd(y2, 2, training, g2.detach(), be2.detach(), bn2.running_mean, bn2.running_var,
-                         bn2.num_batches_tracked, R2, 32, 32, x0, RNN_INPUT, F=41, Tp=Tp, N=N, lens=lens_dev, eps=bn2.eps,
+                         bn2.num_batches_tracked, R2, 32, 32, x0, RNN_INPUT_LD, F=41, Tp=Tp, N=N, lens=lens_dev, eps=bn2.eps,
                          momentum=bn2.momentum)
         ctx.mod, ctx.dims, ctx.sv = mod, (N, T, Tp, dtype), (sv1, sv2)
         ctx.save_for_backward(x, y1, a1, y2, lens_dev, w2)
@@ -178,7 +182,7 @@ class _ConvStackFn(torch.autograd.Function):
         dx0 = dx0.contiguous().to(dtype)
         R1, R2 = N * 81 * Tp, N * 41 * Tp
         dy2 = torch.empty_like(y2)
-        dg2, dbe2 = ops.bn_bwd(dx0, y2, dy2, 2, sv2, R2, 32, RNN_INPUT, 32, 32, F=41, Tp=Tp, N=N, lens=lens_dev)
+        dg2, dbe2 = ops.bn_bwd(dx0, y2, dy2, 2, sv2, R2, 32, RNN_INPUT_LD, 32, 32, F=41, Tp=Tp, N=N, lens=lens_dev)
         db2 = ops.colsum(dy2.view(R2, 32))
         dw2t = ops.conv2_wgrad(dy2, a1)
         dw2 = dw2t.view(21, 11, 32, 32).permute(2, 3, 0, 1).contiguous()
@@ -201,9 +205,9 @@ class _RnnLayerFn(torch.autograd.Function):
         layer = mod.rnns[layer_idx]
         kind, H, D = layer.kind, layer.hidden_size, layer.num_directions
         G = ops.GATES[kind]
-        I = layer.input_size
-        c = mod._cache
         first = layer_idx == 0
+        I = RNN_INPUT_LD if first else layer.input_size    # layer 0 sees the zero-padded conv-stack output
+        c = mod._cache
         wih = [wts[4 * d + 0] for d in range(D)]
         whh = [wts[4 * d + 1] for d in range(D)]
         bih = [wts[4 * d + 2] for d in range(D)]

@@ -97,11 +97,11 @@ def colsum(X, R=None, Cc=None, ld=None, scale=1.0):
 
 
 def transpose(X, R=None, Cc=None, lds=None):
-    """dst[C][ldd] = X[R][C]^T with ldd = roundup(R, 8) and zero fill of the pad columns."""
+    """dst[C][ldd] = X[R][C]^T with ldd = roundup(R, 64) (the K-tile of the MFMA GEMM) and zero fill of the pad columns."""
     R = X.shape[0] if R is None else R
     Cc = X.shape[1] if Cc is None else Cc
     lds = X.stride(0) if lds is None else lds
-    ldd = rup(R, 8)
+    ldd = rup(R, 64)
     out = torch.empty((Cc, ldd), dtype=X.dtype, device=X.device)
     call("ds2_transpose", dt(X), P(X), P(out), R, Cc, lds, ldd, S())
     return out

@@ -40,7 +40,8 @@ TOL = {torch.float32: 2e-5, torch.bfloat16: 1.2e-2}
 
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K", [(200, 77, 96), (128, 128, 64), (257, 300, 1312), (29, 64, 40), (1000, 29, 64)])
+@pytest.mark.parametrize("M,N,K", [(200, 77, 96), (128, 128, 64), (257, 300, 1312), (29, 64, 40), (1000, 29, 64),
+                                   (384, 256, 192), (130, 70, 1344), (1500, 1312, 512)])
 def test_gemm_nt(dtype, M, N, K):
     rs = np.random.RandomState(M + N + K)
     A, B, bias = rs.standard_normal((M, K)), rs.standard_normal((N, K)), rs.standard_normal(N)
@@ -76,7 +77,7 @@ def test_transpose_colsum_add(dtype):
     for R, Cc in [(93, 96), (64, 64), (300, 1312), (7, 8)]:
         X = rs.standard_normal((R, Cc))
         t = o.transpose(cu(X, dtype))
-        assert t.shape == (Cc, (R + 7) // 8 * 8)
+        assert t.shape == (Cc, (R + 63) // 64 * 64)     # padded to the K-tile of the MFMA GEMM, zero filled
         got = np64(t)
         assert np.array_equal(got[:, :R], rnd(X, dtype).T)
         assert np.all(got[:, R:] == 0)
