@@ -13,9 +13,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libds2hip.so")
-SOURCES = ["ds2_norm.hip", "ds2_gemm.hip", "ds2_rnn.hip", "ds2_rnn_persist.hip", "ds2_conv.hip", "ds2_ctc.hip", "ds2_seqops.hip"]
+SOURCES = ["ds2_norm.hip", "ds2_gemm.hip", "ds2_rnn.hip", "ds2_rnn_persist.hip", "ds2_rnn_persist_gru.hip", "ds2_rnn_persist_lstm.hip",
+           "ds2_rnn_persist_rnn.hip", "ds2_conv.hip", "ds2_ctc.hip", "ds2_seqops.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-pass-failed"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-pass-failed"] + \
+    os.environ.get("DS2_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _stale(target, deps):
@@ -27,7 +29,8 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, "ds2_common.h"), os.path.join(HERE, "..", "..", "include", "ds2hip.h")]
+    headers = [os.path.join(CSRC, "ds2_common.h"), os.path.join(CSRC, "ds2_rnn_persist_impl.h"),
+               os.path.join(HERE, "..", "..", "include", "ds2hip.h")]
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
@@ -40,7 +43,7 @@ def build(force=False, verbose=True):
         r = subprocess.run([HIPCC] + FLAGS + ["-c", s, "-o", o], capture_output=True, text=True)
         return s, r.returncode, r.stdout + r.stderr
 
-    with ThreadPoolExecutor(max_workers=6) as ex:
+    with ThreadPoolExecutor(max_workers=8) as ex:
         for s, rc, out in ex.map(cc, jobs):
             if verbose and out.strip():
                 print(out, file=sys.stderr)

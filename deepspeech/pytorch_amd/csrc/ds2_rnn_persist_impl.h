@@ -1,0 +1,676 @@
+// Persistent recurrent sweeps (forward and BPTT) of BatchRNN (reference model.py:94-102) for bf16 storage:
+// ONE launch per layer and sweep, all T' dependent time steps inside the kernel, W_hh resident in registers.
+//
+// Why: the recurrence is 2*L*T' dependent steps per training step (7 510 for the LibriSpeech configuration); a kernel
+// boundary per step costs >= 10 us in practice (ds2_rnn.hip: launch gap + cold dependent-load chain + W_hh re-streamed
+// from L2), the arithmetic of one step is < 0.5 us of MFMA time.  Here the chip is cut into 8 independent GROUPS of 32
+// workgroups (one workgroup per CU; group = blockIdx % 8, which the dispatcher places on one XCD -- a speed
+// assumption only).  A group owns one direction and a slice of the minibatch (samples are independent, so groups never
+// talk to each other); inside a group, workgroup p owns hidden units [p*U, (p+1)*U) of every gate and keeps its slice
+// of W_hh (G*U rows x H, 192 KiB for GRU-1024) in VGPRs as ready-made MFMA B fragments for the whole sweep.
+// Per time step a workgroup
+//   1. gathers the group's h_{t-1} (samples x H, bf16) from the exchange buffer -- 8-byte {tag = step, 2 x bf16}
+//      granules written write-through (sc1) by their producers and polled with sc1 loads: the data is the flag, no fence,
+//      no barrier (MI355X guide section 6 G16, recipe R2).  Wave w gathers exactly the K-quarter it multiplies, straight
+//      into MFMA A-fragment registers (no LDS staging);
+//   2. multiplies it with its resident W slice (v_mfma_f32_16x16x32_bf16, samples are the M rows), K split over the 4
+//      waves, partial sums to LDS (double-buffered by step parity: one barrier per step);
+//   3. 2 hidden units per thread: adds the hoisted input projection (prefetched at the top of the step), gate math in
+//      fp32 with the fp32 carried state in a register, packed-sequence masking, stores (h_t, saved gates), and publishes
+//      its two new h values as one granule.
+// The BPTT kernel has the same skeleton with W_hh^T resident (U rows x G*H), exchanging the gate gradients.
+//
+// Placement independence: any assignment of workgroups to CUs/XCDs is correct as long as all 256 workgroups are
+// co-resident (grid == CU count, 1 wave per SIMD by register use); every spin is bounded and a timed-out workgroup
+// raises *err, poisons its outputs with NaN and stops waiting, so the launch always terminates.
+// Roofline: MFMA-shaped work (2*samples*G*H*H flops per step and direction) but latency-bound by construction; the
+// measured quantity is us per time step (bench.py roofline object).
+#pragma once
+#include <stdlib.h>
+
+#include "ds2_common.h"
+
+namespace ds2p {
+
+typedef unsigned long long u64;
+
+enum { CELL_GRU = 0, CELL_LSTM = 1, CELL_RNN = 2 };
+constexpr int NGROUPS = 8;
+constexpr int MAXS = 16;                 // samples per group (MFMA M tile)
+constexpr unsigned SPIN_LIMIT = 4000000; // ~ seconds; then give up loudly
+constexpr unsigned TAG_INIT = 0x40000000u;
+
+template <int CELL>
+struct CellInfo;
+template <>
+struct CellInfo<CELL_GRU> {
+  static constexpr int G = 3, NS = 4;
+};
+template <>
+struct CellInfo<CELL_LSTM> {
+  static constexpr int G = 4, NS = 5;
+};
+template <>
+struct CellInfo<CELL_RNN> {
+  static constexpr int G = 1, NS = 0;
+};
+
+struct PArgs {
+  int N, Tp, D, gpd;        // gpd = groups per direction (NGROUPS / D)
+  const int* lens;          // [N]
+  const bf16_t* W;          // fwd: W_hh [D][G*H][H]        bwd: W_hh^T [D][H][G*H]
+  const float* bhh;         // [D][G*H]
+  const bf16_t* GI;         // fwd: input projection [Tp*N][D*G*H]
+  bf16_t* Hseq;             // h_t of direction d at Hseq + d*hseq_dstride + (t*N+n)*H (guard slots at t=-1 and t=Tp are zero)
+  long hseq_dstride;
+  bf16_t* S;                // saved planes [D][Tp][N][NS*H]
+  const float* h0;          // [D][N][H] or null
+  const float* c0;
+  float* hn;                // [D][N][H] or null
+  float* cn;
+  const bf16_t* dOut;       // bwd: [Tp][N][H]
+  bf16_t* dGI;              // bwd: [Tp*N][D*G*H]
+  bf16_t* dGH;              // bwd, GRU only: [D][Tp][N][3H]
+  u64* xbuf;                // [NGROUPS][2][MAXS][X/2] granules, zeroed before the launch
+  int* err;                 // device word, set to 1 on a spin time-out
+  unsigned long long* dbg;  // [NGROUPS][8] cycle counters of workgroup 0 of each group (tools/probe_rnn_persist.py)
+  int dbgmask;              // profiling only: 1 skip GI/dOut/S prefetch loads, 2 skip output stores, 8 skip the gather (no exchange)
+  u64* xcc;                 // [NGROUPS][32] start-up exchange of the workgroups' XCC ids, zeroed before the launch
+};
+
+__device__ __forceinline__ u64 g_load(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void g_store(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Publish one granule.  `local` (all workgroups of the group verified to sit on ONE XCD, see group_is_xcd_local): a plain
+// 8-byte store, which stays in that XCD's L2 where the peers' sc1 (L1-bypassing) loads find it at L2 latency.  Otherwise the
+// write-through (sc1) form that is visible chip-wide but drops the line from L2, so every reader pays a fabric round trip.
+__device__ __forceinline__ void publish(u64* p, u64 v, bool local) {
+  if (local)
+    __builtin_nontemporal_store(v, p);   // lowers to a plain-policy `nt` store: line stays in this XCD's L2, no wait inserted
+  else
+    g_store(p, v);
+}
+
+// Start-up handshake (placement-independent sc1 protocol): every workgroup publishes its XCC id, waits for the 31 peers of
+// its group and returns true iff all 32 ids are equal.  Every member evaluates the same 32 words, so the group agrees.
+__device__ __forceinline__ bool group_is_xcd_local(u64* slots /* this group's [32] */, int p, int tid, int* err, bool& dead) {
+  __shared__ int s_local;
+  if (tid < 64) {
+    const unsigned my = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf;   // HW_REG_XCC_ID[3:0]
+    if (tid == 0) g_store(slots + p, (0x5ca1ab1eull << 32) | my);
+    bool same = true;
+    unsigned spins = 0;
+    for (;;) {
+      u64 v = 0;
+      if (tid < 32) v = g_load(slots + tid);
+      const bool bad = tid < 32 && (unsigned)(v >> 32) != 0x5ca1ab1eu;
+      if (!__any(bad)) {
+        same = !(tid < 32) || ((unsigned)v == my);
+        break;
+      }
+      if (++spins > SPIN_LIMIT) {
+        dead = true;
+        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        same = false;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    const bool all_same = __all(same);
+    if (tid == 0) s_local = all_same ? 1 : 0;
+  }
+  __syncthreads();
+  return s_local != 0;
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+}
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// fast gate math for the bf16 path: v_exp_f32 / v_rcp_f32 (1 ulp) instead of the full-precision expf + IEEE division of
+// the fp32 parity kernels -- the gate phase runs on one wave per SIMD, where every VALU instruction is exposed latency.
+__device__ __forceinline__ float fsigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float ftanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+
+__device__ __forceinline__ uint32_t ror8(uint32_t v) {   // lane i <- lane i^8 within each row of 16 lanes
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xf, 0xf, true);
+}
+
+constexpr int chunk_ksteps(int KS, int SPLIT) {
+  return SPLIT == 2 ? (KS <= 24 ? KS : KS / 2) : (KS <= 12 ? KS : (KS % 12 == 0 ? 12 : 8));
+}
+
+// Exchange buffer layout (per group and parity): the MFMA A-fragment order, so that every gather instruction of a wave
+// reads contiguous memory:  [k-step (K/32)][q (2)][lq (4)][row (NROWS)] x 16 bytes, a 16-byte unit = the two granules
+// {k, k+1}, {k+2, k+3} of one sample row with k = 32*kstep + 8*lq + 4*q.  NROWS = 8 (SPLIT == 2) or 16.
+template <int NROWS>
+__device__ __forceinline__ int xunit_bytes(int kstep, int q, int lq, int row) { return (((kstep * 2 + q) * 4 + lq) * NROWS + row) * 16; }
+// byte offset of the granule that carries elements (k, k+1), k even, of sample row `row`
+template <int NROWS>
+__device__ __forceinline__ int xgranule_bytes(int k, int row) {
+  const int kk = k & 31;
+  return xunit_bytes<NROWS>(k >> 5, (kk & 7) >> 2, kk >> 3, row) + ((kk & 3) >> 1) * 8;
+}
+
+// Gathers this wave's K-quarter of the exchanged vector (granules tagged `epoch`) and multiplies it with the resident
+// fragments: acc[tile] += A(samples x K-quarter) * w[tile](16 rows x K-quarter)^T.
+// Loads are 16-byte sc1 buffer loads (2 granules each: the sweep is priced per load INSTRUCTION, not per byte).  With
+// SPLIT == 2 (at most 8 samples in the group) the otherwise idle upper 8 lanes of every 16-lane row fetch the second
+// half of each chunk's k-steps for sample (lane & 7) and hand it over with a DPP row rotate: half the loads per lane.
+// A rows >= the sample count may hold anything: they only feed D rows that nobody reads.
+// The MFMAs run SPECULATIVELY on whatever the loads returned, k-step by k-step as the data lands; the tags are checked
+// afterwards and a (rare) miss restores the accumulators and repeats the chunk.
+// kstep0 = first k-step of this wave's K-quarter.
+template <int TILES, int KS, int SPLIT>
+__device__ __forceinline__ void gather_mma(ds2_f32x4 (&acc)[TILES], const uint4 (&w)[TILES][KS], __amdgpu_buffer_rsrc_t rsrc,
+                                           int par_off, int kstep0, int lq, int srow, int half, bool need, unsigned epoch,
+                                           int* err, bool& dead, unsigned& rounds) {
+  constexpr int CH = chunk_ksteps(KS, SPLIT);
+  constexpr int PER = CH / SPLIT;   // k-steps a lane loads per chunk
+  constexpr int NROWS = SPLIT == 2 ? 8 : 16;
+  static_assert(KS % CH == 0 && CH % SPLIT == 0, "k-steps per wave must tile into poll chunks");
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+#pragma unroll
+  for (int c = 0; c < KS / CH; ++c) {
+    u32x4 v[PER][2];
+    // products of this chunk: straight into `acc` when the K-quarter is a single chunk (the caller passes zeros)
+    ds2_f32x4 part_[KS == CH ? 1 : TILES];
+    ds2_f32x4 (&part)[TILES] = *reinterpret_cast<ds2_f32x4 (*)[TILES]>(KS == CH ? &acc[0] : &part_[0]);
+    // straight-line helpers (the retry path below repeats them; keeping the MFMAs out of the poll loop keeps the
+    // register allocator away from spilling the resident fragments)
+#define DS2_GATHER_LOAD()                                                                                              \
+    if (need) {                                                                                                        \
+      _Pragma("unroll") for (int i = 0; i < PER; ++i) _Pragma("unroll") for (int q = 0; q < 2; ++q)                    \
+          v[i][q] = __builtin_amdgcn_raw_buffer_load_b128(                                                              \
+              rsrc, par_off + xunit_bytes<NROWS>(kstep0 + c * CH + half * PER + i, q, lq, srow), 0, 16 /* sc1 */);      \
+    }
+#define DS2_GATHER_MMA()                                                                                               \
+    _Pragma("unroll") for (int t = 0; t < TILES; ++t) part[t] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};                        \
+    _Pragma("unroll") for (int k = 0; k < CH; ++k) {                                                                   \
+      const int i = k % PER;                                                                                           \
+      uint4 a = make_uint4(0, 0, 0, 0);                                                                                \
+      if (need) a = make_uint4(v[i][0][0], v[i][0][2], v[i][1][0], v[i][1][2]);                                        \
+      if (SPLIT == 2 && k >= PER) a = make_uint4(ror8(a.x), ror8(a.y), ror8(a.z), ror8(a.w));                          \
+      _Pragma("unroll") for (int t = 0; t < TILES; ++t) Mma<bf16_t>::mma16(part[t], a, w[t][c * CH + k]);              \
+    }
+#define DS2_GATHER_CHECK(bad)                                                                                          \
+    bool bad = false;                                                                                                  \
+    if (need) {                                                                                                        \
+      _Pragma("unroll") for (int i = 0; i < PER; ++i) _Pragma("unroll") for (int q = 0; q < 2; ++q)                    \
+          bad |= (v[i][q][1] != epoch) | (v[i][q][3] != epoch);                                                        \
+    }
+    DS2_GATHER_LOAD()
+    DS2_GATHER_MMA()          // speculative: runs k-step by k-step as the loads land
+    DS2_GATHER_CHECK(bad0)
+    if (__any(bad0) && !dead) {   // some granule was not there yet: one more speculative pass (products overlap the reload)
+      __builtin_amdgcn_s_sleep(1);
+      ++rounds;
+      DS2_GATHER_LOAD()
+      DS2_GATHER_MMA()
+      DS2_GATHER_CHECK(bad1)
+      if (__any(bad1)) {          // still not: poll without products until everything is there, then multiply
+        unsigned spins = 0;
+        for (;;) {
+          __builtin_amdgcn_s_sleep(1);
+          ++rounds;
+          DS2_GATHER_LOAD()
+          DS2_GATHER_CHECK(bad2)
+          if (!__any(bad2)) break;
+          if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            dead = true;
+            __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+        DS2_GATHER_MMA()
+      }
+    }
+#undef DS2_GATHER_LOAD
+#undef DS2_GATHER_MMA
+#undef DS2_GATHER_CHECK
+    if (KS != CH) {
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) acc[t] += part[t];
+    }
+  }
+}
+
+template <int TILES>
+__device__ __forceinline__ void store_partials(float* part, const ds2_f32x4 (&acc)[TILES], int wave, int lane) {
+#pragma unroll
+  for (int t = 0; t < TILES; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[((wave * TILES + t) * 16 + mma16_row(r, lane)) * 16 + (lane & 15)] = acc[t][r];
+}
+// sum over the 4 waves of the two adjacent columns (col, col+1) of row `row` of tile `t`
+template <int TILES>
+__device__ __forceinline__ float2 load_partials(const float* part, int t, int row, int col) {
+  float2 s = make_float2(0.f, 0.f);
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const float2 v = *reinterpret_cast<const float2*>(part + ((w * TILES + t) * 16 + row) * 16 + col);
+    s.x += v.x;
+    s.y += v.y;
+  }
+  return s;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// forward sweep
+// ------------------------------------------------------------------------------------------------------------------
+template <int CELL, int H, int P, int SPLIT>
+__global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd(PArgs a) {
+  constexpr int G = CellInfo<CELL>::G, NS = CellInfo<CELL>::NS;
+  constexpr int U = H / P;                 // hidden units owned by a workgroup
+  constexpr int TILES = G * U / 16;        // 16-row MFMA tiles of the resident W slice
+  constexpr int KS = H / 128;              // k-steps (of 32) per wave: K quarter = H/4
+  constexpr int X2 = H / 2;                // granules per sample
+  static_assert(U % 16 == 0 && H % 128 == 0, "unsupported hidden size for the persistent kernel");
+  __shared__ __attribute__((aligned(16))) float part[2][4 * TILES * 256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = blockIdx.x % NGROUPS, p = blockIdx.x / NGROUPS;
+  const int d = grp / a.gpd, slice = grp % a.gpd;
+  const int N = a.N, Tp = a.Tp;
+  const int Ns = (N - slice + a.gpd - 1) / a.gpd;          // samples n = slice + gpd*i, i < Ns
+  const int li = lane & 15, lq = lane >> 4;
+  constexpr long GH = (long)G * H;
+  const long ldgi = (long)a.D * GH;
+
+  // ---- resident W fragments: tile t row li = local row r = 16 t + li -> gate r / U, unit p*U + r % U
+  uint4 w[TILES][KS];
+  {
+    const bf16_t* Wd = a.W + (long)d * GH * H;
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+      const int r = 16 * t + li;
+      const bf16_t* row = Wd + ((long)(r / U) * H + p * U + (r % U)) * H + wave * (H / 4) + lq * 8;
+#pragma unroll
+      for (int k = 0; k < KS; ++k) w[t][k] = *reinterpret_cast<const uint4*>(row + 32 * k);
+    }
+  }
+  u64* xg = a.xbuf + (long)grp * 2 * MAXS * X2;
+  const int srow = SPLIT == 2 ? (li & 7) : li, half = SPLIT == 2 ? (li >> 3) : 0;
+  const bool need = srow < Ns;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, 2 * MAXS * X2 * 8, 0x00020000);
+  constexpr int NROWS = SPLIT == 2 ? 8 : 16;
+  constexpr int PAR_BYTES = MAXS * X2 * 8;     // one parity of the group's buffer
+
+  // ---- gate-phase identity: thread -> (sample i, unit pair)
+  constexpr int UP = U / 2;
+  // Gate threads: the LAST NROWS*16 threads (with <= 8 samples they fill waves 2-3, so that waves 0-1 never issue stores:
+  // vmcnt retires in order and a gather would otherwise wait for the wave's own previous publish to be acknowledged).
+  // Thread bits = (pos, sample row, lq, q) in the order of the exchange layout, so a wave's publish is one contiguous
+  // 512-byte (1 KiB) run; the unit pair of the thread is up = lq*4 + q*2 + pos.
+  static_assert(UP == 16, "the gate-thread <-> exchange-layout map assumes 32 hidden units per workgroup");
+  constexpr int NROWS_ = SPLIT == 2 ? 8 : 16, LR_ = SPLIT == 2 ? 3 : 4;
+  const int gtid = tid - (256 - NROWS_ * UP);
+  const int gi_i = gtid >= 0 ? ((gtid >> 1) & (NROWS_ - 1)) : MAXS;
+  const int up = gtid >= 0 ? (((gtid >> (1 + LR_)) & 3) * 4 + ((gtid >> (3 + LR_)) & 1) * 2 + (gtid & 1)) : 0;
+  const bool gate_thread = gtid >= 0 && gi_i < Ns;
+  const int n = slice + a.gpd * gi_i;
+  const int j = p * U + 2 * up;              // first of the two hidden units of this thread
+  int len = 0;
+  float hprev0 = 0.f, hprev1 = 0.f, cprev0 = 0.f, cprev1 = 0.f;
+  float bh[G][2];
+#pragma unroll
+  for (int g = 0; g < G; ++g) bh[g][0] = bh[g][1] = 0.f;
+  if (gate_thread) {
+    len = a.lens[n];
+    const long so = ((long)d * N + n) * H + j;
+    if (a.h0) {
+      hprev0 = a.h0[so];
+      hprev1 = a.h0[so + 1];
+    }
+    if (CELL == CELL_LSTM && a.c0) {
+      cprev0 = a.c0[so];
+      cprev1 = a.c0[so + 1];
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      bh[g][0] = a.bhh[(long)d * GH + (long)g * H + j];
+      bh[g][1] = a.bhh[(long)d * GH + (long)g * H + j + 1];
+    }
+  }
+  bool dead = false;
+  const bool local = group_is_xcd_local(a.xcc + grp * 32, p, tid, a.err, dead);
+  if (gate_thread && a.h0)   // initial state as "step -1": parity 1, tag TAG_INIT
+    publish((u64*)((char*)xg + PAR_BYTES + xgranule_bytes<NROWS>(j, gi_i)), ((u64)TAG_INIT << 32) | pack_bf16x2(hprev0, hprev1), local);
+  unsigned rounds = 0;
+  unsigned long long c_gather = 0, c_mma = 0, c_bar = 0, c_gate = 0;
+
+  for (int s = 0; s < Tp; ++s) {
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    const int t = d == 0 ? s : Tp - 1 - s;
+    const int par = s & 1;
+    // prefetch the hoisted input projection of this step
+    uint32_t gi[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) gi[g] = 0;
+    if (gate_thread && !(a.dbgmask & 1)) {
+      const bf16_t* gp = a.GI + ((long)t * N + n) * ldgi + (long)d * GH + j;
+#pragma unroll
+      for (int g = 0; g < G; ++g) gi[g] = *reinterpret_cast<const uint32_t*>(gp + (long)g * H);
+    }
+    ds2_f32x4 acc[TILES];
+#pragma unroll
+    for (int tt = 0; tt < TILES; ++tt) acc[tt] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
+    if ((s > 0 || a.h0) && !(a.dbgmask & 8))
+      gather_mma<TILES, KS, SPLIT>(acc, w, rsrc, (par ^ 1) * PAR_BYTES, wave * KS, lq, srow, half, need, s > 0 ? (unsigned)s : TAG_INIT,
+                                   a.err, dead, rounds);
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    store_partials<TILES>(part[par], acc, wave, lane);
+    __syncthreads();
+    const unsigned long long t2 = __builtin_readcyclecounter();
+    if (gate_thread) {
+      const bool act = t < len;
+      float hn0 = 0.f, hn1 = 0.f;     // emitted h_t (0 when inactive)
+      const bool st_on = !(a.dbgmask & 2);
+      bf16_t* sv = NS ? a.S + (((long)d * Tp + t) * N + n) * (long)(NS ? NS : 1) * H + j : nullptr;
+      float2 gh[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const int r = g * U + 2 * up;
+        gh[g] = load_partials<TILES>(part[par], r / 16, gi_i, r % 16);
+      }
+      if (CELL == CELL_GRU) {
+        float r0 = 0.f, r1 = 0.f, z0 = 0.f, z1 = 0.f, n0 = 0.f, n1 = 0.f, q0 = 0.f, q1 = 0.f;
+        if (act) {
+          q0 = gh[2].x + bh[2][0];
+          q1 = gh[2].y + bh[2][1];
+          r0 = fsigmoid(bf_lo(gi[0]) + gh[0].x + bh[0][0]);
+          r1 = fsigmoid(bf_hi(gi[0]) + gh[0].y + bh[0][1]);
+          z0 = fsigmoid(bf_lo(gi[1]) + gh[1].x + bh[1][0]);
+          z1 = fsigmoid(bf_hi(gi[1]) + gh[1].y + bh[1][1]);
+          n0 = ftanh(bf_lo(gi[2]) + r0 * q0);
+          n1 = ftanh(bf_hi(gi[2]) + r1 * q1);
+          hn0 = (1.f - z0) * n0 + z0 * hprev0;
+          hn1 = (1.f - z1) * n1 + z1 * hprev1;
+          hprev0 = hn0;
+          hprev1 = hn1;
+        }
+        if (st_on) *reinterpret_cast<uint32_t*>(sv) = pack_bf16x2(r0, r1);
+        if (st_on) *reinterpret_cast<uint32_t*>(sv + H) = pack_bf16x2(z0, z1);
+        if (st_on) *reinterpret_cast<uint32_t*>(sv + 2 * H) = pack_bf16x2(n0, n1);
+        if (st_on) *reinterpret_cast<uint32_t*>(sv + 3 * H) = pack_bf16x2(q0, q1);
+      } else if (CELL == CELL_LSTM) {
+        float i0 = 0.f, i1 = 0.f, f0 = 0.f, f1 = 0.f, g0 = 0.f, g1 = 0.f, o0 = 0.f, o1 = 0.f, c0 = 0.f, c1 = 0.f;
+        if (act) {
+          i0 = fsigmoid(bf_lo(gi[0]) + gh[0].x + bh[0][0]);
+          i1 = fsigmoid(bf_hi(gi[0]) + gh[0].y + bh[0][1]);
+          f0 = fsigmoid(bf_lo(gi[1]) + gh[1].x + bh[1][0]);
+          f1 = fsigmoid(bf_hi(gi[1]) + gh[1].y + bh[1][1]);
+          g0 = ftanh(bf_lo(gi[2]) + gh[2].x + bh[2][0]);
+          g1 = ftanh(bf_hi(gi[2]) + gh[2].y + bh[2][1]);
+          o0 = fsigmoid(bf_lo(gi[3 % G]) + gh[3 % G].x + bh[3 % G][0]);
+          o1 = fsigmoid(bf_hi(gi[3 % G]) + gh[3 % G].y + bh[3 % G][1]);
+          c0 = f0 * cprev0 + i0 * g0;
+          c1 = f1 * cprev1 + i1 * g1;
+          hn0 = o0 * ftanh(c0);
+          hn1 = o1 * ftanh(c1);
+          cprev0 = c0;
+          cprev1 = c1;
+          hprev0 = hn0;
+          hprev1 = hn1;
+        }
+        if (st_on) *reinterpret_cast<uint32_t*>(sv) = pack_bf16x2(i0, i1);
+        if (st_on) *reinterpret_cast<uint32_t*>(sv + H) = pack_bf16x2(f0, f1);
+        if (st_on) *reinterpret_cast<uint32_t*>(sv + 2 * H) = pack_bf16x2(g0, g1);
+        if (st_on) *reinterpret_cast<uint32_t*>(sv + 3 * H) = pack_bf16x2(o0, o1);
+        if (st_on) *reinterpret_cast<uint32_t*>(sv + 4 * H) = pack_bf16x2(c0, c1);
+      } else {
+        if (act) {
+          hn0 = ftanh(bf_lo(gi[0]) + gh[0].x + bh[0][0]);
+          hn1 = ftanh(bf_hi(gi[0]) + gh[0].y + bh[0][1]);
+          hprev0 = hn0;
+          hprev1 = hn1;
+        }
+      }
+      if (dead) hn0 = hn1 = hprev0 = hprev1 = __uint_as_float(0x7fc00000u);   // fail loudly downstream
+      if (st_on) *reinterpret_cast<uint32_t*>(a.Hseq + (long)d * a.hseq_dstride + ((long)t * N + n) * H + j) = pack_bf16x2(hn0, hn1);
+      // publish the carried state (inactive samples republish their unchanged state)
+      publish((u64*)((char*)xg + par * PAR_BYTES + xgranule_bytes<NROWS>(j, gi_i)), ((u64)(unsigned)(s + 1) << 32) | pack_bf16x2(hprev0, hprev1),
+              local);
+    }
+    const unsigned long long t3 = __builtin_readcyclecounter();
+    c_gather += t1 - t0;
+    c_bar += t2 - t1;
+    c_gate += t3 - t2;
+  }
+  if (a.dbg && p == 0 && (tid == 0 || tid == 255)) {
+    const int o = grp * 8 + (tid == 0 ? 0 : 4);
+    a.dbg[o + 0] = c_gather;
+    a.dbg[o + 1] = c_bar;
+    a.dbg[o + 2] = c_gate;
+    a.dbg[o + 3] = rounds;
+  }
+  (void)c_mma;
+  if (gate_thread) {
+    const long so = ((long)d * N + n) * H + j;
+    if (a.hn) {
+      a.hn[so] = hprev0;
+      a.hn[so + 1] = hprev1;
+    }
+    if (CELL == CELL_LSTM && a.cn) {
+      a.cn[so] = cprev0;
+      a.cn[so + 1] = cprev1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// BPTT sweep.  dh_t = dOut[t] + carry (elementwise part of dh from the step processed before) + dgh_{t'} * W_hh.
+// ------------------------------------------------------------------------------------------------------------------
+template <int CELL, int H, int P, int SPLIT>
+__global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd(PArgs a) {
+  constexpr int G = CellInfo<CELL>::G, NS = CellInfo<CELL>::NS;
+  constexpr int U = H / P;
+  constexpr int TILES = U / 16;            // rows of W_hh^T owned: the U output units
+  constexpr int KS = G * H / 128;          // K = G*H split over 4 waves, 32 per k-step
+  constexpr int X2 = G * H / 2;
+  static_assert(U % 16 == 0 && (G * H) % 128 == 0, "unsupported hidden size for the persistent kernel");
+  __shared__ __attribute__((aligned(16))) float part[2][4 * TILES * 256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = blockIdx.x % NGROUPS, p = blockIdx.x / NGROUPS;
+  const int d = grp / a.gpd, slice = grp % a.gpd;
+  const int N = a.N, Tp = a.Tp;
+  const int Ns = (N - slice + a.gpd - 1) / a.gpd;
+  const int li = lane & 15, lq = lane >> 4;
+  constexpr long GH = (long)G * H;
+  const long ldgi = (long)a.D * GH;
+
+  uint4 w[TILES][KS];
+  {
+    const bf16_t* WT = a.W + (long)d * H * GH;
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+      const bf16_t* row = WT + (long)(p * U + 16 * t + li) * GH + wave * (GH / 4) + lq * 8;
+#pragma unroll
+      for (int k = 0; k < KS; ++k) w[t][k] = *reinterpret_cast<const uint4*>(row + 32 * k);
+    }
+  }
+  u64* xg = a.xbuf + (long)grp * 2 * MAXS * X2;
+  const int srow = SPLIT == 2 ? (li & 7) : li, half = SPLIT == 2 ? (li >> 3) : 0;
+  const bool need = srow < Ns;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, 2 * MAXS * X2 * 8, 0x00020000);
+  constexpr int NROWS = SPLIT == 2 ? 8 : 16;
+  constexpr int PAR_BYTES = MAXS * X2 * 8;
+
+  constexpr int UP = U / 2;
+  // Gate threads: the LAST NROWS*16 threads (with <= 8 samples they fill waves 2-3, so that waves 0-1 never issue stores:
+  // vmcnt retires in order and a gather would otherwise wait for the wave's own previous publish to be acknowledged).
+  // Thread bits = (pos, sample row, lq, q) in the order of the exchange layout, so a wave's publish is one contiguous
+  // 512-byte (1 KiB) run; the unit pair of the thread is up = lq*4 + q*2 + pos.
+  static_assert(UP == 16, "the gate-thread <-> exchange-layout map assumes 32 hidden units per workgroup");
+  constexpr int NROWS_ = SPLIT == 2 ? 8 : 16, LR_ = SPLIT == 2 ? 3 : 4;
+  const int gtid = tid - (256 - NROWS_ * UP);
+  const int gi_i = gtid >= 0 ? ((gtid >> 1) & (NROWS_ - 1)) : MAXS;
+  const int up = gtid >= 0 ? (((gtid >> (1 + LR_)) & 3) * 4 + ((gtid >> (3 + LR_)) & 1) * 2 + (gtid & 1)) : 0;
+  const bool gate_thread = gtid >= 0 && gi_i < Ns;
+  const int n = slice + a.gpd * gi_i;
+  const int j = p * U + 2 * up;
+  int len = 0;
+  if (gate_thread) len = a.lens[n];
+  float car0 = 0.f, car1 = 0.f, dc0 = 0.f, dc1 = 0.f;   // carried dh (elementwise part) and dc
+  bool dead = false;
+  const bool local = group_is_xcd_local(a.xcc + grp * 32, p, tid, a.err, dead);
+  unsigned rounds = 0;
+  unsigned long long c_gather = 0, c_bar = 0, c_gate = 0;
+  constexpr long NSH = (long)(NS ? NS : 1) * H;
+
+  for (int s = 0; s < Tp; ++s) {
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    const int t = d == 0 ? Tp - 1 - s : s;
+    const int par = s & 1;
+    // ---- prefetch everything the gate phase needs
+    uint32_t dout = 0, sp[NS ? NS : 1], hp = 0, cp = 0;
+#pragma unroll
+    for (int q = 0; q < (NS ? NS : 1); ++q) sp[q] = 0;
+    const int tprev = d == 0 ? t - 1 : t + 1;            // previous step in FORWARD order of this direction
+    if (gate_thread && !(a.dbgmask & 1)) {
+      dout = *reinterpret_cast<const uint32_t*>(a.dOut + ((long)t * N + n) * H + j);
+      const long seq = ((long)d * Tp + t) * N + n;
+      if (NS) {
+        const bf16_t* sv = a.S + seq * NSH + j;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) sp[q] = *reinterpret_cast<const uint32_t*>(sv + (long)q * H);
+      }
+      // h_{prev}: guard slots / inactive frames hold zeros, so the read is unconditional (tprev in [-1, Tp])
+      hp = *reinterpret_cast<const uint32_t*>(a.Hseq + (long)d * a.hseq_dstride + ((long)tprev * N + n) * H + j);
+      if (CELL == CELL_LSTM) {
+        const bool has_prev = d == 0 ? (t > 0) : (t + 1 < len);
+        if (has_prev) cp = *reinterpret_cast<const uint32_t*>(a.S + (((long)d * Tp + tprev) * N + n) * NSH + 4 * H + j);
+      }
+      if (CELL == CELL_RNN) hp = *reinterpret_cast<const uint32_t*>(a.Hseq + (long)d * a.hseq_dstride + ((long)t * N + n) * H + j);
+    }
+    ds2_f32x4 acc[TILES];
+#pragma unroll
+    for (int tt = 0; tt < TILES; ++tt) acc[tt] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
+    if (s > 0 && !(a.dbgmask & 8))
+      gather_mma<TILES, KS, SPLIT>(acc, w, rsrc, (par ^ 1) * PAR_BYTES, wave * KS, lq, srow, half, need, (unsigned)s, a.err, dead, rounds);
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    store_partials<TILES>(part[par], acc, wave, lane);
+    __syncthreads();
+    const unsigned long long t2 = __builtin_readcyclecounter();
+    if (gate_thread) {
+      const bool act = t < len;
+      const float2 mp = load_partials<TILES>(part[par], (2 * up) / 16, gi_i, (2 * up) % 16);
+      const float din0 = car0 + mp.x, din1 = car1 + mp.y;
+      bf16_t* dgi = a.dGI + ((long)t * N + n) * ldgi + (long)d * GH + j;
+      char* xo = (char*)xg + par * PAR_BYTES;   // granule of gate g, units (j, j+1): element k = g*H + j
+      const u64 tag = (u64)(unsigned)(s + 1) << 32;
+      const bool st_on = !(a.dbgmask & 2);
+      if (CELL == CELL_GRU) {
+        float dr0 = 0.f, dr1 = 0.f, dz0 = 0.f, dz1 = 0.f, dn0 = 0.f, dn1 = 0.f, dq0 = 0.f, dq1 = 0.f;
+        car0 = din0;
+        car1 = din1;
+        if (act) {
+          const float r0 = bf_lo(sp[0]), r1 = bf_hi(sp[0]), z0 = bf_lo(sp[1 % (NS ? NS : 1)]), z1 = bf_hi(sp[1 % (NS ? NS : 1)]);
+          const float n0 = bf_lo(sp[2 % (NS ? NS : 1)]), n1 = bf_hi(sp[2 % (NS ? NS : 1)]);
+          const float q0 = bf_lo(sp[3 % (NS ? NS : 1)]), q1 = bf_hi(sp[3 % (NS ? NS : 1)]);
+          const float dh0 = bf_lo(dout) + din0, dh1 = bf_hi(dout) + din1;
+          dn0 = dh0 * (1.f - z0) * (1.f - n0 * n0);
+          dn1 = dh1 * (1.f - z1) * (1.f - n1 * n1);
+          dz0 = dh0 * (bf_lo(hp) - n0) * z0 * (1.f - z0);
+          dz1 = dh1 * (bf_hi(hp) - n1) * z1 * (1.f - z1);
+          dr0 = dn0 * q0 * r0 * (1.f - r0);
+          dr1 = dn1 * q1 * r1 * (1.f - r1);
+          dq0 = dn0 * r0;
+          dq1 = dn1 * r1;
+          car0 = dh0 * z0;
+          car1 = dh1 * z1;
+        }
+        if (dead) dr0 = dr1 = __uint_as_float(0x7fc00000u);
+        const uint32_t pr = pack_bf16x2(dr0, dr1), pz = pack_bf16x2(dz0, dz1), pn = pack_bf16x2(dn0, dn1), pq = pack_bf16x2(dq0, dq1);
+        if (st_on) *reinterpret_cast<uint32_t*>(dgi) = pr;
+        if (st_on) *reinterpret_cast<uint32_t*>(dgi + H) = pz;
+        if (st_on) *reinterpret_cast<uint32_t*>(dgi + 2 * H) = pn;
+        bf16_t* dgh = a.dGH + (((long)d * Tp + t) * N + n) * GH + j;
+        if (st_on) *reinterpret_cast<uint32_t*>(dgh) = pr;
+        if (st_on) *reinterpret_cast<uint32_t*>(dgh + H) = pz;
+        if (st_on) *reinterpret_cast<uint32_t*>(dgh + 2 * H) = pq;
+        publish((u64*)(xo + xgranule_bytes<NROWS>(j, gi_i)), tag | pr, local);
+        publish((u64*)(xo + xgranule_bytes<NROWS>(H + j, gi_i)), tag | pz, local);
+        publish((u64*)(xo + xgranule_bytes<NROWS>(2 * H + j, gi_i)), tag | pq, local);
+      } else if (CELL == CELL_LSTM) {
+        float di0 = 0.f, di1 = 0.f, df0 = 0.f, df1 = 0.f, dg0 = 0.f, dg1 = 0.f, do0 = 0.f, do1 = 0.f;
+        car0 = din0;
+        car1 = din1;
+        if (act) {
+          constexpr int M = NS ? NS : 1;
+          const float i0 = bf_lo(sp[0]), i1 = bf_hi(sp[0]), f0 = bf_lo(sp[1 % M]), f1 = bf_hi(sp[1 % M]);
+          const float g0 = bf_lo(sp[2 % M]), g1 = bf_hi(sp[2 % M]), o0 = bf_lo(sp[3 % M]), o1 = bf_hi(sp[3 % M]);
+          const float tc0 = ftanh(bf_lo(sp[4 % M])), tc1 = ftanh(bf_hi(sp[4 % M]));
+          const float dh0 = bf_lo(dout) + din0, dh1 = bf_hi(dout) + din1;
+          const float dcn0 = dc0 + dh0 * o0 * (1.f - tc0 * tc0), dcn1 = dc1 + dh1 * o1 * (1.f - tc1 * tc1);
+          di0 = dcn0 * g0 * i0 * (1.f - i0);
+          di1 = dcn1 * g1 * i1 * (1.f - i1);
+          df0 = dcn0 * bf_lo(cp) * f0 * (1.f - f0);
+          df1 = dcn1 * bf_hi(cp) * f1 * (1.f - f1);
+          dg0 = dcn0 * i0 * (1.f - g0 * g0);
+          dg1 = dcn1 * i1 * (1.f - g1 * g1);
+          do0 = dh0 * tc0 * o0 * (1.f - o0);
+          do1 = dh1 * tc1 * o1 * (1.f - o1);
+          car0 = car1 = 0.f;
+          dc0 = dcn0 * f0;
+          dc1 = dcn1 * f1;
+        }
+        if (dead) di0 = di1 = __uint_as_float(0x7fc00000u);
+        const uint32_t pi = pack_bf16x2(di0, di1), pf = pack_bf16x2(df0, df1), pg = pack_bf16x2(dg0, dg1), po = pack_bf16x2(do0, do1);
+        if (st_on) *reinterpret_cast<uint32_t*>(dgi) = pi;
+        if (st_on) *reinterpret_cast<uint32_t*>(dgi + H) = pf;
+        if (st_on) *reinterpret_cast<uint32_t*>(dgi + 2 * H) = pg;
+        if (st_on) *reinterpret_cast<uint32_t*>(dgi + 3 * H) = po;
+        publish((u64*)(xo + xgranule_bytes<NROWS>(j, gi_i)), tag | pi, local);
+        publish((u64*)(xo + xgranule_bytes<NROWS>(H + j, gi_i)), tag | pf, local);
+        publish((u64*)(xo + xgranule_bytes<NROWS>(2 * H + j, gi_i)), tag | pg, local);
+        publish((u64*)(xo + xgranule_bytes<NROWS>(3 * H + j, gi_i)), tag | po, local);
+      } else {
+        float dg0 = 0.f, dg1 = 0.f;
+        car0 = din0;
+        car1 = din1;
+        if (act) {
+          const float h0v = bf_lo(hp), h1v = bf_hi(hp);
+          dg0 = (bf_lo(dout) + din0) * (1.f - h0v * h0v);
+          dg1 = (bf_hi(dout) + din1) * (1.f - h1v * h1v);
+          car0 = car1 = 0.f;
+        }
+        if (dead) dg0 = dg1 = __uint_as_float(0x7fc00000u);
+        const uint32_t pg = pack_bf16x2(dg0, dg1);
+        if (st_on) *reinterpret_cast<uint32_t*>(dgi) = pg;
+        publish((u64*)(xo + xgranule_bytes<NROWS>(j, gi_i)), tag | pg, local);
+      }
+    }
+    const unsigned long long t3 = __builtin_readcyclecounter();
+    c_gather += t1 - t0;
+    c_bar += t2 - t1;
+    c_gate += t3 - t2;
+  }
+  if (a.dbg && p == 0 && (tid == 0 || tid == 255)) {
+    const int o = grp * 8 + (tid == 0 ? 0 : 4);
+    a.dbg[o + 0] = c_gather;
+    a.dbg[o + 1] = c_bar;
+    a.dbg[o + 2] = c_gate;
+    a.dbg[o + 3] = rounds;
+  }
+}
+
+template <int CELL, int H, int P>
+int launch(bool bwd, const PArgs& a, hipStream_t st) {
+  const bool split = (a.N + a.gpd - 1) / a.gpd <= 8;   // <= 8 samples per group: lane pairs share the gather
+  if (bwd) {
+    if (split)
+      hipLaunchKernelGGL((k_rnn_persist_bwd<CELL, H, P, 2>), dim3(NGROUPS * P), dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((k_rnn_persist_bwd<CELL, H, P, 1>), dim3(NGROUPS * P), dim3(256), 0, st, a);
+  } else {
+    if (split)
+      hipLaunchKernelGGL((k_rnn_persist_fwd<CELL, H, P, 2>), dim3(NGROUPS * P), dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((k_rnn_persist_fwd<CELL, H, P, 1>), dim3(NGROUPS * P), dim3(256), 0, st, a);
+  }
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+
+}  // namespace ds2p

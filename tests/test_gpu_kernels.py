@@ -247,9 +247,9 @@ def test_rnn_sweeps(dtype, kind, D, N, H, Tp):
     _rnn_sweep_case(dtype, kind, D, N, H, Tp, 0.3)
 
 
-@pytest.mark.parametrize("kind,D,N,H,Tp", [("gru", 2, 11, 512, 21), ("gru", 1, 32, 512, 12), ("gru", 2, 32, 1024, 9),
-                                           ("lstm", 2, 13, 512, 14), ("lstm", 1, 5, 1024, 6), ("rnn", 2, 9, 512, 11),
-                                           ("gru", 2, 1, 512, 7), ("gru", 2, 64, 512, 5)])
+@pytest.mark.parametrize("kind,D,N,H,Tp", [("gru", 2, 11, 1024, 13), ("gru", 1, 32, 1024, 8), ("gru", 2, 32, 1024, 9),
+                                           ("lstm", 2, 13, 1024, 7), ("lstm", 1, 5, 1024, 6), ("rnn", 2, 9, 1024, 11),
+                                           ("gru", 2, 1, 1024, 7), ("gru", 2, 64, 1024, 5), ("lstm", 2, 64, 1024, 4)])
 def test_rnn_persistent_sweeps(kind, D, N, H, Tp):
     """The persistent recurrent kernels (one launch per sweep, W_hh resident in registers, tagged-granule exchange) against
     the oracle, and against the per-time-step kernels on the same inputs."""
@@ -319,7 +319,7 @@ def _rnn_sweep_case(dtype, kind, D, N, H, Tp, wscale):
 def test_rnn_persistent_initial_state():
     """h0/c0 carry (reference inference.py:86-96) through the persistent forward kernel, batch 1 and batch 3."""
     rs = np.random.RandomState(12)
-    for kind, D, N, H, Tp in (("lstm", 2, 1, 512, 6), ("gru", 1, 3, 512, 5)):
+    for kind, D, N, H, Tp in (("lstm", 2, 1, 1024, 6), ("gru", 1, 3, 1024, 5)):
         G = O.GATES[kind]
         GI = rs.standard_normal((Tp * N, D * G * H))
         Whh, bhh = rs.uniform(-0.05, 0.05, (D, G * H, H)), rs.uniform(-0.2, 0.2, (D, G * H))
