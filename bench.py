@@ -75,20 +75,9 @@ def train_flops(cfg_name, lengths):
     return 3 * 2.0 * macs * frames
 
 
-class StepModule(torch.nn.Module):
-    """forward(batch) = training_step(batch): lets torch DDP (RCCL) hook the backward of the drop-in class exactly the
-    way Lightning's DDP strategy wraps a LightningModule."""
-
-    def __init__(self, model):
-        super().__init__()
-        self.model = model
-
-    def forward(self, inputs, targets, pct, tsz):
-        return self.model.training_step((inputs, targets, pct, tsz), 0)
-
-
 def run_native(args, rank, world, device):
     from deepspeech.pytorch_amd import configs, ops
+    from deepspeech.pytorch_amd import dist as dsdist
     from deepspeech.pytorch_amd.model import DeepSpeech
     kind, H, L, bi, N, tmin, tmax, dtype = CONFIGS[args.config]
     torch.manual_seed(0)
@@ -99,10 +88,7 @@ def run_native(args, rank, world, device):
     model.train()
     lengths, batch = build_batch(args.config, rank, device)
     opt = model.configure_optimizers()[0][0]
-    step_mod = StepModule(model)
-    if world > 1:
-        step_mod = torch.nn.parallel.DistributedDataParallel(step_mod, device_ids=[device.index], broadcast_buffers=False,
-                                                             bucket_cap_mb=64, gradient_as_bucket_view=True)
+    step_mod = dsdist.wrap_data_parallel(dsdist.StepModule(model), device, world)
     params = [p for p in model.parameters()]
 
     def step():
@@ -124,38 +110,43 @@ def run_native(args, rank, world, device):
         first_loss = float("nan")
     log("timed region")
     ops.SWEEP_EVENTS = []
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        last = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt, last = dsdist.timed_steps(step, args.steps, device, world)
     events, ops.SWEEP_EVENTS = ops.SWEEP_EVENTS, None
     log("timed region done: %.1f ms/step" % (dt / args.steps * 1e3))
     last_loss = float(last.detach().item())
 
-    # ---- roofline of the dominant kernel: the per-time-step recurrent kernel (one launch per time step and sweep)
-    launches = sum(e[1] for e in events)
-    sweep_ms = sum(e[2].elapsed_time(e[3]) for e in events)
+    ops.check_persistent_kernels()
+    # ---- roofline of the dominant kernel: the recurrent sweep (persistent kernel: ONE launch per layer and sweep; the
+    #      per-time-step kernels of ds2_rnn.hip when the persistent path does not cover the shape).  Durations come from
+    #      HIP events recorded around every sweep launch on the launch stream, inside the timed region.
     D, G = (2 if bi else 1), GATES[kind]
     frames = int(out_frames(lengths).sum())
-    # algorithmic flops of one sweep = 2 * (valid frames) * D * G*H*H ; per launch = that / T'
-    flops_per_sweep = 2.0 * frames * D * G * H * H
-    n_sweeps = max(1, len(events))
-    avg_launch_s = (sweep_ms / 1e3) / max(1, launches)
     tp = int(out_frames(lengths).max())
-    achieved = (flops_per_sweep / tp) / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
+    flops_per_sweep = 2.0 * frames * D * G * H * H          # algorithmic: valid frames only
     peak = PEAK_TFLOPS[dtype]
-    roofline = {"bound": "mfma", "kernel": "k_rnn_step_fwd/bwd (one launch per time step)", "achieved": round(achieved, 3),
-                "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 6), "traffic": None,
-                "avg_launch_us": round(avg_launch_s * 1e6, 3), "launches_per_step": launches // max(1, args.steps),
-                "sweep_ms_per_step": round(sweep_ms / max(1, args.steps), 3),
+    per_kind = {}
+    for tag, launches, e0, e1 in events:
+        d = per_kind.setdefault(tag, [0, 0.0])
+        d[0] += 1
+        d[1] += e0.elapsed_time(e1)
+    kernels = {}
+    for tag, (n, ms) in per_kind.items():
+        persistent = tag.endswith("persistent")
+        avg_s = ms / 1e3 / n / (1 if persistent else tp)       # per launch
+        fl = flops_per_sweep if persistent else flops_per_sweep / tp
+        kernels[tag] = {"launches_per_step": (n if persistent else n * tp) // max(1, args.steps), "avg_launch_us": round(avg_s * 1e6, 2),
+                        "us_per_time_step": round(ms * 1e3 / n / tp, 3), "achieved_tflops": round(fl / avg_s / 1e12, 2),
+                        "ms_per_train_step": round(ms / max(1, args.steps), 3)}
+    dom = max(kernels, key=lambda k: kernels[k]["ms_per_train_step"]) if kernels else None
+    names = {"rnn_fwd_persistent": "k_rnn_persist_fwd", "rnn_bwd_persistent": "k_rnn_persist_bwd", "rnn_fwd": "k_rnn_step_fwd",
+             "rnn_bwd": "k_rnn_step_bwd"}
+    roofline = {"bound": "mfma", "kernel": names.get(dom, dom), "achieved": kernels[dom]["achieved_tflops"] if dom else 0.0,
+                "peak": peak, "unit": "TFLOP/s", "frac": round((kernels[dom]["achieved_tflops"] if dom else 0.0) / peak, 6),
+                "traffic": None, "avg_launch_us": kernels[dom]["avg_launch_us"] if dom else None,
+                "us_per_time_step": kernels[dom]["us_per_time_step"] if dom else None,
+                "note": "latency-bound serial recurrence: 2*L*T' dependent steps per train step; flops are the algorithmic "
+                        "h2h products over valid frames",
+                "recurrent_kernels": {names.get(k, k): v for k, v in kernels.items()},
                 "whole_step_frac_of_mfma_roofline": None}
     return lengths, dt, first_loss, last_loss, roofline
 
@@ -266,16 +257,12 @@ def main():
         print(json.dumps(cpu_baseline(args)))
         return
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from deepspeech.pytorch_amd import dist as dsdist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path for the product)")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    rank, world, local_rank = dsdist.init_from_env("nccl")
     device = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
@@ -285,15 +272,7 @@ def main():
 
     from deepspeech.pytorch_amd import synth
     secs_local = synth.audio_seconds(lengths)
-    tt = torch.tensor([dt, secs_local], dtype=torch.float64, device=device)
-    if world > 1:
-        tmax = tt.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = tt.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt_max, secs_total = float(tmax[0]), float(tsum[1])
-    else:
-        dt_max, secs_total = dt, secs_local
+    dt_max, secs_total = dsdist.aggregate(dt, secs_local, device, world)
     kind, H, L, bi, N, tmin, tmax_, dtype = CONFIGS[args.config]
     value = secs_total * args.steps / dt_max
     ms_per_step = dt_max / args.steps * 1e3
@@ -319,9 +298,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline_subprocess(args)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    dsdist.shutdown(world)
 
 
 if __name__ == "__main__":

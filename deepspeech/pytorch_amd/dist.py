@@ -1,0 +1,96 @@
+"""Data-parallel plumbing of the training step: one process per GPU, ``torch.distributed`` over RCCL (backend "nccl" on
+ROCm), gradients all-reduced by torch DDP's bucketed hooks while the backward of the lower layers is still running.
+
+The reference has no explicit collective: Lightning's ``strategy: ddp`` (configs/an4.yaml:13, librispeech.yaml:14) wraps
+the LightningModule in ``DistributedDataParallel`` with ``sync_batchnorm=False`` (lightning_config.py:53), i.e. BatchNorm
+statistics stay rank-local and the only exchange is the gradient mean.  The drop-in class works unchanged under that
+wrapper: every stage of its backward is one autograd node that returns the layer's parameter gradients, so DDP's reducer
+sees a layer's gradients the moment its BPTT sweep ends and overlaps their all-reduce with the sweeps of the layers
+below.  Buckets are sized for xGMI (point-to-point links, ring collectives are per-link bound): 64 MB, one RNN layer's
+gradients (~50 MB fp32 for GRU-1024) per bucket.
+
+Everything here is device-agnostic so that the N > 1 path is covered on CPU with the gloo backend (tests/test_dist.py).
+"""
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+
+class StepModule(torch.nn.Module):
+    """forward(batch...) = model.training_step(batch): what Lightning's DDP strategy does with a LightningModule, so that
+    DDP's forward/backward hooks bracket the whole training step of the drop-in class."""
+
+    def __init__(self, model):
+        super().__init__()
+        self.model = model
+
+    def forward(self, inputs, targets, input_percentages, target_sizes):
+        return self.model.training_step((inputs, targets, input_percentages, target_sizes), 0)
+
+
+def init_from_env(backend):
+    """(rank, world, local_rank) from the launcher's environment (torch.distributed.run); initialises the process group
+    when WORLD_SIZE > 1.  Rendezvous defaults to 127.0.0.1 (single node)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world, local_rank
+
+
+def wrap_data_parallel(step_module, device, world, bucket_cap_mb=64):
+    """DDP over the step module (identity for world == 1).  broadcast_buffers=False: BatchNorm running statistics are
+    per-rank like the reference's sync_batchnorm=False; gradient_as_bucket_view avoids one copy per parameter."""
+    if world == 1:
+        return step_module
+    ids = [device.index] if device.type == "cuda" else None
+    return torch.nn.parallel.DistributedDataParallel(step_module, device_ids=ids, broadcast_buffers=False,
+                                                     bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True)
+
+
+def _sync(device):
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+def timed_steps(step_fn, steps, device, world):
+    """Runs `steps` calls of step_fn bracketed by barrier + device synchronisation on both sides; returns (seconds on this
+    rank, last return value)."""
+    _sync(device)
+    if world > 1:
+        dist.barrier()
+    _sync(device)
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(steps):
+        last = step_fn()
+    _sync(device)
+    if world > 1:
+        dist.barrier()
+    _sync(device)
+    return time.perf_counter() - t0, last
+
+
+def aggregate(seconds, units, device, world):
+    """(max over ranks of the timed seconds, sum over ranks of the processed units)."""
+    if world == 1:
+        return float(seconds), float(units)
+    t = torch.tensor([seconds, units], dtype=torch.float64, device=device)
+    tmax, tsum = t.clone(), t.clone()
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+    return float(tmax[0]), float(tsum[1])
+
+
+def shutdown(world):
+    if world > 1 and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()

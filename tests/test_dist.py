@@ -1,0 +1,111 @@
+"""N > 1 path on CPU: two processes, gloo backend (runs with -m "not gpu").  Covers the data-parallel plumbing that
+bench.py and a Lightning-style DDP launch use around the drop-in class (deepspeech/pytorch_amd/dist.py): the StepModule
+wrapper under torch DDP (gradient mean over ranks, rank-local BatchNorm buffers), the barrier-bracketed timing, the
+max-over-ranks / sum-over-ranks aggregation of the metric, and the per-rank sharding of the synthetic minibatches.
+The HIP kernels themselves cannot run here, so a small CPU stand-in with the drop-in class's training_step signature is
+stepped instead; on the GPU the same wrapper carries the real class (bench.py --gpus N)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+class _StandIn(torch.nn.Module):
+    """training_step((inputs, targets, input_percentages, target_sizes), batch_idx) -> scalar loss (sum over the batch)."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.bn = torch.nn.BatchNorm1d(8)
+        self.fc = torch.nn.Linear(8, 4)
+
+    def training_step(self, batch, batch_idx):
+        x, targets, pct, tsz = batch
+        return (self.fc(self.bn(x)) ** 2).sum() * float(pct.sum())
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from deepspeech.pytorch_amd import dist as dsdist
+    r, w, lr = dsdist.init_from_env("gloo")
+    assert (r, w, lr) == (rank, world, rank)
+    dev = torch.device("cpu")
+    model = _StandIn()
+    step_mod = dsdist.wrap_data_parallel(dsdist.StepModule(model), dev, world)
+    g = torch.Generator().manual_seed(100 + rank)          # every rank has its own minibatch
+    x = torch.randn(6, 8, generator=g)
+    pct = torch.ones(6)
+
+    def step():
+        model.zero_grad()
+        loss = step_mod(x, torch.zeros(1), pct.clone(), torch.ones(6, dtype=torch.int32))
+        loss.backward()
+        return loss
+
+    secs, last = dsdist.timed_steps(step, 3, dev, world)
+    grad = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    # reference: mean over ranks of the gradients of the per-rank losses, computed locally without DDP
+    refs = []
+    for rr in range(world):
+        m2 = _StandIn()
+        gg = torch.Generator().manual_seed(100 + rr)
+        x2 = torch.randn(6, 8, generator=gg)
+        l2 = m2.training_step((x2, None, torch.ones(6), None), 0)
+        l2.backward()
+        refs.append(torch.cat([p.grad.reshape(-1) for p in m2.parameters()]))
+    ref = torch.stack(refs).mean(0)
+    tmax, total = dsdist.aggregate(float(rank + 1), 10.0 * (rank + 1), dev, world)
+    out[rank] = dict(grad_err=float((grad - ref).abs().max()), grad_norm=float(ref.abs().max()), tmax=tmax, total=total,
+                     bn_mean=model.bn.running_mean.clone().numpy(), secs=secs, loss=float(last.detach()))
+    dsdist.shutdown(world)
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_data_parallel_step():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert sorted(out.keys()) == [0, 1]
+    for r in range(world):
+        o = out[r]
+        assert o["grad_err"] <= 1e-5 * max(1.0, o["grad_norm"]), o       # DDP: every rank holds the MEAN gradient
+        assert o["tmax"] == 2.0 and o["total"] == 30.0                     # max over ranks / sum over ranks
+        assert o["secs"] > 0
+    # BatchNorm statistics are rank-local (sync_batchnorm=False in the reference): different minibatches -> different buffers
+    assert not np.allclose(out[0]["bn_mean"], out[1]["bn_mean"])
+
+
+def test_single_rank_is_identity():
+    from deepspeech.pytorch_amd import dist as dsdist
+    m = dsdist.StepModule(_StandIn())
+    assert dsdist.wrap_data_parallel(m, torch.device("cpu"), 1) is m
+    assert dsdist.aggregate(1.5, 7.0, torch.device("cpu"), 1) == (1.5, 7.0)
+
+
+def test_bench_shards_distinct_minibatches_per_rank():
+    import bench
+    l0, _ = bench_lengths(bench, 0)
+    l1, _ = bench_lengths(bench, 1)
+    assert len(l0) == len(l1) == 32 and l0[0] == l1[0] == 1501          # weak scaling: 32 clips per rank, same Tmax
+    assert not np.array_equal(l0, l1)
+    assert all(np.diff(l0) <= 0)                                       # sorted by length, descending (collate contract)
+
+
+def bench_lengths(bench, rank):
+    from deepspeech.pytorch_amd import synth
+    kind, H, L, bi, N, tmin, tmax, dtype = bench.CONFIGS["cfg3"]
+    lengths = synth.synth_lengths(N, tmin, tmax, seed=3 * 1000 + rank)
+    return lengths, None
