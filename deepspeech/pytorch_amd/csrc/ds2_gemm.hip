@@ -258,35 +258,56 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16_glds(GemmArgs g) {
       const uint4 a1 = *reinterpret_cast<const uint4*>(sa + 32 * ROW + off);
       const uint4 b0 = *reinterpret_cast<const uint4*>(sb + off);
       const uint4 b1 = *reinterpret_cast<const uint4*>(sb + 32 * ROW + off);
-      Mma<bf16_t>::mma32(acc[0][0], a0, b0);
-      Mma<bf16_t>::mma32(acc[0][1], a0, b1);
-      Mma<bf16_t>::mma32(acc[1][0], a1, b0);
-      Mma<bf16_t>::mma32(acc[1][1], a1, b1);
+      // operands swapped on purpose: D rows = n (the B matrix' rows), D cols = m, so that a lane holds 4 CONSECUTIVE n
+      // of one output row m per register group -> 8-byte (bf16) / 16-byte (f32) stores instead of 2-byte ones
+      Mma<bf16_t>::mma32(acc[0][0], b0, a0);
+      Mma<bf16_t>::mma32(acc[0][1], b1, a0);
+      Mma<bf16_t>::mma32(acc[1][0], b0, a1);
+      Mma<bf16_t>::mma32(acc[1][1], b1, a1);
     }
   }
 
   const float* bias = g.bias ? g.bias + (long)batch * g.sBias : nullptr;
+  const bool n_vec_ok = (g.ldc % 4 == 0);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
+    const int row = m0 + wm * 64 + i * 32 + li;                 // output row m of this lane
+    if (row >= g.M) continue;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wn * 64 + j * 32 + li;
-      if (col >= g.N) continue;
-      const float bv = (bias && ks == 0) ? bias[col] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + i * 32 + mma32_row(r, lane);
-        if (row >= g.M) continue;
-        const float v = acc[i][j][r] + bv;
+      for (int q = 0; q < 4; ++q) {                              // register group: columns n = base + 8q + 4lq + {0..3}
+        const int col = n0 + wn * 64 + j * 32 + 8 * q + 4 * lq;
+        if (col >= g.N) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] + ((bias && ks == 0 && col + e < g.N) ? bias[col + e] : 0.f);
         const long off = (long)batch * g.sC + (long)row * g.ldc + col;
         if (g.out_is_f32) {
           float* cp = (float*)g.C + off;
-          if (g.splitk > 1)
-            atomicAdd(cp, v);
-          else
-            *cp = v;
+          if (g.splitk > 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (col + e < g.N) atomicAdd(cp + e, v[e]);
+          } else if (col + 3 < g.N && n_vec_ok) {
+            *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (col + e < g.N) cp[e] = v[e];
+          }
         } else {
-          stf((bf16_t*)g.C + off, v);
+          bf16_t* cp = (bf16_t*)g.C + off;
+          if (col + 3 < g.N && n_vec_ok) {
+            uint2 pk;
+            pk.x = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
+            pk.y = (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16);
+            *reinterpret_cast<uint2*>(cp) = pk;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (col + e < g.N) stf(cp + e, v[e]);
+          }
         }
       }
     }
@@ -320,7 +341,8 @@ int ds2_gemm_nt(int dtype, const void* A, const void* B, void* C, const float* b
       attr_f = true;
     }
     hipLaunchKernelGGL(k_gemm_nt<float>, grid, blk, shm, st, g);
-  } else if (K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && getenv("DS2_GEMM_NO_GLDS") == nullptr) {
+  } else if (splitk == 1 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && getenv("DS2_GEMM_NO_GLDS") == nullptr) {
+    // (split-K accumulates with atomics: the register-staged kernel below keeps them coalesced along n)
     static bool attr_g = false;
     const size_t shm_g = 2 * (BM + BN) * 128;
     if (!attr_g) {

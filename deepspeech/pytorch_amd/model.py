@@ -128,6 +128,15 @@ class _WeightCache:
         self._store.clear()
 
 
+def _wgrad_splitk(M, N, K):
+    """Split-K factor of a weight-gradient GEMM (long K = T'*N, few output tiles): enough 128x128 tiles x K-slices to
+    fill the 256 CUs twice over, every slice keeping >= 32 K-tiles."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if tiles > 256:          # already fills the chip: the DMA-staged kernel without atomics is faster (tools/bench_gemm.py)
+        return 1
+    return max(1, min(8, 768 // max(tiles, 1), K // (64 * 32)))
+
+
 def _perm_cols_to_internal(w):
     """rnns.0 weight_ih columns: reference feature c*41+f -> internal f*32+c, zero-padded to RNN_INPUT_LD columns."""
     g = w.shape[0]
@@ -197,113 +206,158 @@ class _ConvStackFn(torch.autograd.Function):
         return (None, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, None, None, None, None, None)
 
 
-class _RnnLayerFn(torch.autograd.Function):
-    """BatchRNN.forward (model.py:94-102): [SequenceWise BatchNorm1d] -> packed bi/uni GRU/LSTM/RNN -> direction sum."""
+class _RnnStackFn(torch.autograd.Function):
+    """The whole stack of BatchRNN layers (model.py:228-230 over BatchRNN.forward, model.py:94-102):
+    per layer [SequenceWise BatchNorm1d] -> input projection GEMM -> packed bi/uni GRU/LSTM/RNN sweep -> direction sum.
+
+    One autograd node for all layers so that backward controls the schedule: the BPTT sweeps, the dX GEMM and the
+    BatchNorm backward form the dependent chain on the caller's stream, while every layer's weight-gradient work
+    (operand transposes, dW_ih / dW_hh GEMMs, bias column sums) runs on a second HIP stream UNDER the next layer's sweep --
+    the persistent recurrent kernel is latency-bound and leaves most of each CU's registers, LDS and MFMA issue slots free.
+    The streams join before backward returns, so the gradients handed to autograd / DDP are complete."""
 
     @staticmethod
-    def forward(ctx, X, bn_w, bn_b, mod, layer_idx, lens_dev, N, Tp, dtype, training, h0, c0, *wts):
-        layer = mod.rnns[layer_idx]
-        kind, H, D = layer.kind, layer.hidden_size, layer.num_directions
-        G = ops.GATES[kind]
-        first = layer_idx == 0
-        I = RNN_INPUT_LD if first else layer.input_size    # layer 0 sees the zero-padded conv-stack output
+    def forward(ctx, X, mod, lens_dev, N, Tp, dtype, training, n_layers, *rest):
+        L = n_layers
+        hs0, cs0, params = rest[:L], rest[L:2 * L], rest[2 * L:]
         c = mod._cache
-        wih = [wts[4 * d + 0] for d in range(D)]
-        whh = [wts[4 * d + 1] for d in range(D)]
-        bih = [wts[4 * d + 2] for d in range(D)]
-        bhh = [wts[4 * d + 3] for d in range(D)]
-
-        def build_ih():
-            w = torch.cat([p.detach() for p in wih], 0)
-            if first:
-                w = _perm_cols_to_internal(w)
-            return w.to(dtype).contiguous()
-        Wih = c.get(("wih", layer_idx, dtype), wih, build_ih)
-        Whh = c.get(("whh", layer_idx, dtype), whh, lambda: torch.stack([p.detach() for p in whh], 0).to(dtype).contiguous())
-        Bih = c.get(("bih", layer_idx), bih, lambda: torch.cat([p.detach() for p in bih], 0).contiguous())
-        Bhh = c.get(("bhh", layer_idx), bhh, lambda: torch.stack([p.detach() for p in bhh], 0).contiguous())
         R = Tp * N
-        sv = None
-        Xh = X
-        if layer.batch_norm is not None:
-            bn = layer.batch_norm.module
-            Xh = torch.empty_like(X)
-            sv = ops.bn_fwd(X, 0, training, bn_w.detach(), bn_b.detach(), bn.running_mean, bn.running_var,
-                            bn.num_batches_tracked, R, I, I, Xh, I, eps=bn.eps, momentum=bn.momentum)
-        GI = ops.gemm_nt(Xh, Wih, bias=Bih)                                  # [R][D*G*H]
-        hext, Sv, hn, cn = ops.rnn_fwd(kind, GI, Whh, Bhh, lens_dev, D, N, H, Tp, h0=h0, c0=c0)
-        del GI
-        if D == 2:
-            out = ops.add2(hext[0, 1:Tp + 1].reshape(R, H), hext[1, 1:Tp + 1].reshape(R, H))
-        else:
-            out = hext[0, 1:Tp + 1].reshape(R, H).clone()
-        ctx.mod, ctx.layer_idx, ctx.dims, ctx.sv = mod, layer_idx, (N, Tp, dtype, kind, H, D, G, I), sv
-        ctx.has_bn = layer.batch_norm is not None
-        ctx.had_state = h0 is not None
-        ctx.save_for_backward(X, Xh if ctx.has_bn else None, hext, Sv, lens_dev, *whh, *wih)
-        ctx.mark_non_differentiable(hn)
-        if cn is not None:
-            ctx.mark_non_differentiable(cn)
-            return out, hn, cn
-        return out, hn
+        saved, meta, outs_h, outs_c, pos = [], [], [], [], 0
+        for li in range(L):
+            layer = mod.rnns[li]
+            kind, H, D = layer.kind, layer.hidden_size, layer.num_directions
+            first = li == 0
+            I = RNN_INPUT_LD if first else layer.input_size    # layer 0 sees the zero-padded conv-stack output
+            has_bn = layer.batch_norm is not None
+            bn_w, bn_b = (params[pos], params[pos + 1]) if has_bn else (None, None)
+            pos += 2 if has_bn else 0
+            wts = params[pos:pos + 4 * D]
+            pos += 4 * D
+            wih = [wts[4 * d + 0] for d in range(D)]
+            whh = [wts[4 * d + 1] for d in range(D)]
+            bih = [wts[4 * d + 2] for d in range(D)]
+            bhh = [wts[4 * d + 3] for d in range(D)]
+
+            def build_ih(wih=wih, first=first):
+                w = torch.cat([p.detach() for p in wih], 0)
+                if first:
+                    w = _perm_cols_to_internal(w)
+                return w.to(dtype).contiguous()
+            Wih = c.get(("wih", li, dtype), wih, build_ih)
+            Whh = c.get(("whh", li, dtype), whh, lambda whh=whh: torch.stack([p.detach() for p in whh], 0).to(dtype).contiguous())
+            Bih = c.get(("bih", li), bih, lambda bih=bih: torch.cat([p.detach() for p in bih], 0).contiguous())
+            Bhh = c.get(("bhh", li), bhh, lambda bhh=bhh: torch.stack([p.detach() for p in bhh], 0).contiguous())
+            sv, Xh = None, X
+            if has_bn:
+                bn = layer.batch_norm.module
+                Xh = torch.empty_like(X)
+                sv = ops.bn_fwd(X, 0, training, bn_w.detach(), bn_b.detach(), bn.running_mean, bn.running_var,
+                                bn.num_batches_tracked, R, I, I, Xh, I, eps=bn.eps, momentum=bn.momentum)
+            GI = ops.gemm_nt(Xh, Wih, bias=Bih)                                  # [R][D*G*H]
+            hext, Sv, hn, cn = ops.rnn_fwd(kind, GI, Whh, Bhh, lens_dev, D, N, H, Tp, h0=hs0[li], c0=cs0[li])
+            del GI
+            if D == 2:
+                out = ops.add2(hext[0, 1:Tp + 1].reshape(R, H), hext[1, 1:Tp + 1].reshape(R, H))
+            else:
+                out = hext[0, 1:Tp + 1].reshape(R, H).clone()
+            saved += [X, Xh if has_bn else None, hext, Sv]
+            meta.append((kind, H, D, ops.GATES[kind], I, has_bn, sv))
+            outs_h.append(hn)
+            if cn is not None:
+                outs_c.append(cn)
+            X = out
+        ctx.mod, ctx.dims, ctx.meta = mod, (N, Tp, dtype, L), meta
+        ctx.had_state = any(h is not None for h in hs0)
+        ctx.n_params = len(params)
+        ctx.save_for_backward(lens_dev, *saved, *params)
+        ctx.mark_non_differentiable(*outs_h, *outs_c)
+        return (X, *outs_h, *outs_c)
 
     @staticmethod
     def backward(ctx, dout, *unused):
-        N, Tp, dtype, kind, H, D, G, I = ctx.dims
+        N, Tp, dtype, L = ctx.dims
         if ctx.had_state:
             raise Ds2HipError("backward through a forward that was given initial hidden states (hs) is not supported")
-        saved = ctx.saved_tensors
-        X, Xh, hext, Sv, lens_dev = saved[:5]
-        whh, wih = saved[5:5 + D], saved[5 + D:5 + 2 * D]
-        if Xh is None:
-            Xh = X
-        c = ctx.mod._cache
-        li = ctx.layer_idx
-        first = li == 0
-        R, GH = Tp * N, G * H
-        WhhT = c.get(("whhT", li, dtype), list(whh),
-                     lambda: torch.stack([p.detach().t() for p in whh], 0).to(dtype).contiguous())      # [D][H][G*H]
-
-        def build_ihT():
-            w = torch.cat([p.detach() for p in wih], 0)
-            if first:
-                w = _perm_cols_to_internal(w)
-            return w.t().to(dtype).contiguous()                                                         # [I][D*G*H]
-        WihT = c.get(("wihT", li, dtype), list(wih), build_ihT)
+        mod = ctx.mod
+        c = mod._cache
+        st = ctx.saved_tensors
+        lens_dev, saved, params = st[0], st[1:1 + 4 * L], st[1 + 4 * L:]
+        R = Tp * N
+        main = torch.cuda.current_stream()
+        side = mod._wgrad_stream(dout.device)
+        # parameter offsets per layer
+        offs, pos = [], 0
+        for li in range(L):
+            has_bn, D = ctx.meta[li][5], ctx.meta[li][2]
+            offs.append(pos)
+            pos += (2 if has_bn else 0) + 4 * D
+        grads = [None] * len(params)
         dout = dout.contiguous().to(dtype)
-        dGI, dGH = ops.rnn_bwd(kind, dout, WhhT, hext, Sv, lens_dev, D, N, H, Tp)
-        # ---- parameter gradients: contraction over the T'*N rows -> transposed operands for the NT GEMM
-        dGI_T = ops.transpose(dGI)                                  # [D*G*H][ldT]
-        Xh_T = ops.transpose(Xh)                                    # [I][ldT]
-        ldT = dGI_T.shape[1]
-        dWih = ops.gemm_nt(dGI_T, Xh_T, out_dtype=torch.float32)    # [D*G*H][I]
-        del Xh_T
-        if first:
-            dWih = torch.cat([_perm_cols_to_reference(dWih[d * GH:(d + 1) * GH]) for d in range(D)], 0)
-        dBih = ops.colsum(dGI)
-        grads_w = []
-        for d in range(D):
-            # h_{t-1} of the forward direction is slot t of the guarded buffer, h_{t+1} of the reverse direction slot t+2
-            hprev = hext[d, 0:Tp] if d == 0 else hext[d, 2:Tp + 2]
-            Hp_T = ops.transpose(hprev.reshape(R, H))               # [H][ldT]
-            if kind == "gru":
-                dGH_T = ops.transpose(dGH[d].reshape(R, GH))        # [G*H][ldT]
-                dBhh = ops.colsum(dGH[d].reshape(R, GH))
+        for li in reversed(range(L)):
+            kind, H, D, G, I, has_bn, sv = ctx.meta[li]
+            X, Xh, hext, Sv = saved[4 * li:4 * li + 4]
+            if Xh is None:
+                Xh = X
+            first = li == 0
+            GH = G * H
+            po = offs[li] + (2 if has_bn else 0)
+            wts = params[po:po + 4 * D]
+            wih = [wts[4 * d + 0] for d in range(D)]
+            whh = [wts[4 * d + 1] for d in range(D)]
+            WhhT = c.get(("whhT", li, dtype), list(whh),
+                         lambda whh=whh: torch.stack([p.detach().t() for p in whh], 0).to(dtype).contiguous())   # [D][H][G*H]
+
+            def build_ihT(wih=wih, first=first):
+                w = torch.cat([p.detach() for p in wih], 0)
+                if first:
+                    w = _perm_cols_to_internal(w)
+                return w.t().to(dtype).contiguous()                                                             # [I][D*G*H]
+            WihT = c.get(("wihT", li, dtype), list(wih), build_ihT)
+            # ---- dependent chain (caller's stream): BPTT sweep -> dX -> BatchNorm backward
+            dGI, dGH = ops.rnn_bwd(kind, dout, WhhT, hext, Sv, lens_dev, D, N, H, Tp)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            dXh = ops.gemm_nt(dGI, WihT)                                # [R][I]
+            if has_bn:
+                dX = torch.empty_like(dXh)
+                grads[offs[li]], grads[offs[li] + 1] = ops.bn_bwd(dXh, X, dX, 0, sv, R, I, I, I, I)
             else:
-                dGH_T = dGI_T[d * GH:(d + 1) * GH]
-                dBhh = dBih[d * GH:(d + 1) * GH]
-            dWhh = ops.gemm_nt(dGH_T, Hp_T, out_dtype=torch.float32, M=GH, N=H, K=ldT, lda=ldT, ldb=ldT)
-            grads_w += [dWih[d * GH:(d + 1) * GH].contiguous(), dWhh, dBih[d * GH:(d + 1) * GH].contiguous(),
-                        dBhh.contiguous()]
-        del dGI_T
-        dXh = ops.gemm_nt(dGI, WihT)                                # [R][I]
-        dbn_w = dbn_b = None
-        if ctx.has_bn:
-            dX = torch.empty_like(dXh)
-            dbn_w, dbn_b = ops.bn_bwd(dXh, X, dX, 0, ctx.sv, R, I, I, I, I)
-        else:
-            dX = dXh
-        return (dX, dbn_w, dbn_b, None, None, None, None, None, None, None, None, None, *grads_w)
+                dX = dXh
+            # ---- weight gradients (second stream, under the next layer's sweep): contraction over the T'*N rows
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                for t in (dGI, dGH, Xh, hext):
+                    if t is not None:
+                        t.record_stream(side)
+                dGI_T = ops.transpose(dGI)                              # [D*G*H][ldT]
+                Xh_T = ops.transpose(Xh)                                # [I][ldT]
+                ldT = dGI_T.shape[1]
+                dWih = ops.gemm_nt(dGI_T, Xh_T, out_dtype=torch.float32, splitk=_wgrad_splitk(dGI_T.shape[0], Xh_T.shape[0], ldT))
+                del Xh_T
+                if first:
+                    dWih = torch.cat([_perm_cols_to_reference(dWih[d * GH:(d + 1) * GH]) for d in range(D)], 0)
+                dBih = ops.colsum(dGI)
+                for d in range(D):
+                    # h_{t-1} of the forward direction is slot t of the guarded buffer, h_{t+1} of the reverse direction slot t+2
+                    hprev = hext[d, 0:Tp] if d == 0 else hext[d, 2:Tp + 2]
+                    Hp_T = ops.transpose(hprev.reshape(R, H))           # [H][ldT]
+                    if kind == "gru":
+                        dGH_T = ops.transpose(dGH[d].reshape(R, GH))    # [G*H][ldT]
+                        dBhh = ops.colsum(dGH[d].reshape(R, GH))
+                    else:
+                        dGH_T = dGI_T[d * GH:(d + 1) * GH]
+                        dBhh = dBih[d * GH:(d + 1) * GH]
+                    dWhh = ops.gemm_nt(dGH_T, Hp_T, out_dtype=torch.float32, M=GH, N=H, K=ldT, lda=ldT, ldb=ldT,
+                                       splitk=_wgrad_splitk(GH, H, ldT))
+                    grads[po + 4 * d:po + 4 * d + 4] = [dWih[d * GH:(d + 1) * GH].contiguous(), dWhh,
+                                                        dBih[d * GH:(d + 1) * GH].contiguous(), dBhh.contiguous()]
+                del dGI_T
+            dout = dX
+        main.wait_stream(side)          # every parameter gradient is complete before autograd / DDP sees it
+        for g in grads:
+            if g is not None:
+                g.record_stream(main)
+        return (dout, None, None, None, None, None, None, None, *([None] * (2 * L)), *grads)
 
 
 class _LookaheadFn(torch.autograd.Function):
@@ -433,7 +487,16 @@ class DeepSpeech(_Base):
         self.fc = nn.Sequential(SequenceWise(fully_connected))
         self.blank_index = self.labels.index('_')      # model.py:203
         self._cache = _WeightCache()
+        self._side_streams = {}
         self._kind = kind
+
+    def _wgrad_stream(self, device):
+        """Second HIP stream of this module on `device` (weight-gradient work of the RNN stack's backward)."""
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        st = self._side_streams.get(key)
+        if st is None:
+            st = self._side_streams[key] = torch.cuda.Stream(device=device)
+        return st
 
     # ---- precision policy -------------------------------------------------------------------------------------
     def compute_dtype(self):
@@ -461,9 +524,10 @@ class DeepSpeech(_Base):
         with torch.autocast("cuda", enabled=False):
             X = _ConvStackFn.apply(x, sm[0].weight, sm[0].bias, sm[1].weight, sm[1].bias, sm[3].weight, sm[3].bias,
                                    sm[4].weight, sm[4].bias, self, lens_dev, Tp, dtype, training)
+            L = len(self.rnns)
             if hs is None:
-                hs = [None] * len(self.rnns)
-            new_hs = []
+                hs = [None] * L
+            h0s, c0s, params = [], [], []
             for i, layer in enumerate(self.rnns):
                 h0 = c0 = None
                 if hs[i] is not None:
@@ -471,16 +535,21 @@ class DeepSpeech(_Base):
                         h0, c0 = hs[i][0].float().contiguous(), hs[i][1].float().contiguous()
                     else:
                         h0 = hs[i].float().contiguous()
+                h0s.append(h0)
+                c0s.append(c0)
+                if layer.batch_norm is not None:
+                    bn = layer.batch_norm.module
+                    params += [bn.weight, bn.bias]
                 p = layer.rnn
-                wts = []
                 for suf in [""] + (["_reverse"] if self.bidirectional else []):
-                    wts += [getattr(p, "weight_ih_l0" + suf), getattr(p, "weight_hh_l0" + suf),
-                            getattr(p, "bias_ih_l0" + suf), getattr(p, "bias_hh_l0" + suf)]
-                bn = layer.batch_norm.module if layer.batch_norm is not None else None
-                res = _RnnLayerFn.apply(X, bn.weight if bn else None, bn.bias if bn else None, self, i, lens_dev, N, Tp,
-                                        dtype, training, h0, c0, *wts)
-                X = res[0]
-                new_hs.append((res[1], res[2]) if self._kind == "lstm" else res[1])
+                    params += [getattr(p, "weight_ih_l0" + suf), getattr(p, "weight_hh_l0" + suf),
+                               getattr(p, "bias_ih_l0" + suf), getattr(p, "bias_hh_l0" + suf)]
+            res = _RnnStackFn.apply(X, self, lens_dev, N, Tp, dtype, training, L, *h0s, *c0s, *params)
+            X = res[0]
+            if self._kind == "lstm":
+                new_hs = [(res[1 + i], res[1 + L + i]) for i in range(L)]
+            else:
+                new_hs = [res[1 + i] for i in range(L)]
             if not self.bidirectional:
                 X = _LookaheadFn.apply(X, self.lookahead[0].conv.weight, N, Tp)
             fcm = self.fc[0].module
