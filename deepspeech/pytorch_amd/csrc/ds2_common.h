@@ -39,6 +39,15 @@ __device__ __host__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
   return (uint16_t)(u >> 16);
 }
 
+// two fp32 -> packed bf16x2 (lo in bits 15:0) in ONE instruction: gfx950's v_cvt_pk_bf16_f32 (round-to-nearest-even,
+// NaN stays NaN).  The portable bit-twiddling version above costs ~10 instructions and an exec-mask branch per value
+// (the NaN test), which dominated the epilogues of latency-bound kernels.
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
 template <typename T>
 struct Store;
 template <>
@@ -49,7 +58,7 @@ struct Store<float> {
 template <>
 struct Store<bf16_t> {
   static __device__ __forceinline__ float ld(const bf16_t* p) { return bf16_bits_to_f32(p->v); }
-  static __device__ __forceinline__ void st(bf16_t* p, float v) { p->v = f32_to_bf16_bits(v); }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { p->v = (uint16_t)cvt_pk_bf16(v, 0.f); }
 };
 
 template <typename T>
@@ -90,8 +99,7 @@ struct Vec16<bf16_t> {
   static __device__ __forceinline__ void store(bf16_t* p, const float (&o)[8]) {
     uint32_t w[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      w[i] = (uint32_t)f32_to_bf16_bits(o[2 * i]) | ((uint32_t)f32_to_bf16_bits(o[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) w[i] = cvt_pk_bf16(o[2 * i], o[2 * i + 1]);
     *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
   }
 };

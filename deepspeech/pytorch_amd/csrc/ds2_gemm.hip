@@ -300,8 +300,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16_glds(GemmArgs g) {
           bf16_t* cp = (bf16_t*)g.C + off;
           if (col + 3 < g.N && n_vec_ok) {
             uint2 pk;
-            pk.x = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
-            pk.y = (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16);
+            pk.x = cvt_pk_bf16(v[0], v[1]);
+            pk.y = cvt_pk_bf16(v[2], v[3]);
             *reinterpret_cast<uint2*>(cp) = pk;
           } else {
 #pragma unroll

@@ -121,9 +121,7 @@ __device__ __forceinline__ bool group_is_xcd_local(u64* slots /* this group's [3
   __syncthreads();
   return s_local != 0;
 }
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
-}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) { return cvt_pk_bf16(lo, hi); }
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
@@ -331,6 +329,18 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd(PArgs a) {
       bh[g][1] = a.bhh[(long)d * GH + (long)g * H + j + 1];
     }
   }
+  // per-thread running pointers (advanced by a constant stride per step: 64-bit address arithmetic with multiplies inside
+  // the gate phase costs hundreds of cycles on a single wave per SIMD)
+  const long dstep = d == 0 ? 1 : -1;
+  const int t_first = d == 0 ? 0 : Tp - 1;
+  const int nn_ = gate_thread ? n : 0;
+  const bf16_t* gi_ptr = a.GI + ((long)t_first * N + nn_) * ldgi + (long)d * GH + j;
+  const long gi_stride = dstep * N * ldgi;
+  constexpr long NSH_ = (long)(NS ? NS : 1) * H;
+  bf16_t* sv_ptr = NS ? a.S + (((long)d * Tp + t_first) * N + nn_) * NSH_ + j : nullptr;
+  const long sv_stride = dstep * N * NSH_;
+  bf16_t* hs_ptr = a.Hseq + (long)d * a.hseq_dstride + ((long)t_first * N + nn_) * H + j;
+  const long hs_stride = dstep * N * H;
   bool dead = false;
   const bool local = group_is_xcd_local(a.xcc + grp * 32, p, tid, a.err, dead);
   if (gate_thread && a.h0)   // initial state as "step -1": parity 1, tag TAG_INIT
@@ -347,7 +357,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd(PArgs a) {
 #pragma unroll
     for (int g = 0; g < G; ++g) gi[g] = 0;
     if (gate_thread && !(a.dbgmask & 1)) {
-      const bf16_t* gp = a.GI + ((long)t * N + n) * ldgi + (long)d * GH + j;
+      const bf16_t* gp = gi_ptr;
 #pragma unroll
       for (int g = 0; g < G; ++g) gi[g] = *reinterpret_cast<const uint32_t*>(gp + (long)g * H);
     }
@@ -365,7 +375,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd(PArgs a) {
       const bool act = t < len;
       float hn0 = 0.f, hn1 = 0.f;     // emitted h_t (0 when inactive)
       const bool st_on = !(a.dbgmask & 2);
-      bf16_t* sv = NS ? a.S + (((long)d * Tp + t) * N + n) * (long)(NS ? NS : 1) * H + j : nullptr;
+      bf16_t* sv = sv_ptr;
       float2 gh[G];
 #pragma unroll
       for (int g = 0; g < G; ++g) {
@@ -426,11 +436,14 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd(PArgs a) {
         }
       }
       if (dead) hn0 = hn1 = hprev0 = hprev1 = __uint_as_float(0x7fc00000u);   // fail loudly downstream
-      if (st_on) *reinterpret_cast<uint32_t*>(a.Hseq + (long)d * a.hseq_dstride + ((long)t * N + n) * H + j) = pack_bf16x2(hn0, hn1);
+      if (st_on) *reinterpret_cast<uint32_t*>(hs_ptr) = pack_bf16x2(hn0, hn1);
       // publish the carried state (inactive samples republish their unchanged state)
       publish((u64*)((char*)xg + par * PAR_BYTES + xgranule_bytes<NROWS>(j, gi_i)), ((u64)(unsigned)(s + 1) << 32) | pack_bf16x2(hprev0, hprev1),
               local);
     }
+    gi_ptr += gi_stride;
+    if (NS) sv_ptr += sv_stride;
+    hs_ptr += hs_stride;
     const unsigned long long t3 = __builtin_readcyclecounter();
     c_gather += t1 - t0;
     c_bar += t2 - t1;
@@ -511,6 +524,16 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd(PArgs a) {
   int len = 0;
   if (gate_thread) len = a.lens[n];
   float car0 = 0.f, car1 = 0.f, dc0 = 0.f, dc1 = 0.f;   // carried dh (elementwise part) and dc
+  const long dstep = d == 0 ? -1 : 1;                       // BPTT walks the direction's time axis backwards
+  const int t_first = d == 0 ? Tp - 1 : 0;
+  const int nn_ = gate_thread ? n : 0;
+  constexpr long NSH_ = (long)(NS ? NS : 1) * H;
+  const bf16_t* do_ptr = a.dOut + ((long)t_first * N + nn_) * H + j;
+  const bf16_t* sv_ptr = NS ? a.S + (((long)d * Tp + t_first) * N + nn_) * NSH_ + j : nullptr;
+  const bf16_t* hs_ptr = a.Hseq + (long)d * a.hseq_dstride + ((long)t_first * N + nn_) * H + j;   // h_t
+  bf16_t* dgi_ptr = a.dGI + ((long)t_first * N + nn_) * ldgi + (long)d * GH + j;
+  bf16_t* dgh_ptr = a.dGH ? a.dGH + (((long)d * Tp + t_first) * N + nn_) * GH + j : nullptr;
+  const long prev_off = d == 0 ? -1 : 1;                    // previous step in FORWARD order of this direction
   bool dead = false;
   const bool local = group_is_xcd_local(a.xcc + grp * 32, p, tid, a.err, dead);
   unsigned rounds = 0;
@@ -527,20 +550,19 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd(PArgs a) {
     for (int q = 0; q < (NS ? NS : 1); ++q) sp[q] = 0;
     const int tprev = d == 0 ? t - 1 : t + 1;            // previous step in FORWARD order of this direction
     if (gate_thread && !(a.dbgmask & 1)) {
-      dout = *reinterpret_cast<const uint32_t*>(a.dOut + ((long)t * N + n) * H + j);
-      const long seq = ((long)d * Tp + t) * N + n;
+      dout = *reinterpret_cast<const uint32_t*>(do_ptr);
       if (NS) {
-        const bf16_t* sv = a.S + seq * NSH + j;
+        const bf16_t* sv = sv_ptr;
 #pragma unroll
         for (int q = 0; q < NS; ++q) sp[q] = *reinterpret_cast<const uint32_t*>(sv + (long)q * H);
       }
       // h_{prev}: guard slots / inactive frames hold zeros, so the read is unconditional (tprev in [-1, Tp])
-      hp = *reinterpret_cast<const uint32_t*>(a.Hseq + (long)d * a.hseq_dstride + ((long)tprev * N + n) * H + j);
+      hp = *reinterpret_cast<const uint32_t*>(hs_ptr + prev_off * N * H);
       if (CELL == CELL_LSTM) {
         const bool has_prev = d == 0 ? (t > 0) : (t + 1 < len);
-        if (has_prev) cp = *reinterpret_cast<const uint32_t*>(a.S + (((long)d * Tp + tprev) * N + n) * NSH + 4 * H + j);
+        if (has_prev) cp = *reinterpret_cast<const uint32_t*>(sv_ptr + prev_off * N * NSH_ + 4 * H);
       }
-      if (CELL == CELL_RNN) hp = *reinterpret_cast<const uint32_t*>(a.Hseq + (long)d * a.hseq_dstride + ((long)t * N + n) * H + j);
+      if (CELL == CELL_RNN) hp = *reinterpret_cast<const uint32_t*>(hs_ptr);
     }
     ds2_f32x4 acc[TILES];
 #pragma unroll
@@ -555,7 +577,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd(PArgs a) {
       const bool act = t < len;
       const float2 mp = load_partials<TILES>(part[par], (2 * up) / 16, gi_i, (2 * up) % 16);
       const float din0 = car0 + mp.x, din1 = car1 + mp.y;
-      bf16_t* dgi = a.dGI + ((long)t * N + n) * ldgi + (long)d * GH + j;
+      bf16_t* dgi = dgi_ptr;
       char* xo = (char*)xg + par * PAR_BYTES;   // granule of gate g, units (j, j+1): element k = g*H + j
       const u64 tag = (u64)(unsigned)(s + 1) << 32;
       const bool st_on = !(a.dbgmask & 2);
@@ -584,7 +606,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd(PArgs a) {
         if (st_on) *reinterpret_cast<uint32_t*>(dgi) = pr;
         if (st_on) *reinterpret_cast<uint32_t*>(dgi + H) = pz;
         if (st_on) *reinterpret_cast<uint32_t*>(dgi + 2 * H) = pn;
-        bf16_t* dgh = a.dGH + (((long)d * Tp + t) * N + n) * GH + j;
+        bf16_t* dgh = dgh_ptr;
         if (st_on) *reinterpret_cast<uint32_t*>(dgh) = pr;
         if (st_on) *reinterpret_cast<uint32_t*>(dgh + H) = pz;
         if (st_on) *reinterpret_cast<uint32_t*>(dgh + 2 * H) = pq;
@@ -640,6 +662,11 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd(PArgs a) {
         publish((u64*)(xo + xgranule_bytes<NROWS>(j, gi_i)), tag | pg, local);
       }
     }
+    do_ptr += dstep * N * H;
+    if (NS) sv_ptr += dstep * N * NSH_;
+    hs_ptr += dstep * N * H;
+    dgi_ptr += dstep * N * ldgi;
+    if (CELL == CELL_GRU) dgh_ptr += dstep * N * GH;
     const unsigned long long t3 = __builtin_readcyclecounter();
     c_gather += t1 - t0;
     c_bar += t2 - t1;
