@@ -7,7 +7,8 @@
 //   d nll / d lp[t][c] = - sum_{s: l'_s = c} exp(alpha_t(s) + beta_t(s) - ll) / y_t(c)
 // (every term exp(alpha+beta-ll) <= 1, so the total log-likelihood ll is a safe common shift), followed by the
 // log_softmax backward  dlogit = g - softmax * sum_c g.  Infeasible samples (ll = -inf): loss 0, gradient 0.
-// Latency-bound (T' dependent steps, 3 barriers per step); bytes: logits once, alpha scratch write+read.
+// Latency-bound: alpha and beta run concurrently on the two halves of the workgroup (T' dependent steps, ONE barrier per
+// step), the gradient pass is frame-parallel (one wave per frame); bytes: logits once, alpha/beta scratch write+read.
 #include <math.h>
 
 #include "ds2_common.h"
@@ -27,13 +28,15 @@ __global__ void __launch_bounds__(CTC_THREADS) k_ctc(const float* __restrict__ l
                                                       const int* __restrict__ toff, const int* __restrict__ in_len,
                                                       const int* __restrict__ tg_len, int Tp, int N, int C, int blank, int Lmax,
                                                       float grad_scale, float* __restrict__ nll_out, float* __restrict__ dlogits,
-                                                      long ldg, float* __restrict__ ws_lp, float* __restrict__ ws_alpha) {
+                                                      long ldg, float* __restrict__ ws_lp, float* __restrict__ ws_alpha,
+                                                      float* __restrict__ ws_beta) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* rowA = reinterpret_cast<float*>(smem);      // [Lmax]
-  float* rowB = rowA + Lmax;                         // [Lmax]
-  int* ext = reinterpret_cast<int*>(rowB + Lmax);    // [Lmax]
-  float* acc = reinterpret_cast<float*>(ext + Lmax); // [CP]
-  float* wred = acc + CP;                            // [8]
+  float* rowA0 = reinterpret_cast<float*>(smem);     // alpha rows (double buffer)   [Lmax] each
+  float* rowA1 = rowA0 + Lmax;
+  float* rowB0 = rowA1 + Lmax;                       // beta rows
+  float* rowB1 = rowB0 + Lmax;
+  int* ext = reinterpret_cast<int*>(rowB1 + Lmax);   // [Lmax]
+  float* acc = reinterpret_cast<float*>(ext + Lmax); // [4 waves][CP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = blockIdx.x;
   int Ti = in_len[n];
@@ -43,6 +46,7 @@ __global__ void __launch_bounds__(CTC_THREADS) k_ctc(const float* __restrict__ l
   const int* tg = targets + toff[n];
   float* lp = ws_lp + (long)n * Tp * CP;                 // [Tp][CP] of this sample
   float* alpha = ws_alpha + (long)n * Tp * Lmax;         // [Tp][Lmax]
+  float* beta = ws_beta + (long)n * Tp * Lmax;
 
   for (int s = tid; s < L; s += CTC_THREADS) ext[s] = (s & 1) ? tg[s >> 1] : blank;
   // ---- log_softmax of every valid frame
@@ -63,104 +67,96 @@ __global__ void __launch_bounds__(CTC_THREADS) k_ctc(const float* __restrict__ l
   __syncthreads();
 
   bool feasible = Ti > 0 && L <= 2 * Ti + 1;   // necessary; the recursion decides exactly
-  float ll = -INFINITY;
-  if (Ti > 0) {
-    // ---- alpha
-    float* prev = rowA;
-    float* cur = rowB;
-    for (int s = tid; s < L; s += CTC_THREADS) {
-      float v = -INFINITY;
-      if (s == 0) v = lp[blank];
-      if (s == 1) v = lp[ext[1]];
-      prev[s] = v;
-      alpha[s] = v;
-    }
-    __syncthreads();
-    for (int t = 1; t < Ti; ++t) {
+  if (Ti <= 0) {
+    if (tid == 0) nll_out[n] = 0.f;
+    return;
+  }
+  // ---- alpha (threads 0..127, t = 0 .. Ti-1) and beta (threads 128..255, t = Ti-1 .. 0) run CONCURRENTLY: the two
+  //      recursions are independent, so the serial depth is Ti instead of 2 Ti; one barrier per step serves both.
+  {
+    constexpr int HALF = CTC_THREADS / 2;
+    const bool is_beta = tid >= HALF;
+    const int ht = is_beta ? tid - HALF : tid;
+    float* prev = is_beta ? rowB0 : rowA0;
+    float* cur = is_beta ? rowB1 : rowA1;
+    float* dst = is_beta ? beta : alpha;
+    for (int i = 0; i < Ti; ++i) {
+      const int t = is_beta ? Ti - 1 - i : i;
       const float* lpt = lp + (long)t * CP;
-      for (int s = tid; s < L; s += CTC_THREADS) {
+      for (int s = ht; s < L; s += HALF) {
         const int e = ext[s];
-        const float a = prev[s];
-        const float b = s >= 1 ? prev[s - 1] : -INFINITY;
-        const float c = (s >= 2 && e != blank && e != ext[s - 2]) ? prev[s - 2] : -INFINITY;
-        const float v = lse3(a, b, c) + lpt[e];
+        float v;
+        if (i == 0) {
+          if (!is_beta)
+            v = s == 0 ? lpt[blank] : (s == 1 ? lpt[e] : -INFINITY);
+          else
+            v = (s == L - 1 || s == L - 2) ? lpt[e] : -INFINITY;
+        } else if (!is_beta) {
+          const float a0 = prev[s];
+          const float a1 = s >= 1 ? prev[s - 1] : -INFINITY;
+          const float a2 = (s >= 2 && e != blank && e != ext[s - 2]) ? prev[s - 2] : -INFINITY;
+          v = lse3(a0, a1, a2) + lpt[e];
+        } else {
+          const float b0 = prev[s];
+          const float b1 = s + 1 < L ? prev[s + 1] : -INFINITY;
+          const float b2 = (s + 2 < L && ext[s + 2] != blank && ext[s + 2] != e) ? prev[s + 2] : -INFINITY;
+          v = lse3(b0, b1, b2) + lpt[e];
+        }
         cur[s] = v;
-        alpha[(long)t * Lmax + s] = v;
+        dst[(long)t * Lmax + s] = v;
       }
       __syncthreads();
       float* tmp = prev;
       prev = cur;
       cur = tmp;
     }
-    const float l1 = prev[L - 1];
-    const float l2 = L > 1 ? prev[L - 2] : -INFINITY;
-    ll = lse3(l1, l2, -INFINITY);
-    __syncthreads();
-    feasible = feasible && (ll != -INFINITY) && !isnan(ll);
-    if (tid == 0) nll_out[n] = feasible ? -ll : 0.f;
-
-    if (!feasible) {
-      for (long i = tid; i < (long)Ti * ldg; i += CTC_THREADS) {
-        const long t = i / ldg, c = i % ldg;
-        dlogits[(t * N + n) * ldg + c] = 0.f;
-      }
-    } else {
-      // ---- beta + gradient, t = Ti-1 .. 0 ; prev = beta_{t+1}, cur = beta_t
-      float* bnext = rowA;
-      float* bcur = rowB;
-      for (int t = Ti - 1; t >= 0; --t) {
-        const float* lpt = lp + (long)t * CP;
-        const float* al = alpha + (long)t * Lmax;
-        if (tid < CP) acc[tid] = 0.f;
-        float blank_part = 0.f;
-        // beta_t
-        for (int s = tid; s < L; s += CTC_THREADS) {
-          const int e = ext[s];
-          float v;
-          if (t == Ti - 1) {
-            v = (s == L - 1 || s == L - 2) ? lpt[e] : -INFINITY;
-          } else {
-            const float a = bnext[s];
-            const float b = s + 1 < L ? bnext[s + 1] : -INFINITY;
-            const float c = (s + 2 < L && ext[s + 2] != blank && ext[s + 2] != e) ? bnext[s + 2] : -INFINITY;
-            v = lse3(a, b, c) + lpt[e];
-          }
-          bcur[s] = v;
-        }
-        __syncthreads();   // acc zeroed, beta_t complete
-        for (int s = tid; s < L; s += CTC_THREADS) {
-          const float w = expf(al[s] + bcur[s] - ll);   // <= 1
-          if (s & 1)
-            atomicAdd(&acc[ext[s]], w);
-          else
-            blank_part += w;
-        }
-        blank_part = wave_sum(blank_part);
-        if (lane == 0) wred[wave] = blank_part;
-        __syncthreads();   // label atomics + per-wave blank sums visible
-        if (tid < 64) {
-          float g = 0.f, y = 0.f;
-          if (tid < C) {
-            float a = acc[tid];
-            if (tid == blank) a += wred[0] + wred[1] + wred[2] + wred[3];
-            y = expf(lpt[tid]);
-            g = a > 0.f ? -a / y : 0.f;
-          }
-          const float gs = wave_sum(g);
-          float* dl = dlogits + ((long)t * N + n) * ldg;
-          if (tid < C)
-            dl[tid] = (g - y * gs) * grad_scale;
-          else if (tid < ldg)
-            dl[tid] = 0.f;
-        }
-        __syncthreads();   // acc / wred consumed before the next step zeroes them
-        float* tmp = bnext;
-        bnext = bcur;
-        bcur = tmp;
-      }
+  }
+  // after the loop every thread's `prev` of the alpha half holds alpha_{Ti-1}: it is rowA0 or rowA1 by parity
+  const float* alast = (Ti & 1) ? rowA1 : rowA0;
+  const float l1 = alast[L - 1];
+  const float l2 = L > 1 ? alast[L - 2] : -INFINITY;
+  const float ll = lse3(l1, l2, -INFINITY);
+  feasible = feasible && (ll != -INFINITY) && !isnan(ll);
+  if (tid == 0) nll_out[n] = feasible ? -ll : 0.f;
+  if (!feasible) {
+    for (long i = tid; i < (long)Ti * ldg; i += CTC_THREADS) {
+      const long t = i / ldg, c = i % ldg;
+      dlogits[(t * N + n) * ldg + c] = 0.f;
     }
-  } else {
-    if (tid == 0) nll_out[n] = 0.f;
+    return;
+  }
+  // ---- gradient: frames are independent now -> one wave per frame (alpha/beta rows come back from L2)
+  float* wacc = acc + wave * CP;
+  for (int t = wave; t < Ti; t += CTC_THREADS / 64) {
+    const float* lpt = lp + (long)t * CP;
+    const float* al = alpha + (long)t * Lmax;
+    const float* be = beta + (long)t * Lmax;
+    if (lane < CP) wacc[lane] = 0.f;
+    __builtin_amdgcn_wave_barrier();
+    float blank_part = 0.f;
+    for (int s = lane; s < L; s += 64) {
+      const float w = expf(al[s] + be[s] - ll);   // <= 1
+      if (s & 1)
+        atomicAdd(&wacc[ext[s]], w);
+      else
+        blank_part += w;
+    }
+    blank_part = wave_sum(blank_part);
+    __builtin_amdgcn_wave_barrier();
+    float g = 0.f, y = 0.f;
+    if (lane < C) {
+      float a = wacc[lane];
+      if (lane == blank) a += blank_part;
+      y = expf(lpt[lane]);
+      g = a > 0.f ? -a / y : 0.f;
+    }
+    const float gs = wave_sum(g);
+    float* dl = dlogits + ((long)t * N + n) * ldg;
+    if (lane < C)
+      dl[lane] = (g - y * gs) * grad_scale;
+    else if (lane < ldg)
+      dl[lane] = 0.f;
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -178,7 +174,7 @@ extern "C" {
 long ds2_ctc_ws_floats(int Tp, int N, int C, int max_target_len) {
   (void)C;
   const long Lmax = 2L * max_target_len + 1;
-  return (long)N * Tp * CP + (long)N * Tp * Lmax;
+  return (long)N * Tp * CP + 2L * N * Tp * Lmax;
 }
 
 int ds2_ctc_loss_grad(const float* logits, long ldl, const int* targets, const int* target_offsets, const int* input_lengths,
@@ -188,12 +184,13 @@ int ds2_ctc_loss_grad(const float* logits, long ldl, const int* targets, const i
   DS2_REQUIRE(Tp > 0 && N > 0 && C > 0 && C <= CP && blank >= 0 && blank < C && max_target_len >= 0, DS2_ERR_ARG);
   DS2_REQUIRE(ldg >= C && ldg <= 64 && ldl >= C, DS2_ERR_ARG);
   const int Lmax = 2 * max_target_len + 1;
-  const size_t shm = (size_t)Lmax * 12 + CP * 4 + 8 * 4;
+  const size_t shm = (size_t)Lmax * 20 + 4 * CP * 4;
   DS2_REQUIRE(shm <= 60 * 1024, DS2_ERR_ARG);
   float* ws_lp = ws;
   float* ws_alpha = ws + (long)N * Tp * CP;
+  float* ws_beta = ws_alpha + (long)N * Tp * Lmax;
   hipLaunchKernelGGL(k_ctc, dim3(N), dim3(CTC_THREADS), shm, st, logits, ldl, targets, target_offsets, input_lengths,
-                     target_lengths, Tp, N, C, blank, Lmax, grad_scale, nll, dlogits, ldg, ws_lp, ws_alpha);
+                     target_lengths, Tp, N, C, blank, Lmax, grad_scale, nll, dlogits, ldg, ws_lp, ws_alpha, ws_beta);
   DS2_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_sum_small, dim3(1), dim3(64), 0, st, nll, N, loss_sum);
   DS2_CHECK_LAUNCH();

@@ -25,20 +25,55 @@ struct RowMap {
 // ---------------------------------------------------------------------------------------------------------
 // column sums / sums of squares -> partial[blockIdx.y][C]
 // ---------------------------------------------------------------------------------------------------------
+// Thread map shared by the two reduction kernels.  A block is NORM_CX x NORM_RY threads; with fewer than NORM_CX 16-byte
+// column chunks (the conv activations have C = 32 channels = 4 bf16 chunks) the spare x-lanes take extra ROWS instead
+// of idling: x = rsub * cpb + chunk, and one block iteration covers NORM_RY * rpx rows.
+struct RedMap {
+  int cpb, rpx, chunk, rsub;   // chunks per block in x, row sub-groups in x, this thread's chunk / row sub-group
+  bool ok;
+  __device__ __forceinline__ RedMap(int chunks) {
+    cpb = chunks < NORM_CX ? chunks : NORM_CX;
+    rpx = NORM_CX / cpb;
+    const int tx = threadIdx.x;
+    rsub = tx / cpb;
+    chunk = blockIdx.x * cpb + tx % cpb;
+    ok = rsub < rpx && chunk < chunks;
+  }
+  __device__ __forceinline__ long first_row() const { return ((long)blockIdx.y * NORM_RY + threadIdx.y) * rpx + rsub; }
+  __device__ __forceinline__ long row_step() const { return (long)gridDim.y * NORM_RY * rpx; }
+};
+// block reduction of V values per thread over threadIdx.y and the row sub-groups; result in the threads (y = 0, rsub = 0)
+template <int V>
+__device__ __forceinline__ void red_block(float (*red)[NORM_CX * V + 1], const RedMap& m, const float (&v)[V], float (&out)[V]) {
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < V; ++i) red[threadIdx.y][threadIdx.x * V + i] = v[i];
+  __syncthreads();
+  if (threadIdx.y == 0 && m.rsub == 0) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      float a = 0.f;
+      for (int k = 0; k < m.rpx; ++k)
+#pragma unroll
+        for (int y = 0; y < NORM_RY; ++y) a += red[y][(threadIdx.x + k * m.cpb) * V + i];
+      out[i] = a;
+    }
+  }
+}
+
 template <typename T, bool SQ>
 __global__ void __launch_bounds__(NORM_RY* NORM_CX) k_colstats(const T* __restrict__ X, long R, int C, long ld,
                                                                 float* __restrict__ psum, float* __restrict__ psq) {
   constexpr int V = Vec16<T>::N;
   __shared__ float red[NORM_RY][NORM_CX * V + 1];
-  const int cx = blockIdx.x * NORM_CX + threadIdx.x;
-  const bool ok = (long)cx * V < C;
+  const RedMap m(C / V);
   float s[V], q[V];
 #pragma unroll
   for (int i = 0; i < V; ++i) s[i] = q[i] = 0.f;
-  if (ok) {
-    for (long r = (long)blockIdx.y * NORM_RY + threadIdx.y; r < R; r += (long)gridDim.y * NORM_RY) {
+  if (m.ok) {
+    for (long r = m.first_row(); r < R; r += m.row_step()) {
       float v[V];
-      Vec16<T>::load(X + r * ld + (long)cx * V, v);
+      Vec16<T>::load(X + r * ld + (long)m.chunk * V, v);
 #pragma unroll
       for (int i = 0; i < V; ++i) {
         s[i] += v[i];
@@ -46,20 +81,17 @@ __global__ void __launch_bounds__(NORM_RY* NORM_CX) k_colstats(const T* __restri
       }
     }
   }
-  for (int pass = 0; pass < (SQ ? 2 : 1); ++pass) {
-    __syncthreads();
+  float o[V];
+  red_block<V>(red, m, s, o);
+  if (threadIdx.y == 0 && m.rsub == 0 && m.ok) {
 #pragma unroll
-    for (int i = 0; i < V; ++i) red[threadIdx.y][threadIdx.x * V + i] = pass ? q[i] : s[i];
-    __syncthreads();
-    if (threadIdx.y == 0 && ok) {
-      float* dst = (pass ? psq : psum) + (long)blockIdx.y * C + (long)cx * V;
+    for (int i = 0; i < V; ++i) psum[(long)blockIdx.y * C + (long)m.chunk * V + i] = o[i];
+  }
+  if (SQ) {
+    red_block<V>(red, m, q, o);
+    if (threadIdx.y == 0 && m.rsub == 0 && m.ok) {
 #pragma unroll
-      for (int i = 0; i < V; ++i) {
-        float a = 0.f;
-#pragma unroll
-        for (int y = 0; y < NORM_RY; ++y) a += red[y][threadIdx.x * V + i];
-        dst[i] = a;
-      }
+      for (int i = 0; i < V; ++i) psq[(long)blockIdx.y * C + (long)m.chunk * V + i] = o[i];
     }
   }
 }
@@ -234,15 +266,14 @@ __global__ void __launch_bounds__(NORM_RY* NORM_CX)
                     float* __restrict__ psum_g, float* __restrict__ psum_gx) {
   constexpr int V = Vec16<T>::N;
   __shared__ float red[NORM_RY][NORM_CX * V + 1];
-  const int cx = blockIdx.x * NORM_CX + threadIdx.x;
-  const bool ok = (long)cx * V < C;
+  const RedMap m(C / V);
   float s[V], q[V];
 #pragma unroll
   for (int i = 0; i < V; ++i) s[i] = q[i] = 0.f;
-  if (ok) {
-    for (long r = (long)blockIdx.y * NORM_RY + threadIdx.y; r < R; r += (long)gridDim.y * NORM_RY) {
+  if (m.ok) {
+    for (long r = m.first_row(); r < R; r += m.row_step()) {
       float g[V], xh[V];
-      if (load_gated<T, CONV, SEQ_IN>(G, X, r, cx * V, C, ldg, ldx, scale, shift, mean, rstd, rm, lens, N, g, xh)) {
+      if (load_gated<T, CONV, SEQ_IN>(G, X, r, m.chunk * V, C, ldg, ldx, scale, shift, mean, rstd, rm, lens, N, g, xh)) {
 #pragma unroll
         for (int i = 0; i < V; ++i) {
           s[i] += g[i];
@@ -251,21 +282,16 @@ __global__ void __launch_bounds__(NORM_RY* NORM_CX)
       }
     }
   }
-  for (int pass = 0; pass < 2; ++pass) {
-    __syncthreads();
+  float o[V];
+  red_block<V>(red, m, s, o);
+  if (threadIdx.y == 0 && m.rsub == 0 && m.ok) {
 #pragma unroll
-    for (int i = 0; i < V; ++i) red[threadIdx.y][threadIdx.x * V + i] = pass ? q[i] : s[i];
-    __syncthreads();
-    if (threadIdx.y == 0 && ok) {
-      float* dst = (pass ? psum_gx : psum_g) + (long)blockIdx.y * C + (long)cx * V;
+    for (int i = 0; i < V; ++i) psum_g[(long)blockIdx.y * C + (long)m.chunk * V + i] = o[i];
+  }
+  red_block<V>(red, m, q, o);
+  if (threadIdx.y == 0 && m.rsub == 0 && m.ok) {
 #pragma unroll
-      for (int i = 0; i < V; ++i) {
-        float a = 0.f;
-#pragma unroll
-        for (int y = 0; y < NORM_RY; ++y) a += red[y][threadIdx.x * V + i];
-        dst[i] = a;
-      }
-    }
+    for (int i = 0; i < V; ++i) psum_gx[(long)blockIdx.y * C + (long)m.chunk * V + i] = o[i];
   }
 }
 
