@@ -185,7 +185,11 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16_glds(GemmArgs g) {
   constexpr int KT = 64;                         // elements of K per stage (128 bytes per row)
   constexpr int ROW = 128;                       // LDS bytes per tile row
   constexpr int STAGE = (BM + BN) * ROW;         // 32 KiB
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // TWO separate LDS objects, one per stage, and a K loop unrolled by two so that every access names its stage statically:
+  // the compiler can then prove that the DMA into one stage does not alias the fragment reads of the other and leaves the
+  // DMA in flight under the MFMAs (with one array + a run-time stage index it drains vmcnt(0) before the first ds_read).
+  __shared__ __attribute__((aligned(16))) unsigned char stage0[STAGE];
+  __shared__ __attribute__((aligned(16))) unsigned char stage1[STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   // XCD-aware remap of the (x, y) tile id (bijective for any grid size)
@@ -231,8 +235,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16_glds(GemmArgs g) {
     a_src[j] = A + (long)min(m0 + r, g.M - 1) * g.lda + chunk * 8;
     b_src[j] = B + (long)min(n0 + r, g.N - 1) * g.ldb + chunk * 8;
   }
-  auto dma = [&](int stage, int kt) {
-    unsigned char* sa = smem + stage * STAGE + wave * 32 * ROW;
+  auto dma = [&](unsigned char* st, int kt) {
+    unsigned char* sa = st + wave * 32 * ROW;
     unsigned char* sb = sa + BM * ROW;
     const int k0 = kt * KT;
 #pragma unroll
@@ -244,13 +248,9 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16_glds(GemmArgs g) {
 
   const int li = lane & 31, lq = lane >> 5;
   const int key = (li >> 1) & 7;                 // rows wm*64 + i*32 + li: the swizzle key depends on li only
-  if (kt_begin < kt_end) dma(0, kt_begin);
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int stage = (kt - kt_begin) & 1;
-    __syncthreads();                              // (the compiler drains the DMA queue -- vmcnt(0) -- ahead of the barrier)
-    if (kt + 1 < kt_end) dma(stage ^ 1, kt + 1);
-    const unsigned char* sa = smem + stage * STAGE + (wm * 64 + li) * ROW;
-    const unsigned char* sb = smem + stage * STAGE + BM * ROW + (wn * 64 + li) * ROW;
+  auto compute = [&](const unsigned char* st) {
+    const unsigned char* sa = st + (wm * 64 + li) * ROW;
+    const unsigned char* sb = st + BM * ROW + (wn * 64 + li) * ROW;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {                 // k-step of 16 elements = chunks 2c (lq = 0) and 2c+1 (lq = 1)
       const int off = ((2 * c + lq) ^ key) * 16;
@@ -265,6 +265,17 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16_glds(GemmArgs g) {
       Mma<bf16_t>::mma32(acc[1][0], b0, a1);
       Mma<bf16_t>::mma32(acc[1][1], b1, a1);
     }
+  };
+  if (kt_begin < kt_end) dma(stage0, kt_begin);
+  for (int kt = kt_begin; kt < kt_end;) {
+    __syncthreads();                              // stage0 landed (DMA queue drained ahead of the barrier); stage1 free
+    if (kt + 1 < kt_end) dma(stage1, kt + 1);
+    compute(stage0);
+    if (++kt >= kt_end) break;
+    __syncthreads();
+    if (kt + 1 < kt_end) dma(stage0, kt + 1);
+    compute(stage1);
+    ++kt;
   }
 
   const float* bias = g.bias ? g.bias + (long)batch * g.sBias : nullptr;
@@ -343,14 +354,8 @@ int ds2_gemm_nt(int dtype, const void* A, const void* B, void* C, const float* b
     hipLaunchKernelGGL(k_gemm_nt<float>, grid, blk, shm, st, g);
   } else if (splitk == 1 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && getenv("DS2_GEMM_NO_GLDS") == nullptr) {
     // (split-K accumulates with atomics: the register-staged kernel below keeps them coalesced along n)
-    static bool attr_g = false;
-    const size_t shm_g = 2 * (BM + BN) * 128;
-    if (!attr_g) {
-      (void)hipFuncSetAttribute((const void*)k_gemm_nt_bf16_glds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_g);
-      attr_g = true;
-    }
     g.out_is_f32 = out_f32;
-    hipLaunchKernelGGL(k_gemm_nt_bf16_glds, grid, blk, shm_g, st, g);
+    hipLaunchKernelGGL(k_gemm_nt_bf16_glds, grid, blk, 0, st, g);
   } else {
     static bool attr_b = false;
     if (!attr_b) {

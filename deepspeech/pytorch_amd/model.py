@@ -132,7 +132,7 @@ def _wgrad_splitk(M, N, K):
     """Split-K factor of a weight-gradient GEMM (long K = T'*N, few output tiles): enough 128x128 tiles x K-slices to
     fill the 256 CUs twice over, every slice keeping >= 32 K-tiles."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    if tiles > 256:          # already fills the chip: the DMA-staged kernel without atomics is faster (tools/bench_gemm.py)
+    if tiles >= 128:         # fills enough of the chip: the DMA-staged kernel without atomics is faster (tools/bench_gemm.py)
         return 1
     return max(1, min(8, 768 // max(tiles, 1), K // (64 * 32)))
 
