@@ -140,9 +140,17 @@ def run_native(args, rank, world, device):
     dom = max(kernels, key=lambda k: kernels[k]["ms_per_train_step"]) if kernels else None
     names = {"rnn_fwd_persistent": "k_rnn_persist_fwd", "rnn_bwd_persistent": "k_rnn_persist_bwd", "rnn_fwd": "k_rnn_step_fwd",
              "rnn_bwd": "k_rnn_step_bwd"}
+    traffic, traffic_src = None, None
+    try:   # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/pmc_traffic.json)
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if pm.get("config") == args.config and names.get(dom, dom) in pm["kernels"]:
+            k = pm["kernels"][names.get(dom, dom)]
+            traffic, traffic_src = int(k["fetch_bytes"] + k["write_bytes"]), pm["source"]
+    except Exception:
+        pass
     roofline = {"bound": "mfma", "kernel": names.get(dom, dom), "achieved": kernels[dom]["achieved_tflops"] if dom else 0.0,
                 "peak": peak, "unit": "TFLOP/s", "frac": round((kernels[dom]["achieved_tflops"] if dom else 0.0) / peak, 6),
-                "traffic": None, "avg_launch_us": kernels[dom]["avg_launch_us"] if dom else None,
+                "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": kernels[dom]["avg_launch_us"] if dom else None,
                 "us_per_time_step": kernels[dom]["us_per_time_step"] if dom else None,
                 "note": "latency-bound serial recurrence: 2*L*T' dependent steps per train step; flops are the algorithmic "
                         "h2h products over valid frames",
