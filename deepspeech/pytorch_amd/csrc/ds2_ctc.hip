@@ -15,7 +15,7 @@
 
 namespace {
 
-constexpr int CTC_THREADS = 256;
+constexpr int CTC_THREADS = 512;   // two halves of 256: alpha and beta, <= 2 states per thread for targets up to 255 labels
 constexpr int CP = 32;  // padded class stride of the log-prob scratch
 
 // log(exp a + exp b + exp c).  v_exp_f32 / v_log_f32 (1 ulp in the base-2 domain) instead of the full-precision libm
@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(CTC_THREADS) k_ctc(const float* __restrict__ l
   float* rowB0 = rowA1 + Lmax;                       // beta rows
   float* rowB1 = rowB0 + Lmax;
   int* ext = reinterpret_cast<int*>(rowB1 + Lmax);   // [Lmax]
-  float* acc = reinterpret_cast<float*>(ext + Lmax); // [4 waves][CP]
+  float* acc = reinterpret_cast<float*>(ext + Lmax); // [CTC_THREADS / 64 waves][CP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = blockIdx.x;
   int Ti = in_len[n];
@@ -187,7 +187,7 @@ int ds2_ctc_loss_grad(const float* logits, long ldl, const int* targets, const i
   DS2_REQUIRE(Tp > 0 && N > 0 && C > 0 && C <= CP && blank >= 0 && blank < C && max_target_len >= 0, DS2_ERR_ARG);
   DS2_REQUIRE(ldg >= C && ldg <= 64 && ldl >= C, DS2_ERR_ARG);
   const int Lmax = 2 * max_target_len + 1;
-  const size_t shm = (size_t)Lmax * 20 + 4 * CP * 4;
+  const size_t shm = (size_t)Lmax * 20 + (CTC_THREADS / 64) * CP * 4;
   DS2_REQUIRE(shm <= 60 * 1024, DS2_ERR_ARG);
   float* ws_lp = ws;
   float* ws_alpha = ws + (long)N * Tp * CP;

@@ -490,6 +490,31 @@ class DeepSpeech(_Base):
         self._side_streams = {}
         self._kind = kind
 
+    def _prep_rnn_weights(self, dtype, need_backward):
+        """Builds (or revalidates) every kernel-layout copy of the RNN weights -- bf16 casts, direction stacking, transposes
+        for the dX / BPTT kernels -- in one place, so that forward can run it on the second stream under the conv stack
+        (after an optimizer step every copy is stale: ~130 MB of fp32 reads per step)."""
+        c = self._cache
+        for li, layer in enumerate(self.rnns):
+            p, D, first = layer.rnn, layer.num_directions, li == 0
+            sufs = [""] + (["_reverse"] if D == 2 else [])
+            wih = [getattr(p, "weight_ih_l0" + s_) for s_ in sufs]
+            whh = [getattr(p, "weight_hh_l0" + s_) for s_ in sufs]
+            bih = [getattr(p, "bias_ih_l0" + s_) for s_ in sufs]
+            bhh = [getattr(p, "bias_hh_l0" + s_) for s_ in sufs]
+
+            def cat_ih(wih=wih, first=first):
+                w = torch.cat([q.detach() for q in wih], 0)
+                return _perm_cols_to_internal(w) if first else w
+            c.get(("wih", li, dtype), wih, lambda: cat_ih().to(dtype).contiguous())
+            c.get(("whh", li, dtype), whh, lambda whh=whh: torch.stack([q.detach() for q in whh], 0).to(dtype).contiguous())
+            c.get(("bih", li), bih, lambda bih=bih: torch.cat([q.detach() for q in bih], 0).contiguous())
+            c.get(("bhh", li), bhh, lambda bhh=bhh: torch.stack([q.detach() for q in bhh], 0).contiguous())
+            if need_backward:
+                c.get(("whhT", li, dtype), list(whh),
+                      lambda whh=whh: torch.stack([q.detach().t() for q in whh], 0).to(dtype).contiguous())
+                c.get(("wihT", li, dtype), list(wih), lambda: cat_ih().t().to(dtype).contiguous())
+
     def _wgrad_stream(self, device):
         """Second HIP stream of this module on `device` (weight-gradient work of the RNN stack's backward)."""
         key = device.index if device.index is not None else torch.cuda.current_device()
@@ -522,8 +547,16 @@ class DeepSpeech(_Base):
         training = self.training
         sm = self.conv.seq_module
         with torch.autocast("cuda", enabled=False):
+            # weight re-layouts for the RNN stack: second stream, hidden under the conv front-end
+            main, side = torch.cuda.current_stream(), self._wgrad_stream(dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._prep_rnn_weights(dtype, training and torch.is_grad_enabled())
+            prep_done = torch.cuda.Event()
+            prep_done.record(side)
             X = _ConvStackFn.apply(x, sm[0].weight, sm[0].bias, sm[1].weight, sm[1].bias, sm[3].weight, sm[3].bias,
                                    sm[4].weight, sm[4].bias, self, lens_dev, Tp, dtype, training)
+            main.wait_event(prep_done)
             L = len(self.rnns)
             if hs is None:
                 hs = [None] * L
