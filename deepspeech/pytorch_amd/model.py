@@ -353,11 +353,59 @@ class _RnnStackFn(torch.autograd.Function):
                                                         dBih[d * GH:(d + 1) * GH].contiguous(), dBhh.contiguous()]
                 del dGI_T
             dout = dX
-        main.wait_stream(side)          # every parameter gradient is complete before autograd / DDP sees it
-        for g in grads:
-            if g is not None:
-                g.record_stream(main)
+        if getattr(ctx, "defer_join", False):
+            ctx.pending = (main, side, grads)     # the composite node joins after the conv backward
+        else:
+            _join_side(main, side, grads)
         return (dout, None, None, None, None, None, None, None, *([None] * (2 * L)), *grads)
+
+
+def _join_side(main, side, grads):
+    """Every parameter gradient produced on the second stream is complete before autograd / DDP sees it."""
+    main.wait_stream(side)
+    for g in grads:
+        if g is not None:
+            g.record_stream(main)
+
+
+class _SubCtx:
+    """Stands in for an autograd ctx when a stage runs as a plain function inside the composite node below."""
+
+    def save_for_backward(self, *t):
+        self.saved_tensors = t
+
+    def mark_non_differentiable(self, *a):
+        pass
+
+
+class _FrontFn(torch.autograd.Function):
+    """Conv front-end + RNN stack as ONE autograd node (model.py:217-230).  Same arithmetic as running _ConvStackFn and
+    _RnnStackFn back to back; being one node lets backward keep the layer-0 weight-gradient GEMMs on the second stream
+    while the conv backward runs on the caller's stream, and join the streams once, at the very end."""
+
+    @staticmethod
+    def forward(ctx, x, mod, lens_dev, N, Tp, dtype, training, n_layers, *rest):
+        conv_params, rnn_rest = rest[:8], rest[8:]
+        c1, c2 = _SubCtx(), _SubCtx()
+        X0 = _ConvStackFn.forward(c1, x, *conv_params, mod, lens_dev, Tp, dtype, training)
+        if mod._prep_done is not None:           # RNN weight re-layouts were prepared on the second stream meanwhile
+            torch.cuda.current_stream().wait_event(mod._prep_done)
+            mod._prep_done = None
+        outs = _RnnStackFn.forward(c2, X0, mod, lens_dev, N, Tp, dtype, training, n_layers, *rnn_rest)
+        ctx.c1, ctx.c2, ctx.L = c1, c2, n_layers
+        ctx.mark_non_differentiable(*outs[1:])
+        return outs
+
+    @staticmethod
+    def backward(ctx, dout, *unused):
+        c1, c2, L = ctx.c1, ctx.c2, ctx.L
+        c2.defer_join = True
+        r = _RnnStackFn.backward(c2, dout)
+        rnn_grads = r[8 + 2 * L:]
+        cg = _ConvStackFn.backward(c1, r[0])
+        _join_side(*c2.pending)
+        ctx.c1 = ctx.c2 = None
+        return (None,) * 8 + tuple(cg[1:9]) + (None,) * (2 * L) + tuple(rnn_grads)
 
 
 class _LookaheadFn(torch.autograd.Function):
@@ -488,6 +536,7 @@ class DeepSpeech(_Base):
         self.blank_index = self.labels.index('_')      # model.py:203
         self._cache = _WeightCache()
         self._side_streams = {}
+        self._prep_done = None
         self._kind = kind
 
     def _prep_rnn_weights(self, dtype, need_backward):
@@ -554,9 +603,7 @@ class DeepSpeech(_Base):
                 self._prep_rnn_weights(dtype, training and torch.is_grad_enabled())
             prep_done = torch.cuda.Event()
             prep_done.record(side)
-            X = _ConvStackFn.apply(x, sm[0].weight, sm[0].bias, sm[1].weight, sm[1].bias, sm[3].weight, sm[3].bias,
-                                   sm[4].weight, sm[4].bias, self, lens_dev, Tp, dtype, training)
-            main.wait_event(prep_done)
+            self._prep_done = prep_done          # awaited inside the composite node, between the conv and the RNN stack
             L = len(self.rnns)
             if hs is None:
                 hs = [None] * L
@@ -577,7 +624,8 @@ class DeepSpeech(_Base):
                 for suf in [""] + (["_reverse"] if self.bidirectional else []):
                     params += [getattr(p, "weight_ih_l0" + suf), getattr(p, "weight_hh_l0" + suf),
                                getattr(p, "bias_ih_l0" + suf), getattr(p, "bias_hh_l0" + suf)]
-            res = _RnnStackFn.apply(X, self, lens_dev, N, Tp, dtype, training, L, *h0s, *c0s, *params)
+            res = _FrontFn.apply(x, self, lens_dev, N, Tp, dtype, training, L, sm[0].weight, sm[0].bias, sm[1].weight, sm[1].bias,
+                                 sm[3].weight, sm[3].bias, sm[4].weight, sm[4].bias, *h0s, *c0s, *params)
             X = res[0]
             if self._kind == "lstm":
                 new_hs = [(res[1 + i], res[1 + L + i]) for i in range(L)]
