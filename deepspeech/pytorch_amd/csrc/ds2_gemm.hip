@@ -177,6 +177,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt(GemmArgs g) {
 // Two LDS stages; iteration kt: wait for stage kt (vmcnt(0) + barrier), issue the DMA of tile kt+1, MFMA on tile kt.
 // Requires K % 64 == 0 and 16-byte aligned rows (the binding pads K); rows past M / N re-read the last row.
 // Workgroup ids are remapped so that each XCD (own L2) works on a contiguous band of the tile grid.
+// (Measured and rejected: four stages at one workgroup per CU with asm-issued DMA and counted vmcnt waits -- 456-695
+// TFLOP/s on the step's shapes against 566-798 for this two-stage, two-workgroups-per-CU form.)
 // ------------------------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
@@ -324,6 +326,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16_glds(GemmArgs g) {
     }
   }
 }
+
 
 }  // namespace
 

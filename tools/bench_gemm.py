@@ -32,7 +32,7 @@ for name, M, N, K, f32, sk in shapes:
         ts.append(e0.elapsed_time(e1))
     t = sorted(ts[2:])[len(ts[2:]) // 2]
     print("%-14s M=%5d N=%5d K=%5d  %.3f ms  %.0f TFLOP/s" % (name, M, N, K, t, 2.0 * M * N * K / t / 1e9))
-    if name == "dgrad":
-        ref = (A[:256].float() @ B.float().t())
-        err = (C[:256].float() - ref).abs().max().item() / ref.abs().max().item()
-        print("   check rel err %.2e" % err)
+    rows = torch.cat([torch.arange(0, 130), torch.arange(M - 130, M)]).to(dev)
+    ref = (A[rows].float() @ B.float().t())
+    err = (C[rows].float() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < (1e-5 if f32 else 6e-3), (name, err)
