@@ -40,6 +40,7 @@ __global__ void __launch_bounds__(CTC_THREADS) k_ctc(const float* __restrict__ l
   float* rowB1 = rowB0 + Lmax;
   int* ext = reinterpret_cast<int*>(rowB1 + Lmax);   // [Lmax]
   float* acc = reinterpret_cast<float*>(ext + Lmax); // [CTC_THREADS / 64 waves][CP]
+  float* lpbuf = acc + (CTC_THREADS / 64) * CP;      // [2 recursions][2 parities][CP]: log-prob rows of the current step
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = blockIdx.x;
   int Ti = in_len[n];
@@ -83,9 +84,16 @@ __global__ void __launch_bounds__(CTC_THREADS) k_ctc(const float* __restrict__ l
     float* prev = is_beta ? rowB0 : rowA0;
     float* cur = is_beta ? rowB1 : rowA1;
     float* dst = is_beta ? beta : alpha;
+    float* lpl = lpbuf + (is_beta ? 2 * CP : 0);       // this recursion's two row buffers
+    // the frame's 29 log-probs are staged in LDS one step AHEAD (a dependent L2 round trip per step otherwise)
+    if (ht < CP) lpl[ht] = lp[(long)(is_beta ? Ti - 1 : 0) * CP + ht];
+    __syncthreads();
     for (int i = 0; i < Ti; ++i) {
       const int t = is_beta ? Ti - 1 - i : i;
-      const float* lpt = lp + (long)t * CP;
+      const float* lpt = lpl + (i & 1) * CP;
+      float nxt = 0.f;
+      const bool pre = ht < CP && i + 1 < Ti;
+      if (pre) nxt = lp[(long)(is_beta ? t - 1 : t + 1) * CP + ht];
       for (int s = ht; s < L; s += HALF) {
         const int e = ext[s];
         float v;
@@ -108,6 +116,7 @@ __global__ void __launch_bounds__(CTC_THREADS) k_ctc(const float* __restrict__ l
         cur[s] = v;
         dst[(long)t * Lmax + s] = v;
       }
+      if (pre) lpl[((i + 1) & 1) * CP + ht] = nxt;
       __syncthreads();
       float* tmp = prev;
       prev = cur;
@@ -187,7 +196,7 @@ int ds2_ctc_loss_grad(const float* logits, long ldl, const int* targets, const i
   DS2_REQUIRE(Tp > 0 && N > 0 && C > 0 && C <= CP && blank >= 0 && blank < C && max_target_len >= 0, DS2_ERR_ARG);
   DS2_REQUIRE(ldg >= C && ldg <= 64 && ldl >= C, DS2_ERR_ARG);
   const int Lmax = 2 * max_target_len + 1;
-  const size_t shm = (size_t)Lmax * 20 + (CTC_THREADS / 64) * CP * 4;
+  const size_t shm = (size_t)Lmax * 20 + (CTC_THREADS / 64) * CP * 4 + 4 * CP * 4;
   DS2_REQUIRE(shm <= 60 * 1024, DS2_ERR_ARG);
   float* ws_lp = ws;
   float* ws_alpha = ws + (long)N * Tp * CP;
