@@ -78,8 +78,8 @@ __global__ void __launch_bounds__(256) k_conv1_fwd(const float* __restrict__ x, 
 // ============================================================================================================
 // conv1 weight gradient: thread <-> kernel tap, 32 output-channel accumulators, dy as the wave-uniform operand
 // ============================================================================================================
-constexpr int C1W_THREADS = 512;
-constexpr int C1W_MAXBLOCKS = 512;
+constexpr int C1W_THREADS = 256;
+constexpr int C1W_MAXBLOCKS = 1024;
 
 template <typename T>
 __device__ __forceinline__ void load_dy32(const T* __restrict__ p, float (&d)[CH]);
@@ -103,13 +103,19 @@ template <typename T>
 __global__ void __launch_bounds__(C1W_THREADS) k_conv1_wgrad(const float* __restrict__ x, const T* __restrict__ dy1,
                                                              float* __restrict__ partial, int N, int Tin, int Tp,
                                                              int nchunk_t, int nchunk_f) {
+  // TWO kernel taps per thread (tid and tid + 256): the output-gradient channels arrive through scalar loads and are
+  // unpacked bf16 -> fp32 on the scalar ALU, one unit per CU shared by all waves -- with one tap per thread that unpack
+  // (32 SALU ops per position and wave) outran the 32 v_fmac it feeds; two taps per thread halve the SALU work per FMA.
   __shared__ float patch[C1_PR * C1_PCP];
   const int tid = threadIdx.x;
-  const int tap = tid < K1F * K1T ? tid : 0;
-  const int kf = tap / K1T, kt = tap - kf * K1T;
-  float acc[CH];
+  constexpr int NTAP = K1F * K1T;
+  const int tap0 = tid, tap1 = tid + C1W_THREADS < NTAP ? tid + C1W_THREADS : tid;
+  const bool has1 = tid + C1W_THREADS < NTAP;
+  const int kf0 = tap0 / K1T, kt0 = tap0 - kf0 * K1T;
+  const int kf1 = tap1 / K1T, kt1 = tap1 - kf1 * K1T;
+  float acc0[CH], acc1[CH];
 #pragma unroll
-  for (int co = 0; co < CH; ++co) acc[co] = 0.f;
+  for (int co = 0; co < CH; ++co) acc0[co] = acc1[co] = 0.f;
   const int total = N * nchunk_f * nchunk_t;
   for (int chunk = blockIdx.x; chunk < total; chunk += gridDim.x) {
     const int ct = chunk % nchunk_t, cf = (chunk / nchunk_t) % nchunk_f, n = chunk / (nchunk_t * nchunk_f);
@@ -120,21 +126,29 @@ __global__ void __launch_bounds__(C1W_THREADS) k_conv1_wgrad(const float* __rest
     const int rmax = min(C1_FB, F1 - fo0), cmax = min(C1_TB, Tp - to0);
     for (int r = 0; r < rmax; ++r) {
       const T* dyrow = dy1 + (((long)n * F1 + fo0 + r) * Tp + to0) * CH;
-      const float* prow = patch + (2 * r + kf) * C1_PCP + kt;
+      const float* prow0 = patch + (2 * r + kf0) * C1_PCP + kt0;
+      const float* prow1 = patch + (2 * r + kf1) * C1_PCP + kt1;
       for (int c = 0; c < cmax; ++c) {
         float d[CH];
         load_dy32<T>(dyrow + (long)c * CH, d);   // address depends only on loop counters: scalar loads
-        const float xv = prow[2 * c];
+        const float xv0 = prow0[2 * c], xv1 = prow1[2 * c];
 #pragma unroll
-        for (int co = 0; co < CH; ++co) acc[co] = fmaf(xv, d[co], acc[co]);
+        for (int co = 0; co < CH; ++co) {
+          acc0[co] = fmaf(xv0, d[co], acc0[co]);
+          acc1[co] = fmaf(xv1, d[co], acc1[co]);
+        }
       }
     }
   }
-  if (tid < K1F * K1T) {
-    float* dst = partial + ((long)blockIdx.x * (K1F * K1T) + tid) * CH;
+  float* dst0 = partial + ((long)blockIdx.x * NTAP + tap0) * CH;
+#pragma unroll
+  for (int v = 0; v < CH / 4; ++v)
+    *reinterpret_cast<float4*>(dst0 + 4 * v) = make_float4(acc0[4 * v], acc0[4 * v + 1], acc0[4 * v + 2], acc0[4 * v + 3]);
+  if (has1) {
+    float* dst1 = partial + ((long)blockIdx.x * NTAP + tap1) * CH;
 #pragma unroll
     for (int v = 0; v < CH / 4; ++v)
-      *reinterpret_cast<float4*>(dst + 4 * v) = make_float4(acc[4 * v], acc[4 * v + 1], acc[4 * v + 2], acc[4 * v + 3]);
+      *reinterpret_cast<float4*>(dst1 + 4 * v) = make_float4(acc1[4 * v], acc1[4 * v + 1], acc1[4 * v + 2], acc1[4 * v + 3]);
   }
 }
 
