@@ -31,9 +31,10 @@ __device__ __forceinline__ void conv1_load_patch(float* patch, const float* __re
   for (int i = tid; i < C1_PR * C1_PC; i += nthreads) {
     const int pr = i / C1_PC, pc = i - pr * C1_PC;
     const int fi = f_base + pr, ti = t_base + pc;
-    float v = 0.f;
-    if (fi >= 0 && fi < F0 && ti >= 0 && ti < T) v = xn[(long)fi * T + ti];
-    patch[pr * C1_PCP + pc] = v;
+    // unconditional load from a clamped address, zeroed by a select afterwards: keeps all of a thread's ~25 loads in flight
+    const bool ok = fi >= 0 && fi < F0 && ti >= 0 && ti < T;
+    const float v = xn[(long)min(max(fi, 0), F0 - 1) * T + min(max(ti, 0), T - 1)];
+    patch[pr * C1_PCP + pc] = ok ? v : 0.f;
   }
 }
 
@@ -202,9 +203,12 @@ __global__ void __launch_bounds__(256, 1) k_conv_tap(ConvTapArgs a) {
       const int v = i & 3, pos = i >> 2;
       const int pr = pos / CT_PC, pc = pos - pr * CT_PC;
       const int fi = fi0 + pr, ti = ti0 + pc;
-      uint4 val = make_uint4(0, 0, 0, 0);
-      if (fi >= 0 && fi < a.Fin && ti >= 0 && ti < a.Tp)
-        val = *reinterpret_cast<const uint4*>(Xn + ((long)fi * a.Tp + ti) * CH + c0 + v * V);
+      // unconditional load from a clamped address + bit mask (a predicated load = branch + s_waitcnt vmcnt(0) per load:
+      // the ~18 loads of a thread would be 18 serial memory round trips)
+      const uint32_t m = (fi >= 0 && fi < a.Fin && ti >= 0 && ti < a.Tp) ? 0xffffffffu : 0u;
+      const int fc = min(max(fi, 0), a.Fin - 1), tc = min(max(ti, 0), a.Tp - 1);
+      uint4 val = *reinterpret_cast<const uint4*>(Xn + ((long)fc * a.Tp + tc) * CH + c0 + v * V);
+      val.x &= m; val.y &= m; val.z &= m; val.w &= m;
       *reinterpret_cast<uint4*>(patch + pos * CT_POSB + v * 16) = val;
     }
     // ---- weights of kernel row 0 of this pass
@@ -298,15 +302,17 @@ __global__ void __launch_bounds__(256, 1) k_conv2_wgrad(const T* __restrict__ dY
       __syncthreads();
       for (int i = tid; i < CW_TB * (CH / V); i += 256) {
         const int p = i / (CH / V), v = i - p * (CH / V);
-        uint4 val = make_uint4(0, 0, 0, 0);
-        if (t0 + p < Tp) val = *reinterpret_cast<const uint4*>(dyrow + (long)(t0 + p) * CH + v * V);
+        const uint32_t mk = t0 + p < Tp ? 0xffffffffu : 0u;
+        uint4 val = *reinterpret_cast<const uint4*>(dyrow + (long)min(t0 + p, Tp - 1) * CH + v * V);
+        val.x &= mk; val.y &= mk; val.z &= mk; val.w &= mk;
         *reinterpret_cast<uint4*>(sdy + p * CH + v * V) = val;
       }
       for (int i = tid; i < (CW_TB + K2T - 1) * (CH / V); i += 256) {
         const int p = i / (CH / V), v = i - p * (CH / V);
         const int t = t0 - 5 + p;
-        uint4 val = make_uint4(0, 0, 0, 0);
-        if (t >= 0 && t < Tp) val = *reinterpret_cast<const uint4*>(xrow + (long)t * CH + v * V);
+        const uint32_t mk = (t >= 0 && t < Tp) ? 0xffffffffu : 0u;
+        uint4 val = *reinterpret_cast<const uint4*>(xrow + (long)min(max(t, 0), Tp - 1) * CH + v * V);
+        val.x &= mk; val.y &= mk; val.z &= mk; val.w &= mk;
         *reinterpret_cast<uint4*>(sx + p * CH + v * V) = val;
       }
       __syncthreads();
