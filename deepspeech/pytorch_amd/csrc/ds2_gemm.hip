@@ -183,15 +183,17 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt(GemmArgs g) {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
+template <bool LOWREG>
 __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16_glds(GemmArgs g) {
   constexpr int KT = 64;                         // elements of K per stage (128 bytes per row)
   constexpr int ROW = 128;                       // LDS bytes per tile row
   constexpr int STAGE = (BM + BN) * ROW;         // 32 KiB
-  // TWO separate LDS objects, one per stage, and a K loop unrolled by two so that every access names its stage statically:
-  // the compiler can then prove that the DMA into one stage does not alias the fragment reads of the other and leaves the
-  // DMA in flight under the MFMAs (with one array + a run-time stage index it drains vmcnt(0) before the first ds_read).
-  __shared__ __attribute__((aligned(16))) unsigned char stage0[STAGE];
-  __shared__ __attribute__((aligned(16))) unsigned char stage1[STAGE];
+  // !LOWREG: TWO separate LDS objects, one per stage, and a K loop unrolled by two so that every access names its stage
+  // statically: the compiler can then prove that the DMA into one stage does not alias the fragment reads of the other and
+  // leaves the DMA in flight under the MFMAs (with one array + a run-time stage index it drains vmcnt(0) before the first
+  // ds_read).  LOWREG: that one-array form -- slower in isolation (no in-block overlap) but ~115 instead of ~196 VGPRs, which
+  // lets its waves share a SIMD with the persistent recurrent kernels (used for the weight-gradient GEMMs on the second stream).
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   // XCD-aware remap of the (x, y) tile id (bijective for any grid size)
@@ -268,16 +270,28 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16_glds(GemmArgs g) {
       Mma<bf16_t>::mma32(acc[1][1], b1, a1);
     }
   };
-  if (kt_begin < kt_end) dma(stage0, kt_begin);
-  for (int kt = kt_begin; kt < kt_end;) {
-    __syncthreads();                              // stage0 landed (DMA queue drained ahead of the barrier); stage1 free
-    if (kt + 1 < kt_end) dma(stage1, kt + 1);
-    compute(stage0);
-    if (++kt >= kt_end) break;
-    __syncthreads();
-    if (kt + 1 < kt_end) dma(stage0, kt + 1);
-    compute(stage1);
-    ++kt;
+  if constexpr (LOWREG) {
+    if (kt_begin < kt_end) dma(smem_dyn, kt_begin);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const int stage = (kt - kt_begin) & 1;
+      __syncthreads();
+      if (kt + 1 < kt_end) dma(smem_dyn + (stage ^ 1) * STAGE, kt + 1);
+      compute(smem_dyn + stage * STAGE);
+    }
+  } else {
+    __shared__ __attribute__((aligned(16))) unsigned char stage0[STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned char stage1[STAGE];
+    if (kt_begin < kt_end) dma(stage0, kt_begin);
+    for (int kt = kt_begin; kt < kt_end;) {
+      __syncthreads();                            // stage0 landed (DMA queue drained ahead of the barrier); stage1 free
+      if (kt + 1 < kt_end) dma(stage1, kt + 1);
+      compute(stage0);
+      if (++kt >= kt_end) break;
+      __syncthreads();
+      if (kt + 1 < kt_end) dma(stage0, kt + 1);
+      compute(stage1);
+      ++kt;
+    }
   }
 
   const float* bias = g.bias ? g.bias + (long)batch * g.sBias : nullptr;
@@ -335,9 +349,9 @@ extern "C" {
 // C (f32 if out_f32 else `dtype`) [M][ldc] = A[M][lda] * B[N][ldb]^T (+bias[N]); batched over `batch` with element strides.
 // K, lda, ldb must be multiples of 16 bytes / sizeof(T); A/B 16-byte aligned.  splitk>1 requires out_f32 and a
 // zero-initialised C (results are atomically accumulated).
-int ds2_gemm_nt(int dtype, const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long lda, long ldb,
-                long ldc, int out_f32, int batch, long strideA, long strideB, long strideC, long strideBias, int splitk,
-                ds2_stream_t st_) {
+static int gemm_nt_impl(int dtype, const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long lda,
+                        long ldb, long ldc, int out_f32, int batch, long strideA, long strideB, long strideC, long strideBias,
+                        int splitk, bool coresident, ds2_stream_t st_) {
   hipStream_t st = (hipStream_t)st_;
   DS2_REQUIRE(dtype == DS2_F32 || dtype == DS2_BF16, DS2_ERR_DTYPE);
   const int V = dtype == DS2_F32 ? 4 : 8;
@@ -358,7 +372,17 @@ int ds2_gemm_nt(int dtype, const void* A, const void* B, void* C, const float* b
   } else if (splitk == 1 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && getenv("DS2_GEMM_NO_GLDS") == nullptr) {
     // (split-K accumulates with atomics: the register-staged kernel below keeps them coalesced along n)
     g.out_is_f32 = out_f32;
-    hipLaunchKernelGGL(k_gemm_nt_bf16_glds, grid, blk, 0, st, g);
+    if (coresident) {
+      static bool attr_lr = false;
+      const size_t shm_lr = 2 * (BM + BN) * 128;
+      if (!attr_lr) {
+        (void)hipFuncSetAttribute((const void*)k_gemm_nt_bf16_glds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_lr);
+        attr_lr = true;
+      }
+      hipLaunchKernelGGL(k_gemm_nt_bf16_glds<true>, grid, blk, shm_lr, st, g);
+    } else {
+      hipLaunchKernelGGL(k_gemm_nt_bf16_glds<false>, grid, blk, 0, st, g);
+    }
   } else {
     static bool attr_b = false;
     if (!attr_b) {
@@ -369,6 +393,22 @@ int ds2_gemm_nt(int dtype, const void* A, const void* B, void* C, const float* b
   }
   DS2_CHECK_LAUNCH();
   return 0;
+}
+
+int ds2_gemm_nt(int dtype, const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long lda, long ldb,
+                long ldc, int out_f32, int batch, long strideA, long strideB, long strideC, long strideBias, int splitk,
+                ds2_stream_t st) {
+  return gemm_nt_impl(dtype, A, B, C, bias, M, N, K, lda, ldb, ldc, out_f32, batch, strideA, strideB, strideC, strideBias, splitk,
+                      false, st);
+}
+
+// Same contract; picks the low-register kernel variant whose waves can share a SIMD with the persistent recurrent kernels
+// (for GEMMs issued on a second stream while a recurrent sweep owns the CUs).
+int ds2_gemm_nt_coresident(int dtype, const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long lda,
+                           long ldb, long ldc, int out_f32, int batch, long strideA, long strideB, long strideC, long strideBias,
+                           int splitk, ds2_stream_t st) {
+  return gemm_nt_impl(dtype, A, B, C, bias, M, N, K, lda, ldb, ldc, out_f32, batch, strideA, strideB, strideC, strideBias, splitk,
+                      true, st);
 }
 
 }  // extern "C"

@@ -135,7 +135,14 @@ __device__ __forceinline__ uint32_t ror8(uint32_t v) {   // lane i <- lane i^8 w
 }
 
 constexpr int chunk_ksteps(int KS, int SPLIT) {
-  return SPLIT == 2 ? (KS <= 24 ? KS : KS / 2) : (KS <= 12 ? KS : (KS % 12 == 0 ? 12 : 8));
+#ifdef DS2_CHUNK
+  return (KS % DS2_CHUNK == 0 && DS2_CHUNK % SPLIT == 0) ? DS2_CHUNK : KS;
+#else
+  // measured on cfg3 (tools/probe_rnn_persist.py): forward (KS = 8) 2.73 us/step with chunks of 4 vs 2.80 with 8; BPTT (KS = 24)
+  // 3.65 with chunks of 8 vs 3.68 (6, 12), 4.04 (4), 4.29 (24): several small polls overlap better with the products of
+  // the previous chunk and keep the register footprint low enough for other kernels to share the CU
+  return KS <= 8 ? (KS / 2 >= SPLIT && KS % 2 == 0 ? KS / 2 : KS) : 8;
+#endif
 }
 
 // Exchange buffer layout (per group and parity): the MFMA A-fragment order, so that every gather instruction of a wave

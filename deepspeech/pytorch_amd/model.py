@@ -111,11 +111,17 @@ class Lookahead(nn.Module):  # model.py:105-135 (container only)
 # weight cache: kernel layouts derived from the fp32 parameters, rebuilt when a parameter's version changes
 # ==================================================================================================================
 class _WeightCache:
+    """Kernel-layout copies of parameters.  An entry is valid for the parameters' (version, storage) AND the cache epoch:
+    the module advances the epoch at every training-mode forward (and at the first eval forward after training), because
+    in-place updates that do not bump ``Tensor._version`` exist -- torch's fused optimizers (``AdamW(fused=True)``) are
+    one -- and a stale bf16 copy would silently freeze training."""
+
     def __init__(self):
         self._store = {}
+        self.epoch = 0
 
     def get(self, key, params, builder):
-        ver = tuple((p._version, p.data_ptr()) for p in params)
+        ver = (self.epoch,) + tuple((p._version, p.data_ptr()) for p in params)
         hit = self._store.get(key)
         if hit is not None and hit[0] == ver:
             return hit[1]
@@ -332,7 +338,8 @@ class _RnnStackFn(torch.autograd.Function):
                 dGI_T = ops.transpose(dGI)                              # [D*G*H][ldT]
                 Xh_T = ops.transpose(Xh)                                # [I][ldT]
                 ldT = dGI_T.shape[1]
-                dWih = ops.gemm_nt(dGI_T, Xh_T, out_dtype=torch.float32, splitk=_wgrad_splitk(dGI_T.shape[0], Xh_T.shape[0], ldT))
+                dWih = ops.gemm_nt(dGI_T, Xh_T, out_dtype=torch.float32, splitk=_wgrad_splitk(dGI_T.shape[0], Xh_T.shape[0], ldT),
+                                   coresident=True)
                 del Xh_T
                 if first:
                     dWih = torch.cat([_perm_cols_to_reference(dWih[d * GH:(d + 1) * GH]) for d in range(D)], 0)
@@ -348,7 +355,7 @@ class _RnnStackFn(torch.autograd.Function):
                         dGH_T = dGI_T[d * GH:(d + 1) * GH]
                         dBhh = dBih[d * GH:(d + 1) * GH]
                     dWhh = ops.gemm_nt(dGH_T, Hp_T, out_dtype=torch.float32, M=GH, N=H, K=ldT, lda=ldT, ldb=ldT,
-                                       splitk=_wgrad_splitk(GH, H, ldT))
+                                       splitk=_wgrad_splitk(GH, H, ldT), coresident=True)
                     grads[po + 4 * d:po + 4 * d + 4] = [dWih[d * GH:(d + 1) * GH].contiguous(), dWhh,
                                                         dBih[d * GH:(d + 1) * GH].contiguous(), dBhh.contiguous()]
                 del dGI_T
@@ -537,6 +544,7 @@ class DeepSpeech(_Base):
         self._cache = _WeightCache()
         self._side_streams = {}
         self._prep_done = None
+        self._weights_dirty = False
         self._kind = kind
 
     def _prep_rnn_weights(self, dtype, need_backward):
@@ -587,6 +595,12 @@ class DeepSpeech(_Base):
         if not x.is_cuda:
             raise Ds2HipError("DeepSpeech (gfx950) needs its input on a HIP device; there is no CPU fallback")
         dtype = self.compute_dtype()
+        if self.training:
+            self._cache.epoch += 1                         # parameters may have been updated in place since the last forward
+            self._weights_dirty = True
+        elif self._weights_dirty:
+            self._cache.epoch += 1
+            self._weights_dirty = False
         lengths = lengths.cpu().int()                      # model.py:215
         output_lengths = self.get_seq_lens(lengths)        # model.py:216
         N, T = x.shape[0], x.shape[3]

@@ -68,7 +68,7 @@ class _sweep_timer:
 
 # ---------------------------------------------------------------------------------------------------------------
 def gemm_nt(A, B, bias=None, out_dtype=None, M=None, N=None, K=None, lda=None, ldb=None, out=None, ldc=None, splitk=1,
-            batch=1, sA=0, sB=0, sC=0, sBias=0):
+            batch=1, sA=0, sB=0, sC=0, sBias=0, coresident=False):
     """C[M][N] = A[M][K] * B[N][K]^T (+bias).  A, B: 2-D row-major tensors (or explicit M/N/K/ld for views)."""
     M = A.shape[-2] if M is None else M
     N = B.shape[-2] if N is None else N
@@ -82,7 +82,8 @@ def gemm_nt(A, B, bias=None, out_dtype=None, M=None, N=None, K=None, lda=None, l
         ldc = N
         sC = M * N
     out_f32 = 1 if out.dtype == torch.float32 else 0
-    call("ds2_gemm_nt", dt(A), P(A), P(B), P(out), P(bias), M, N, K, lda, ldb, ldc, out_f32, batch, sA, sB, sC, sBias, splitk, S())
+    call("ds2_gemm_nt_coresident" if coresident else "ds2_gemm_nt", dt(A), P(A), P(B), P(out), P(bias), M, N, K, lda, ldb, ldc,
+         out_f32, batch, sA, sB, sC, sBias, splitk, S())
     return out
 
 

@@ -52,6 +52,12 @@ int ds2_gemm_nt(int dtype, const void* A, const void* B, void* C, const float* b
                 long ldc, int out_f32, int batch, long strideA, long strideB, long strideC, long strideBias, int splitk,
                 ds2_stream_t stream);
 
+/* same contract as ds2_gemm_nt; selects the low-register kernel variant whose waves can share a CU with the persistent
+ * recurrent kernels (weight-gradient GEMMs issued on a second stream while a sweep runs). */
+int ds2_gemm_nt_coresident(int dtype, const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long lda,
+                           long ldb, long ldc, int out_f32, int batch, long strideA, long strideB, long strideC, long strideBias,
+                           int splitk, ds2_stream_t stream);
+
 /* ---- BatchNorm (model.py:159,162 BatchNorm2d in NFTC; model.py:28-33,86,196 SequenceWise BatchNorm1d) ---------------
  * mode 0: sequence matrix X[R][ldx], C features.   mode 1: conv activation NFTC (R = N*F*Tp rows, C = 32): output also
  * gets Hardtanh(0,20) (model.py:160,163) and the MaskConv time mask (model.py:61-68; t >= lens[n] -> 0).

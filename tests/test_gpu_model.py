@@ -212,3 +212,33 @@ def test_librispeech_shape_matches_stock_torch_on_device():
         assert torch.isfinite(a).all(), k
         cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
         assert cos >= 0.97, (k, cos)
+
+
+def test_in_place_updates_without_version_bump_are_seen():
+    """torch's fused optimizers update parameters in place WITHOUT bumping Tensor._version.  The kernel-layout weight
+    copies must still be refreshed: three training steps with AdamW(fused=True) follow the same loss trajectory as the
+    unfused optimizer (and the loss moves)."""
+    fx = Fixture("gru_bi_mid")
+    inputs, targets, pct, tsz = fx.batch()
+    traj = {}
+    for fused in (False, True):
+        m = build(fx, "bf16").train()
+        opt = torch.optim.AdamW(m.parameters(), lr=1e-2, fused=fused)
+        ls = []
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            loss = m.training_step((torch.from_numpy(inputs).to(DEV), torch.from_numpy(targets), torch.from_numpy(pct.copy()),
+                                    torch.from_numpy(tsz)), 0)
+            loss.backward()
+            opt.step()
+            ls.append(float(loss.item()))
+        traj[fused] = ls
+        # eval after training must see the trained weights too
+        m.eval()
+        with torch.no_grad():
+            p1, _, _ = m(torch.from_numpy(inputs).to(DEV), torch.from_numpy(fx.z["input_sizes"].copy()))
+        assert torch.isfinite(p1).all()
+    assert abs(traj[True][0] - traj[False][0]) <= 1e-6 * abs(traj[False][0])
+    assert abs(traj[False][2] - traj[False][0]) > 1e-2 * abs(traj[False][0])          # the loss moves at all
+    for a, b in zip(traj[True], traj[False]):
+        assert abs(a - b) <= 2e-2 * abs(b), (traj[True], traj[False])
