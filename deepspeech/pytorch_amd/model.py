@@ -321,14 +321,16 @@ class _RnnStackFn(torch.autograd.Function):
             WihT = c.get(("wihT", li, dtype), list(wih), build_ihT)
             # ---- dependent chain (caller's stream): BPTT sweep -> dX -> BatchNorm backward
             dGI, dGH = ops.rnn_bwd(kind, dout, WhhT, hext, Sv, lens_dev, D, N, H, Tp)
-            ready = torch.cuda.Event()
-            ready.record(main)
             dXh = ops.gemm_nt(dGI, WihT)                                # [R][I]
             if has_bn:
                 dX = torch.empty_like(dXh)
                 grads[offs[li]], grads[offs[li] + 1] = ops.bn_bwd(dXh, X, dX, 0, sv, R, I, I, I, I)
             else:
                 dX = dXh
+            # the second stream starts this layer's weight gradients only once dX / BatchNorm backward are through, i.e. together
+            # with the next layer's sweep: the dependent chain never competes with them for the CUs
+            ready = torch.cuda.Event()
+            ready.record(main)
             # ---- weight gradients (second stream, under the next layer's sweep): contraction over the T'*N rows
             with torch.cuda.stream(side):
                 side.wait_event(ready)
