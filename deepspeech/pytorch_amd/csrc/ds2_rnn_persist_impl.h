@@ -272,6 +272,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd(PArgs a) {
   constexpr int X2 = H / 2;                // granules per sample
   static_assert(U % 16 == 0 && H % 128 == 0, "unsupported hidden size for the persistent kernel");
   __shared__ __attribute__((aligned(16))) float part[2][4 * TILES * 256];
+  __builtin_amdgcn_s_setprio(3);   // latency-critical: outrank any throughput kernel's waves that share the SIMD
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = blockIdx.x % NGROUPS, p = blockIdx.x / NGROUPS;
   const int d = grp / a.gpd, slice = grp % a.gpd;
@@ -383,6 +384,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd(PArgs a) {
       float hn0 = 0.f, hn1 = 0.f;     // emitted h_t (0 when inactive)
       const bool st_on = !(a.dbgmask & 2);
       bf16_t* sv = sv_ptr;
+      uint32_t pl[NS ? NS : 1];   // packed saved planes; stored AFTER the publish (the publish is what the peers wait for)
       float2 gh[G];
 #pragma unroll
       for (int g = 0; g < G; ++g) {
@@ -405,10 +407,10 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd(PArgs a) {
           hprev0 = hn0;
           hprev1 = hn1;
         }
-        if (st_on) *reinterpret_cast<uint32_t*>(sv) = pack_bf16x2(r0, r1);
-        if (st_on) *reinterpret_cast<uint32_t*>(sv + H) = pack_bf16x2(z0, z1);
-        if (st_on) *reinterpret_cast<uint32_t*>(sv + 2 * H) = pack_bf16x2(n0, n1);
-        if (st_on) *reinterpret_cast<uint32_t*>(sv + 3 * H) = pack_bf16x2(q0, q1);
+        pl[0] = pack_bf16x2(r0, r1);
+        pl[1 % (NS ? NS : 1)] = pack_bf16x2(z0, z1);
+        pl[2 % (NS ? NS : 1)] = pack_bf16x2(n0, n1);
+        pl[3 % (NS ? NS : 1)] = pack_bf16x2(q0, q1);
       } else if (CELL == CELL_LSTM) {
         float i0 = 0.f, i1 = 0.f, f0 = 0.f, f1 = 0.f, g0 = 0.f, g1 = 0.f, o0 = 0.f, o1 = 0.f, c0 = 0.f, c1 = 0.f;
         if (act) {
@@ -429,11 +431,11 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd(PArgs a) {
           hprev0 = hn0;
           hprev1 = hn1;
         }
-        if (st_on) *reinterpret_cast<uint32_t*>(sv) = pack_bf16x2(i0, i1);
-        if (st_on) *reinterpret_cast<uint32_t*>(sv + H) = pack_bf16x2(f0, f1);
-        if (st_on) *reinterpret_cast<uint32_t*>(sv + 2 * H) = pack_bf16x2(g0, g1);
-        if (st_on) *reinterpret_cast<uint32_t*>(sv + 3 * H) = pack_bf16x2(o0, o1);
-        if (st_on) *reinterpret_cast<uint32_t*>(sv + 4 * H) = pack_bf16x2(c0, c1);
+        pl[0] = pack_bf16x2(i0, i1);
+        pl[1 % (NS ? NS : 1)] = pack_bf16x2(f0, f1);
+        pl[2 % (NS ? NS : 1)] = pack_bf16x2(g0, g1);
+        pl[3 % (NS ? NS : 1)] = pack_bf16x2(o0, o1);
+        pl[4 % (NS ? NS : 1)] = pack_bf16x2(c0, c1);
       } else {
         if (act) {
           hn0 = ftanh(bf_lo(gi[0]) + gh[0].x + bh[0][0]);
@@ -443,10 +445,14 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd(PArgs a) {
         }
       }
       if (dead) hn0 = hn1 = hprev0 = hprev1 = __uint_as_float(0x7fc00000u);   // fail loudly downstream
-      if (st_on) *reinterpret_cast<uint32_t*>(hs_ptr) = pack_bf16x2(hn0, hn1);
-      // publish the carried state (inactive samples republish their unchanged state)
+      // publish the carried state first (inactive samples republish their unchanged state), then the bookkeeping stores
       publish((u64*)((char*)xg + par * PAR_BYTES + xgranule_bytes<NROWS>(j, gi_i)), ((u64)(unsigned)(s + 1) << 32) | pack_bf16x2(hprev0, hprev1),
               local);
+      if (st_on) {
+        *reinterpret_cast<uint32_t*>(hs_ptr) = pack_bf16x2(hn0, hn1);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) *reinterpret_cast<uint32_t*>(sv + (long)q * H) = pl[q];
+      }
     }
     gi_ptr += gi_stride;
     if (NS) sv_ptr += sv_stride;
@@ -489,6 +495,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd(PArgs a) {
   constexpr int X2 = G * H / 2;
   static_assert(U % 16 == 0 && (G * H) % 128 == 0, "unsupported hidden size for the persistent kernel");
   __shared__ __attribute__((aligned(16))) float part[2][4 * TILES * 256];
+  __builtin_amdgcn_s_setprio(3);   // latency-critical: outrank any throughput kernel's waves that share the SIMD
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = blockIdx.x % NGROUPS, p = blockIdx.x / NGROUPS;
   const int d = grp / a.gpd, slice = grp % a.gpd;
@@ -610,16 +617,18 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd(PArgs a) {
         }
         if (dead) dr0 = dr1 = __uint_as_float(0x7fc00000u);
         const uint32_t pr = pack_bf16x2(dr0, dr1), pz = pack_bf16x2(dz0, dz1), pn = pack_bf16x2(dn0, dn1), pq = pack_bf16x2(dq0, dq1);
-        if (st_on) *reinterpret_cast<uint32_t*>(dgi) = pr;
-        if (st_on) *reinterpret_cast<uint32_t*>(dgi + H) = pz;
-        if (st_on) *reinterpret_cast<uint32_t*>(dgi + 2 * H) = pn;
-        bf16_t* dgh = dgh_ptr;
-        if (st_on) *reinterpret_cast<uint32_t*>(dgh) = pr;
-        if (st_on) *reinterpret_cast<uint32_t*>(dgh + H) = pz;
-        if (st_on) *reinterpret_cast<uint32_t*>(dgh + 2 * H) = pq;
-        publish((u64*)(xo + xgranule_bytes<NROWS>(j, gi_i)), tag | pr, local);
+        publish((u64*)(xo + xgranule_bytes<NROWS>(j, gi_i)), tag | pr, local);       // peers wait for these: first
         publish((u64*)(xo + xgranule_bytes<NROWS>(H + j, gi_i)), tag | pz, local);
         publish((u64*)(xo + xgranule_bytes<NROWS>(2 * H + j, gi_i)), tag | pq, local);
+        bf16_t* dgh = dgh_ptr;
+        if (st_on) {
+          *reinterpret_cast<uint32_t*>(dgi) = pr;
+          *reinterpret_cast<uint32_t*>(dgi + H) = pz;
+          *reinterpret_cast<uint32_t*>(dgi + 2 * H) = pn;
+          *reinterpret_cast<uint32_t*>(dgh) = pr;
+          *reinterpret_cast<uint32_t*>(dgh + H) = pz;
+          *reinterpret_cast<uint32_t*>(dgh + 2 * H) = pq;
+        }
       } else if (CELL == CELL_LSTM) {
         float di0 = 0.f, di1 = 0.f, df0 = 0.f, df1 = 0.f, dg0 = 0.f, dg1 = 0.f, do0 = 0.f, do1 = 0.f;
         car0 = din0;
