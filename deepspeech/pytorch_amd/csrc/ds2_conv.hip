@@ -175,33 +175,39 @@ struct ConvTapArgs {
   int U, OSF, OQ;     // output rows handled: f_out = u*OSF + OQ, u in [0,U)
 };
 
-template <typename T>
+// NT = 32-position tiles per output row and workgroup.  NT = 2 (used by the stride-1 dgrad launches, whose input patch is
+// only 14 rows tall) re-uses every weight fragment for two MFMAs and amortises the per-kernel-row weight staging over twice
+// the work: the single-tile form is LDS-bound (2 fragment reads per MFMA + 22.5 KB of weights per kernel row).
+template <typename T, int NT>
 __global__ void __launch_bounds__(256, 1) k_conv_tap(ConvTapArgs a) {
   constexpr int V = Vec16<T>::N;
   constexpr int NPASS = (CH * (int)sizeof(T)) / 64;   // bf16: 1 pass of 32 channels; f32: 2 passes of 16 channels
   constexpr int CPB = 64 / (int)sizeof(T);            // channels per pass
+  constexpr int TB = CT_TB * NT, PC = TB + K2T - 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* patch = smem;
-  unsigned char* wst = smem + CT_PATCH_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lq = lane >> 5;
-  const int to0 = blockIdx.x * CT_TB, u0 = blockIdx.y * CT_UB, n = blockIdx.z;
+  const int to0 = blockIdx.x * TB, u0 = blockIdx.y * CT_UB, n = blockIdx.z;
   const int PR = (CT_UB - 1) * a.SF + a.KF;
+  unsigned char* patch = smem;
+  unsigned char* wst = smem + PR * PC * CT_POSB;
   const int fi0 = u0 * a.SF - a.PF, ti0 = to0 - 5;
   const T* Xn = (const T*)a.X + (long)n * a.Fin * a.Tp * CH;
   const T* Wg = (const T*)a.W;
 
-  ds2_f32x16 acc;
+  ds2_f32x16 acc[NT];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   for (int pass = 0; pass < NPASS; ++pass) {
     const int c0 = pass * CPB;
     __syncthreads();   // previous pass finished reading patch / wst
-    // ---- stage the input patch: PR x 42 positions x 64 bytes
-    for (int i = tid; i < PR * CT_PC * 4; i += 256) {
+    // ---- stage the input patch: PR x PC positions x 64 bytes
+    for (int i = tid; i < PR * PC * 4; i += 256) {
       const int v = i & 3, pos = i >> 2;
-      const int pr = pos / CT_PC, pc = pos - pr * CT_PC;
+      const int pr = pos / PC, pc = pos - pr * PC;
       const int fi = fi0 + pr, ti = ti0 + pc;
       // unconditional load from a clamped address + bit mask (a predicated load = branch + s_waitcnt vmcnt(0) per load:
       // the ~18 loads of a thread would be 18 serial memory round trips)
@@ -225,44 +231,50 @@ __global__ void __launch_bounds__(256, 1) k_conv_tap(ConvTapArgs a) {
       const int buf = kf & 1;
       if (kf + 1 < a.KF) wload(kf + 1, buf ^ 1);   // other buffer: last read two iterations ago (barrier in between)
       const unsigned char* wb = wst + buf * CT_WST_BYTES + li * CT_POSB + lq * 16;
-      const unsigned char* pb = patch + ((wave * a.SF + kf) * CT_PC + li) * CT_POSB + lq * 16;
+      const unsigned char* pb = patch + ((wave * a.SF + kf) * PC + li) * CT_POSB + lq * 16;
 #pragma unroll
       for (int kt = 0; kt < K2T; ++kt) {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
           const uint4 af = *reinterpret_cast<const uint4*>(wb + kt * CH * CT_POSB + c * 32);
-          const uint4 bf = *reinterpret_cast<const uint4*>(pb + kt * CT_POSB + c * 32);
-          Mma<T>::mma32(acc, af, bf);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const uint4 bf = *reinterpret_cast<const uint4*>(pb + (kt + CT_TB * t) * CT_POSB + c * 32);
+            Mma<T>::mma32(acc[t], af, bf);
+          }
         }
       }
       __syncthreads();
     }
   }
 
-  // ---- epilogue: transpose the wave's [32 m][32 pos] tile through LDS, then 64-byte channel-vector stores
-  __syncthreads();
+  // ---- epilogue: transpose the wave's [32 m][32 pos] tiles through LDS, then 64-byte channel-vector stores
   float* tile = reinterpret_cast<float*>(smem) + wave * (32 * 33);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) tile[li * 33 + mma32_row(r, lane)] = acc[r];   // tile[pos][m]
-  __syncthreads();
   const int u = u0 + wave;
-  if (u < a.U) {
-    const int fo = u * a.OSF + a.OQ;
-    const int pos = lane >> 1, half = lane & 1;
-    const int to = to0 + pos;
-    if (to < a.Tp) {
-      const bool live = a.lens ? (to < a.lens[n]) : true;
-      T* dst = (T*)a.Y + (((long)n * a.Fout + fo) * a.Tp + to) * CH + half * 16;
 #pragma unroll
-      for (int v = 0; v < 16 / V; ++v) {
-        float o[V];
+  for (int t = 0; t < NT; ++t) {
+    __syncthreads();
 #pragma unroll
-        for (int i = 0; i < V; ++i) {
-          const int m = half * 16 + v * V + i;
-          float val = tile[pos * 33 + m] + (a.bias ? a.bias[m] : 0.f);
-          o[i] = live ? val : 0.f;
+    for (int r = 0; r < 16; ++r) tile[li * 33 + mma32_row(r, lane)] = acc[t][r];   // tile[pos][m]
+    __syncthreads();
+    if (u < a.U) {
+      const int fo = u * a.OSF + a.OQ;
+      const int pos = lane >> 1, half = lane & 1;
+      const int to = to0 + CT_TB * t + pos;
+      if (to < a.Tp) {
+        const bool live = a.lens ? (to < a.lens[n]) : true;
+        T* dst = (T*)a.Y + (((long)n * a.Fout + fo) * a.Tp + to) * CH + half * 16;
+#pragma unroll
+        for (int v = 0; v < 16 / V; ++v) {
+          float o[V];
+#pragma unroll
+          for (int i = 0; i < V; ++i) {
+            const int m = half * 16 + v * V + i;
+            float val = tile[pos * 33 + m] + (a.bias ? a.bias[m] : 0.f);
+            o[i] = live ? val : 0.f;
+          }
+          Vec16<T>::store(dst + v * V, o);
         }
-        Vec16<T>::store(dst + v * V, o);
       }
     }
   }
@@ -484,17 +496,26 @@ __global__ void __launch_bounds__(256, 1) k_conv2_wgrad_bf16(const bf16_t* __res
   }
 }
 
-template <typename T>
-int conv_tap_launch(const ConvTapArgs& a, hipStream_t st) {
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)k_conv_tap<T>, hipFuncAttributeMaxDynamicSharedMemorySize, CT_SMEM);
-    attr = true;
+template <typename T, int NT>
+int conv_tap_launch_nt(const ConvTapArgs& a, hipStream_t st) {
+  const int PR = (CT_UB - 1) * a.SF + a.KF, PC = CT_TB * NT + K2T - 1;
+  const int shm = PR * PC * CT_POSB + 2 * CT_WST_BYTES;
+  static int attr = 0;
+  if (attr < shm) {
+    (void)hipFuncSetAttribute((const void*)k_conv_tap<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+    attr = shm;
   }
-  dim3 grid(ds2_cdiv(a.Tp, CT_TB), ds2_cdiv(a.U, CT_UB), a.N);
-  hipLaunchKernelGGL(k_conv_tap<T>, grid, dim3(256), CT_SMEM, st, a);
+  dim3 grid(ds2_cdiv(a.Tp, CT_TB * NT), ds2_cdiv(a.U, CT_UB), a.N);
+  hipLaunchKernelGGL((k_conv_tap<T, NT>), grid, dim3(256), shm, st, a);
   DS2_CHECK_LAUNCH();
   return 0;
+}
+template <typename T>
+int conv_tap_launch(const ConvTapArgs& a, hipStream_t st) {
+  // two position tiles per row whenever the taller patch still fits the 160 KiB of LDS (the stride-1 dgrad launches)
+  const int PR = (CT_UB - 1) * a.SF + a.KF;
+  if (PR * (2 * CT_TB + K2T - 1) * CT_POSB + 2 * CT_WST_BYTES <= 150 * 1024) return conv_tap_launch_nt<T, 2>(a, st);
+  return conv_tap_launch_nt<T, 1>(a, st);
 }
 
 }  // namespace
