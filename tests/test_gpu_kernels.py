@@ -51,6 +51,9 @@ def test_gemm_nt(dtype, M, N, K):
     assert relerr(np64(got), ref) < (1e-5 if dtype == torch.float32 else 1e-4)   # fp32 accumulate, fp32 out
     got_t = o.gemm_nt(cu(A, dtype), cu(B, dtype), bias=cu(bias))
     assert relerr(np64(got_t), ref) < TOL[dtype]
+    # the low-register variant used for GEMMs that share the CUs with a persistent recurrent sweep
+    got_c = o.gemm_nt(cu(A, dtype), cu(B, dtype), bias=cu(bias), coresident=True)
+    assert relerr(np64(got_c), ref) < TOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
