@@ -148,6 +148,53 @@ __global__ void __launch_bounds__(256) k_softmax_rows(const float* __restrict__ 
   }
 }
 
+// Weight re-layout after an optimizer step, one pass: fp32 parameter matrix [R][C] -> bf16 copy dst[R][ldd] and (optional)
+// bf16 transpose dstT[Cout][lddT]; both may be windows of direction-stacked operands.  perm_c > 0 additionally maps the
+// reference's conv feature order to the internal one (out column j = f*perm_c + c  <-  source column c*perm_f + f) and
+// zero-fills the columns [C, Cout).  64x64 tiles: coalesced 4-byte loads, row pairs packed into LDS words (33-word column
+// stride: conflict-free), 16-byte transposed stores.  Bytes: 4 read + 2 (+2) written per element -- HBM-bound.
+__global__ void __launch_bounds__(256) k_cast_transpose(const float* __restrict__ src, long lds_, int R, int C, int perm_c,
+                                                        int perm_f, int Cout, uint16_t* __restrict__ dst, long ldd,
+                                                        uint16_t* __restrict__ dstT, long lddT) {
+  __shared__ uint32_t tileT[64 * 33];
+  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+  const int j = c0 + tx;                       // output column
+  int sc = j;                                  // source column
+  if (perm_c > 0) sc = (j % perm_c) * perm_f + j / perm_c;
+  const bool cvalid = j < C;                   // real data (pad columns are zero)
+  if (!cvalid) sc = 0;
+  float v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    int r = r0 + ty * 16 + i;
+    if (r >= R) r = R - 1;
+    v[i] = src[(long)r * lds_ + sc];
+  }
+#pragma unroll
+  for (int i = 0; i < 16; i += 2) {
+    const float a = cvalid ? v[i] : 0.f, b = cvalid ? v[i + 1] : 0.f;
+    const uint32_t pk = cvt_pk_bf16(a, b);
+    const int r = r0 + ty * 16 + i;
+    if (dst != nullptr && j < Cout) {
+      if (r < R) dst[(long)r * ldd + j] = (uint16_t)(pk & 0xffffu);
+      if (r + 1 < R) dst[(long)(r + 1) * ldd + j] = (uint16_t)(pk >> 16);
+    }
+    tileT[tx * 33 + ty * 8 + (i >> 1)] = pk;
+  }
+  if (dstT == nullptr) return;
+  __syncthreads();
+  const int col = tid >> 2, part = tid & 3;    // 16 rows (32 bytes) of one output row of the transpose
+  const int jo = c0 + col, ro = r0 + part * 16;
+  if (jo >= Cout || ro >= R) return;           // R % 16 == 0: a 16-row run is valid as a whole
+  uint32_t w[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) w[k] = tileT[col * 33 + part * 8 + k];
+  uint4* o = reinterpret_cast<uint4*>(dstT + (long)jo * lddT + ro);
+  o[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
 inline int ew_grid(long n) {
   long g = (n + 255) / 256;
   if (g > 2048) g = 2048;
@@ -194,6 +241,20 @@ int ds2_transpose(int dtype, const void* src, void* dst, long R, int C, long lds
     hipLaunchKernelGGL(k_transpose<float>, grid, dim3(256), 0, st, (const float*)src, (float*)dst, R, C, lds_, ldd);
   else
     hipLaunchKernelGGL(k_transpose<uint16_t>, grid, dim3(256), 0, st, (const uint16_t*)src, (uint16_t*)dst, R, C, lds_, ldd);
+  DS2_CHECK_LAUNCH();
+  return 0;
+}
+
+int ds2_cast_transpose_bf16(const float* src, long lds_, int R, int C, int perm_c, int perm_f, int Cout, void* dst, long ldd,
+                            void* dstT, long lddT, ds2_stream_t st_) {
+  hipStream_t st = (hipStream_t)st_;
+  DS2_REQUIRE(src != nullptr && R > 0 && C > 0 && Cout >= C && (dst != nullptr || dstT != nullptr), DS2_ERR_ARG);
+  DS2_REQUIRE(perm_c == 0 || (perm_c > 0 && perm_f > 0 && perm_c * perm_f == C), DS2_ERR_ARG);
+  DS2_REQUIRE(R % 16 == 0, DS2_ERR_ALIGN);
+  if (dst != nullptr) DS2_REQUIRE(ldd >= Cout, DS2_ERR_ARG);
+  if (dstT != nullptr) DS2_REQUIRE(lddT >= R && lddT % 8 == 0 && ((uintptr_t)dstT & 15) == 0, DS2_ERR_ALIGN);
+  hipLaunchKernelGGL(k_cast_transpose, dim3(ds2_cdiv(Cout, 64), ds2_cdiv(R, 64)), dim3(256), 0, st, src, lds_, R, C, perm_c,
+                     perm_f, Cout, (uint16_t*)dst, ldd, (uint16_t*)dstT, lddT);
   DS2_CHECK_LAUNCH();
   return 0;
 }

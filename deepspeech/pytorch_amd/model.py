@@ -130,6 +130,16 @@ class _WeightCache:
         self._store[key] = (ver, val)
         return val
 
+    def _ver(self, params):
+        return (self.epoch,) + tuple((p._version, p.data_ptr()) for p in params)
+
+    def valid(self, key, params):
+        hit = self._store.get(key)
+        return hit is not None and hit[0] == self._ver(params)
+
+    def put(self, key, params, val):
+        self._store[key] = (self._ver(params), val)
+
     def clear(self):
         self._store.clear()
 
@@ -561,6 +571,32 @@ class DeepSpeech(_Base):
             whh = [getattr(p, "weight_hh_l0" + s_) for s_ in sufs]
             bih = [getattr(p, "bias_ih_l0" + s_) for s_ in sufs]
             bhh = [getattr(p, "bias_hh_l0" + s_) for s_ in sufs]
+
+            if dtype == torch.bfloat16:
+                # one fused cast(+transpose) kernel per parameter matrix: 4 B read, 2 (+2) B written per element
+                keys = [("wih", li, dtype), ("whh", li, dtype)]
+                if need_backward:
+                    keys += [("wihT", li, dtype), ("whhT", li, dtype)]
+                if not all(c.valid(k, wih if k[0].startswith("wih") else whh) for k in keys):
+                    GH, H = whh[0].shape
+                    I = wih[0].shape[1]
+                    Io = RNN_INPUT_LD if first else I
+                    perm = (32, N_FREQ_CONV2) if first else None
+                    dev = wih[0].device
+                    Wih = torch.empty((D * GH, Io), dtype=dtype, device=dev)
+                    Whh = torch.empty((D, GH, H), dtype=dtype, device=dev)
+                    WihT = torch.empty((Io, D * GH), dtype=dtype, device=dev) if need_backward else None
+                    WhhT = torch.empty((D, H, GH), dtype=dtype, device=dev) if need_backward else None
+                    with torch.no_grad():
+                        for d in range(D):
+                            ops.cast_transpose_bf16(wih[d].detach(), Wih[d * GH:], Io,
+                                                    WihT[:, d * GH:] if need_backward else None, D * GH, perm=perm, cout=Io)
+                            ops.cast_transpose_bf16(whh[d].detach(), Whh[d], H, WhhT[d] if need_backward else None, GH)
+                    c.put(("wih", li, dtype), wih, Wih)
+                    c.put(("whh", li, dtype), whh, Whh)
+                    if need_backward:
+                        c.put(("wihT", li, dtype), wih, WihT)
+                        c.put(("whhT", li, dtype), whh, WhhT)
 
             def cat_ih(wih=wih, first=first):
                 w = torch.cat([q.detach() for q in wih], 0)

@@ -108,6 +108,15 @@ def transpose(X, R=None, Cc=None, lds=None):
     return out
 
 
+def cast_transpose_bf16(src, dst=None, ldd=0, dstT=None, lddT=0, perm=None, cout=None):
+    """fp32 parameter matrix -> bf16 copy (window `dst`, row stride ldd) and/or bf16 transpose (window `dstT`, row stride
+    lddT); `perm` = (c, f) re-orders the conv features of rnns.0, `cout` pads the columns with zeros."""
+    R, Cc = src.shape
+    pc, pf = perm if perm is not None else (0, 0)
+    call("ds2_cast_transpose_bf16", P(src), src.stride(0), R, Cc, pc, pf, Cc if cout is None else cout,
+         P(dst) if dst is not None else None, ldd, P(dstT) if dstT is not None else None, lddT, S())
+
+
 def add2(a, b):
     out = torch.empty_like(a)
     call("ds2_add2", dt(a), P(a), P(b), P(out), a.numel(), S())

@@ -129,6 +129,12 @@ int ds2_rnn_persist_bwd(int cell, int D, int N, int H, int Tp, const int* lens, 
  * bwd: dx and dw (dw via ws of ds2_lookahead_ws_floats). */
 int ds2_add2(int dtype, const void* a, const void* b, void* out, long n, ds2_stream_t stream);
 int ds2_transpose(int dtype, const void* src, void* dst, long R, int C, long lds, long ldd, ds2_stream_t stream);
+/* Weight re-layout of the recurrent layers (what nn.GRU/LSTM/RNN.flatten_parameters + the autocast weight casts do in the
+ * reference, model.py:97-99): fp32 src[R][C] -> bf16 dst[R][ldd] and/or bf16 transpose dstT[Cout][lddT] in one pass.
+ * perm_c > 0: output column j = f*perm_c + c takes source column c*perm_f + f (rnns.0 reads the conv features in the
+ * kernels' [f][c] order; the reference flattens [c][f], model.py:219-220); columns [C, Cout) are zero.  R % 16 == 0. */
+int ds2_cast_transpose_bf16(const float* src, long lds, int R, int C, int perm_c, int perm_f, int Cout, void* dst, long ldd,
+                            void* dstT, long lddT, ds2_stream_t stream);
 int ds2_lookahead_fwd(int dtype, const void* x, const float* w, void* y, void* pre, int Tp, int N, int H, int ctx,
                       ds2_stream_t stream);
 long ds2_lookahead_ws_floats(int Tp, int N, int H, int ctx);

@@ -73,6 +73,33 @@ def test_gemm_nt_transposed_operands_and_splitk(dtype):
     assert relerr(np64(gotb), refb) < 1e-4
 
 
+def test_cast_transpose_bf16_windows_and_feature_permutation():
+    """The weight re-layout kernel: bf16 copy and transpose written into windows of direction-stacked operands, bit-exact
+    against torch's round-to-nearest-even cast; rnns.0's column permutation (reference c*41+f -> internal f*32+c) + pad."""
+    o = ops()
+    g = torch.Generator().manual_seed(12)
+    for R, Cc, perm, cout in [(96, 64, None, None), (2400, 800, None, None), (48, 1312, (32, 41), 1344), (16, 16, None, None),
+                              (3072, 1024, None, None)]:
+        W = [torch.randn((R, Cc), generator=g).cuda() for _ in range(2)]
+        Co = cout or Cc
+        dst = torch.full((2 * R, Co), 7.0, dtype=torch.bfloat16, device="cuda")
+        dstT = torch.full((Co, 2 * R), 7.0, dtype=torch.bfloat16, device="cuda")
+        for d in range(2):
+            o.cast_transpose_bf16(W[d], dst[d * R:], Co, dstT[:, d * R:], 2 * R, perm=perm, cout=Co)
+        ref = torch.cat(W, 0)
+        if perm is not None:
+            full = ref.new_zeros((2 * R, Co))
+            full[:, :Cc] = ref.reshape(2 * R, perm[0], perm[1]).permute(0, 2, 1).reshape(2 * R, Cc)
+            ref = full
+        ref = ref.to(torch.bfloat16)
+        assert torch.equal(dst, ref)
+        assert torch.equal(dstT, ref.t())
+        only = torch.empty_like(dst)
+        for d in range(2):
+            o.cast_transpose_bf16(W[d], only[d * R:], Co, None, 0, perm=perm, cout=Co)      # forward-only: no transpose
+        assert torch.equal(only, ref)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_transpose_colsum_add(dtype):
     rs = np.random.RandomState(4)
