@@ -1,13 +1,16 @@
 """Data-parallel plumbing of the training step: one process per GPU, ``torch.distributed`` over RCCL (backend "nccl" on
-ROCm), gradients all-reduced by torch DDP's bucketed hooks while the backward of the lower layers is still running.
+ROCm), gradients averaged by torch DDP's bucketed all-reduce.
 
 The reference has no explicit collective: Lightning's ``strategy: ddp`` (configs/an4.yaml:13, librispeech.yaml:14) wraps
 the LightningModule in ``DistributedDataParallel`` with ``sync_batchnorm=False`` (lightning_config.py:53), i.e. BatchNorm
 statistics stay rank-local and the only exchange is the gradient mean.  The drop-in class works unchanged under that
-wrapper: every stage of its backward is one autograd node that returns the layer's parameter gradients, so DDP's reducer
-sees a layer's gradients the moment its BPTT sweep ends and overlaps their all-reduce with the sweeps of the layers
-below.  Buckets are sized for xGMI (point-to-point links, ring collectives are per-link bound): 64 MB, one RNN layer's
-gradients (~50 MB fp32 for GRU-1024) per bucket.
+wrapper.  The conv front-end and the RNN stack are ONE autograd node (their weight-gradient GEMMs run on a second HIP
+stream under the BPTT sweeps of the layers below and are joined at the end of that node), so DDP's reducer receives the
+recurrent layers' gradients together when the node returns and the all-reduce of those buckets is exposed after the
+backward (~260 MB fp32 on cfg3; the head's bucket overlaps).  Buckets are sized for xGMI (point-to-point links, ring
+collectives are per-link bound): 64 MB, about one GRU-1024 layer (~50 MB fp32) per bucket, few large collectives.
+DS2_FORCE_DDP=1 wraps (and initialises a 1-rank process group) even for world == 1, to exercise the wrapper + RCCL on a
+single-GPU box.
 
 Everything here is device-agnostic so that the N > 1 path is covered on CPU with the gloo backend (tests/test_dist.py).
 """
@@ -30,13 +33,17 @@ class StepModule(torch.nn.Module):
         return self.model.training_step((inputs, targets, input_percentages, target_sizes), 0)
 
 
+def force_ddp():
+    return os.environ.get("DS2_FORCE_DDP", "0") not in ("", "0")
+
+
 def init_from_env(backend):
     """(rank, world, local_rank) from the launcher's environment (torch.distributed.run); initialises the process group
     when WORLD_SIZE > 1.  Rendezvous defaults to 127.0.0.1 (single node)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_ddp()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         kw = {}
@@ -49,7 +56,7 @@ def init_from_env(backend):
 def wrap_data_parallel(step_module, device, world, bucket_cap_mb=64):
     """DDP over the step module (identity for world == 1).  broadcast_buffers=False: BatchNorm running statistics are
     per-rank like the reference's sync_batchnorm=False; gradient_as_bucket_view avoids one copy per parameter."""
-    if world == 1:
+    if world == 1 and not (force_ddp() and dist.is_initialized()):
         return step_module
     ids = [device.index] if device.type == "cuda" else None
     return torch.nn.parallel.DistributedDataParallel(step_module, device_ids=ids, broadcast_buffers=False,
@@ -91,6 +98,7 @@ def aggregate(seconds, units, device, world):
 
 
 def shutdown(world):
-    if world > 1 and dist.is_initialized():
-        dist.barrier()
+    if dist.is_initialized():
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
