@@ -242,3 +242,43 @@ def test_in_place_updates_without_version_bump_are_seen():
     assert abs(traj[False][2] - traj[False][0]) > 1e-2 * abs(traj[False][0])          # the loss moves at all
     for a, b in zip(traj[True], traj[False]):
         assert abs(a - b) <= 2e-2 * abs(b), (traj[True], traj[False])
+
+
+def test_step_on_a_non_default_stream_gives_the_same_gradients():
+    """The class runs on the caller's CURRENT stream (every launch takes it explicitly; the second stream forks from and
+    joins it): a full-size bf16 step on a high-priority side stream must reproduce the default-stream step -- same loss
+    bit for bit, gradients equal up to the order of the fp32 atomics of the split reductions."""
+    from deepspeech.pytorch_amd import configs, ops, synth
+    from deepspeech.pytorch_amd.model import DeepSpeech
+    lengths = synth.synth_lengths(32, 1201, 1501, seed=77)
+    inputs, targets, pct, tsz = synth.synth_batch(lengths, seed=77)
+    mc = configs.BiDirectionalConfig(rnn_type=configs.RNNType.gru, hidden_size=1024, hidden_layers=5)
+    torch.manual_seed(5)
+    m = DeepSpeech(configs.LABELS, mc, "bf16", configs.AdamConfig(), configs.SpectConfig()).to(DEV).train()
+
+    def step():
+        m.zero_grad()
+        batch = (torch.from_numpy(inputs).to(DEV), torch.from_numpy(targets), torch.from_numpy(pct.copy()),
+                 torch.from_numpy(tsz))
+        loss = m.training_step(batch, 0)
+        loss.backward()
+        return float(loss.item()), {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+
+    l0, g0 = step()
+    torch.cuda.synchronize()
+    hp = torch.cuda.Stream(priority=-1)
+    hp.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(hp):
+        l1, g1 = step()
+        hp.synchronize()
+    torch.cuda.synchronize()
+    ops.check_persistent_kernels()
+    assert l0 == l1
+    worst = 0.0
+    for k in g0:
+        a, b = g0[k].float(), g1[k].float()
+        assert torch.isfinite(b).all(), k
+        d = float((a - b).abs().max() / (a.abs().max() + 1e-30))
+        worst = max(worst, d)
+        assert d <= 1e-4, (k, d)
+    print("worst relative gradient difference between streams: %.3g" % worst)
