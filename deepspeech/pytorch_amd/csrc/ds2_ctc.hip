@@ -1,155 +1,253 @@
-// log_softmax + CTC loss + gradient in one launch (reference model.py:246 log_softmax(-1); model.py:203,248
+// log_softmax + CTC loss + gradient (reference model.py:246 log_softmax(-1); model.py:203,248
 // CTCLoss(blank, reduction='sum', zero_infinity=True) -> torch native _ctc_loss).
 //
-// One workgroup per sample (samples are independent).  Log-space alpha/beta recursion over the extended label sequence
-// l' (2S+1 states, blank-interleaved); alpha rows are kept in a global scratch, the current/previous rows in LDS, one
-// thread per state (strided for long targets).  Gradient: with both alpha_t(s) and beta_t(s) including y_t(l'_s),
+// Log-space alpha/beta recursion over the extended label sequence l' (2S+1 states, blank-interleaved).  With both
+// alpha_t(s) and beta_t(s) including y_t(l'_s),
 //   d nll / d lp[t][c] = - sum_{s: l'_s = c} exp(alpha_t(s) + beta_t(s) - ll) / y_t(c)
 // (every term exp(alpha+beta-ll) <= 1, so the total log-likelihood ll is a safe common shift), followed by the
 // log_softmax backward  dlogit = g - softmax * sum_c g.  Infeasible samples (ll = -inf): loss 0, gradient 0.
-// Latency-bound: alpha and beta run concurrently on the two halves of the workgroup (T' dependent steps, ONE barrier per
-// step), the gradient pass is frame-parallel (one wave per frame); bytes: logits once, alpha/beta scratch write+read.
+//
+// Four launches on the caller's stream, split by what bounds each stage:
+//   k_ctc_logsoftmax  one thread per frame; bytes: logits once -> log-prob scratch [N][Tp][32].
+//   k_ctc_recursion   grid (N, 2): the alpha and the beta recursion of a sample are independent workgroups of 4 waves.  T'
+//                     dependent steps, pure latency: the step is branch-free (operand addresses and transition masks are
+//                     fixed per thread before the loop), the frames' log-probs are staged in LDS a chunk ahead, and the
+//                     per-step barrier drains the LDS counter only -- the alpha/beta row stores stay in flight.
+//   k_ctc_gradient    frame-parallel, grid (T'/16, N) x one wave per frame: the alpha/beta rows (2 x 4 x T' x L bytes per
+//                     sample, beyond one XCD's L2 for long clips) stream back once at full-chip parallelism.
+//   k_sum_small       loss = sum of the per-sample nll.
 #include <math.h>
 
 #include "ds2_common.h"
 
 namespace {
 
-constexpr int CTC_THREADS = 512;   // two halves of 256: alpha and beta, <= 2 states per thread for targets up to 255 labels
-constexpr int CP = 32;  // padded class stride of the log-prob scratch
+constexpr int REC_THREADS = 256;  // one recursion: <= 4 states per thread (fast path) for targets up to 511 labels
+constexpr int CP = 32;            // padded class stride of the log-prob scratch
+constexpr int LP_CHUNK = 8;       // recursion steps whose log-prob rows are staged in LDS together
+constexpr int NS_FAST = 4;        // extended-label states per thread the branch-free recursion keeps in registers
+constexpr int GRAD_WAVES = 4;     // waves (= frames in flight) per workgroup of the gradient pass
+constexpr int GRAD_FRAMES = 16;   // frames per workgroup of the gradient pass
 
-// log(exp a + exp b + exp c).  v_exp_f32 / v_log_f32 (1 ulp in the base-2 domain) instead of the full-precision libm
-// sequences: the argument of the log is in [1, 3], where the absolute error of the fast form is < 2e-7 -- far below the
-// fp32 resolution of the alpha/beta values themselves (magnitude ~3 T').
+// workgroup barrier that orders LDS traffic only (s_waitcnt lgkmcnt(0) + s_barrier): outstanding global stores and
+// prefetch loads stay in flight across it
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// log(exp a + exp b + exp c), branch-free.  v_exp_f32 / v_log_f32 (1 ulp in the base-2 domain) instead of the full-precision
+// libm sequences: the argument of the log is in [1, 3], where the absolute error of the fast form is < 2e-7 -- far below
+// the fp32 resolution of the alpha/beta values themselves (magnitude ~3 T').  All three -inf: exp(-inf) = 0, log(0) = -inf.
 __device__ __forceinline__ float lse3(float a, float b, float c) {
   const float m = fmaxf(fmaxf(a, b), c);
-  if (m == -INFINITY) return -INFINITY;
-  return m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
+  const float ms = m == -INFINITY ? 0.f : m;
+  return ms + __logf(__expf(a - ms) + __expf(b - ms) + __expf(c - ms));
 }
 
-__global__ void __launch_bounds__(CTC_THREADS) k_ctc(const float* __restrict__ logits, long ldl, const int* __restrict__ targets,
-                                                      const int* __restrict__ toff, const int* __restrict__ in_len,
-                                                      const int* __restrict__ tg_len, int Tp, int N, int C, int blank, int Lmax,
-                                                      float grad_scale, float* __restrict__ nll_out, float* __restrict__ dlogits,
-                                                      long ldg, float* __restrict__ ws_lp, float* __restrict__ ws_alpha,
-                                                      float* __restrict__ ws_beta) {
+__global__ void __launch_bounds__(256) k_ctc_logsoftmax(const float* __restrict__ logits, long ldl,
+                                                        const int* __restrict__ in_len, int Tp, int N, int C,
+                                                        float* __restrict__ ws_lp) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;     // frame row t*N + n
+  if (i >= (long)Tp * N) return;
+  const int t = (int)(i / N), n = (int)(i % N);
+  if (t >= in_len[n]) return;
+  const float* x = logits + i * ldl;
+  float v[CP];
+  float m = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < CP; ++c) {
+    v[c] = x[c < C ? c : 0];
+    if (c < C) m = fmaxf(m, v[c]);
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < CP; ++c)
+    if (c < C) sum += expf(v[c] - m);
+  const float lz = m + logf(sum);
+  float* lp = ws_lp + ((long)n * Tp + t) * CP;
+#pragma unroll
+  for (int c = 0; c < CP; ++c)
+    if (c < C) lp[c] = v[c] - lz;
+}
+
+// blockIdx.x = sample, blockIdx.y = 0: alpha (t = 0 .. Ti-1), 1: beta (t = Ti-1 .. 0)
+__global__ void __launch_bounds__(REC_THREADS) k_ctc_recursion(const int* __restrict__ targets, const int* __restrict__ toff,
+                                                               const int* __restrict__ in_len, const int* __restrict__ tg_len,
+                                                               int Tp, int blank, int Lmax, float* __restrict__ nll_out,
+                                                               const float* __restrict__ ws_lp, float* __restrict__ ws_alpha,
+                                                               float* __restrict__ ws_beta, float* __restrict__ ws_ll) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* rowA0 = reinterpret_cast<float*>(smem);     // alpha rows (double buffer)   [Lmax] each
-  float* rowA1 = rowA0 + Lmax;
-  float* rowB0 = rowA1 + Lmax;                       // beta rows
-  float* rowB1 = rowB0 + Lmax;
-  int* ext = reinterpret_cast<int*>(rowB1 + Lmax);   // [Lmax]
-  float* acc = reinterpret_cast<float*>(ext + Lmax); // [CTC_THREADS / 64 waves][CP]
-  float* lpbuf = acc + (CTC_THREADS / 64) * CP;      // [2 recursions][2 parities][CP]: log-prob rows of the current step
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* row0 = reinterpret_cast<float*>(smem);      // previous / current rows (double buffer)   [Lmax] each
+  float* row1 = row0 + Lmax;
+  int* ext = reinterpret_cast<int*>(row1 + Lmax);    // [Lmax]
+  float* lpl = reinterpret_cast<float*>(ext + Lmax); // [2 chunk buffers][LP_CHUNK][CP]: staged log-prob rows
+  const int tid = threadIdx.x;
   const int n = blockIdx.x;
+  const bool is_beta = blockIdx.y != 0;
   int Ti = in_len[n];
   if (Ti > Tp) Ti = Tp;
   const int S = tg_len[n];
   const int L = 2 * S + 1;
-  const int* tg = targets + toff[n];
-  float* lp = ws_lp + (long)n * Tp * CP;                 // [Tp][CP] of this sample
-  float* alpha = ws_alpha + (long)n * Tp * Lmax;         // [Tp][Lmax]
-  float* beta = ws_beta + (long)n * Tp * Lmax;
-
-  for (int s = tid; s < L; s += CTC_THREADS) ext[s] = (s & 1) ? tg[s >> 1] : blank;
-  // ---- log_softmax of every valid frame
-  for (int t = tid; t < Ti; t += CTC_THREADS) {
-    const float* x = logits + ((long)t * N + n) * ldl;
-    float m = -INFINITY;
-    for (int c = 0; c < C; ++c) m = fmaxf(m, x[c]);
-    float sum = 0.f;
-    for (int c = 0; c < C; ++c) sum += expf(x[c] - m);
-    const float lz = m + logf(sum);
-    for (int c = 0; c < C; ++c) lp[(long)t * CP + c] = x[c] - lz;
-  }
-  // rows past the sample's length get a zero gradient
-  for (long i = tid; i < (long)(Tp - Ti) * ldg; i += CTC_THREADS) {
-    const long t = Ti + i / ldg, c = i % ldg;
-    dlogits[(t * N + n) * ldg + c] = 0.f;
-  }
-  __syncthreads();
-
-  bool feasible = Ti > 0 && L <= 2 * Ti + 1;   // necessary; the recursion decides exactly
   if (Ti <= 0) {
-    if (tid == 0) nll_out[n] = 0.f;
+    if (!is_beta && tid == 0) {
+      nll_out[n] = 0.f;
+      ws_ll[n] = INFINITY;                           // sentinel: no gradient for this sample
+    }
     return;
   }
-  // ---- alpha (threads 0..127, t = 0 .. Ti-1) and beta (threads 128..255, t = Ti-1 .. 0) run CONCURRENTLY: the two
-  //      recursions are independent, so the serial depth is Ti instead of 2 Ti; one barrier per step serves both.
+  const int* tg = targets + toff[n];
+  const float* lp = ws_lp + (long)n * Tp * CP;                               // [Tp][CP] of this sample
+  float* dst = (is_beta ? ws_beta : ws_alpha) + (long)n * Tp * Lmax;         // [Tp][Lmax]
+  for (int s = tid; s < L; s += REC_THREADS) ext[s] = (s & 1) ? tg[s >> 1] : blank;
+  static_assert(REC_THREADS == LP_CHUNK * CP, "one prefetch element per thread");
+  const int prow = tid / CP, pcol = tid % CP;        // element of a chunk this thread stages
   {
-    constexpr int HALF = CTC_THREADS / 2;
-    const bool is_beta = tid >= HALF;
-    const int ht = is_beta ? tid - HALF : tid;
-    float* prev = is_beta ? rowB0 : rowA0;
-    float* cur = is_beta ? rowB1 : rowA1;
-    float* dst = is_beta ? beta : alpha;
-    float* lpl = lpbuf + (is_beta ? 2 * CP : 0);       // this recursion's two row buffers
-    // the frame's 29 log-probs are staged in LDS one step AHEAD (a dependent L2 round trip per step otherwise)
-    if (ht < CP) lpl[ht] = lp[(long)(is_beta ? Ti - 1 : 0) * CP + ht];
-    __syncthreads();
-    for (int i = 0; i < Ti; ++i) {
+    const int i = prow < Ti ? prow : Ti - 1;
+    lpl[prow * CP + pcol] = lp[(long)(is_beta ? Ti - 1 - i : i) * CP + pcol];
+  }
+  __syncthreads();
+  // per-thread state tables of the branch-free step.  States past L are clamped to L-1: those lanes recompute and rewrite
+  // the last state's value (same value, same address) instead of branching.  Masks are additive: 0 = transition allowed,
+  // -inf = not.
+  const int ns = (L + REC_THREADS - 1) / REC_THREADS;
+  const bool fast = ns <= NS_FAST;
+  int st_s[NS_FAST], st_e[NS_FAST], st_i1[NS_FAST], st_i2[NS_FAST];
+  float st_m0[NS_FAST], st_m1[NS_FAST], st_m2[NS_FAST];
+#pragma unroll
+  for (int q = 0; q < NS_FAST; ++q) {
+    int sq = tid + q * REC_THREADS;
+    if (sq > L - 1) sq = L - 1;
+    const int e = ext[sq];
+    bool ok1, ok2;
+    int j1, j2;
+    if (!is_beta) {
+      j1 = sq >= 1 ? sq - 1 : 0;
+      j2 = sq >= 2 ? sq - 2 : 0;
+      ok1 = sq >= 1;
+      ok2 = sq >= 2 && e != blank && e != ext[j2];
+      st_m0[q] = sq <= 1 ? 0.f : -INFINITY;          // alpha_0: the first blank and the first label
+    } else {
+      j1 = sq + 1 < L ? sq + 1 : L - 1;
+      j2 = sq + 2 < L ? sq + 2 : L - 1;
+      ok1 = sq + 1 < L;
+      ok2 = sq + 2 < L && ext[j2] != blank && ext[j2] != e;
+      st_m0[q] = sq >= L - 2 ? 0.f : -INFINITY;      // beta_{T-1}: the last blank and the last label
+    }
+    st_s[q] = sq;
+    st_e[q] = e;
+    st_i1[q] = j1;
+    st_i2[q] = j2;
+    st_m1[q] = ok1 ? 0.f : -INFINITY;
+    st_m2[q] = ok2 ? 0.f : -INFINITY;
+  }
+  float* prev = row0;
+  float* cur = row1;
+  for (int i0 = 0; i0 < Ti; i0 += LP_CHUNK) {
+    const float* lpc = lpl + ((i0 / LP_CHUNK) & 1) * LP_CHUNK * CP;
+    int pi = i0 + LP_CHUNK + prow;                   // step whose row goes into the other chunk buffer
+    if (pi > Ti - 1) pi = Ti - 1;
+    const float nxt = lp[(long)(is_beta ? Ti - 1 - pi : pi) * CP + pcol];
+    const int kend = Ti - i0 < LP_CHUNK ? Ti - i0 : LP_CHUNK;
+    for (int k = 0; k < kend; ++k) {
+      const int i = i0 + k;
       const int t = is_beta ? Ti - 1 - i : i;
-      const float* lpt = lpl + (i & 1) * CP;
-      float nxt = 0.f;
-      const bool pre = ht < CP && i + 1 < Ti;
-      if (pre) nxt = lp[(long)(is_beta ? t - 1 : t + 1) * CP + ht];
-      for (int s = ht; s < L; s += HALF) {
-        const int e = ext[s];
-        float v;
-        if (i == 0) {
-          if (!is_beta)
-            v = s == 0 ? lpt[blank] : (s == 1 ? lpt[e] : -INFINITY);
-          else
-            v = (s == L - 1 || s == L - 2) ? lpt[e] : -INFINITY;
-        } else if (!is_beta) {
-          const float a0 = prev[s];
-          const float a1 = s >= 1 ? prev[s - 1] : -INFINITY;
-          const float a2 = (s >= 2 && e != blank && e != ext[s - 2]) ? prev[s - 2] : -INFINITY;
-          v = lse3(a0, a1, a2) + lpt[e];
-        } else {
-          const float b0 = prev[s];
-          const float b1 = s + 1 < L ? prev[s + 1] : -INFINITY;
-          const float b2 = (s + 2 < L && ext[s + 2] != blank && ext[s + 2] != e) ? prev[s + 2] : -INFINITY;
-          v = lse3(b0, b1, b2) + lpt[e];
+      const float* lpt = lpc + k * CP;
+      if (fast) {
+        float p0[NS_FAST], p1[NS_FAST], p2[NS_FAST], pe[NS_FAST];
+#pragma unroll
+        for (int q = 0; q < NS_FAST; ++q)
+          if (q < ns) {
+            p0[q] = prev[st_s[q]];
+            p1[q] = prev[st_i1[q]];
+            p2[q] = prev[st_i2[q]];
+            pe[q] = lpt[st_e[q]];
+          }
+#pragma unroll
+        for (int q = 0; q < NS_FAST; ++q)
+          if (q < ns) {
+            const float rec = lse3(p0[q], p1[q] + st_m1[q], p2[q] + st_m2[q]);
+            const float v = (i == 0 ? st_m0[q] : rec) + pe[q];
+            cur[st_s[q]] = v;
+            dst[(long)t * Lmax + st_s[q]] = v;
+          }
+      } else {
+        // very long targets (> 511 labels): strided states, same arithmetic
+        for (int s = tid; s < L; s += REC_THREADS) {
+          const int e = ext[s];
+          float v;
+          if (i == 0) {
+            const bool entry = is_beta ? s >= L - 2 : s <= 1;
+            v = entry ? lpt[e] : -INFINITY;
+          } else if (!is_beta) {
+            const float a0 = prev[s];
+            const float a1 = s >= 1 ? prev[s - 1] : -INFINITY;
+            const float a2 = (s >= 2 && e != blank && e != ext[s - 2]) ? prev[s - 2] : -INFINITY;
+            v = lse3(a0, a1, a2) + lpt[e];
+          } else {
+            const float b0 = prev[s];
+            const float b1 = s + 1 < L ? prev[s + 1] : -INFINITY;
+            const float b2 = (s + 2 < L && ext[s + 2] != blank && ext[s + 2] != e) ? prev[s + 2] : -INFINITY;
+            v = lse3(b0, b1, b2) + lpt[e];
+          }
+          cur[s] = v;
+          dst[(long)t * Lmax + s] = v;
         }
-        cur[s] = v;
-        dst[(long)t * Lmax + s] = v;
       }
-      if (pre) lpl[((i + 1) & 1) * CP + ht] = nxt;
-      __syncthreads();
+      lds_barrier();
       float* tmp = prev;
       prev = cur;
       cur = tmp;
     }
+    lpl[(((i0 / LP_CHUNK) + 1) & 1) * LP_CHUNK * CP + prow * CP + pcol] = nxt;
+    lds_barrier();
   }
-  // after the loop every thread's `prev` of the alpha half holds alpha_{Ti-1}: it is rowA0 or rowA1 by parity
-  const float* alast = (Ti & 1) ? rowA1 : rowA0;
-  const float l1 = alast[L - 1];
-  const float l2 = L > 1 ? alast[L - 2] : -INFINITY;
-  const float ll = lse3(l1, l2, -INFINITY);
-  feasible = feasible && (ll != -INFINITY) && !isnan(ll);
-  if (tid == 0) nll_out[n] = feasible ? -ll : 0.f;
-  if (!feasible) {
-    for (long i = tid; i < (long)Ti * ldg; i += CTC_THREADS) {
-      const long t = i / ldg, c = i % ldg;
-      dlogits[(t * N + n) * ldg + c] = 0.f;
+  if (!is_beta && tid == 0) {
+    // `prev` holds alpha_{Ti-1}
+    const float l1 = prev[L - 1];
+    const float l2 = L > 1 ? prev[L - 2] : -INFINITY;
+    const float ll = lse3(l1, l2, -INFINITY);
+    const bool feasible = L <= 2 * Ti + 1 && ll != -INFINITY && !isnan(ll);
+    nll_out[n] = feasible ? -ll : 0.f;
+    ws_ll[n] = feasible ? ll : INFINITY;
+  }
+}
+
+// grid (ceil(Tp / GRAD_FRAMES), N); one wave per frame.  Writes EVERY row of dlogits of its frames (zeros past the
+// sample's length and for infeasible samples).
+__global__ void __launch_bounds__(GRAD_WAVES * 64) k_ctc_gradient(const int* __restrict__ targets, const int* __restrict__ toff,
+                                                                  const int* __restrict__ in_len,
+                                                                  const int* __restrict__ tg_len, int Tp, int N, int C,
+                                                                  int blank, int Lmax, float grad_scale,
+                                                                  float* __restrict__ dlogits, long ldg,
+                                                                  const float* __restrict__ ws_lp,
+                                                                  const float* __restrict__ ws_alpha,
+                                                                  const float* __restrict__ ws_beta,
+                                                                  const float* __restrict__ ws_ll) {
+  __shared__ float acc[GRAD_WAVES][CP];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.y;
+  int Ti = in_len[n];
+  if (Ti > Tp) Ti = Tp;
+  const int L = 2 * tg_len[n] + 1;
+  const int* tg = targets + toff[n];
+  const float ll = ws_ll[n];
+  const bool live = ll != INFINITY;
+  float* wacc = acc[wave];
+  const int t_end = min((int)(blockIdx.x + 1) * GRAD_FRAMES, Tp);
+  for (int t = blockIdx.x * GRAD_FRAMES + wave; t < t_end; t += GRAD_WAVES) {
+    float* dl = dlogits + ((long)t * N + n) * ldg;
+    if (!live || t >= Ti) {                          // wave-uniform
+      if (lane < ldg) dl[lane] = 0.f;
+      continue;
     }
-    return;
-  }
-  // ---- gradient: frames are independent now -> one wave per frame (alpha/beta rows come back from L2)
-  float* wacc = acc + wave * CP;
-  for (int t = wave; t < Ti; t += CTC_THREADS / 64) {
-    const float* lpt = lp + (long)t * CP;
-    const float* al = alpha + (long)t * Lmax;
-    const float* be = beta + (long)t * Lmax;
+    const float* lpt = ws_lp + ((long)n * Tp + t) * CP;
+    const float* al = ws_alpha + ((long)n * Tp + t) * Lmax;
+    const float* be = ws_beta + ((long)n * Tp + t) * Lmax;
     if (lane < CP) wacc[lane] = 0.f;
     __builtin_amdgcn_wave_barrier();
     float blank_part = 0.f;
     for (int s = lane; s < L; s += 64) {
-      const float w = expf(al[s] + be[s] - ll);   // <= 1
+      const float w = expf(al[s] + be[s] - ll);      // <= 1
       if (s & 1)
-        atomicAdd(&wacc[ext[s]], w);
+        atomicAdd(&wacc[tg[s >> 1]], w);             // within one wave: the order is fixed
       else
         blank_part += w;
     }
@@ -163,7 +261,6 @@ __global__ void __launch_bounds__(CTC_THREADS) k_ctc(const float* __restrict__ l
       g = a > 0.f ? -a / y : 0.f;
     }
     const float gs = wave_sum(g);
-    float* dl = dlogits + ((long)t * N + n) * ldg;
     if (lane < C)
       dl[lane] = (g - y * gs) * grad_scale;
     else if (lane < ldg)
@@ -186,7 +283,7 @@ extern "C" {
 long ds2_ctc_ws_floats(int Tp, int N, int C, int max_target_len) {
   (void)C;
   const long Lmax = 2L * max_target_len + 1;
-  return (long)N * Tp * CP + 2L * N * Tp * Lmax;
+  return (long)N * Tp * CP + 2L * N * Tp * Lmax + N;
 }
 
 int ds2_ctc_loss_grad(const float* logits, long ldl, const int* targets, const int* target_offsets, const int* input_lengths,
@@ -196,13 +293,26 @@ int ds2_ctc_loss_grad(const float* logits, long ldl, const int* targets, const i
   DS2_REQUIRE(Tp > 0 && N > 0 && C > 0 && C <= CP && blank >= 0 && blank < C && max_target_len >= 0, DS2_ERR_ARG);
   DS2_REQUIRE(ldg >= C && ldg <= 64 && ldl >= C, DS2_ERR_ARG);
   const int Lmax = 2 * max_target_len + 1;
-  const size_t shm = (size_t)Lmax * 20 + (CTC_THREADS / 64) * CP * 4 + 4 * CP * 4;
-  DS2_REQUIRE(shm <= 60 * 1024, DS2_ERR_ARG);
+  const size_t shm = (size_t)Lmax * 12 + 2 * LP_CHUNK * CP * 4;
+  DS2_REQUIRE(shm <= 160 * 1024, DS2_ERR_ARG);
+  static size_t attr = 0;
+  if (attr < shm) {
+    (void)hipFuncSetAttribute((const void*)k_ctc_recursion, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    attr = shm;
+  }
   float* ws_lp = ws;
   float* ws_alpha = ws + (long)N * Tp * CP;
   float* ws_beta = ws_alpha + (long)N * Tp * Lmax;
-  hipLaunchKernelGGL(k_ctc, dim3(N), dim3(CTC_THREADS), shm, st, logits, ldl, targets, target_offsets, input_lengths,
-                     target_lengths, Tp, N, C, blank, Lmax, grad_scale, nll, dlogits, ldg, ws_lp, ws_alpha, ws_beta);
+  float* ws_ll = ws_beta + (long)N * Tp * Lmax;
+  hipLaunchKernelGGL(k_ctc_logsoftmax, dim3(ds2_cdiv((long)Tp * N, 256)), dim3(256), 0, st, logits, ldl, input_lengths, Tp, N,
+                     C, ws_lp);
+  DS2_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_ctc_recursion, dim3(N, 2), dim3(REC_THREADS), shm, st, targets, target_offsets, input_lengths,
+                     target_lengths, Tp, blank, Lmax, nll, ws_lp, ws_alpha, ws_beta, ws_ll);
+  DS2_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_ctc_gradient, dim3(ds2_cdiv(Tp, GRAD_FRAMES), N), dim3(GRAD_WAVES * 64), 0, st, targets, target_offsets,
+                     input_lengths, target_lengths, Tp, N, C, blank, Lmax, grad_scale, dlogits, ldg, ws_lp, ws_alpha, ws_beta,
+                     ws_ll);
   DS2_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_sum_small, dim3(1), dim3(64), 0, st, nll, N, loss_sum);
   DS2_CHECK_LAUNCH();

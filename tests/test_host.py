@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert lib.ds2_rnn_gates(0) == 3 and lib.ds2_rnn_gates(1) == 4 and lib.ds2_rnn_gates(2) == 1
     assert lib.ds2_rnn_state_bytes(2, 32, 1024) == 2 * 32 * 1024 * 24
     assert lib.ds2_norm_partials(10) == 2 and lib.ds2_norm_partials(10 ** 7) == 256
-    assert lib.ds2_ctc_ws_floats(751, 32, 29, 180) == 32 * 751 * 32 + 2 * 32 * 751 * 361
+    assert lib.ds2_ctc_ws_floats(751, 32, 29, 180) == 32 * 751 * 32 + 2 * 32 * 751 * 361 + 32
 
 
 def build_model(fx):
