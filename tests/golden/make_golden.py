@@ -2,7 +2,7 @@
 """Generate golden vectors from the REAL reference (``/root/reference/deepspeech_pytorch/model.py``, imported
 unmodified through ``ref_harness``) on CPU fp32.  Run in the build container only:
 
-    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+    python tests/golden/make_golden.py [case ...]   # rewrites tests/golden/*.npz (all cases, or the named ones)
 
 A fixture stores: the config, the seeds that regenerate inputs/parameters (``deepspeech.pytorch_amd.synth`` with
 numpy's frozen RandomState stream), and the reference's OUTPUTS: training-step loss, logits, output lengths
@@ -49,6 +49,11 @@ CASES = [
          lengths=[141, 130, 122, 101, 90], data_seed=17, param_seed=107),
     dict(name="single_sample", rnn_type="lstm", hidden_size=32, hidden_layers=2, bidirectional=True,
          lengths=[73], data_seed=18, param_seed=108),
+    # the headline width (BASELINE.json config 3: hidden 1024, bi-directional GRU): the shape the persistent recurrent
+    # kernels and the DMA-staged GEMMs cover, pinned to the real reference (2 layers / 4 short clips keep the CPU run and
+    # the fixture small; big gradients are subsampled with a large stride)
+    dict(name="gru_bi_1024", rnn_type="gru", hidden_size=1024, hidden_layers=2, bidirectional=True,
+         lengths=[121, 101, 90, 77], data_seed=19, param_seed=109, stride=1009),
 ]
 
 
@@ -105,7 +110,11 @@ def run_train_step(model, inputs, targets, pct, tsz, double):
 def main():
     ns = ref_harness.load_reference()
     torch.set_num_threads(8)
+    only = set(sys.argv[1:])
     for case in CASES:
+        if only and case["name"] not in only:
+            continue
+        stride = case.get("stride", STRIDE)
         probe = ref_harness.build_reference_model(ns, case["rnn_type"], case["hidden_size"], case["hidden_layers"],
                                                   case["bidirectional"], case.get("lookahead_context", 20))
         shapes = {k: tuple(v.shape) for k, v in probe.state_dict().items()}
@@ -141,7 +150,7 @@ def main():
             sc = max(np.abs(g).max(), 1e-30)
             out["noise." + k] = np.float64(np.abs(g32[k].astype(np.float64) - g).max() / sc)
             if g.size > BIG:
-                out["gradsub." + k] = g.reshape(-1)[::STRIDE].astype(np.float32)
+                out["gradsub." + k] = g.reshape(-1)[::stride].astype(np.float32)
                 out["gradsum." + k] = np.float64(g.sum())
                 out["gradl2." + k] = np.float64(np.sqrt((g ** 2).sum()))
             else:
@@ -173,7 +182,7 @@ def main():
         meta["shapes"] = {k: list(v) for k, v in shapes.items()}
         meta["torch_version"] = torch.__version__
         meta["big"] = BIG
-        meta["stride"] = STRIDE
+        meta["stride"] = stride
         out["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
         path = os.path.join(HERE, case["name"] + ".npz")
         np.savez_compressed(path, **out)

@@ -102,20 +102,25 @@ def test_fp32_logits_eval_transcripts_and_carry(name):
     assert np.abs(hl.cpu().numpy() - fx.z["carry_h_last"]).max() <= 1e-4
 
 
-@pytest.mark.parametrize("name", ["gru_bi_tiny", "lstm_bi_tiny", "gru_uni_la", "gru_bi_mid"])
+@pytest.mark.parametrize("name", ["gru_bi_tiny", "lstm_bi_tiny", "gru_uni_la", "gru_bi_mid", "gru_bi_1024"])
 def test_bf16_train_step_close_to_reference(name):
     """bf16 storage + bf16 MFMA operands (the performance mode).  Stated tolerance: loss within 2e-2 relative, logits
     within 0.15 absolute, every parameter gradient within 15% of the tensor's max AND cosine similarity >= 0.985 with the
     fp32 reference gradient -- bf16 has 8 mantissa bits, these are tiny models (H <= 96) whose BatchNorm-bias gradients
     are sums of heavily cancelling terms, and the reference's own bf16-autocast run differs from its fp32 run by a
-    similar amount."""
+    similar amount.  gru_bi_1024 is the headline width: it runs the persistent recurrent kernels and
+    the DMA-staged GEMMs against outputs of the REAL reference model."""
+    from deepspeech.pytorch_amd import ops as O_
     fx = Fixture(name)
+    if name == "gru_bi_1024":
+        assert O_.use_persistent("gru", torch.bfloat16, 2, len(fx.lengths), 1024)
     m = build(fx, "bf16")
     inputs, targets, pct, tsz = fx.batch()
     m.train()
     batch = (torch.from_numpy(inputs).to(DEV), torch.from_numpy(targets), torch.from_numpy(pct.copy()), torch.from_numpy(tsz))
     loss = m.training_step(batch, 0)
     loss.backward()
+    O_.check_persistent_kernels()
     ref = float(fx.z["loss64"])
     assert abs(float(loss.item()) - ref) <= 2e-2 * abs(ref)
     worst = 0.0
