@@ -54,6 +54,9 @@ CASES = [
     # the fixture small; big gradients are subsampled with a large stride)
     dict(name="gru_bi_1024", rnn_type="gru", hidden_size=1024, hidden_layers=2, bidirectional=True,
          lengths=[121, 101, 90, 77], data_seed=19, param_seed=109, stride=1009),
+    # uni-directional LSTM + Lookahead at the same width (the BASELINE config-5b direction/cell type)
+    dict(name="lstm_uni_1024_la", rnn_type="lstm", hidden_size=1024, hidden_layers=2, bidirectional=False,
+         lookahead_context=20, lengths=[111, 96, 83], data_seed=20, param_seed=110, stride=1009),
 ]
 
 

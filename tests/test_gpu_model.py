@@ -102,7 +102,7 @@ def test_fp32_logits_eval_transcripts_and_carry(name):
     assert np.abs(hl.cpu().numpy() - fx.z["carry_h_last"]).max() <= 1e-4
 
 
-@pytest.mark.parametrize("name", ["gru_bi_tiny", "lstm_bi_tiny", "gru_uni_la", "gru_bi_mid", "gru_bi_1024"])
+@pytest.mark.parametrize("name", ["gru_bi_tiny", "lstm_bi_tiny", "gru_uni_la", "gru_bi_mid", "gru_bi_1024", "lstm_uni_1024_la"])
 def test_bf16_train_step_close_to_reference(name):
     """bf16 storage + bf16 MFMA operands (the performance mode).  Stated tolerance: loss within 2e-2 relative, logits
     within 0.15 absolute, every parameter gradient within 15% of the tensor's max AND cosine similarity >= 0.985 with the
@@ -112,8 +112,8 @@ def test_bf16_train_step_close_to_reference(name):
     the DMA-staged GEMMs against outputs of the REAL reference model."""
     from deepspeech.pytorch_amd import ops as O_
     fx = Fixture(name)
-    if name == "gru_bi_1024":
-        assert O_.use_persistent("gru", torch.bfloat16, 2, len(fx.lengths), 1024)
+    if fx.cfg["hidden_size"] == 1024:
+        assert O_.use_persistent(fx.cfg["rnn_type"], torch.bfloat16, 2 if fx.cfg["bidirectional"] else 1, len(fx.lengths), 1024)
     m = build(fx, "bf16")
     inputs, targets, pct, tsz = fx.batch()
     m.train()
