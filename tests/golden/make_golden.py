@@ -57,6 +57,8 @@ CASES = [
     # uni-directional LSTM + Lookahead at the same width (the BASELINE config-5b direction/cell type)
     dict(name="lstm_uni_1024_la", rnn_type="lstm", hidden_size=1024, hidden_layers=2, bidirectional=False,
          lookahead_context=20, lengths=[111, 96, 83], data_seed=20, param_seed=110, stride=1009),
+    dict(name="rnn_bi_1024", rnn_type="rnn", hidden_size=1024, hidden_layers=2, bidirectional=True,
+         lengths=[101, 88, 61, 45, 33], data_seed=21, param_seed=111, stride=1009),
 ]
 
 

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from fixtures import Fixture, fixture_names
+from fixtures import Fixture, gpu_fixture_names as fixture_names
 from oracle import ds2_oracle as O
 
 pytestmark = pytest.mark.gpu
