@@ -95,10 +95,13 @@ def run_native(args, rank, world, device):
         opt.zero_grad(set_to_none=True)
         loss = step_mod(batch[0], batch[1], batch[2].clone(), batch[3])
         loss.backward()
+        if finish_backward is not None:
+            finish_backward()
         torch.nn.utils.clip_grad_norm_(params, 400.0)
         opt.step()
         return loss
 
+    finish_backward = getattr(step_mod, "finish_backward", None)     # opt-in OverlappedDataParallel (no-op under DDP)
     first_loss = None
     log("model + batch ready; warm-up")
     for i in range(args.warmup):

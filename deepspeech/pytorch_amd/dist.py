@@ -53,11 +53,103 @@ def init_from_env(backend):
     return rank, world, local_rank
 
 
-def wrap_data_parallel(step_module, device, world, bucket_cap_mb=64):
+class OverlappedGradSync:
+    """Gradient mean over the ranks for a model whose backward hands finished gradients over EARLY (opt-in, see
+    wrap_data_parallel).  The drop-in class computes each recurrent layer's weight gradients on a second stream while the
+    BPTT sweeps of the layers below are still running; with this object attached (``model._grad_sync``) the composite
+    backward node calls ``layer_ready`` right after enqueueing those GEMMs, in that stream's context, so RCCL's stream picks
+    the all-reduce up as soon as the gradients exist and the exchange runs under the remaining sweeps -- what DDP's
+    reducer cannot do for a node that returns all its gradients at once.  Everything not handed over early (conv, BN,
+    head: ~1 MB) goes through one flat bucket in ``finish`` (queued as an autograd-engine callback, like DDP's finalize).
+    Device-agnostic: tests/test_dist.py drives it over gloo."""
+
+    def __init__(self, world, group=None):
+        self.world, self.group = world, group
+        self._params = []
+        self._handles, self._early = [], set()
+        self._queued = self._done = False
+
+    def attach(self, params):
+        self._params = list(params)
+
+    def begin_step(self):
+        self._handles, self._early = [], set()
+        self._queued = self._done = False
+
+    def _start(self, t):
+        if dist.get_backend(self.group) == "nccl":
+            return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+        t.mul_(1.0 / self.world)                       # gloo has no AVG
+        return dist.all_reduce(t, group=self.group, async_op=True)
+
+    def layer_ready(self, tensors, params):
+        """tensors: gradient storages that are final (distinct storages; the gradients returned to autograd may be views
+        of them); params: the parameters they belong to.  Call inside backward, on the stream that produces them."""
+        if not self._queued:
+            torch.autograd.Variable._execution_engine.queue_callback(self.finish)
+            self._queued = True
+        for t in tensors:
+            self._handles.append(self._start(t))
+        self._early.update(p.data_ptr() for p in params)
+
+    def wait_early(self):
+        """Orders the caller's stream (CPU: the caller) after every all-reduce started so far; call before the early
+        gradients are returned to autograd."""
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+
+    def finish(self):
+        if self._done:
+            return
+        self.wait_early()
+        rest = [p for p in self._params if p.grad is not None and p.data_ptr() not in self._early]
+        if rest:
+            flat = torch.cat([p.grad.reshape(-1).float() for p in rest])
+            self._start(flat).wait()
+            off = 0
+            for p in rest:
+                n = p.grad.numel()
+                p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                off += n
+        self._done = True
+
+
+class OverlappedDataParallel(torch.nn.Module):
+    """The step module with an OverlappedGradSync attached to its model (opt-in alternative to torch DDP).  Replicas
+    start from rank 0's parameters and buffers, as under DDP; BatchNorm statistics stay rank-local afterwards."""
+
+    def __init__(self, step_module, world):
+        super().__init__()
+        self.module = step_module
+        self.sync = OverlappedGradSync(world)
+        self.sync.attach(step_module.parameters())
+        with torch.no_grad():
+            for t in list(step_module.parameters()) + list(step_module.buffers()):
+                dist.broadcast(t, 0)
+        step_module.model._grad_sync = self.sync
+
+    def forward(self, *args):
+        self.sync.begin_step()
+        return self.module(*args)
+
+    def finish_backward(self):
+        """Explicit end of backward for loops that want it (idempotent: the engine callback normally ran already)."""
+        self.sync.finish()
+
+
+def overlap_allreduce():
+    return os.environ.get("DS2_OVERLAP_ALLREDUCE", "0") not in ("", "0")
+
+
+def wrap_data_parallel(step_module, device, world, bucket_cap_mb=64, overlap=None):
     """DDP over the step module (identity for world == 1).  broadcast_buffers=False: BatchNorm running statistics are
-    per-rank like the reference's sync_batchnorm=False; gradient_as_bucket_view avoids one copy per parameter."""
+    per-rank like the reference's sync_batchnorm=False; gradient_as_bucket_view avoids one copy per parameter.
+    overlap=True (or DS2_OVERLAP_ALLREDUCE=1): OverlappedDataParallel instead of DDP."""
     if world == 1 and not (force_ddp() and dist.is_initialized()):
         return step_module
+    if overlap_allreduce() if overlap is None else overlap:
+        return OverlappedDataParallel(step_module, world)
     ids = [device.index] if device.type == "cuda" else None
     return torch.nn.parallel.DistributedDataParallel(step_module, device_ids=ids, broadcast_buffers=False,
                                                      bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True)

@@ -371,17 +371,30 @@ class _RnnStackFn(torch.autograd.Function):
                     grads[po + 4 * d:po + 4 * d + 4] = [dWih[d * GH:(d + 1) * GH].contiguous(), dWhh,
                                                         dBih[d * GH:(d + 1) * GH].contiguous(), dBhh.contiguous()]
                 del dGI_T
+                sync = getattr(mod, "_grad_sync", None)
+                if sync is not None:
+                    # data parallel with the opt-in early hand-off (dist.OverlappedGradSync): this layer's gradients start
+                    # their all-reduce now, ordered after the GEMMs above, under the sweeps of the layers below.  The
+                    # returned gradients are views of dWih / dBih (and of dBih for the biases of LSTM / RNN cells).
+                    own = [dWih, dBih] + [grads[po + 4 * d + 1] for d in range(D)]
+                    if kind == "gru":
+                        own += [grads[po + 4 * d + 3] for d in range(D)]
+                    sync.layer_ready(own, params[po:po + 4 * D])
             dout = dX
         if getattr(ctx, "defer_join", False):
-            ctx.pending = (main, side, grads)     # the composite node joins after the conv backward
+            ctx.pending = (main, side, grads, mod)     # the composite node joins after the conv backward
         else:
-            _join_side(main, side, grads)
+            _join_side(main, side, grads, mod)
         return (dout, None, None, None, None, None, None, None, *([None] * (2 * L)), *grads)
 
 
-def _join_side(main, side, grads):
-    """Every parameter gradient produced on the second stream is complete before autograd / DDP sees it."""
+def _join_side(main, side, grads, mod=None):
+    """Every parameter gradient produced on the second stream is complete (and, with the opt-in early hand-off, averaged
+    over the ranks) before autograd / DDP sees it."""
     main.wait_stream(side)
+    sync = getattr(mod, "_grad_sync", None)
+    if sync is not None:
+        sync.wait_early()
     for g in grads:
         if g is not None:
             g.record_stream(main)

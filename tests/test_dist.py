@@ -88,6 +88,94 @@ def test_two_rank_gloo_data_parallel_step():
     assert not np.allclose(out[0]["bn_mean"], out[1]["bn_mean"])
 
 
+class _EarlyNode(torch.autograd.Function):
+    """Stand-in for the drop-in class's composite backward node: two 'layers' whose weight gradients are final before the
+    node returns; each is handed to model._grad_sync the moment it exists (as views of one stacked storage, like the
+    direction-stacked dW_ih), and the node waits for the early all-reduces before it returns them to autograd."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, owner):
+        h = x @ w1
+        ctx.save_for_backward(x, w1, w2, h)
+        ctx.owner = owner
+        return h @ w2
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, w2, h = ctx.saved_tensors
+        sync = getattr(ctx.owner, "_grad_sync", None)
+        stacked = torch.cat([h.t() @ dy, torch.zeros(1, w2.shape[1])], 0)      # gradient = a view of a larger storage
+        g2 = stacked[:w2.shape[0]]
+        if sync is not None:
+            sync.layer_ready([stacked], [w2])
+        dh = dy @ w2.t()
+        g1 = x.t() @ dh
+        if sync is not None:
+            sync.layer_ready([g1], [w1])
+            sync.wait_early()
+        return None, g1, g2, None
+
+
+class _EarlyStandIn(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(1)
+        self.w1 = torch.nn.Parameter(torch.randn(8, 8))
+        self.w2 = torch.nn.Parameter(torch.randn(8, 4))
+        self.bn = torch.nn.BatchNorm1d(4)            # parameters that are NOT handed over early: the flat bucket of finish()
+
+    def training_step(self, batch, batch_idx):
+        x, targets, pct, tsz = batch
+        return (self.bn(_EarlyNode.apply(x, self.w1, self.w2, self)) ** 2).sum() * float(pct.sum())
+
+
+def _worker_overlap(rank, world, port, out):
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from deepspeech.pytorch_amd import dist as dsdist
+    dsdist.init_from_env("gloo")
+    dev = torch.device("cpu")
+    model = _EarlyStandIn()
+    with torch.no_grad():
+        model.w1.add_(float(rank))                   # replicas differ before wrapping: the wrapper must broadcast rank 0's
+    step_mod = dsdist.wrap_data_parallel(dsdist.StepModule(model), dev, world, overlap=True)
+    assert isinstance(step_mod, dsdist.OverlappedDataParallel)
+    g = torch.Generator().manual_seed(200 + rank)
+    x = torch.randn(6, 8, generator=g)
+    errs = []
+    for it in range(2):                              # two steps: the per-step state of the sync object is reset
+        model.zero_grad()
+        loss = step_mod(x, torch.zeros(1), torch.ones(6), torch.ones(6, dtype=torch.int32))
+        loss.backward()                              # finish() runs as an engine callback: no explicit call needed
+        assert step_mod.sync._done
+        step_mod.finish_backward()                   # idempotent
+        grad = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+        refs = []
+        for rr in range(world):
+            m2 = _EarlyStandIn()
+            gg = torch.Generator().manual_seed(200 + rr)
+            l2 = m2.training_step((torch.randn(6, 8, generator=gg), None, torch.ones(6), None), 0)
+            l2.backward()
+            refs.append(torch.cat([p.grad.reshape(-1) for p in m2.parameters()]))
+        ref = torch.stack(refs).mean(0)
+        errs.append(float((grad - ref).abs().max() / ref.abs().max()))
+    out[rank] = dict(errs=errs, early=len(step_mod.sync._early), w1=model.w1.detach().clone().numpy())
+    dsdist.shutdown(world)
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_overlapped_gradient_sync():
+    """The opt-in early hand-off (dist.OverlappedGradSync): gradients handed over inside backward and the flat rest bucket
+    both end up as the mean over the ranks; replicas are broadcast from rank 0 at wrap time."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_overlap, args=(world, _free_port(), out), nprocs=world, join=True)
+    for r in range(world):
+        assert max(out[r]["errs"]) <= 1e-5, out[r]
+        assert out[r]["early"] == 2                                          # w1 and w2 went early, the BN pair through finish()
+    assert np.array_equal(out[0]["w1"], out[1]["w1"])
+
+
 def test_single_rank_is_identity():
     from deepspeech.pytorch_amd import dist as dsdist
     m = dsdist.StepModule(_StandIn())
