@@ -16,9 +16,12 @@ def fixture_names():
 
 
 # Golden cases the oracle and the torch port are pinned to on CPU but that the whole-class GPU tests do not run yet:
-# rnn_bi_1024 (tanh RNN, hidden 1024): the fp32 path reproduces loss and logits, but the conv1 weight gradient deviates
-# 2.5e-3 of its scale from the reference (bar: 1e-3) -- the un-gated tanh recurrence at this width amplifies fp32
-# summation-order differences ~100x more than the GRU/LSTM cases.  Open item.
+# rnn_bi_1024: on the GPU the fp32 path reproduces loss and logits, the conv1 weight gradient is 2.513e-3 of its scale away
+# (bar 1e-3).  Cause (reproduced on CPU, tests/test_oracle_vs_golden.py::test_hardtanh_boundary_flip_explains_...): ONE
+# pre-Hardtanh value of the second conv block is 5.5e-7 from the clamp boundary 0 -- inside fp32 rounding of the BatchNorm
+# output -- and Hardtanh's gradient is discontinuous there; flipping that single decision in the oracle moves the conv1
+# weight gradient by exactly 2.513e-3 (2.800e-2 absolute).  check_grads_or_flip_variant below accepts such a result;
+# the case joins the GPU run once that path has been exercised on the device.
 GPU_PENDING = ("rnn_bi_1024",)
 
 
@@ -85,3 +88,63 @@ class Fixture:
         assert err <= rtol, "grad %s: max err %.3e of scale %.3e (rel %.3e > %.1e)" % (
             name, np.abs(got - ref).max(), scale, err, rtol)
         return err
+
+
+def hardtanh_flip_variants(fx, thresh=2e-6, max_elems=3):
+    """Gradients of every parameter (oracle, float64) with the Hardtanh decisions of the boundary-degenerate
+    pre-activations flipped.  The reference function's gradient is discontinuous where a pre-Hardtanh value equals a clamp
+    boundary (model.py:160,163,192: Hardtanh(0, 20)); an element closer to it than fp32 rounding of the BatchNorm output
+    (a few 1e-7 at unit scale) can legitimately fall on either side in any fp32 implementation, the reference's own
+    included.  Returns [dict(name -> grad)] for every non-empty subset of the (at most max_elems) elements within `thresh`
+    of a boundary; empty when the case has none."""
+    import itertools
+    from oracle import ds2_oracle as O
+    P = {k: v.astype(np.float64) for k, v in fx.params().items()}
+    inputs, targets, pct, tsz = fx.batch()
+    sizes = O.input_sizes_from_percentages(pct, inputs.shape[3])
+    out, out_lens, _, cache = O.model_forward(P, fx.cfg, inputs.astype(np.float64), sizes, train=True)
+    lp = O.log_softmax(cache["logits_tnc"])
+    loss, nll, dlp = O.ctc_loss_and_grad_fast(lp, targets, out_lens, tsz, blank=0)
+    dlogits = dlp - np.exp(lp) * dlp.sum(-1, keepdims=True)
+    sites = []                                           # (array, index, boundary)
+    planes = [(cache["conv"]["z1"], ~cache["conv"]["m1"]), (cache["conv"]["z2"], ~cache["conv"]["m2"])]
+    if "la_pre" in cache:
+        planes.append((cache["la_pre"], np.ones(cache["la_pre"].shape, dtype=bool)))
+    for z, valid in planes:
+        for b in (O.HT_MIN, O.HT_MAX):
+            near = valid & (np.abs(z - b) < thresh)
+            for idx in zip(*np.nonzero(near)):
+                sites.append((z, idx, float(b)))
+    sites = sorted(sites, key=lambda s_: abs(s_[0][s_[1]] - s_[2]))[:max_elems]
+    variants = []
+    for r in range(1, len(sites) + 1):
+        for subset in itertools.combinations(sites, r):
+            old = [z[idx] for z, idx, b in subset]
+            for z, idx, b in subset:
+                z[idx] = 2.0 * b - z[idx]               # reflect across the boundary: the other Hardtanh decision
+            variants.append(O.model_backward(P, fx.cfg, cache, dlogits))
+            for (z, idx, b), o in zip(subset, old):
+                z[idx] = o
+    return variants
+
+
+def check_grads_or_flip_variant(fx, grads, rtol_of):
+    """grads: name -> full gradient array of the implementation under test; rtol_of(name) -> bar relative to the tensor's
+    max.  Passes if every gradient matches the stored reference gradient, or -- for a boundary-degenerate case -- one and
+    the same flip variant of hardtanh_flip_variants.  Returns "reference" or "flip-variant"."""
+    try:
+        for k, g in grads.items():
+            fx.check_grad(k, g, rtol=rtol_of(k))
+        return "reference"
+    except AssertionError as first:
+        for v in hardtanh_flip_variants(fx):
+            ok = True
+            for k, g in grads.items():
+                ref = np.asarray(v[k], dtype=np.float64)
+                scale = max(np.abs(ref).max(), 1e-3)
+                if np.abs(np.asarray(g, dtype=np.float64).reshape(ref.shape) - ref).max() / scale > rtol_of(k):
+                    ok = False
+                    break
+            if ok:
+                return "flip-variant"
+        raise first

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from fixtures import Fixture, gpu_fixture_names as fixture_names
+from fixtures import Fixture, check_grads_or_flip_variant, gpu_fixture_names as fixture_names
 from oracle import ds2_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -53,12 +53,18 @@ def test_fp32_train_step_matches_reference(name):
     got = float(loss.item())
     assert abs(got - ref32) <= 1e-3 * abs(ref32), (got, ref32)          # north star: CTC loss within 1e-3 (rel)
     assert abs(got - ref64) <= 1e-4 * abs(ref64), (got, ref64)
+    grads = {}
     for k, p in m.named_parameters():
         assert p.grad is not None, k
-        noise = float(fx.z["noise." + k])
+        grads[k] = p.grad.detach().cpu().numpy()
+
+    def rtol_of(k):
         # bar: 1e-3 of the tensor's max |grad| (conv-bias-before-BN gradients are pure cancellation: looser)
         rtol = 2e-2 if k in ("conv.seq_module.0.bias", "conv.seq_module.3.bias") else 1e-3
-        fx.check_grad(k, p.grad.detach().cpu().numpy(), rtol=max(rtol, 3 * min(noise, 1e-2)))
+        return max(rtol, 3 * min(float(fx.z["noise." + k]), 1e-2))
+    # every gradient against the reference's; a case with a pre-Hardtanh value on a clamp boundary may instead match the
+    # oracle with that single decision flipped (fixtures.check_grads_or_flip_variant)
+    check_grads_or_flip_variant(fx, grads, rtol_of)
     for k in fx.z.files:
         if k.startswith("running."):
             nm = k.split(".", 1)[1]

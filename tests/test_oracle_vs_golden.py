@@ -101,3 +101,29 @@ def test_torch_port_matches_reference(name):
     for gname in fx.grad_names():
         noise = float(fx.z["noise." + gname]) if "noise." + gname in fx.z.files else 0.0
         fx.check_grad(gname, port.P[gname].grad.numpy(), rtol=max(2e-3, 3 * min(noise, 1e-2)))
+
+
+def test_hardtanh_boundary_flip_explains_the_gpu_deviation_of_rnn_bi_1024():
+    """rnn_bi_1024 has ONE pre-Hardtanh value (second conv block) 5.5e-7 from the clamp boundary 0.  An fp32 implementation
+    may land on either side; flipping that single decision in the oracle moves the conv1 weight gradient by 2.513e-3 of its
+    scale (2.800e-2 absolute) -- exactly the deviation measured on the MI355X fp32 path -- while everything matches the
+    reference when the decision is left alone.  The flip-aware comparison accepts the flipped result and still rejects a
+    result that matches neither."""
+    from fixtures import check_grads_or_flip_variant, hardtanh_flip_variants
+    fx = Fixture("rnn_bi_1024")
+    variants = hardtanh_flip_variants(fx)
+    assert 1 <= len(variants) <= 7
+    k = "conv.seq_module.0.weight"
+    ref = fx.z["grad." + k].astype(np.float64)
+    scale = np.abs(ref).max()
+    devs = [np.abs(v[k].reshape(ref.shape) - ref).max() / scale for v in variants]
+    assert any(abs(d - 2.513e-3) < 2e-5 for d in devs), devs
+    flipped = {n: np.asarray(g, dtype=np.float32) for n, g in variants[int(np.argmin([abs(d - 2.513e-3) for d in devs]))].items()}
+    with pytest.raises(AssertionError):
+        for n, g in flipped.items():
+            fx.check_grad(n, g, rtol=1e-3)
+    assert check_grads_or_flip_variant(fx, flipped, lambda n: 1e-3) == "flip-variant"
+    wrong = dict(flipped)
+    wrong[k] = flipped[k] * 1.01
+    with pytest.raises(AssertionError):
+        check_grads_or_flip_variant(fx, wrong, lambda n: 1e-3)
