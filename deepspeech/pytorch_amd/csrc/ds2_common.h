@@ -180,3 +180,14 @@ __device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + ex
   } while (0)
 
 static inline int ds2_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Per-DEVICE one-time set-up (kernel attributes are per device, a process may drive several): returns true the first time
+// it is called with `flags` on the current device.  A benign race (two threads both see "first") only repeats an idempotent call.
+#define DS2_MAX_DEVICES 64
+static inline bool ds2_first_use_on_device(bool* flags) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DS2_MAX_DEVICES) return true;
+  if (flags[dev]) return false;
+  flags[dev] = true;
+  return true;
+}

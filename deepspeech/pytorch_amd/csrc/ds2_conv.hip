@@ -500,10 +500,13 @@ template <typename T, int NT>
 int conv_tap_launch_nt(const ConvTapArgs& a, hipStream_t st) {
   const int PR = (CT_UB - 1) * a.SF + a.KF, PC = CT_TB * NT + K2T - 1;
   const int shm = PR * PC * CT_POSB + 2 * CT_WST_BYTES;
-  static int attr = 0;
-  if (attr < shm) {
+  static int attr[DS2_MAX_DEVICES];              // per device
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  dev = dev >= 0 && dev < DS2_MAX_DEVICES ? dev : 0;
+  if (attr[dev] < shm) {
     (void)hipFuncSetAttribute((const void*)k_conv_tap<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
-    attr = shm;
+    attr[dev] = shm;
   }
   dim3 grid(ds2_cdiv(a.Tp, CT_TB * NT), ds2_cdiv(a.U, CT_UB), a.N);
   hipLaunchKernelGGL((k_conv_tap<T, NT>), grid, dim3(256), shm, st, a);

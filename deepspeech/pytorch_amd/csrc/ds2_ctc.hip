@@ -204,7 +204,10 @@ __global__ void __launch_bounds__(REC_THREADS) k_ctc_recursion(const int* __rest
     const float l1 = prev[L - 1];
     const float l2 = L > 1 ? prev[L - 2] : -INFINITY;
     const float ll = lse3(l1, l2, -INFINITY);
-    const bool feasible = L <= 2 * Ti + 1 && ll != -INFINITY && !isnan(ll);
+    // zero_infinity (reference model.py:203): ONLY an infinite loss -- an infeasible alignment -- is zeroed, loss and
+    // gradient.  A NaN (poisoned logits, e.g. from a timed-out recurrent sweep) stays NaN in the loss and in the gradient,
+    // as torch's ctc_loss does: it must never look like a sample that contributes nothing.
+    const bool feasible = L <= 2 * Ti + 1 && ll != -INFINITY;
     nll_out[n] = feasible ? -ll : 0.f;
     ws_ll[n] = feasible ? ll : INFINITY;
   }
@@ -295,10 +298,13 @@ int ds2_ctc_loss_grad(const float* logits, long ldl, const int* targets, const i
   const int Lmax = 2 * max_target_len + 1;
   const size_t shm = (size_t)Lmax * 12 + 2 * LP_CHUNK * CP * 4;
   DS2_REQUIRE(shm <= 160 * 1024, DS2_ERR_ARG);
-  static size_t attr = 0;
-  if (attr < shm) {
+  static size_t attr[DS2_MAX_DEVICES];           // per device: the attribute belongs to the device's copy of the kernel
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  dev = dev >= 0 && dev < DS2_MAX_DEVICES ? dev : 0;
+  if (attr[dev] < shm) {
     (void)hipFuncSetAttribute((const void*)k_ctc_recursion, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    attr = shm;
+    attr[dev] = shm;
   }
   float* ws_lp = ws;
   float* ws_alpha = ws + (long)N * Tp * CP;

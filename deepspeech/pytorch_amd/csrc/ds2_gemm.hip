@@ -363,32 +363,24 @@ static int gemm_nt_impl(int dtype, const void* A, const void* B, void* C, const 
   dim3 grid(ds2_cdiv(N, BN), ds2_cdiv(M, BM), batch * splitk), blk(256);
   const size_t shm = 2 * STAGE_BYTES;
   if (dtype == DS2_F32) {
-    static bool attr_f = false;
-    if (!attr_f) {
-      hipFuncSetAttribute((const void*)k_gemm_nt<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-      attr_f = true;
-    }
+    static bool attr_f[DS2_MAX_DEVICES];
+    if (ds2_first_use_on_device(attr_f)) (void)hipFuncSetAttribute((const void*)k_gemm_nt<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     hipLaunchKernelGGL(k_gemm_nt<float>, grid, blk, shm, st, g);
-  } else if (splitk == 1 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && getenv("DS2_GEMM_NO_GLDS") == nullptr) {
+  } else if (splitk == 1 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0) {
     // (split-K accumulates with atomics: the register-staged kernel below keeps them coalesced along n)
     g.out_is_f32 = out_f32;
     if (coresident) {
-      static bool attr_lr = false;
+      static bool attr_lr[DS2_MAX_DEVICES];
       const size_t shm_lr = 2 * (BM + BN) * 128;
-      if (!attr_lr) {
+      if (ds2_first_use_on_device(attr_lr))
         (void)hipFuncSetAttribute((const void*)k_gemm_nt_bf16_glds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_lr);
-        attr_lr = true;
-      }
       hipLaunchKernelGGL(k_gemm_nt_bf16_glds<true>, grid, blk, shm_lr, st, g);
     } else {
       hipLaunchKernelGGL(k_gemm_nt_bf16_glds<false>, grid, blk, 0, st, g);
     }
   } else {
-    static bool attr_b = false;
-    if (!attr_b) {
-      hipFuncSetAttribute((const void*)k_gemm_nt<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-      attr_b = true;
-    }
+    static bool attr_b[DS2_MAX_DEVICES];
+    if (ds2_first_use_on_device(attr_b)) (void)hipFuncSetAttribute((const void*)k_gemm_nt<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     hipLaunchKernelGGL(k_gemm_nt<bf16_t>, grid, blk, shm, st, g);
   }
   DS2_CHECK_LAUNCH();

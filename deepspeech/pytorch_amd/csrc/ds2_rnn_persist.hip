@@ -11,14 +11,12 @@ int launch_rnn(bool bwd, int H, const PArgs& a, hipStream_t st);
 namespace {
 using namespace ds2p;
 
-int cu_count() {
-  static int n = -1;
-  if (n < 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) n = v;
-    else n = 0;
-  }
-  return n;
+int cu_count() {   // of the CURRENT device (cached per device)
+  static int n[DS2_MAX_DEVICES];
+  int dev = 0, v = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DS2_MAX_DEVICES) return 0;
+  if (n[dev] == 0 && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) n[dev] = v;
+  return n[dev];
 }
 
 int dispatch(bool bwd, int cell, int H, const PArgs& a, hipStream_t st) {
@@ -30,7 +28,9 @@ int dispatch(bool bwd, int cell, int H, const PArgs& a, hipStream_t st) {
   return DS2_ERR_ARG;
 }
 
-constexpr long AUX_BYTES = 4096;   // [0,1024) cycle counters, [1024,3072) XCC-id handshake slots; exchange buffer follows
+// scratch head: [0,1024) cycle counters (-DDS2_PROBE builds only), [1024,3072) XCC-id handshake slots, [3072] the per-launch
+// error word; the exchange buffer follows.  All of it is zeroed before every launch.
+constexpr long AUX_BYTES = 4096;
 
 long xbuf_bytes(int cell, int H, bool bwd) {
   const int G = cell == CELL_GRU ? 3 : cell == CELL_LSTM ? 4 : 1;
@@ -71,8 +71,11 @@ int ds2_rnn_persist_fwd(int cell, int D, int N, int H, int Tp, const int* lens, 
   a.N = N; a.Tp = Tp; a.D = D; a.gpd = NGROUPS / D; a.lens = lens; a.W = (const bf16_t*)Whh; a.bhh = bhh;
   a.GI = (const bf16_t*)GI; a.Hseq = (bf16_t*)Hseq; a.hseq_dstride = hseq_dstride; a.S = (bf16_t*)S; a.h0 = h0; a.c0 = c0;
   a.hn = hn; a.cn = cn; a.xbuf = (u64*)((char*)ws + AUX_BYTES); a.err = err;
-  a.dbg = (unsigned long long*)ws; a.xcc = (u64*)((char*)ws + 1024);
+  a.xcc = (u64*)((char*)ws + 1024); a.lerr = (int*)((char*)ws + 3072);
+#ifdef DS2_PROBE
+  a.dbg = (unsigned long long*)ws;
   { const char* e_ = getenv("DS2_PERSIST_DBG"); a.dbgmask = e_ ? atoi(e_) : 0; }
+#endif
   return dispatch(false, cell, H, a, st);
 }
 
@@ -90,8 +93,11 @@ int ds2_rnn_persist_bwd(int cell, int D, int N, int H, int Tp, const int* lens, 
   a.N = N; a.Tp = Tp; a.D = D; a.gpd = NGROUPS / D; a.lens = lens; a.W = (const bf16_t*)WhhT;
   a.Hseq = (bf16_t*)Hseq; a.hseq_dstride = hseq_dstride; a.S = (bf16_t*)S; a.dOut = (const bf16_t*)dOut;
   a.dGI = (bf16_t*)dGI; a.dGH = (bf16_t*)dGH; a.xbuf = (u64*)((char*)ws + AUX_BYTES); a.err = err;
-  a.dbg = (unsigned long long*)ws; a.xcc = (u64*)((char*)ws + 1024);
+  a.xcc = (u64*)((char*)ws + 1024); a.lerr = (int*)((char*)ws + 3072);
+#ifdef DS2_PROBE
+  a.dbg = (unsigned long long*)ws;
   { const char* e_ = getenv("DS2_PERSIST_DBG"); a.dbgmask = e_ ? atoi(e_) : 0; }
+#endif
   return dispatch(true, cell, H, a, st);
 }
 

@@ -72,11 +72,21 @@ struct PArgs {
   bf16_t* dGI;              // bwd: [Tp*N][D*G*H]
   bf16_t* dGH;              // bwd, GRU only: [D][Tp][N][3H]
   u64* xbuf;                // [NGROUPS][2][MAXS][X/2] granules, zeroed before the launch
-  int* err;                 // device word, set to 1 on a spin time-out
-  unsigned long long* dbg;  // [NGROUPS][8] cycle counters of workgroup 0 of each group (tools/probe_rnn_persist.py)
-  int dbgmask;              // profiling only: 1 skip GI/dOut/S prefetch loads, 2 skip output stores, 8 skip the gather (no exchange)
+  int* err;                 // device word, set to 1 on a spin time-out (sticky: the host reads it)
+  int* lerr;                // per-LAUNCH word in the zeroed scratch: lets the peers of a timed-out workgroup stop early
   u64* xcc;                 // [NGROUPS][32] start-up exchange of the workgroups' XCC ids, zeroed before the launch
+#ifdef DS2_PROBE            // tools/probe_rnn_persist.py builds its own library with -DDS2_PROBE; the shipping kernels carry none of it
+  unsigned long long* dbg;  // [NGROUPS][8] cycle counters of workgroup 0 of each group
+  int dbgmask;              // 1 skip GI/dOut/S prefetch loads, 2 skip output stores, 8 skip the gather (no exchange)
+#endif
 };
+#ifdef DS2_PROBE
+#define DS2_PROBE_ONLY(...) __VA_ARGS__
+#define DS2_DBG(a, bit) ((a).dbgmask & (bit))
+#else
+#define DS2_PROBE_ONLY(...)
+#define DS2_DBG(a, bit) 0
+#endif
 
 __device__ __forceinline__ u64 g_load(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void g_store(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -92,7 +102,11 @@ __device__ __forceinline__ void publish(u64* p, u64 v, bool local) {
 
 // Start-up handshake (placement-independent sc1 protocol): every workgroup publishes its XCC id, waits for the 31 peers of
 // its group and returns true iff all 32 ids are equal.  Every member evaluates the same 32 words, so the group agrees.
-__device__ __forceinline__ bool group_is_xcd_local(u64* slots /* this group's [32] */, int p, int tid, int* err, bool& dead) {
+__device__ __forceinline__ void raise_err(int* err, int* lerr) {
+  __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(lerr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool group_is_xcd_local(u64* slots /* this group's [32] */, int p, int tid, int* err, int* lerr, bool& dead) {
   __shared__ int s_local;
   if (tid < 64) {
     const unsigned my = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf;   // HW_REG_XCC_ID[3:0]
@@ -109,7 +123,7 @@ __device__ __forceinline__ bool group_is_xcd_local(u64* slots /* this group's [3
       }
       if (++spins > SPIN_LIMIT) {
         dead = true;
-        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        raise_err(err, lerr);
         same = false;
         break;
       }
@@ -169,7 +183,7 @@ __device__ __forceinline__ int xgranule_bytes(int k, int row) {
 template <int TILES, int KS, int SPLIT>
 __device__ __forceinline__ void gather_mma(ds2_f32x4 (&acc)[TILES], const uint4 (&w)[TILES][KS], __amdgpu_buffer_rsrc_t rsrc,
                                            int par_off, int kstep0, int lq, int srow, int half, bool need, unsigned epoch,
-                                           int* err, bool& dead, unsigned& rounds) {
+                                           int* err, int* lerr, bool& dead, unsigned& rounds) {
   constexpr int CH = chunk_ksteps(KS, SPLIT);
   constexpr int PER = CH / SPLIT;   // k-steps a lane loads per chunk
   constexpr int NROWS = SPLIT == 2 ? 8 : 16;
@@ -221,9 +235,11 @@ __device__ __forceinline__ void gather_mma(ds2_f32x4 (&acc)[TILES], const uint4 
           DS2_GATHER_LOAD()
           DS2_GATHER_CHECK(bad2)
           if (!__any(bad2)) break;
-          if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          // give up after the spin limit, or early when a peer of THIS launch already did (the per-launch word lives in the
+          // scratch that is zeroed before every launch: a time-out of an earlier launch never shortens this one's patience)
+          if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(lerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
             dead = true;
-            __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            raise_err(err, lerr);
             break;
           }
         }
@@ -350,21 +366,21 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd(PArgs a) {
   bf16_t* hs_ptr = a.Hseq + (long)d * a.hseq_dstride + ((long)t_first * N + nn_) * H + j;
   const long hs_stride = dstep * N * H;
   bool dead = false;
-  const bool local = group_is_xcd_local(a.xcc + grp * 32, p, tid, a.err, dead);
+  const bool local = group_is_xcd_local(a.xcc + grp * 32, p, tid, a.err, a.lerr, dead);
   if (gate_thread && a.h0)   // initial state as "step -1": parity 1, tag TAG_INIT
     publish((u64*)((char*)xg + PAR_BYTES + xgranule_bytes<NROWS>(j, gi_i)), ((u64)TAG_INIT << 32) | pack_bf16x2(hprev0, hprev1), local);
   unsigned rounds = 0;
-  unsigned long long c_gather = 0, c_mma = 0, c_bar = 0, c_gate = 0;
+  DS2_PROBE_ONLY(unsigned long long c_gather = 0, c_bar = 0, c_gate = 0;)
 
   for (int s = 0; s < Tp; ++s) {
-    const unsigned long long t0 = __builtin_readcyclecounter();
+    DS2_PROBE_ONLY(const unsigned long long t0 = __builtin_readcyclecounter();)
     const int t = d == 0 ? s : Tp - 1 - s;
     const int par = s & 1;
     // prefetch the hoisted input projection of this step
     uint32_t gi[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) gi[g] = 0;
-    if (gate_thread && !(a.dbgmask & 1)) {
+    if (gate_thread && !DS2_DBG(a, 1)) {
       const bf16_t* gp = gi_ptr;
 #pragma unroll
       for (int g = 0; g < G; ++g) gi[g] = *reinterpret_cast<const uint32_t*>(gp + (long)g * H);
@@ -372,17 +388,17 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd(PArgs a) {
     ds2_f32x4 acc[TILES];
 #pragma unroll
     for (int tt = 0; tt < TILES; ++tt) acc[tt] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
-    if ((s > 0 || a.h0) && !(a.dbgmask & 8))
+    if ((s > 0 || a.h0) && !DS2_DBG(a, 8))
       gather_mma<TILES, KS, SPLIT>(acc, w, rsrc, (par ^ 1) * PAR_BYTES, wave * KS, lq, srow, half, need, s > 0 ? (unsigned)s : TAG_INIT,
-                                   a.err, dead, rounds);
-    const unsigned long long t1 = __builtin_readcyclecounter();
+                                   a.err, a.lerr, dead, rounds);
+    DS2_PROBE_ONLY(const unsigned long long t1 = __builtin_readcyclecounter();)
     store_partials<TILES>(part[par], acc, wave, lane);
     __syncthreads();
-    const unsigned long long t2 = __builtin_readcyclecounter();
+    DS2_PROBE_ONLY(const unsigned long long t2 = __builtin_readcyclecounter();)
     if (gate_thread) {
       const bool act = t < len;
       float hn0 = 0.f, hn1 = 0.f;     // emitted h_t (0 when inactive)
-      const bool st_on = !(a.dbgmask & 2);
+      const bool st_on = !DS2_DBG(a, 2);
       bf16_t* sv = sv_ptr;
       uint32_t pl[NS ? NS : 1];   // packed saved planes; stored AFTER the publish (the publish is what the peers wait for)
       float2 gh[G];
@@ -457,11 +473,9 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd(PArgs a) {
     gi_ptr += gi_stride;
     if (NS) sv_ptr += sv_stride;
     hs_ptr += hs_stride;
-    const unsigned long long t3 = __builtin_readcyclecounter();
-    c_gather += t1 - t0;
-    c_bar += t2 - t1;
-    c_gate += t3 - t2;
+    DS2_PROBE_ONLY(const unsigned long long t3 = __builtin_readcyclecounter(); c_gather += t1 - t0; c_bar += t2 - t1; c_gate += t3 - t2;)
   }
+#ifdef DS2_PROBE
   if (a.dbg && p == 0 && (tid == 0 || tid == 255)) {
     const int o = grp * 8 + (tid == 0 ? 0 : 4);
     a.dbg[o + 0] = c_gather;
@@ -469,7 +483,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd(PArgs a) {
     a.dbg[o + 2] = c_gate;
     a.dbg[o + 3] = rounds;
   }
-  (void)c_mma;
+#endif
   if (gate_thread) {
     const long so = ((long)d * N + n) * H + j;
     if (a.hn) {
@@ -549,13 +563,12 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd(PArgs a) {
   bf16_t* dgh_ptr = a.dGH ? a.dGH + (((long)d * Tp + t_first) * N + nn_) * GH + j : nullptr;
   const long prev_off = d == 0 ? -1 : 1;                    // previous step in FORWARD order of this direction
   bool dead = false;
-  const bool local = group_is_xcd_local(a.xcc + grp * 32, p, tid, a.err, dead);
+  const bool local = group_is_xcd_local(a.xcc + grp * 32, p, tid, a.err, a.lerr, dead);
   unsigned rounds = 0;
-  unsigned long long c_gather = 0, c_bar = 0, c_gate = 0;
-  constexpr long NSH = (long)(NS ? NS : 1) * H;
+  DS2_PROBE_ONLY(unsigned long long c_gather = 0, c_bar = 0, c_gate = 0;)
 
   for (int s = 0; s < Tp; ++s) {
-    const unsigned long long t0 = __builtin_readcyclecounter();
+    DS2_PROBE_ONLY(const unsigned long long t0 = __builtin_readcyclecounter();)
     const int t = d == 0 ? Tp - 1 - s : s;
     const int par = s & 1;
     // ---- prefetch everything the gate phase needs
@@ -563,7 +576,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd(PArgs a) {
 #pragma unroll
     for (int q = 0; q < (NS ? NS : 1); ++q) sp[q] = 0;
     const int tprev = d == 0 ? t - 1 : t + 1;            // previous step in FORWARD order of this direction
-    if (gate_thread && !(a.dbgmask & 1)) {
+    if (gate_thread && !DS2_DBG(a, 1)) {
       dout = *reinterpret_cast<const uint32_t*>(do_ptr);
       if (NS) {
         const bf16_t* sv = sv_ptr;
@@ -581,12 +594,13 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd(PArgs a) {
     ds2_f32x4 acc[TILES];
 #pragma unroll
     for (int tt = 0; tt < TILES; ++tt) acc[tt] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
-    if (s > 0 && !(a.dbgmask & 8))
-      gather_mma<TILES, KS, SPLIT>(acc, w, rsrc, (par ^ 1) * PAR_BYTES, wave * KS, lq, srow, half, need, (unsigned)s, a.err, dead, rounds);
-    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (s > 0 && !DS2_DBG(a, 8))
+      gather_mma<TILES, KS, SPLIT>(acc, w, rsrc, (par ^ 1) * PAR_BYTES, wave * KS, lq, srow, half, need, (unsigned)s, a.err, a.lerr, dead,
+                                   rounds);
+    DS2_PROBE_ONLY(const unsigned long long t1 = __builtin_readcyclecounter();)
     store_partials<TILES>(part[par], acc, wave, lane);
     __syncthreads();
-    const unsigned long long t2 = __builtin_readcyclecounter();
+    DS2_PROBE_ONLY(const unsigned long long t2 = __builtin_readcyclecounter();)
     if (gate_thread) {
       const bool act = t < len;
       const float2 mp = load_partials<TILES>(part[par], (2 * up) / 16, gi_i, (2 * up) % 16);
@@ -594,7 +608,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd(PArgs a) {
       bf16_t* dgi = dgi_ptr;
       char* xo = (char*)xg + par * PAR_BYTES;   // granule of gate g, units (j, j+1): element k = g*H + j
       const u64 tag = (u64)(unsigned)(s + 1) << 32;
-      const bool st_on = !(a.dbgmask & 2);
+      const bool st_on = !DS2_DBG(a, 2);
       if (CELL == CELL_GRU) {
         float dr0 = 0.f, dr1 = 0.f, dz0 = 0.f, dz1 = 0.f, dn0 = 0.f, dn1 = 0.f, dq0 = 0.f, dq1 = 0.f;
         car0 = din0;
@@ -683,11 +697,9 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd(PArgs a) {
     hs_ptr += dstep * N * H;
     dgi_ptr += dstep * N * ldgi;
     if (CELL == CELL_GRU) dgh_ptr += dstep * N * GH;
-    const unsigned long long t3 = __builtin_readcyclecounter();
-    c_gather += t1 - t0;
-    c_bar += t2 - t1;
-    c_gate += t3 - t2;
+    DS2_PROBE_ONLY(const unsigned long long t3 = __builtin_readcyclecounter(); c_gather += t1 - t0; c_bar += t2 - t1; c_gate += t3 - t2;)
   }
+#ifdef DS2_PROBE
   if (a.dbg && p == 0 && (tid == 0 || tid == 255)) {
     const int o = grp * 8 + (tid == 0 ? 0 : 4);
     a.dbg[o + 0] = c_gather;
@@ -695,6 +707,8 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd(PArgs a) {
     a.dbg[o + 2] = c_gate;
     a.dbg[o + 3] = rounds;
   }
+#endif
+  (void)rounds;
 }
 
 template <int CELL, int H, int P>

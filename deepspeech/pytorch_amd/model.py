@@ -431,6 +431,10 @@ class _FrontFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, *unused):
         c1, c2, L = ctx.c1, ctx.c2, ctx.L
+        if c1 is None:
+            # the saved activations (hundreds of MB) are dropped after the first backward, like autograd frees its buffers
+            raise RuntimeError("DeepSpeech (gfx950): trying to backward through the conv + RNN stack a second time -- its saved "
+                               "activations were freed by the first backward; run the forward again (retain_graph is not supported)")
         c2.defer_join = True
         r = _RnnStackFn.backward(c2, dout)
         rnn_grads = r[8 + 2 * L:]
@@ -713,6 +717,8 @@ class DeepSpeech(_Base):
 
     def training_step(self, batch, batch_idx):
         inputs, targets, input_percentages, target_sizes = batch
+        if inputs.is_cuda:
+            ops.poll_persistent_error(inputs.device)      # a sweep that timed out in an earlier step raises here (no host sync)
         input_sizes = input_percentages.mul_(int(inputs.size(3))).int()       # model.py:243
         logits, output_sizes, _, lens_dev, N, Tp = self._logits(inputs, input_sizes)
         return _CtcFn.apply(logits, targets, lens_dev, target_sizes, N, Tp, len(self.labels), self.blank_index)

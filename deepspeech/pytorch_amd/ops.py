@@ -35,6 +35,15 @@ def P(t):
     return C.c_void_p(t.data_ptr())
 
 
+def PF(t):
+    """device pointer of an fp32 parameter / buffer / statistics tensor.  The kernels read these as float: a module cast with
+    .half() / .to(bfloat16) (or a 'bf16-true' precision plugin) must fail loudly instead of being read as garbage."""
+    if t is not None and t.dtype != torch.float32:
+        raise _lib.Ds2HipError("ds2hip kernels keep parameters, BatchNorm statistics and carried states in float32 (bf16 is an "
+                               "activation/operand type selected by `precision`/autocast); got %s" % t.dtype)
+    return P(t)
+
+
 def S():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -82,7 +91,7 @@ def gemm_nt(A, B, bias=None, out_dtype=None, M=None, N=None, K=None, lda=None, l
         ldc = N
         sC = M * N
     out_f32 = 1 if out.dtype == torch.float32 else 0
-    call("ds2_gemm_nt_coresident" if coresident else "ds2_gemm_nt", dt(A), P(A), P(B), P(out), P(bias), M, N, K, lda, ldb, ldc,
+    call("ds2_gemm_nt_coresident" if coresident else "ds2_gemm_nt", dt(A), P(A), P(B), P(out), PF(bias), M, N, K, lda, ldb, ldc,
          out_f32, batch, sA, sB, sC, sBias, splitk, S())
     return out
 
@@ -113,7 +122,7 @@ def cast_transpose_bf16(src, dst=None, ldd=0, dstT=None, lddT=0, perm=None, cout
     lddT); `perm` = (c, f) re-orders the conv features of rnns.0, `cout` pads the columns with zeros."""
     R, Cc = src.shape
     pc, pf = perm if perm is not None else (0, 0)
-    call("ds2_cast_transpose_bf16", P(src), src.stride(0), R, Cc, pc, pf, Cc if cout is None else cout,
+    call("ds2_cast_transpose_bf16", PF(src), src.stride(0), R, Cc, pc, pf, Cc if cout is None else cout,
          P(dst) if dst is not None else None, ldd, P(dstT) if dstT is not None else None, lddT, S())
 
 
@@ -135,8 +144,8 @@ def bn_fwd(X, mode, training, gamma, beta, rmean, rvar, nbt, R, Cc, ldx, Y, ldy,
            momentum=0.1):
     sv = BnSaved(Cc, X.device)
     ws = torch.empty(2 * query("ds2_norm_partials", R) * Cc, dtype=torch.float32, device=X.device)
-    call("ds2_bn_fwd", dt(X), mode, 1 if training else 0, P(X), P(Y), R, Cc, ldx, ldy, F, Tp, N, P(lens), P(gamma), P(beta),
-         P(rmean), P(rvar), P(nbt) if training else C.c_void_p(0), float(eps), float(momentum), P(sv.mean), P(sv.rstd),
+    call("ds2_bn_fwd", dt(X), mode, 1 if training else 0, P(X), P(Y), R, Cc, ldx, ldy, F, Tp, N, P(lens), PF(gamma), PF(beta),
+         PF(rmean), PF(rvar), P(nbt) if training else C.c_void_p(0), float(eps), float(momentum), P(sv.mean), P(sv.rstd),
          P(sv.scale), P(sv.shift), P(ws), S())
     return sv
 
@@ -154,7 +163,7 @@ def bn_bwd(G, X, DX, mode, sv, R, Cc, ldg, ldx, lddx, F=0, Tp=0, N=0, lens=None)
 def conv1_fwd(x, w1k, b1, lens, Tp, dtype):
     N, _, F, T = x.shape
     y1 = torch.empty((N, 81, Tp, 32), dtype=dtype, device=x.device)
-    call("ds2_conv1_fwd", dt(dtype), P(x), P(w1k), P(b1), P(lens), P(y1), N, T, Tp, S())
+    call("ds2_conv1_fwd", dt(dtype), PF(x), PF(w1k), PF(b1), P(lens), P(y1), N, T, Tp, S())
     return y1
 
 
@@ -169,7 +178,7 @@ def conv1_wgrad(x, dy1, Tp):
 def conv2_fwd(a1, w2t, b2, lens):
     N, _, Tp, _ = a1.shape
     y2 = torch.empty((N, 41, Tp, 32), dtype=a1.dtype, device=a1.device)
-    call("ds2_conv2_fwd", dt(a1), P(a1), P(w2t), P(b2), P(lens), P(y2), N, Tp, S())
+    call("ds2_conv2_fwd", dt(a1), P(a1), P(w2t), PF(b2), P(lens), P(y2), N, Tp, S())
     return y2
 
 
@@ -209,11 +218,41 @@ def check_persistent_kernels():
             raise _lib.Ds2HipError("a persistent recurrent kernel timed out on device %d (outputs were NaN-poisoned)" % key)
 
 
+_ERR_MIRROR = {}   # device index -> [pinned host int32 tensor, event of the copy in flight or None]
+
+
+def poll_persistent_error(dev):
+    """Surfaces a timed-out persistent sweep WITHOUT a host synchronisation (DeepSpeech.training_step calls this once per
+    step): raises if the asynchronous copy of the device's error word enqueued by an earlier call has landed non-zero,
+    then enqueues a fresh copy behind the work queued so far.  A stalled sweep therefore raises one step late at the
+    latest; its outputs are NaN-poisoned meanwhile (and the CTC loss stays NaN), never silently zero."""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    t = _PERSIST_ERR.get(key)
+    if t is None:
+        return
+    m = _ERR_MIRROR.get(key)
+    if m is None:
+        m = _ERR_MIRROR[key] = [torch.zeros(1, dtype=torch.int32).pin_memory(), None]
+    if m[1] is not None:
+        if not m[1].query():
+            return                                   # the previous copy has not landed yet: look again next step
+        m[1] = None
+        if int(m[0][0]) != 0:
+            raise _lib.Ds2HipError("a persistent recurrent kernel timed out on device %d waiting for its peer workgroups "
+                                   "(are other kernels occupying CUs?); its outputs were NaN-poisoned" % key)
+    m[0].copy_(t[:1], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    m[1] = ev
+
+
+PERSIST_ENABLED = True   # tests flip this to run the per-time-step kernels on shapes the persistent kernels cover
+
+
 def use_persistent(kind, dtype, D, N, H):
-    import os
-    if os.environ.get("DS2_RNN_PERSIST", "1") == "0" or dtype != torch.bfloat16:
+    if not PERSIST_ENABLED:
         return False
-    return bool(query("ds2_rnn_persist_supported", BF16, CELLS[kind], D, N, H))
+    return bool(query("ds2_rnn_persist_supported", dt(dtype), CELLS[kind], D, N, H))
 
 
 def rnn_fwd(kind, GI, Whh, bhh, lens, D, N, H, Tp, h0=None, c0=None, save=True):
@@ -231,12 +270,12 @@ def rnn_fwd(kind, GI, Whh, bhh, lens, D, N, H, Tp, h0=None, c0=None, save=True):
         global LAST_PERSIST_WS
         LAST_PERSIST_WS = ws
         with _sweep_timer("rnn_fwd_persistent", Tp):
-            call("ds2_rnn_persist_fwd", CELLS[kind], D, N, H, Tp, P(lens), P(GI), P(Whh), P(bhh), P(h0), P(c0),
+            call("ds2_rnn_persist_fwd", CELLS[kind], D, N, H, Tp, P(lens), P(GI), P(Whh), PF(bhh), PF(h0), PF(c0),
                  P(hext[:, 1]), (Tp + 2) * N * H, P(Sv), P(hn), P(cn), P(ws), P(_persist_err(dev)), S())
         return hext, Sv, hn, cn
     state = torch.empty(query("ds2_rnn_state_bytes", D, N, H), dtype=torch.uint8, device=dev)
     with _sweep_timer("rnn_fwd", Tp):
-        call("ds2_rnn_fwd", dt(dtype), CELLS[kind], D, N, H, Tp, P(lens), P(GI), P(Whh), P(bhh), P(h0), P(c0),
+        call("ds2_rnn_fwd", dt(dtype), CELLS[kind], D, N, H, Tp, P(lens), P(GI), P(Whh), PF(bhh), PF(h0), PF(c0),
              P(hext[:, 1]), (Tp + 2) * N * H, P(Sv), P(hn), P(cn), P(state), S())
     return hext, Sv, hn, cn
 
@@ -265,7 +304,7 @@ def rnn_bwd(kind, dOut, WhhT, hext, Sv, lens, D, N, H, Tp):
 def lookahead_fwd(x, w, Tp, N, H, save=True):
     y = torch.empty_like(x)
     pre = torch.empty_like(x) if save else None
-    call("ds2_lookahead_fwd", dt(x), P(x), P(w), P(y), P(pre), Tp, N, H, w.shape[1], S())
+    call("ds2_lookahead_fwd", dt(x), P(x), PF(w), P(y), P(pre), Tp, N, H, w.shape[1], S())
     return y, pre
 
 

@@ -59,6 +59,20 @@ CASES = [
          lookahead_context=20, lengths=[111, 96, 83], data_seed=20, param_seed=110, stride=1009),
     dict(name="rnn_bi_1024", rnn_type="rnn", hidden_size=1024, hidden_layers=2, bidirectional=True,
          lengths=[101, 88, 61, 45, 33], data_seed=21, param_seed=111, stride=1009),
+    # ---- BASELINE.json configurations at their own size / width (round 2) -------------------------------------
+    # configs[1] (AN4 shape) at FULL size: 5 x BiGRU-800, 8 clips of 2.01 ... 1.01 s, fp32
+    dict(name="cfg2_full", rnn_type="gru", hidden_size=800, hidden_layers=5, bidirectional=True,
+         lengths=[201, 187, 172, 158, 144, 130, 115, 101], data_seed=22, param_seed=112, stride=1009),
+    # configs[4] family: LSTM hidden 1280, bi-directional (5a) and uni-directional + Lookahead (5b)
+    dict(name="lstm_bi_1280", rnn_type="lstm", hidden_size=1280, hidden_layers=2, bidirectional=True,
+         lengths=[131, 120, 101, 77, 60], data_seed=23, param_seed=113, stride=1009),
+    dict(name="lstm_uni_1280_la", rnn_type="lstm", hidden_size=1280, hidden_layers=2, bidirectional=False,
+         lookahead_context=20, lengths=[125, 110, 96, 71], data_seed=24, param_seed=114, stride=1009),
+    # configs[2] at full DEPTH and BATCH (5 x BiGRU-1024, 32 clips), clips shortened to 2.4-3 s so that the reference's
+    # fp32 + fp64 CPU runs stay in minutes
+    dict(name="gru_bi_1024_l5_n32", rnn_type="gru", hidden_size=1024, hidden_layers=5, bidirectional=True,
+         lengths=[301, 300, 298, 297, 295, 293, 291, 290, 288, 286, 284, 282, 281, 279, 277, 275, 273, 272, 270, 268, 266, 264,
+                  262, 260, 258, 256, 254, 252, 249, 247, 244, 241], data_seed=25, param_seed=115, stride=4001),
 ]
 
 
@@ -160,6 +174,30 @@ def main():
                 out["gradl2." + k] = np.float64(np.sqrt((g ** 2).sum()))
             else:
                 out["grad." + k] = g.astype(np.float32)
+        # ---- (C) the reference under torch.autocast(bfloat16) (what Lightning's precision=16/bf16 plugin wraps the step
+        # in; CPU autocast here -- the GPU box has no reference): loss, logits and every gradient, plus "acnoise.<param>" =
+        # relative L2 distance of its gradient from the float64 run (B).  The bf16 mode of the HIP path is held against
+        # these (tests/test_gpu_model.py::test_bf16_train_step_vs_reference_autocast).
+        mac = fresh_model(ns, case, P)
+        mac.train()
+        mac.zero_grad()
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            xin = torch.from_numpy(inputs)
+            isz = torch.from_numpy(pct.copy()).mul_(int(inputs.shape[3])).int()
+            lg_ac, osz_ac, _ = mac(xin, isz)
+            lp_ac = lg_ac.transpose(0, 1).log_softmax(-1)
+            loss_ac = mac.criterion(lp_ac, torch.from_numpy(targets), osz_ac, torch.from_numpy(tsz))
+        loss_ac.backward()
+        out["loss_ac"] = np.float64(loss_ac.item())
+        out["logits_ac"] = lg_ac.detach().float().numpy()
+        g64 = {k: p.grad.detach().numpy() for k, p in m64.named_parameters()}
+        for k, p in mac.named_parameters():
+            g = p.grad.detach().float().numpy().astype(np.float64)
+            out["acnoise." + k] = np.float64(np.sqrt(((g - g64[k]) ** 2).sum()) / max(np.sqrt((g64[k] ** 2).sum()), 1e-30))
+            if g.size > BIG:
+                out["gradsub_ac." + k] = g.reshape(-1)[::stride].astype(np.float32)
+            else:
+                out["grad_ac." + k] = g.astype(np.float32)
         # ---- eval forward (fresh weights = the fixture's running stats), softmax probs + transcripts
         mev = fresh_model(ns, case, P)
         mev.eval()

@@ -287,12 +287,11 @@ def test_rnn_persistent_sweeps(kind, D, N, H, Tp):
     assert o.use_persistent(kind, torch.bfloat16, D, N, H), "persistent path not selected on this device"
     res_p = _rnn_sweep_case(torch.bfloat16, kind, D, N, H, Tp, 1.0 / np.sqrt(H))
     o.check_persistent_kernels()
-    import os
-    os.environ["DS2_RNN_PERSIST"] = "0"
+    o.PERSIST_ENABLED = False
     try:
         res_s = _rnn_sweep_case(torch.bfloat16, kind, D, N, H, Tp, 1.0 / np.sqrt(H))
     finally:
-        os.environ.pop("DS2_RNN_PERSIST")
+        o.PERSIST_ENABLED = True
     for a, b in zip(res_p, res_s):   # same bf16 operands; only the fp32 summation order differs
         assert np.abs(a - b).max() <= 2e-2 * max(1.0, np.abs(b).max()), np.abs(a - b).max()
 
