@@ -12,11 +12,17 @@ MFMA operands with fp32 master weights, statistics, gate math and CTC; synthetic
 resident in HBM when the timed region starts; weak scaling (32 clips per GPU).  Audio seconds = true (unpadded) frames
 x 10 ms.  One JSON line is printed by rank 0; it also carries
 
-  "roofline":     the dominant kernel (the per-time-step recurrent kernel k_rnn_step_*): algorithmic FLOPs per launch /
-                  average launch duration measured live with HIP events on the launch stream, against the dense bf16
-                  MFMA peak (2.5 PFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md);
+  "roofline":     the dominant kernel (the persistent recurrent sweep k_rnn_persist_bwd / _fwd: ONE launch per layer and
+                  sweep): algorithmic h2h FLOPs of a sweep over valid frames / average launch duration measured live with
+                  HIP events on the launch stream, against the dense MFMA peak of the compute dtype (bf16 2.5 PFLOP/s, fp32
+                  157.3 TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md);
   "cpu_baseline": oracle/ds2_torch_port.py (the same torch calls the reference makes) timed on the host cores of this
-                  box on a bounded sample of the same model (rank 0, N=1 only).  A reported baseline, not the target.
+                  box on a bounded sample of the same model AT THE SAME BATCH SIZE (short clips; rank 0, N=1 only), plus --
+                  when profiles/cpu_reference_<config>.json exists -- the reference's own model.py timed offline at the full
+                  shape in the build container (tools/cpu_reference_baseline.py).  A reported baseline, not the target.
+
+With `--gpus N` and no launcher environment (WORLD_SIZE unset) the script re-executes itself under torch.distributed.run
+with N ranks on 127.0.0.1.
 
 `--stock` instead times stock PyTorch-ROCm (oracle/ds2_torch_port.py on the GPU under bf16 autocast: MIOpen conv / BN /
 RNN + ATen CTC) on the same batch: the denominator of the north star's ">= 3x over stock PyTorch-ROCm".
@@ -230,43 +236,64 @@ def cpu_baseline(args):
     torch.set_num_threads(cores)
     cfg = dict(rnn_type=kind, hidden_size=H, hidden_layers=L, bidirectional=bi, lookahead_context=20)
     port = TP.Port(cfg, TP.random_state(cfg, 0), "cpu")
-    n, t = args.cpu_clips, args.cpu_frames
-    lengths = synth.synth_lengths(n, max(101, t - 100), t, seed=77)
-    inputs, targets, pct, tsz = synth.synth_batch(lengths, seed=77)
-    batch = (torch.from_numpy(inputs), torch.from_numpy(targets), torch.from_numpy(pct), torch.from_numpy(tsz))
+    n = args.cpu_clips if args.cpu_clips > 0 else N          # default: the configuration's own batch size (the CPU path is
+    t = args.cpu_frames                                      # weight-bandwidth-bound per time step, so the batch size matters)
     opt = port.make_optimizer()
-    port.train_step(batch, opt)          # warm-up
+
+    def make(n_, t_, seed):
+        lengths = synth.synth_lengths(n_, max(41, t_ - t_ // 5), t_, seed=seed)
+        inputs, targets, pct, tsz = synth.synth_batch(lengths, seed=seed)
+        return lengths, (torch.from_numpy(inputs), torch.from_numpy(targets), torch.from_numpy(pct), torch.from_numpy(tsz))
+    port.train_step(make(2, 61, 76)[1], opt)          # warm-up (thread pool, allocator) on a tiny batch
+    lengths, batch = make(n, t, 77)
     times = []
     t_all = time.perf_counter()
-    while len(times) < 2 or (time.perf_counter() - t_all < 12.0 and len(times) < 8):
+    while len(times) < 1 or (time.perf_counter() - t_all < 14.0 and len(times) < 4):
         t0 = time.perf_counter()
         port.train_step(batch, opt)
         times.append(time.perf_counter() - t0)
     best = min(times)
     secs = synth.audio_seconds(lengths)
-    return {"value": round(secs / best, 3), "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
-            "sample": "oracle/ds2_torch_port.py (the reference's torch op sequence) fp32, same model (%s H=%d L=%d %s), %d clips of "
-                      "%.2f-%.2f s, best of %d steps (%.2f s/step), torch %s, %d threads" % (
-                          kind, H, L, "bi" if bi else "uni", n, lengths.min() * 0.01, lengths.max() * 0.01, len(times), best,
-                          torch.__version__, cores)}
+    out = {"value": round(secs / best, 3), "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
+           "sample": "oracle/ds2_torch_port.py (the reference's torch op sequence) fp32, same model (%s H=%d L=%d %s), %d clips of "
+                     "%.2f-%.2f s, best of %d steps (%.2f s/step), torch %s, %d threads" % (
+                         kind, H, L, "bi" if bi else "uni", n, lengths.min() * 0.01, lengths.max() * 0.01, len(times), best,
+                         torch.__version__, cores)}
+    try:   # the reference's own model.py at the FULL shape, timed offline in the build container (no reference on this box)
+        ref = json.load(open(os.path.join(ROOT, "profiles", "cpu_reference_%s.json" % args.config)))
+        out["reference_offline"] = {k: ref[k] for k in ("value", "unit", "cores", "kind", "sample") if k in ref}
+    except Exception:
+        pass
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=150, help="timed steps (default: a >= 5 s timed region on cfg3)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--stock", action="store_true", help="time stock PyTorch-ROCm instead of the native path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-clips", type=int, default=4)
+    ap.add_argument("--cpu-clips", type=int, default=0, help="clips of the CPU sample (0 = the configuration's batch size)")
     ap.add_argument("--cpu-frames", type=int, default=301)
-    ap.add_argument("--cpu-timeout", type=int, default=150)
+    ap.add_argument("--cpu-timeout", type=int, default=170)
     ap.add_argument("--cpu-baseline-only", action="store_true")
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args)))
         return
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: start N ranks (one per GPU, RCCL over 127.0.0.1) of this same command and relay rank 0's JSON line
+        import socket
+        import subprocess
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     from deepspeech.pytorch_amd import dist as dsdist
     if not torch.cuda.is_available():
@@ -274,8 +301,8 @@ def main():
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     rank, world, local_rank = dsdist.init_from_env("nccl")
     device = torch.device("cuda", local_rank)
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
 
     runner = run_stock if args.stock else run_native
     log("start %s on %d rank(s), config %s" % ("stock" if args.stock else "native", world, args.config))
@@ -294,7 +321,7 @@ def main():
     out = {
         "metric": "audio-seconds/sec (train step)", "value": round(value, 2), "unit": "audio-seconds/sec", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic", "rccl_ranks": world,
         "impl": "stock-pytorch-rocm" if args.stock else "ds2hip",
         "config": {"workload": "%s: %dx %s%s hidden=%d, %d clips/GPU of %.1f-%.1f s, train step incl. clip_grad_norm(400)+AdamW" % (
             args.config, L, "Bi" if bi else "Uni", kind.upper(), H, N, tmin * 0.01, tmax_ * 0.01),

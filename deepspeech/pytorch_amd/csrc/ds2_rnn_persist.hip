@@ -1,12 +1,22 @@
-// Host side of the persistent recurrent sweeps: support query, scratch sizing, launch (kernels: ds2_rnn_persist_impl.h,
-// instantiated per cell type in ds2_rnn_persist_{gru,lstm,rnn}.hip).
-#include "ds2_rnn_persist_impl.h"
+// Host side of the persistent recurrent sweeps: support query, scratch sizing, launch.
+//   tuned kernels  (ds2_rnn_persist_impl.h,  instantiated per cell in ds2_rnn_persist_{gru,lstm,rnn}.hip): bf16, H = 1024,
+//                   8 XCD-local groups of 32 workgroups, <= 16 samples per group -- BASELINE.json config 3;
+//   general kernels (ds2_rnn_persist2_impl.h, instantiated in ds2_rnn_persist2_*.hip): H in {800, 1024, 1280}, bf16 and fp32
+//                   storage, GRU / LSTM, up to 64 samples per group -- configs 2 and 5 and the fp32 parity mode.
+#include "ds2_rnn_persist2_impl.h"
 
 namespace ds2p {
 int launch_gru(bool bwd, int H, const PArgs& a, hipStream_t st);
 int launch_lstm(bool bwd, int H, const PArgs& a, hipStream_t st);
 int launch_rnn(bool bwd, int H, const PArgs& a, hipStream_t st);
 }  // namespace ds2p
+namespace ds2q {
+// 0 on success, DS2_ERR_ARG if the combination is not instantiated; `probe` only asks whether it is
+int launch_bf16_800(bool probe, bool bwd, int cell, int MT, const QArgs& a, hipStream_t st);
+int launch_bf16_1280(bool probe, bool bwd, int cell, int MT, const QArgs& a, hipStream_t st);
+int launch_f32_800(bool probe, bool bwd, int cell, int MT, const QArgs& a, hipStream_t st);
+int launch_f32_1024(bool probe, bool bwd, int cell, int MT, const QArgs& a, hipStream_t st);
+}  // namespace ds2q
 
 namespace {
 using namespace ds2p;
@@ -32,73 +42,134 @@ int dispatch(bool bwd, int cell, int H, const PArgs& a, hipStream_t st) {
 // error word; the exchange buffer follows.  All of it is zeroed before every launch.
 constexpr long AUX_BYTES = 4096;
 
+int gates(int cell) { return cell == CELL_GRU ? 3 : cell == CELL_LSTM ? 4 : 1; }
+
 long xbuf_bytes(int cell, int H, bool bwd) {
-  const int G = cell == CELL_GRU ? 3 : cell == CELL_LSTM ? 4 : 1;
-  const long X2 = (bwd ? (long)G * H : (long)H) / 2;
+  const long X2 = (bwd ? (long)gates(cell) * H : (long)H) / 2;
   return (long)NGROUPS * 2 * MAXS * X2 * 8;
+}
+
+bool tuned_ok(int dtype, int cell, int D, int N, int H) {
+  if (dtype != DS2_BF16 || H != 1024 || (D != 1 && D != 2)) return false;
+  const int gpd = NGROUPS / D;
+  return N >= 1 && (N + gpd - 1) / gpd <= MAXS && cu_count() == 256;
+}
+
+// Geometry of the general kernels: P = H/16 workgroups per group, as many groups per direction as the chip holds.
+struct Plan2 {
+  int gpd, NG, MT, P;
+};
+int launch2_any(bool probe, bool bwd, int dtype, int cell, int H, int MT, const ds2q::QArgs& a, hipStream_t st) {
+  if (dtype == DS2_BF16 && H == 800) return ds2q::launch_bf16_800(probe, bwd, cell, MT, a, st);
+  if (dtype == DS2_BF16 && H == 1280) return ds2q::launch_bf16_1280(probe, bwd, cell, MT, a, st);
+  if (dtype == DS2_F32 && H == 800) return ds2q::launch_f32_800(probe, bwd, cell, MT, a, st);
+  if (dtype == DS2_F32 && H == 1024) return ds2q::launch_f32_1024(probe, bwd, cell, MT, a, st);
+  return DS2_ERR_ARG;
+}
+bool plan2(int dtype, int cell, int D, int N, int H, Plan2& pl) {
+  if ((dtype != DS2_BF16 && dtype != DS2_F32) || (D != 1 && D != 2) || N < 1 || H % 16 != 0) return false;
+  const int cus = cu_count();
+  pl.P = H / 16;
+  if (cus < 256 || pl.P * D > cus) return false;
+  pl.gpd = cus / pl.P / D;
+  if (pl.gpd > N) pl.gpd = N;
+  pl.NG = pl.gpd * D;
+  const int ns = (N + pl.gpd - 1) / pl.gpd;
+  pl.MT = ns <= 16 ? 1 : ns <= 32 ? 2 : ns <= 64 ? 4 : 0;
+  if (pl.MT == 0) return false;
+  ds2q::QArgs dummy{};
+  return launch2_any(true, false, dtype, cell, H, pl.MT, dummy, nullptr) == 0;
+}
+long xbuf2_bytes(int dtype, int cell, int H, const Plan2& pl, bool bwd) {
+  const int ksz = dtype == DS2_BF16 ? 32 : 16;
+  const long kt = (bwd ? (long)gates(cell) * H : (long)H) / ksz;
+  return (long)pl.NG * 2 * kt * pl.MT * 2048;
 }
 
 }  // namespace
 
 extern "C" {
 
-// 1 if the persistent kernels cover this problem on the current device (bf16 storage only): H = 1024, the
-// device has exactly 256 CUs (one workgroup per CU, all co-resident), and a direction's share of the minibatch fits
-// the 16-row MFMA tile of each of its 8/D groups.
+// 1 if a persistent kernel covers this problem on the current device (>= 256 CUs: one workgroup per CU, all co-resident).
 int ds2_rnn_persist_supported(int dtype, int cell, int D, int N, int H) {
-  if (dtype != DS2_BF16 || (cell != CELL_GRU && cell != CELL_LSTM && cell != CELL_RNN)) return 0;
-  if (H != 1024) return 0;
-  if (D != 1 && D != 2) return 0;
-  const int gpd = NGROUPS / D;
-  if (N < 1 || (N + gpd - 1) / gpd > MAXS) return 0;
-  return cu_count() == 256 ? 1 : 0;
+  if (cell != CELL_GRU && cell != CELL_LSTM && cell != CELL_RNN) return 0;
+  if (tuned_ok(dtype, cell, D, N, H)) return 1;
+  Plan2 pl;
+  return plan2(dtype, cell, D, N, H, pl) ? 1 : 0;
 }
 
-// bytes of the exchange buffer (max of the forward and backward sweep needs) + 64 for the error word
-long ds2_rnn_persist_ws_bytes(int cell, int H) { return AUX_BYTES + xbuf_bytes(cell, H, true); }
+// scratch bytes of one sweep (exchange buffer for the larger of the forward / BPTT needs + the head described above)
+long ds2_rnn_persist_ws_bytes(int dtype, int cell, int D, int N, int H) {
+  if (tuned_ok(dtype, cell, D, N, H)) return AUX_BYTES + xbuf_bytes(cell, H, true);
+  Plan2 pl;
+  if (!plan2(dtype, cell, D, N, H, pl)) return 0;
+  return AUX_BYTES + xbuf2_bytes(dtype, cell, H, pl, true);
+}
 
-// Same contract as ds2_rnn_fwd (ds2_rnn.hip) for dtype bf16; ws = ds2_rnn_persist_ws_bytes() bytes (zeroed here).
+// Same contract as ds2_rnn_fwd (ds2_rnn.hip); ws = ds2_rnn_persist_ws_bytes() bytes (zeroed here).
 // err: one device int, set to 1 if a workgroup gave up waiting (outputs are then NaN-poisoned).
-int ds2_rnn_persist_fwd(int cell, int D, int N, int H, int Tp, const int* lens, const void* GI, const void* Whh,
+int ds2_rnn_persist_fwd(int dtype, int cell, int D, int N, int H, int Tp, const int* lens, const void* GI, const void* Whh,
                         const float* bhh, const float* h0, const float* c0, void* Hseq, long hseq_dstride, void* S, float* hn,
                         float* cn, void* ws, int* err, ds2_stream_t st_) {
   hipStream_t st = (hipStream_t)st_;
-  DS2_REQUIRE(ds2_rnn_persist_supported(DS2_BF16, cell, D, N, H), DS2_ERR_ARG);
   DS2_REQUIRE(Tp > 0 && Tp < (int)TAG_INIT && ws && err, DS2_ERR_ARG);
-  hipError_t e = hipMemsetAsync(ws, 0, AUX_BYTES + xbuf_bytes(cell, H, false), st);
-  if (e != hipSuccess) return (int)e;
-  PArgs a{};
-  a.N = N; a.Tp = Tp; a.D = D; a.gpd = NGROUPS / D; a.lens = lens; a.W = (const bf16_t*)Whh; a.bhh = bhh;
-  a.GI = (const bf16_t*)GI; a.Hseq = (bf16_t*)Hseq; a.hseq_dstride = hseq_dstride; a.S = (bf16_t*)S; a.h0 = h0; a.c0 = c0;
-  a.hn = hn; a.cn = cn; a.xbuf = (u64*)((char*)ws + AUX_BYTES); a.err = err;
-  a.xcc = (u64*)((char*)ws + 1024); a.lerr = (int*)((char*)ws + 3072);
+  if (tuned_ok(dtype, cell, D, N, H)) {
+    hipError_t e = hipMemsetAsync(ws, 0, AUX_BYTES + xbuf_bytes(cell, H, false), st);
+    if (e != hipSuccess) return (int)e;
+    PArgs a{};
+    a.N = N; a.Tp = Tp; a.D = D; a.gpd = NGROUPS / D; a.lens = lens; a.W = (const bf16_t*)Whh; a.bhh = bhh;
+    a.GI = (const bf16_t*)GI; a.Hseq = (bf16_t*)Hseq; a.hseq_dstride = hseq_dstride; a.S = (bf16_t*)S; a.h0 = h0; a.c0 = c0;
+    a.hn = hn; a.cn = cn; a.xbuf = (u64*)((char*)ws + AUX_BYTES); a.err = err;
+    a.xcc = (u64*)((char*)ws + 1024); a.lerr = (int*)((char*)ws + 3072);
 #ifdef DS2_PROBE
-  a.dbg = (unsigned long long*)ws;
-  { const char* e_ = getenv("DS2_PERSIST_DBG"); a.dbgmask = e_ ? atoi(e_) : 0; }
+    a.dbg = (unsigned long long*)ws;
+    { const char* e_ = getenv("DS2_PERSIST_DBG"); a.dbgmask = e_ ? atoi(e_) : 0; }
 #endif
-  return dispatch(false, cell, H, a, st);
+    return dispatch(false, cell, H, a, st);
+  }
+  Plan2 pl;
+  DS2_REQUIRE(plan2(dtype, cell, D, N, H, pl), DS2_ERR_ARG);
+  const long xb = xbuf2_bytes(dtype, cell, H, pl, false);
+  hipError_t e = hipMemsetAsync(ws, 0, AUX_BYTES + xb, st);
+  if (e != hipSuccess) return (int)e;
+  ds2q::QArgs a{};
+  a.N = N; a.Tp = Tp; a.D = D; a.gpd = pl.gpd; a.NG = pl.NG; a.lens = lens; a.W = Whh; a.bhh = bhh; a.GI = GI; a.Hseq = Hseq;
+  a.hseq_dstride = hseq_dstride; a.S = S; a.h0 = h0; a.c0 = c0; a.hn = hn; a.cn = cn;
+  a.xbuf = (char*)ws + AUX_BYTES; a.xgroup_bytes = xb / pl.NG; a.err = err; a.lerr = (int*)((char*)ws + 3072);
+  return launch2_any(false, false, dtype, cell, H, pl.MT, a, st);
 }
 
-// Same contract as ds2_rnn_bwd for dtype bf16 (zero initial state).
-int ds2_rnn_persist_bwd(int cell, int D, int N, int H, int Tp, const int* lens, const void* dOut, const void* WhhT,
+// Same contract as ds2_rnn_bwd (zero initial state).
+int ds2_rnn_persist_bwd(int dtype, int cell, int D, int N, int H, int Tp, const int* lens, const void* dOut, const void* WhhT,
                         const void* Hseq, long hseq_dstride, const void* S, void* dGI, void* dGH, void* ws, int* err,
                         ds2_stream_t st_) {
   hipStream_t st = (hipStream_t)st_;
-  DS2_REQUIRE(ds2_rnn_persist_supported(DS2_BF16, cell, D, N, H), DS2_ERR_ARG);
   DS2_REQUIRE(Tp > 0 && Tp < (int)TAG_INIT && ws && err, DS2_ERR_ARG);
   DS2_REQUIRE(cell != CELL_GRU || dGH != nullptr, DS2_ERR_ARG);
-  hipError_t e = hipMemsetAsync(ws, 0, AUX_BYTES + xbuf_bytes(cell, H, true), st);
-  if (e != hipSuccess) return (int)e;
-  PArgs a{};
-  a.N = N; a.Tp = Tp; a.D = D; a.gpd = NGROUPS / D; a.lens = lens; a.W = (const bf16_t*)WhhT;
-  a.Hseq = (bf16_t*)Hseq; a.hseq_dstride = hseq_dstride; a.S = (bf16_t*)S; a.dOut = (const bf16_t*)dOut;
-  a.dGI = (bf16_t*)dGI; a.dGH = (bf16_t*)dGH; a.xbuf = (u64*)((char*)ws + AUX_BYTES); a.err = err;
-  a.xcc = (u64*)((char*)ws + 1024); a.lerr = (int*)((char*)ws + 3072);
+  if (tuned_ok(dtype, cell, D, N, H)) {
+    hipError_t e = hipMemsetAsync(ws, 0, AUX_BYTES + xbuf_bytes(cell, H, true), st);
+    if (e != hipSuccess) return (int)e;
+    PArgs a{};
+    a.N = N; a.Tp = Tp; a.D = D; a.gpd = NGROUPS / D; a.lens = lens; a.W = (const bf16_t*)WhhT;
+    a.Hseq = (bf16_t*)Hseq; a.hseq_dstride = hseq_dstride; a.S = (bf16_t*)S; a.dOut = (const bf16_t*)dOut;
+    a.dGI = (bf16_t*)dGI; a.dGH = (bf16_t*)dGH; a.xbuf = (u64*)((char*)ws + AUX_BYTES); a.err = err;
+    a.xcc = (u64*)((char*)ws + 1024); a.lerr = (int*)((char*)ws + 3072);
 #ifdef DS2_PROBE
-  a.dbg = (unsigned long long*)ws;
-  { const char* e_ = getenv("DS2_PERSIST_DBG"); a.dbgmask = e_ ? atoi(e_) : 0; }
+    a.dbg = (unsigned long long*)ws;
+    { const char* e_ = getenv("DS2_PERSIST_DBG"); a.dbgmask = e_ ? atoi(e_) : 0; }
 #endif
-  return dispatch(true, cell, H, a, st);
+    return dispatch(true, cell, H, a, st);
+  }
+  Plan2 pl;
+  DS2_REQUIRE(plan2(dtype, cell, D, N, H, pl), DS2_ERR_ARG);
+  const long xb = xbuf2_bytes(dtype, cell, H, pl, true);
+  hipError_t e = hipMemsetAsync(ws, 0, AUX_BYTES + xb, st);
+  if (e != hipSuccess) return (int)e;
+  ds2q::QArgs a{};
+  a.N = N; a.Tp = Tp; a.D = D; a.gpd = pl.gpd; a.NG = pl.NG; a.lens = lens; a.W = WhhT; a.Hseq = (void*)Hseq;
+  a.hseq_dstride = hseq_dstride; a.S = (void*)S; a.dOut = dOut; a.dGI = dGI; a.dGH = dGH;
+  a.xbuf = (char*)ws + AUX_BYTES; a.xgroup_bytes = xb / pl.NG; a.err = err; a.lerr = (int*)((char*)ws + 3072);
+  return launch2_any(false, true, dtype, cell, H, pl.MT, a, st);
 }
 
 }  // extern "C"

@@ -1,0 +1,649 @@
+// Generalised persistent recurrent sweeps (forward and BPTT) of BatchRNN (reference model.py:94-102): the shapes the tuned
+// H = 1024 / bf16 kernels of ds2_rnn_persist_impl.h do not cover -- hidden sizes 800 / 1024 / 1280 (BASELINE.json configs 2
+// and 5), fp32 storage (the 1e-3 parity mode) and up to 64 samples per group.
+//
+// Same idea: ONE launch per layer and sweep, W_hh resident in registers as MFMA B fragments, h exchanged between the
+// workgroups of a group as 8-byte {tag = step, payload} granules (the data is the flag; MI355X guide section 6 G16, recipe R2).
+// What is generalised:
+//   * every workgroup owns U = 16 hidden units of every gate, so a group is P = H/16 workgroups (50 / 64 / 80) and the chip
+//     holds NG = floor(256/P) groups (5 / 4 / 3); a group owns one direction and a slice of the minibatch (up to 16*MT
+//     samples, MT in {1,2,4} M-tiles of the 16x16 MFMA);
+//   * storage type T: bf16 (granule = 2 x bf16, v_mfma_f32_16x16x32_bf16) or fp32 (granule = 1 x f32, v_mfma_f32_16x16x4_f32,
+//     full-precision gate math) -- the exchange layout is the MFMA A-fragment order for both, so a gather instruction of a
+//     wave always reads 1 KiB of contiguous memory;
+//   * K (= H forward, G*H BPTT) is split over the 4 waves in whole k-steps; when the k-steps do not divide by 4 (H = 800) the
+//     last wave simply owns fewer (wave-uniform predicate, zero weights in the unused fragment registers);
+//   * groups span XCDs (P > 32), so publishes are always the write-through (sc1) form; results never depend on placement.
+// Gathers are NOT speculative here (tags are checked before the MFMAs; the loads of the next chunk are in flight under the
+// MFMAs of the current one): with MT > 1 a second set of accumulators would not fit beside the resident weights.
+// Safety protocol as in the tuned kernels: grid <= CU count, bounded spins, *err / per-launch word, NaN poisoning.
+#pragma once
+#include "ds2_rnn_persist_impl.h"
+
+namespace ds2q {
+using namespace ds2p;
+
+struct QArgs {
+  int N, Tp, D, gpd, NG;    // gpd = groups per direction, NG = D * gpd groups in the grid
+  const int* lens;          // [N]
+  const void* W;            // fwd: W_hh [D][G*H][H]        bwd: W_hh^T [D][H][G*H]            (type T)
+  const float* bhh;         // [D][G*H]
+  const void* GI;           // fwd: input projection [Tp*N][D*G*H]                             (T)
+  void* Hseq;               // h_t of direction d at Hseq + d*hseq_dstride + (t*N+n)*H; zero guard slots at t=-1, t=Tp (T)
+  long hseq_dstride;
+  void* S;                  // saved planes [D][Tp][N][NS*H]                                   (T)
+  const float* h0;          // [D][N][H] or null
+  const float* c0;
+  float* hn;                // [D][N][H] or null
+  float* cn;
+  const void* dOut;         // bwd: [Tp][N][H]                                                 (T)
+  void* dGI;                // bwd: [Tp*N][D*G*H]                                              (T)
+  void* dGH;                // bwd, GRU only: [D][Tp][N][3H]                                   (T)
+  char* xbuf;               // [NG][2 parities][PAR_BYTES], zeroed before the launch
+  long xgroup_bytes;        // 2 * PAR_BYTES
+  int* err;                 // sticky device word (the host reads it)
+  int* lerr;                // per-launch word in the zeroed scratch
+};
+
+// ---- storage-type traits: pair access, granule packing, gate math --------------------------------------------------
+template <typename T>
+struct XT;
+template <>
+struct XT<bf16_t> {
+  static constexpr int KSZ = 32;   // K elements per k-step (one 16-byte fragment per lane and operand)
+  static constexpr int EPL = 8;    // elements per lane and k-step
+  static constexpr int EPG = 2;    // elements per granule
+  typedef uint32_t raw;            // two adjacent elements as stored
+  static __device__ __forceinline__ raw ld(const bf16_t* p) { return *reinterpret_cast<const uint32_t*>(p); }
+  static __device__ __forceinline__ void st(bf16_t* p, float a, float b) { *reinterpret_cast<uint32_t*>(p) = cvt_pk_bf16(a, b); }
+  static __device__ __forceinline__ raw zero() { return 0u; }
+  static __device__ __forceinline__ float lo(raw r) { return bf_lo(r); }
+  static __device__ __forceinline__ float hi(raw r) { return bf_hi(r); }
+  static __device__ __forceinline__ float sig(float x) { return fsigmoid(x); }
+  static __device__ __forceinline__ float tnh(float x) { return ftanh(x); }
+  // publish the pair (a, b) = elements (k, k+1), k even, tagged `tag`, at byte offset `off` of the parity buffer
+  static __device__ __forceinline__ void publish(char* xpar, int off, unsigned tag, float a, float b) {
+    g_store(reinterpret_cast<u64*>(xpar + off), ((u64)tag << 32) | cvt_pk_bf16(a, b));
+  }
+};
+template <>
+struct XT<float> {
+  static constexpr int KSZ = 16;
+  static constexpr int EPL = 4;
+  static constexpr int EPG = 1;
+  typedef float2 raw;
+  static __device__ __forceinline__ raw ld(const float* p) { return *reinterpret_cast<const float2*>(p); }
+  static __device__ __forceinline__ void st(float* p, float a, float b) { *reinterpret_cast<float2*>(p) = make_float2(a, b); }
+  static __device__ __forceinline__ raw zero() { return make_float2(0.f, 0.f); }
+  static __device__ __forceinline__ float lo(raw r) { return r.x; }
+  static __device__ __forceinline__ float hi(raw r) { return r.y; }
+  static __device__ __forceinline__ float sig(float x) { return sigmoid_acc(x); }   // full precision: the 1e-3 parity mode
+  static __device__ __forceinline__ float tnh(float x) { return tanhf_(x); }
+  static __device__ __forceinline__ void publish(char* xpar, int off, unsigned tag, float a, float b) {
+    g_store(reinterpret_cast<u64*>(xpar + off), ((u64)tag << 32) | __float_as_uint(a));
+    g_store(reinterpret_cast<u64*>(xpar + off + 8), ((u64)tag << 32) | __float_as_uint(b));
+  }
+};
+
+// Exchange buffer of one group and parity: [k-step][m-tile (MT)][q (2)][lq (4)][row (16)] x 16 bytes.  A 16-byte unit = two
+// granules = the elements {e, .., e + EPL/2 - 1} of sample row (mt*16 + row) with e = kstep*KSZ + lq*EPL + q*EPL/2.
+template <int MT>
+__device__ __forceinline__ int xunit2(int kstep, int mt, int q, int lq, int row) {
+  return ((((kstep * MT + mt) * 2 + q) * 4 + lq) * 16 + row) * 16;
+}
+// byte offset of the first granule of the pair (k, k+1), k even
+template <typename T, int MT>
+__device__ __forceinline__ int xpair2(int k, int mt, int row) {
+  constexpr int KSZ = XT<T>::KSZ, EPL = XT<T>::EPL, HPL = EPL / 2, EPG = XT<T>::EPG;
+  const int kk = k % KSZ, e = kk % EPL;
+  return xunit2<MT>(k / KSZ, mt, e / HPL, kk / EPL, row) + ((e % HPL) / EPG) * 8;
+}
+
+// gate work item of a thread -> (m-tile, row, offset of the unit pair inside the workgroup's 16 units).  The bit order follows
+// the exchange layout so that the publishes of a wave are contiguous runs.
+template <typename T>
+__device__ __forceinline__ void item_decode(int item, int p, int& mt, int& row, int& jo);
+template <>
+__device__ __forceinline__ void item_decode<bf16_t>(int item, int p, int& mt, int& row, int& jo) {
+  // bits: g(1) row(4) lq_local(1) q(1) mt ; the 16 units of workgroup p are half a k-step: lq = 2*(p&1) + lq_local
+  (void)p;
+  const int g = item & 1, lql = (item >> 5) & 1, q = (item >> 6) & 1;
+  row = (item >> 1) & 15;
+  mt = item >> 7;
+  jo = lql * 8 + q * 4 + g * 2;
+}
+template <>
+__device__ __forceinline__ void item_decode<float>(int item, int p, int& mt, int& row, int& jo) {
+  // bits: row(4) lq(2) q(1) mt ; the 16 units of workgroup p are exactly k-step p
+  (void)p;
+  const int lq = (item >> 4) & 3, q = (item >> 6) & 1;
+  row = item & 15;
+  mt = item >> 7;
+  jo = lq * 4 + q * 2;
+}
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+// Gathers this wave's k-steps [ks0, ks0 + cnt) of the exchanged vector (granules tagged `epoch`) for all MT m-tiles and
+// multiplies: acc[mt][rt] += A(mt: 16 samples x K-slice) * w[rt](16 rows x K-slice)^T.  Chunks of CH k-steps; the loads of
+// chunk c+1 are issued before the products of chunk c.
+template <typename T, int MT, int RT, int KSW, int CH, bool RAGGED>
+__device__ __forceinline__ void gather_mma2(ds2_f32x4 (&acc)[MT][RT], const uint4 (&w)[RT][KSW], __amdgpu_buffer_rsrc_t rsrc,
+                                            int par_off, int ks0, int cnt, int lq, int li, int Ns, unsigned epoch, int* err,
+                                            int* lerr, bool& dead) {
+  constexpr int NCH = (KSW + CH - 1) / CH;
+  u32x4_t v[2][CH][MT][2];
+  bool need[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) need[m] = m * 16 + li < Ns;
+#define DS2Q_LOAD(c, b)                                                                                                  \
+  _Pragma("unroll") for (int i = 0; i < CH; ++i) {                                                                      \
+    const int k_ = (c) * CH + i;                                                                                         \
+    if (k_ < KSW && (!RAGGED || k_ < cnt)) {                                                                             \
+      _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int q = 0; q < 2; ++q)                      \
+          v[b][i][m][q] = need[m] ? __builtin_amdgcn_raw_buffer_load_b128(rsrc, par_off + xunit2<MT>(ks0 + k_, m, q, lq, li), 0, 16 /* sc1 */) \
+                                  : u32x4_t{0u, epoch, 0u, epoch};                                                       \
+    }                                                                                                                    \
+  }
+#define DS2Q_CHECK(c, b, bad)                                                                                            \
+  bool bad = false;                                                                                                      \
+  _Pragma("unroll") for (int i = 0; i < CH; ++i) {                                                                      \
+    const int k_ = (c) * CH + i;                                                                                         \
+    if (k_ < KSW && (!RAGGED || k_ < cnt)) {                                                                             \
+      _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int q = 0; q < 2; ++q)                      \
+          bad |= (v[b][i][m][q][1] != epoch) | (v[b][i][m][q][3] != epoch);                                              \
+    }                                                                                                                    \
+  }
+  DS2Q_LOAD(0, 0)
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int b = c & 1;
+    DS2Q_CHECK(c, b, bad0)
+    if (__any(bad0) && !dead) {        // not all there yet: poll this chunk (bounded)
+      unsigned spins = 0;
+      for (;;) {
+        __builtin_amdgcn_s_sleep(1);
+        DS2Q_LOAD(c, b)
+        DS2Q_CHECK(c, b, bad1)
+        if (!__any(bad1)) break;
+        if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(lerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          dead = true;
+          raise_err(err, lerr);
+          break;
+        }
+      }
+    }
+    if (c + 1 < NCH) { DS2Q_LOAD(c + 1, b ^ 1) }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int k_ = c * CH + i;
+      if (k_ < KSW && (!RAGGED || k_ < cnt)) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const uint4 a = make_uint4(v[b][i][m][0][0], v[b][i][m][0][2], v[b][i][m][1][0], v[b][i][m][1][2]);
+#pragma unroll
+          for (int r = 0; r < RT; ++r) Mma<T>::mma16(acc[m][r], a, w[r][k_]);
+        }
+      }
+    }
+  }
+#undef DS2Q_LOAD
+#undef DS2Q_CHECK
+}
+
+// partial sums of the 4 K-slices: part[wave][mt][rt][sample row][unit col]
+template <int MT, int RT>
+__device__ __forceinline__ void store_partials2(float* part, const ds2_f32x4 (&acc)[MT][RT], int wave, int lane) {
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[(((wave * MT + m) * RT + t) * 16 + mma16_row(r, lane)) * 16 + (lane & 15)] = acc[m][t][r];
+}
+template <int MT, int RT>
+__device__ __forceinline__ float2 load_partials2(const float* part, int m, int t, int row, int col) {
+  float2 s = make_float2(0.f, 0.f);
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const float2 v = *reinterpret_cast<const float2*>(part + (((w * MT + m) * RT + t) * 16 + row) * 16 + col);
+    s.x += v.x;
+    s.y += v.y;
+  }
+  return s;
+}
+
+template <int MT>
+struct Items {
+  static constexpr int TOTAL = MT * 128;                       // (sample row, unit pair) items of a workgroup
+  static constexpr int PER_THREAD = (TOTAL + 255) / 256;
+  static constexpr int FIRST_TID = TOTAL >= 256 ? 0 : 256 - TOTAL;   // MT = 1: the LAST 128 threads (waves 2-3)
+};
+
+constexpr float QNAN = __builtin_nanf("");
+
+// ------------------------------------------------------------------------------------------------------------------
+// forward sweep
+// ------------------------------------------------------------------------------------------------------------------
+template <int CELL, typename T, int H, int MT>
+__global__ void __launch_bounds__(256, 1) k_rnn_persist2_fwd(QArgs a) {
+  typedef XT<T> X;
+  typedef typename X::raw raw_t;
+  constexpr int G = CellInfo<CELL>::G, NS = CellInfo<CELL>::NS;
+  constexpr int RT = G;                                  // 16-row tiles of the resident slice: tile g = gate g, 16 units
+  constexpr int KSZ = X::KSZ, KT = H / KSZ, KSW = (KT + 3) / 4;
+  constexpr bool RAGGED = KT % 4 != 0;
+  constexpr int CH = MT >= 4 ? 1 : (MT == 2 ? 2 : 4);
+  constexpr int IT = Items<MT>::PER_THREAD;
+  constexpr int PAR_BYTES = KT * MT * 2048;
+  static_assert(H % KSZ == 0 && H % 16 == 0, "unsupported hidden size");
+  extern __shared__ __attribute__((aligned(16))) float part[];       // [2][4][MT][RT][256]
+  constexpr int PART_FLOATS = 4 * MT * RT * 256;
+  __builtin_amdgcn_s_setprio(3);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: wave-uniform predicates
+  const int grp = blockIdx.x % a.NG, p = blockIdx.x / a.NG;
+  const int d = grp / a.gpd, slice = grp % a.gpd;
+  const int N = a.N, Tp = a.Tp;
+  const int Ns = (N - slice + a.gpd - 1) / a.gpd;          // samples n = slice + gpd*i, i < Ns
+  const int li = lane & 15, lq = lane >> 4;
+  constexpr long GH = (long)G * H;
+  const long ldgi = (long)a.D * GH;
+  const int ks0 = wave * KSW;
+  const int cnt = RAGGED ? max(0, min(KSW, KT - ks0)) : KSW;
+
+  uint4 w[RT][KSW];
+  {
+    const T* Wd = (const T*)a.W + (long)d * GH * H;
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      const T* row = Wd + ((long)t * H + p * 16 + li) * H + lq * X::EPL;
+#pragma unroll
+      for (int k = 0; k < KSW; ++k)
+        w[t][k] = (!RAGGED || k < cnt) ? *reinterpret_cast<const uint4*>(row + (long)(ks0 + k) * KSZ) : make_uint4(0, 0, 0, 0);
+    }
+  }
+  char* xg = a.xbuf + (long)grp * a.xgroup_bytes;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, 2 * PAR_BYTES, 0x00020000);
+
+  // ---- gate items of this thread
+  bool on[IT];
+  int it_row[IT], it_mt[IT], it_xoff[IT], it_n[IT], it_j[IT], it_len[IT];
+  float hprev[IT][2], cprev[IT][2], bh[IT][G][2];
+  const T* gi_ptr[IT];
+  T* sv_ptr[IT];
+  T* hs_ptr[IT];
+  const long dstep = d == 0 ? 1 : -1;
+  const int t_first = d == 0 ? 0 : Tp - 1;
+  constexpr long NSH_ = (long)(NS ? NS : 1) * H;
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int item = tid - Items<MT>::FIRST_TID + 256 * it;
+    int mt = 0, row = 0, jo = 0;
+    item_decode<T>(item < 0 ? 0 : item, p, mt, row, jo);
+    const int gi_i = mt * 16 + row;
+    on[it] = item >= 0 && item < Items<MT>::TOTAL && gi_i < Ns;
+    it_row[it] = row;
+    it_mt[it] = mt;
+    it_j[it] = p * 16 + jo;
+    it_n[it] = on[it] ? slice + a.gpd * gi_i : 0;
+    it_xoff[it] = xpair2<T, MT>(it_j[it], mt, row);
+    it_len[it] = 0;
+    hprev[it][0] = hprev[it][1] = cprev[it][0] = cprev[it][1] = 0.f;
+#pragma unroll
+    for (int g = 0; g < G; ++g) bh[it][g][0] = bh[it][g][1] = 0.f;
+    const int n = it_n[it], j = it_j[it];
+    if (on[it]) {
+      it_len[it] = a.lens[n];
+      const long so = ((long)d * N + n) * H + j;
+      if (a.h0) {
+        hprev[it][0] = a.h0[so];
+        hprev[it][1] = a.h0[so + 1];
+      }
+      if (CELL == CELL_LSTM && a.c0) {
+        cprev[it][0] = a.c0[so];
+        cprev[it][1] = a.c0[so + 1];
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        bh[it][g][0] = a.bhh[(long)d * GH + (long)g * H + j];
+        bh[it][g][1] = a.bhh[(long)d * GH + (long)g * H + j + 1];
+      }
+    }
+    gi_ptr[it] = (const T*)a.GI + ((long)t_first * N + n) * ldgi + (long)d * GH + j;
+    sv_ptr[it] = NS ? (T*)a.S + (((long)d * Tp + t_first) * N + n) * NSH_ + j : nullptr;
+    hs_ptr[it] = (T*)a.Hseq + (long)d * a.hseq_dstride + ((long)t_first * N + n) * H + j;
+  }
+  const long gi_stride = dstep * N * ldgi, sv_stride = dstep * N * NSH_, hs_stride = dstep * N * H;
+  bool dead = false;
+  if (a.h0) {   // initial state as "step -1": parity 1, tag TAG_INIT
+#pragma unroll
+    for (int it = 0; it < IT; ++it)
+      if (on[it]) X::publish(xg + PAR_BYTES, it_xoff[it], TAG_INIT, hprev[it][0], hprev[it][1]);
+  }
+
+  for (int s = 0; s < Tp; ++s) {
+    const int t = d == 0 ? s : Tp - 1 - s;
+    const int par = s & 1;
+    raw_t gi[IT][G];
+#pragma unroll
+    for (int it = 0; it < IT; ++it)
+#pragma unroll
+      for (int g = 0; g < G; ++g) gi[it][g] = on[it] ? X::ld(gi_ptr[it] + (long)g * H) : X::zero();
+    ds2_f32x4 acc[MT][RT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int tt = 0; tt < RT; ++tt) acc[m][tt] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
+    if (s > 0 || a.h0)
+      gather_mma2<T, MT, RT, KSW, CH, RAGGED>(acc, w, rsrc, (par ^ 1) * PAR_BYTES, ks0, cnt, lq, li, Ns, s > 0 ? (unsigned)s : TAG_INIT,
+                                              a.err, a.lerr, dead);
+    float* pp = part + par * PART_FLOATS;
+    store_partials2<MT, RT>(pp, acc, wave, lane);
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      if (on[it]) {
+        const bool act = t < it_len[it];
+        const int jo = it_j[it] - p * 16;
+        float hn0 = 0.f, hn1 = 0.f;     // emitted h_t (0 when inactive)
+        float2 gh[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) gh[g] = load_partials2<MT, RT>(pp, it_mt[it], g, it_row[it], jo);
+        float pl[NS ? NS : 1][2];
+#pragma unroll
+        for (int q = 0; q < (NS ? NS : 1); ++q) pl[q][0] = pl[q][1] = 0.f;
+        if (CELL == CELL_GRU) {
+          if (act) {
+            const float q0 = gh[2 % G].x + bh[it][2 % G][0], q1 = gh[2 % G].y + bh[it][2 % G][1];
+            const float r0 = X::sig(X::lo(gi[it][0]) + gh[0].x + bh[it][0][0]), r1 = X::sig(X::hi(gi[it][0]) + gh[0].y + bh[it][0][1]);
+            const float z0 = X::sig(X::lo(gi[it][1 % G]) + gh[1 % G].x + bh[it][1 % G][0]);
+            const float z1 = X::sig(X::hi(gi[it][1 % G]) + gh[1 % G].y + bh[it][1 % G][1]);
+            const float n0 = X::tnh(X::lo(gi[it][2 % G]) + r0 * q0), n1 = X::tnh(X::hi(gi[it][2 % G]) + r1 * q1);
+            hn0 = (1.f - z0) * n0 + z0 * hprev[it][0];
+            hn1 = (1.f - z1) * n1 + z1 * hprev[it][1];
+            hprev[it][0] = hn0;
+            hprev[it][1] = hn1;
+            pl[0][0] = r0; pl[0][1] = r1;
+            pl[1 % (NS ? NS : 1)][0] = z0; pl[1 % (NS ? NS : 1)][1] = z1;
+            pl[2 % (NS ? NS : 1)][0] = n0; pl[2 % (NS ? NS : 1)][1] = n1;
+            pl[3 % (NS ? NS : 1)][0] = q0; pl[3 % (NS ? NS : 1)][1] = q1;
+          }
+        } else if (CELL == CELL_LSTM) {
+          if (act) {
+            const float i0 = X::sig(X::lo(gi[it][0]) + gh[0].x + bh[it][0][0]), i1 = X::sig(X::hi(gi[it][0]) + gh[0].y + bh[it][0][1]);
+            const float f0 = X::sig(X::lo(gi[it][1 % G]) + gh[1 % G].x + bh[it][1 % G][0]);
+            const float f1 = X::sig(X::hi(gi[it][1 % G]) + gh[1 % G].y + bh[it][1 % G][1]);
+            const float g0 = X::tnh(X::lo(gi[it][2 % G]) + gh[2 % G].x + bh[it][2 % G][0]);
+            const float g1 = X::tnh(X::hi(gi[it][2 % G]) + gh[2 % G].y + bh[it][2 % G][1]);
+            const float o0 = X::sig(X::lo(gi[it][3 % G]) + gh[3 % G].x + bh[it][3 % G][0]);
+            const float o1 = X::sig(X::hi(gi[it][3 % G]) + gh[3 % G].y + bh[it][3 % G][1]);
+            const float c0 = f0 * cprev[it][0] + i0 * g0, c1 = f1 * cprev[it][1] + i1 * g1;
+            hn0 = o0 * X::tnh(c0);
+            hn1 = o1 * X::tnh(c1);
+            cprev[it][0] = c0;
+            cprev[it][1] = c1;
+            hprev[it][0] = hn0;
+            hprev[it][1] = hn1;
+            pl[0][0] = i0; pl[0][1] = i1;
+            pl[1 % (NS ? NS : 1)][0] = f0; pl[1 % (NS ? NS : 1)][1] = f1;
+            pl[2 % (NS ? NS : 1)][0] = g0; pl[2 % (NS ? NS : 1)][1] = g1;
+            pl[3 % (NS ? NS : 1)][0] = o0; pl[3 % (NS ? NS : 1)][1] = o1;
+            pl[4 % (NS ? NS : 1)][0] = c0; pl[4 % (NS ? NS : 1)][1] = c1;
+          }
+        } else {
+          if (act) {
+            hn0 = X::tnh(X::lo(gi[it][0]) + gh[0].x + bh[it][0][0]);
+            hn1 = X::tnh(X::hi(gi[it][0]) + gh[0].y + bh[it][0][1]);
+            hprev[it][0] = hn0;
+            hprev[it][1] = hn1;
+          }
+        }
+        if (dead) hn0 = hn1 = hprev[it][0] = hprev[it][1] = QNAN;   // fail loudly downstream
+        // publish the carried state first (inactive samples republish their unchanged state), then the bookkeeping stores
+        X::publish(xg + par * PAR_BYTES, it_xoff[it], (unsigned)(s + 1), hprev[it][0], hprev[it][1]);
+        X::st(hs_ptr[it], hn0, hn1);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) X::st(sv_ptr[it] + (long)q * H, pl[q][0], pl[q][1]);
+      }
+      gi_ptr[it] += gi_stride;
+      if (NS) sv_ptr[it] += sv_stride;
+      hs_ptr[it] += hs_stride;
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    if (on[it]) {
+      const long so = ((long)d * N + it_n[it]) * H + it_j[it];
+      if (a.hn) {
+        a.hn[so] = hprev[it][0];
+        a.hn[so + 1] = hprev[it][1];
+      }
+      if (CELL == CELL_LSTM && a.cn) {
+        a.cn[so] = cprev[it][0];
+        a.cn[so + 1] = cprev[it][1];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// BPTT sweep.  dh_t = dOut[t] + carry (elementwise part of dh from the step processed before) + dgates_{t'} * W_hh.
+// The workgroup owns W_hh^T rows of its 16 units (one 16-row tile), K = G*H.
+// ------------------------------------------------------------------------------------------------------------------
+template <int CELL, typename T, int H, int MT>
+__global__ void __launch_bounds__(256, 1) k_rnn_persist2_bwd(QArgs a) {
+  typedef XT<T> X;
+  typedef typename X::raw raw_t;
+  constexpr int G = CellInfo<CELL>::G, NS = CellInfo<CELL>::NS;
+  constexpr int RT = 1;
+  constexpr int KSZ = X::KSZ, KT = G * H / KSZ, KSW = (KT + 3) / 4, KTH = H / KSZ;   // KTH: k-steps per gate
+  constexpr bool RAGGED = KT % 4 != 0;
+  constexpr int CH = MT >= 4 ? 1 : (MT == 2 ? 2 : 4);
+  constexpr int IT = Items<MT>::PER_THREAD;
+  constexpr int PAR_BYTES = KT * MT * 2048;
+  constexpr int GATE_BYTES = KTH * MT * 2048;            // exchange bytes of one gate's H elements
+  static_assert(H % KSZ == 0 && H % 16 == 0, "unsupported hidden size");
+  extern __shared__ __attribute__((aligned(16))) float part[];       // [2][4][MT][1][256]
+  constexpr int PART_FLOATS = 4 * MT * RT * 256;
+  __builtin_amdgcn_s_setprio(3);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: wave-uniform predicates
+  const int grp = blockIdx.x % a.NG, p = blockIdx.x / a.NG;
+  const int d = grp / a.gpd, slice = grp % a.gpd;
+  const int N = a.N, Tp = a.Tp;
+  const int Ns = (N - slice + a.gpd - 1) / a.gpd;
+  const int li = lane & 15, lq = lane >> 4;
+  constexpr long GH = (long)G * H;
+  const long ldgi = (long)a.D * GH;
+  const int ks0 = wave * KSW;
+  const int cnt = RAGGED ? max(0, min(KSW, KT - ks0)) : KSW;
+
+  uint4 w[RT][KSW];
+  {
+    const T* WT = (const T*)a.W + (long)d * H * GH;
+    const T* row = WT + (long)(p * 16 + li) * GH + lq * X::EPL;
+#pragma unroll
+    for (int k = 0; k < KSW; ++k)
+      w[0][k] = (!RAGGED || k < cnt) ? *reinterpret_cast<const uint4*>(row + (long)(ks0 + k) * KSZ) : make_uint4(0, 0, 0, 0);
+  }
+  char* xg = a.xbuf + (long)grp * a.xgroup_bytes;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, 2 * PAR_BYTES, 0x00020000);
+
+  bool on[IT];
+  int it_row[IT], it_mt[IT], it_xoff[IT], it_j[IT], it_len[IT];
+  float car[IT][2], dc[IT][2];
+  const T* do_ptr[IT];
+  const T* sv_ptr[IT];
+  const T* hs_ptr[IT];
+  T* dgi_ptr[IT];
+  T* dgh_ptr[IT];
+  const long dstep = d == 0 ? -1 : 1;                       // BPTT walks the direction's time axis backwards
+  const int t_first = d == 0 ? Tp - 1 : 0;
+  const long prev_off = d == 0 ? -1 : 1;                    // previous step in FORWARD order of this direction
+  constexpr long NSH_ = (long)(NS ? NS : 1) * H;
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int item = tid - Items<MT>::FIRST_TID + 256 * it;
+    int mt = 0, row = 0, jo = 0;
+    item_decode<T>(item < 0 ? 0 : item, p, mt, row, jo);
+    const int gi_i = mt * 16 + row;
+    on[it] = item >= 0 && item < Items<MT>::TOTAL && gi_i < Ns;
+    it_row[it] = row;
+    it_mt[it] = mt;
+    it_j[it] = p * 16 + jo;
+    const int n = on[it] ? slice + a.gpd * gi_i : 0, j = it_j[it];
+    it_xoff[it] = xpair2<T, MT>(j, mt, row);
+    it_len[it] = on[it] ? a.lens[n] : 0;
+    car[it][0] = car[it][1] = dc[it][0] = dc[it][1] = 0.f;
+    do_ptr[it] = (const T*)a.dOut + ((long)t_first * N + n) * H + j;
+    sv_ptr[it] = NS ? (const T*)a.S + (((long)d * Tp + t_first) * N + n) * NSH_ + j : nullptr;
+    hs_ptr[it] = (const T*)a.Hseq + (long)d * a.hseq_dstride + ((long)t_first * N + n) * H + j;   // h_t
+    dgi_ptr[it] = (T*)a.dGI + ((long)t_first * N + n) * ldgi + (long)d * GH + j;
+    dgh_ptr[it] = a.dGH ? (T*)a.dGH + (((long)d * Tp + t_first) * N + n) * GH + j : nullptr;
+  }
+  bool dead = false;
+
+  for (int s = 0; s < Tp; ++s) {
+    const int t = d == 0 ? Tp - 1 - s : s;
+    const int par = s & 1;
+    // ---- prefetch everything the gate phase needs
+    raw_t dout[IT], sp[IT][NS ? NS : 1], hp[IT], cp[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      dout[it] = hp[it] = cp[it] = X::zero();
+#pragma unroll
+      for (int q = 0; q < (NS ? NS : 1); ++q) sp[it][q] = X::zero();
+      if (on[it]) {
+        dout[it] = X::ld(do_ptr[it]);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) sp[it][q] = X::ld(sv_ptr[it] + (long)q * H);
+        // h_{prev}: guard slots / inactive frames hold zeros, so the read is unconditional (tprev in [-1, Tp])
+        hp[it] = X::ld(hs_ptr[it] + prev_off * N * H);
+        if (CELL == CELL_LSTM) {
+          const bool has_prev = d == 0 ? (t > 0) : (t + 1 < it_len[it]);
+          if (has_prev) cp[it] = X::ld(sv_ptr[it] + prev_off * N * NSH_ + 4 * H);
+        }
+        if (CELL == CELL_RNN) hp[it] = X::ld(hs_ptr[it]);
+      }
+    }
+    ds2_f32x4 acc[MT][RT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m][0] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
+    if (s > 0)
+      gather_mma2<T, MT, RT, KSW, CH, RAGGED>(acc, w, rsrc, (par ^ 1) * PAR_BYTES, ks0, cnt, lq, li, Ns, (unsigned)s, a.err, a.lerr, dead);
+    float* pp = part + par * PART_FLOATS;
+    store_partials2<MT, RT>(pp, acc, wave, lane);
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      if (on[it]) {
+        const bool act = t < it_len[it];
+        const int jo = it_j[it] - p * 16;
+        const float2 mp = load_partials2<MT, RT>(pp, it_mt[it], 0, it_row[it], jo);
+        const float din0 = car[it][0] + mp.x, din1 = car[it][1] + mp.y;
+        char* xo = xg + par * PAR_BYTES;
+        const unsigned tag = (unsigned)(s + 1);
+        const int xo_ = it_xoff[it];
+        T* dgi = dgi_ptr[it];
+        constexpr int M = NS ? NS : 1;
+        if (CELL == CELL_GRU) {
+          float dr0 = 0.f, dr1 = 0.f, dz0 = 0.f, dz1 = 0.f, dn0 = 0.f, dn1 = 0.f, dq0 = 0.f, dq1 = 0.f;
+          car[it][0] = din0;
+          car[it][1] = din1;
+          if (act) {
+            const float r0 = X::lo(sp[it][0]), r1 = X::hi(sp[it][0]), z0 = X::lo(sp[it][1 % M]), z1 = X::hi(sp[it][1 % M]);
+            const float n0 = X::lo(sp[it][2 % M]), n1 = X::hi(sp[it][2 % M]), q0 = X::lo(sp[it][3 % M]), q1 = X::hi(sp[it][3 % M]);
+            const float dh0 = X::lo(dout[it]) + din0, dh1 = X::hi(dout[it]) + din1;
+            dn0 = dh0 * (1.f - z0) * (1.f - n0 * n0);
+            dn1 = dh1 * (1.f - z1) * (1.f - n1 * n1);
+            dz0 = dh0 * (X::lo(hp[it]) - n0) * z0 * (1.f - z0);
+            dz1 = dh1 * (X::hi(hp[it]) - n1) * z1 * (1.f - z1);
+            dr0 = dn0 * q0 * r0 * (1.f - r0);
+            dr1 = dn1 * q1 * r1 * (1.f - r1);
+            dq0 = dn0 * r0;
+            dq1 = dn1 * r1;
+            car[it][0] = dh0 * z0;
+            car[it][1] = dh1 * z1;
+          }
+          if (dead) dr0 = dr1 = QNAN;
+          X::publish(xo, xo_, tag, dr0, dr1);                       // peers wait for these: first
+          X::publish(xo, xo_ + GATE_BYTES, tag, dz0, dz1);
+          X::publish(xo, xo_ + 2 * GATE_BYTES, tag, dq0, dq1);
+          T* dgh = dgh_ptr[it];
+          X::st(dgi, dr0, dr1);
+          X::st(dgi + H, dz0, dz1);
+          X::st(dgi + 2 * H, dn0, dn1);
+          X::st(dgh, dr0, dr1);
+          X::st(dgh + H, dz0, dz1);
+          X::st(dgh + 2 * H, dq0, dq1);
+        } else if (CELL == CELL_LSTM) {
+          float di0 = 0.f, di1 = 0.f, df0 = 0.f, df1 = 0.f, dg0 = 0.f, dg1 = 0.f, do0 = 0.f, do1 = 0.f;
+          car[it][0] = din0;
+          car[it][1] = din1;
+          if (act) {
+            const float i0 = X::lo(sp[it][0]), i1 = X::hi(sp[it][0]), f0 = X::lo(sp[it][1 % M]), f1 = X::hi(sp[it][1 % M]);
+            const float g0 = X::lo(sp[it][2 % M]), g1 = X::hi(sp[it][2 % M]), o0 = X::lo(sp[it][3 % M]), o1 = X::hi(sp[it][3 % M]);
+            const float tc0 = X::tnh(X::lo(sp[it][4 % M])), tc1 = X::tnh(X::hi(sp[it][4 % M]));
+            const float dh0 = X::lo(dout[it]) + din0, dh1 = X::hi(dout[it]) + din1;
+            const float dcn0 = dc[it][0] + dh0 * o0 * (1.f - tc0 * tc0), dcn1 = dc[it][1] + dh1 * o1 * (1.f - tc1 * tc1);
+            di0 = dcn0 * g0 * i0 * (1.f - i0);
+            di1 = dcn1 * g1 * i1 * (1.f - i1);
+            df0 = dcn0 * X::lo(cp[it]) * f0 * (1.f - f0);
+            df1 = dcn1 * X::hi(cp[it]) * f1 * (1.f - f1);
+            dg0 = dcn0 * i0 * (1.f - g0 * g0);
+            dg1 = dcn1 * i1 * (1.f - g1 * g1);
+            do0 = dh0 * tc0 * o0 * (1.f - o0);
+            do1 = dh1 * tc1 * o1 * (1.f - o1);
+            car[it][0] = car[it][1] = 0.f;
+            dc[it][0] = dcn0 * f0;
+            dc[it][1] = dcn1 * f1;
+          }
+          if (dead) di0 = di1 = QNAN;
+          X::publish(xo, xo_, tag, di0, di1);
+          X::publish(xo, xo_ + GATE_BYTES, tag, df0, df1);
+          X::publish(xo, xo_ + 2 * GATE_BYTES, tag, dg0, dg1);
+          X::publish(xo, xo_ + 3 * GATE_BYTES, tag, do0, do1);
+          X::st(dgi, di0, di1);
+          X::st(dgi + H, df0, df1);
+          X::st(dgi + 2 * H, dg0, dg1);
+          X::st(dgi + 3 * H, do0, do1);
+        } else {
+          float dg0 = 0.f, dg1 = 0.f;
+          car[it][0] = din0;
+          car[it][1] = din1;
+          if (act) {
+            const float h0v = X::lo(hp[it]), h1v = X::hi(hp[it]);
+            dg0 = (X::lo(dout[it]) + din0) * (1.f - h0v * h0v);
+            dg1 = (X::hi(dout[it]) + din1) * (1.f - h1v * h1v);
+            car[it][0] = car[it][1] = 0.f;
+          }
+          if (dead) dg0 = dg1 = QNAN;
+          X::publish(xo, xo_, tag, dg0, dg1);
+          X::st(dgi, dg0, dg1);
+        }
+      }
+      do_ptr[it] += dstep * N * H;
+      if (NS) sv_ptr[it] += dstep * N * NSH_;
+      hs_ptr[it] += dstep * N * H;
+      dgi_ptr[it] += dstep * N * ldgi;
+      if (CELL == CELL_GRU) dgh_ptr[it] += dstep * N * GH;
+    }
+  }
+}
+
+template <int CELL, typename T, int H, int MT>
+int launch2(bool bwd, const QArgs& a, hipStream_t st) {
+  constexpr int G = CellInfo<CELL>::G;
+  const int P = H / 16;
+  const size_t shm = (size_t)2 * 4 * MT * (bwd ? 1 : G) * 256 * sizeof(float);
+  static bool attr[2][DS2_MAX_DEVICES];
+  const void* fn = bwd ? (const void*)k_rnn_persist2_bwd<CELL, T, H, MT> : (const void*)k_rnn_persist2_fwd<CELL, T, H, MT>;
+  if (ds2_first_use_on_device(attr[bwd ? 1 : 0])) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+  if (bwd)
+    hipLaunchKernelGGL((k_rnn_persist2_bwd<CELL, T, H, MT>), dim3(a.NG * P), dim3(256), shm, st, a);
+  else
+    hipLaunchKernelGGL((k_rnn_persist2_fwd<CELL, T, H, MT>), dim3(a.NG * P), dim3(256), shm, st, a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+}  // namespace ds2q

@@ -266,11 +266,11 @@ def rnn_fwd(kind, GI, Whh, bhh, lens, D, N, H, Tp, h0=None, c0=None, save=True):
     hn = torch.empty((D, N, H), dtype=torch.float32, device=dev)
     cn = torch.empty((D, N, H), dtype=torch.float32, device=dev) if kind == "lstm" else None
     if use_persistent(kind, dtype, D, N, H):
-        ws = torch.empty(query("ds2_rnn_persist_ws_bytes", CELLS[kind], H), dtype=torch.uint8, device=dev)
+        ws = torch.empty(query("ds2_rnn_persist_ws_bytes", dt(dtype), CELLS[kind], D, N, H), dtype=torch.uint8, device=dev)
         global LAST_PERSIST_WS
         LAST_PERSIST_WS = ws
         with _sweep_timer("rnn_fwd_persistent", Tp):
-            call("ds2_rnn_persist_fwd", CELLS[kind], D, N, H, Tp, P(lens), P(GI), P(Whh), PF(bhh), PF(h0), PF(c0),
+            call("ds2_rnn_persist_fwd", dt(dtype), CELLS[kind], D, N, H, Tp, P(lens), P(GI), P(Whh), PF(bhh), PF(h0), PF(c0),
                  P(hext[:, 1]), (Tp + 2) * N * H, P(Sv), P(hn), P(cn), P(ws), P(_persist_err(dev)), S())
         return hext, Sv, hn, cn
     state = torch.empty(query("ds2_rnn_state_bytes", D, N, H), dtype=torch.uint8, device=dev)
@@ -286,11 +286,11 @@ def rnn_bwd(kind, dOut, WhhT, hext, Sv, lens, D, N, H, Tp):
     dGI = torch.empty((Tp * N, D * G * H), dtype=dtype, device=dev)
     dGH = torch.empty((D, Tp, N, G * H), dtype=dtype, device=dev) if kind == "gru" else None
     if use_persistent(kind, dtype, D, N, H):
-        ws = torch.empty(query("ds2_rnn_persist_ws_bytes", CELLS[kind], H), dtype=torch.uint8, device=dev)
+        ws = torch.empty(query("ds2_rnn_persist_ws_bytes", dt(dtype), CELLS[kind], D, N, H), dtype=torch.uint8, device=dev)
         global LAST_PERSIST_WS
         LAST_PERSIST_WS = ws
         with _sweep_timer("rnn_bwd_persistent", Tp):
-            call("ds2_rnn_persist_bwd", CELLS[kind], D, N, H, Tp, P(lens), P(dOut), P(WhhT), P(hext[:, 1]), (Tp + 2) * N * H,
+            call("ds2_rnn_persist_bwd", dt(dtype), CELLS[kind], D, N, H, Tp, P(lens), P(dOut), P(WhhT), P(hext[:, 1]), (Tp + 2) * N * H,
                  P(Sv), P(dGI), P(dGH), P(ws), P(_persist_err(dev)), S())
         return dGI, dGH
     state = torch.empty(query("ds2_rnn_state_bytes", D, N, H), dtype=torch.uint8, device=dev)

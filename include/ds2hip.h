@@ -110,15 +110,18 @@ int ds2_rnn_bwd(int dtype, int cell, int D, int N, int H, int Tp, const int* len
                 const void* Hseq, long hseq_dstride, const void* S, void* dGI, void* dGH, void* state, ds2_stream_t stream);
 
 /* Persistent variant (csrc/ds2_rnn_persist.hip): one launch per sweep, all time steps inside the kernel, W_hh resident in
- * registers, h exchanged between the workgroups of a group through tagged 8-byte granules.  bf16 storage only; same
- * buffer contract as ds2_rnn_fwd / ds2_rnn_bwd.  ws: ds2_rnn_persist_ws_bytes() bytes of scratch; err: one device int that
- * the kernel sets to 1 if a workgroup gave up waiting for its peers (its outputs are then NaN). */
+ * registers, h exchanged between the workgroups of a group through tagged 8-byte granules; same buffer contract as
+ * ds2_rnn_fwd / ds2_rnn_bwd.  Covered (ds2_rnn_persist_supported): bf16 with H = 1024 (any cell, <= 16 samples per group of an
+ * 8-group chip: BASELINE config 3), and GRU / LSTM with bf16 H in {800, 1280} or fp32 H in {800, 1024} (configs 2 and 5, the
+ * 1e-3 parity mode; up to 64 samples per group for bf16 H = 1280, 16 otherwise); everything else runs ds2_rnn_fwd / _bwd.
+ * ws: ds2_rnn_persist_ws_bytes() bytes of scratch; err: one device int that the kernel sets to 1 if a workgroup gave up
+ * waiting for its peers (its outputs are then NaN). */
 int ds2_rnn_persist_supported(int dtype, int cell, int D, int N, int H);
-long ds2_rnn_persist_ws_bytes(int cell, int H);
-int ds2_rnn_persist_fwd(int cell, int D, int N, int H, int Tp, const int* lens, const void* GI, const void* Whh,
+long ds2_rnn_persist_ws_bytes(int dtype, int cell, int D, int N, int H);
+int ds2_rnn_persist_fwd(int dtype, int cell, int D, int N, int H, int Tp, const int* lens, const void* GI, const void* Whh,
                         const float* bhh, const float* h0, const float* c0, void* Hseq, long hseq_dstride, void* S, float* hn,
                         float* cn, void* ws, int* err, ds2_stream_t stream);
-int ds2_rnn_persist_bwd(int cell, int D, int N, int H, int Tp, const int* lens, const void* dOut, const void* WhhT,
+int ds2_rnn_persist_bwd(int dtype, int cell, int D, int N, int H, int Tp, const int* lens, const void* dOut, const void* WhhT,
                         const void* Hseq, long hseq_dstride, const void* S, void* dGI, void* dGH, void* ws, int* err,
                         ds2_stream_t stream);
 

@@ -15,14 +15,12 @@ def fixture_names():
     return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
 
 
-# Golden cases the oracle and the torch port are pinned to on CPU but that the whole-class GPU tests do not run yet:
-# rnn_bi_1024: on the GPU the fp32 path reproduces loss and logits, the conv1 weight gradient is 2.513e-3 of its scale away
-# (bar 1e-3).  Cause (reproduced on CPU, tests/test_oracle_vs_golden.py::test_hardtanh_boundary_flip_explains_...): ONE
-# pre-Hardtanh value of the second conv block is 5.5e-7 from the clamp boundary 0 -- inside fp32 rounding of the BatchNorm
-# output -- and Hardtanh's gradient is discontinuous there; flipping that single decision in the oracle moves the conv1
-# weight gradient by exactly 2.513e-3 (2.800e-2 absolute).  check_grads_or_flip_variant below accepts such a result;
-# the case joins the GPU run once that path has been exercised on the device.
-GPU_PENDING = ("rnn_bi_1024",)
+# Golden cases the whole-class GPU tests skip: none.  (rnn_bi_1024 was parked in round 1: on the GPU its conv1 weight gradient
+# is 2.513e-3 of its scale away from the reference because ONE pre-Hardtanh value of the second conv block is 5.5e-7 from the
+# clamp boundary 0 -- inside fp32 rounding of the BatchNorm output -- and Hardtanh's gradient is discontinuous there
+# (tests/test_oracle_vs_golden.py::test_hardtanh_boundary_flip_explains_...).  check_grads_or_flip_variant below accepts the
+# reference gradient or ONE consistent flip variant for such a case and reports which.)
+GPU_PENDING = ()
 
 
 def gpu_fixture_names():
@@ -69,6 +67,19 @@ class Fixture:
 
     def grad_names(self):
         return sorted(k.split(".", 1)[1] for k in self.z.files if k.startswith("grad.") or k.startswith("gradsub."))
+
+    def rel_l2(self, name, g, which="grad"):
+        """Relative L2 distance of gradient `g` (full array) from the stored reference gradient (on the stored sub-sample for
+        big tensors).  which: "grad" = the reference run in float64, "grad_ac" = the reference under autocast(bfloat16)."""
+        g = np.asarray(g, dtype=np.float64)
+        sub = which.replace("grad", "gradsub")
+        if which + "." + name in self.z.files:
+            ref = self.z[which + "." + name].astype(np.float64)
+            got = g.reshape(ref.shape)
+        else:
+            ref = self.z[sub + "." + name].astype(np.float64)
+            got = g.reshape(-1)[::self.meta["stride"]]
+        return float(np.sqrt(((got - ref) ** 2).sum()) / max(np.sqrt((ref ** 2).sum()), 1e-30))
 
     def check_grad(self, name, g, rtol, atol_scale=1.0):
         """Compare gradient `g` (full array) with the stored reference gradient. Returns max abs err / scale."""

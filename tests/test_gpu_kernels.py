@@ -296,6 +296,61 @@ def test_rnn_persistent_sweeps(kind, D, N, H, Tp):
         assert np.abs(a - b).max() <= 2e-2 * max(1.0, np.abs(b).max()), np.abs(a - b).max()
 
 
+GENERAL_PERSISTENT_CASES = [
+    # fp32 storage (the 1e-3 parity mode): BASELINE config 2's width (H = 800; 25 / 150 k-steps: ragged K split) and 1024
+    (torch.float32, "gru", 2, 8, 800, 9), (torch.float32, "lstm", 1, 5, 800, 7), (torch.float32, "gru", 2, 32, 1024, 6),
+    (torch.float32, "lstm", 2, 3, 1024, 5), (torch.float32, "gru", 1, 1, 800, 4),
+    # bf16 storage: H = 800 and config 5's LSTM-1280 with 1, 2 and 4 m-tiles (up to 64 samples per group)
+    (torch.bfloat16, "gru", 2, 8, 800, 9), (torch.bfloat16, "lstm", 2, 13, 800, 6), (torch.bfloat16, "gru", 2, 7, 1280, 8),
+    (torch.bfloat16, "lstm", 1, 64, 1280, 5), (torch.bfloat16, "lstm", 2, 64, 1280, 5), (torch.bfloat16, "lstm", 2, 40, 1280, 4),
+    (torch.bfloat16, "gru", 2, 64, 1280, 4), (torch.bfloat16, "lstm", 1, 3, 1280, 6),
+]
+
+
+@pytest.mark.parametrize("dtype,kind,D,N,H,Tp", GENERAL_PERSISTENT_CASES)
+def test_rnn_persistent_general_sweeps(dtype, kind, D, N, H, Tp):
+    """The generalised persistent kernels (ds2_rnn_persist2_impl.h: H = 800 / 1024 / 1280, bf16 and fp32 storage, 1-4 m-tiles)
+    against the oracle, and against the per-time-step kernels on the same inputs."""
+    o = ops()
+    assert o.use_persistent(kind, dtype, D, N, H), "persistent path not selected on this device"
+    res_p = _rnn_sweep_case(dtype, kind, D, N, H, Tp, 1.0 / np.sqrt(H))
+    o.check_persistent_kernels()
+    o.PERSIST_ENABLED = False
+    try:
+        res_s = _rnn_sweep_case(dtype, kind, D, N, H, Tp, 1.0 / np.sqrt(H))
+    finally:
+        o.PERSIST_ENABLED = True
+    bar = 2e-2 if dtype == torch.bfloat16 else 1e-5
+    for a_, b_ in zip(res_p, res_s):   # same operands; only the fp32 summation order differs
+        assert np.abs(a_ - b_).max() <= bar * max(1.0, np.abs(b_).max()), np.abs(a_ - b_).max()
+
+
+def test_rnn_persistent_general_initial_state():
+    """h0/c0 carry (reference inference.py:86-96) through the general persistent forward kernels (fp32 and bf16)."""
+    rs = np.random.RandomState(13)
+    for dt_, kind, D, N, H, Tp in ((torch.float32, "lstm", 2, 1, 800, 6), (torch.bfloat16, "gru", 1, 3, 1280, 5)):
+        G = O.GATES[kind]
+        GI = rs.standard_normal((Tp * N, D * G * H))
+        Whh, bhh = rs.uniform(-0.05, 0.05, (D, G * H, H)), rs.uniform(-0.2, 0.2, (D, G * H))
+        h0, c0 = rs.standard_normal((D, N, H)), rs.standard_normal((D, N, H))
+        lens = np.array([Tp] + [max(1, Tp - 2)] * (N - 1), dtype=np.int32)
+        GI_r, Whh_r = rnd(GI, dt_), rnd(Whh, dt_)
+        o = ops()
+        assert o.use_persistent(kind, dt_, D, N, H)
+        hext, Sv, hn, cn = o.rnn_fwd(kind, cu(GI, dt_), cu(Whh, dt_), cu(bhh), torch.from_numpy(lens).to(DEV), D, N, H, Tp,
+                                     h0=cu(h0), c0=cu(c0) if kind == "lstm" else None)
+        o.check_persistent_kernels()
+        tol = 4e-2 if dt_ == torch.bfloat16 else 1e-4
+        for d in range(D):
+            out, hn_ref, cn_ref, _ = O.rnn_dir_fwd(kind, GI_r.reshape(Tp, N, D, G * H)[:, :, d], lens, np.eye(G * H), Whh_r[d],
+                                                   np.zeros(G * H), bhh[d], reverse=(d == 1), h0=h0[d],
+                                                   c0=c0[d] if kind == "lstm" else None)
+            assert np.abs(np64(hext[d, 1:Tp + 1]) - out).max() < tol
+            assert np.abs(np64(hn[d]) - hn_ref).max() < tol
+            if kind == "lstm":
+                assert np.abs(np64(cn[d]) - cn_ref).max() < tol * 1.5
+
+
 def _rnn_sweep_case(dtype, kind, D, N, H, Tp, wscale):
     rs = np.random.RandomState(D * 100 + N + H + Tp)
     G = O.GATES[kind]

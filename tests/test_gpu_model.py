@@ -64,7 +64,7 @@ def test_fp32_train_step_matches_reference(name):
         return max(rtol, 3 * min(float(fx.z["noise." + k]), 1e-2))
     # every gradient against the reference's; a case with a pre-Hardtanh value on a clamp boundary may instead match the
     # oracle with that single decision flipped (fixtures.check_grads_or_flip_variant)
-    check_grads_or_flip_variant(fx, grads, rtol_of)
+    print("%s: gradients match the %s" % (name, check_grads_or_flip_variant(fx, grads, rtol_of)))
     for k in fx.z.files:
         if k.startswith("running."):
             nm = k.split(".", 1)[1]
@@ -108,18 +108,20 @@ def test_fp32_logits_eval_transcripts_and_carry(name):
     assert np.abs(hl.cpu().numpy() - fx.z["carry_h_last"]).max() <= 1e-4
 
 
-@pytest.mark.parametrize("name", ["gru_bi_tiny", "lstm_bi_tiny", "gru_uni_la", "gru_bi_mid", "gru_bi_1024", "lstm_uni_1024_la"])
-def test_bf16_train_step_close_to_reference(name):
-    """bf16 storage + bf16 MFMA operands (the performance mode).  Stated tolerance: loss within 2e-2 relative, logits
-    within 0.15 absolute, every parameter gradient within 15% of the tensor's max AND cosine similarity >= 0.985 with the
-    fp32 reference gradient -- bf16 has 8 mantissa bits, these are tiny models (H <= 96) whose BatchNorm-bias gradients
-    are sums of heavily cancelling terms, and the reference's own bf16-autocast run differs from its fp32 run by a
-    similar amount.  gru_bi_1024 is the headline width: it runs the persistent recurrent kernels and
-    the DMA-staged GEMMs against outputs of the REAL reference model."""
+BF16_CASES = ["gru_bi_tiny", "lstm_bi_tiny", "gru_uni_la", "gru_bi_mid", "gru_bi_1024", "lstm_uni_1024_la", "rnn_bi_1024",
+              "cfg2_full", "lstm_bi_1280", "lstm_uni_1280_la", "gru_bi_1024_l5_n32"]
+# Stated bf16 bounds.  The comparator is the REFERENCE ITSELF under torch.autocast(bfloat16) (fixture keys loss_ac /
+# logits_ac / grad_ac.* / acnoise.*, tests/golden/make_golden.py leg C) next to the reference in float64:
+#   loss     within 3e-3 relative of the reference's autocast loss AND of its float64 loss
+#   logits   within 0.12 absolute of the float64 logits (the reference's own autocast logits deviate by up to ~0.08)
+#   gradient relative L2 distance from the float64 gradient <= max(BF16_GRAD_FACTOR x the reference-autocast's own distance
+#            from float64 ("acnoise"), BF16_GRAD_FLOOR), for EVERY parameter except the two conv biases in front of BatchNorm
+#            (exactly zero in exact arithmetic: pure rounding noise in any implementation)
+BF16_LOSS_RTOL, BF16_LOGITS_ATOL, BF16_GRAD_FACTOR, BF16_GRAD_FLOOR = 3e-3, 0.12, 2.0, 4e-2
+
+
+def bf16_step(fx):
     from deepspeech.pytorch_amd import ops as O_
-    fx = Fixture(name)
-    if fx.cfg["hidden_size"] == 1024:
-        assert O_.use_persistent(fx.cfg["rnn_type"], torch.bfloat16, 2 if fx.cfg["bidirectional"] else 1, len(fx.lengths), 1024)
     m = build(fx, "bf16")
     inputs, targets, pct, tsz = fx.batch()
     m.train()
@@ -127,22 +129,38 @@ def test_bf16_train_step_close_to_reference(name):
     loss = m.training_step(batch, 0)
     loss.backward()
     O_.check_persistent_kernels()
-    ref = float(fx.z["loss64"])
-    assert abs(float(loss.item()) - ref) <= 2e-2 * abs(ref)
-    worst = 0.0
-    for k, p in m.named_parameters():
-        if k in ("conv.seq_module.0.bias", "conv.seq_module.3.bias"):
-            continue
-        g = p.grad.detach().float().cpu().numpy()
-        worst = max(worst, fx.check_grad(k, g, rtol=0.15))
-        if "grad." + k in fx.z.files and g.size >= 16:
-            r = fx.z["grad." + k].astype(np.float64).reshape(-1)
-            cos = float(np.dot(g.reshape(-1).astype(np.float64), r) / (np.linalg.norm(g) * np.linalg.norm(r) + 1e-30))
-            assert cos >= 0.985, (k, cos)
+    grads = {k: p.grad.detach().float().cpu().numpy() for k, p in m.named_parameters()}
     m2 = build(fx, "bf16")
     m2.train()
     logits, _, _ = m2(batch[0], torch.from_numpy(fx.z["input_sizes"].copy()))
-    assert np.abs(logits.detach().cpu().numpy() - fx.z["logits64"]).max() <= 0.15
+    return float(loss.item()), grads, logits.detach().float().cpu().numpy()
+
+
+@pytest.mark.parametrize("name", BF16_CASES)
+def test_bf16_train_step_vs_reference_autocast(name):
+    """bf16 storage + bf16 MFMA operands (the performance mode) against the reference under torch.autocast(bfloat16) and the
+    reference in float64, at the stated bounds above.  Includes BASELINE.json's configurations at their own size / width:
+    cfg2_full (5 x BiGRU-800, 8 clips), lstm_bi_1280 / lstm_uni_1280_la (config 5 family), gru_bi_1024_l5_n32 (config 3's
+    full depth and batch)."""
+    fx = Fixture(name)
+    loss, grads, logits = bf16_step(fx)
+    l_ac, l64 = float(fx.z["loss_ac"]), float(fx.z["loss64"])
+    assert abs(loss - l_ac) <= BF16_LOSS_RTOL * abs(l_ac), (loss, l_ac)
+    assert abs(loss - l64) <= BF16_LOSS_RTOL * abs(l64), (loss, l64)
+    assert np.abs(logits - fx.z["logits64"]).max() <= BF16_LOGITS_ATOL
+    worst = ("", 0.0, 0.0)
+    for k, g in grads.items():
+        if k in ("conv.seq_module.0.bias", "conv.seq_module.3.bias"):
+            continue
+        assert np.isfinite(g).all(), k
+        d64 = fx.rel_l2(k, g, "grad")
+        bound = max(BF16_GRAD_FACTOR * float(fx.z["acnoise." + k]), BF16_GRAD_FLOOR)
+        assert d64 <= bound, "grad %s: relative L2 distance %.3e from the float64 reference > %.3e (reference autocast: %.3e)" % (
+            k, d64, bound, float(fx.z["acnoise." + k]))
+        if d64 / bound > worst[1]:
+            worst = (k, d64 / bound, d64)
+    print("%s: loss %.4f (reference autocast %.4f, float64 %.4f); worst gradient %s at %.2f of its bound (rel L2 %.3e)" % (
+        name, loss, l_ac, l64, worst[0], worst[1], worst[2]))
 
 
 def test_full_size_properties():
@@ -216,13 +234,23 @@ def test_librispeech_shape_matches_stock_torch_on_device():
     ref.backward()
     rl = float(ref.item())
     assert abs(losses[0] - rl) <= 2e-3 * abs(rl), (losses[0], rl)
+    # EVERY parameter gradient: relative L2 distance between the two bf16 pipelines (different summation orders and
+    # rounding points; the reference's own autocast run sits 2-7e-2 from its float64 run on the small fixtures)
     own = dict(m.named_parameters())
-    for k in ("fc.0.module.1.weight", "rnns.4.rnn.weight_hh_l0", "rnns.2.rnn.weight_ih_l0_reverse", "rnns.0.rnn.weight_ih_l0",
-              "rnns.0.rnn.bias_hh_l0", "conv.seq_module.3.weight", "conv.seq_module.0.weight", "rnns.3.batch_norm.module.weight"):
-        a, b = own[k].grad.float().reshape(-1), port.P[k].grad.float().reshape(-1)
+    worst = ("", 0.0)
+    for k, p in port.P.items():
+        if k in ("conv.seq_module.0.bias", "conv.seq_module.3.bias") or p.grad is None:
+            continue
+        a, b = own[k].grad.float().reshape(-1).double(), p.grad.float().reshape(-1).double()
         assert torch.isfinite(a).all(), k
-        cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
-        assert cos >= 0.97, (k, cos)
+        d = float((a - b).norm() / (b.norm() + 1e-30))
+        if d > worst[1]:
+            worst = (k, d)
+        assert d <= FULL_SIZE_GRAD_REL_L2, (k, d)
+    print("cfg3 full size vs stock PyTorch-ROCm: loss %.3f vs %.3f; worst gradient rel L2 %.3e (%s)" % (losses[0], rl, worst[1], worst[0]))
+
+
+FULL_SIZE_GRAD_REL_L2 = 5e-2
 
 
 def test_in_place_updates_without_version_bump_are_seen():
