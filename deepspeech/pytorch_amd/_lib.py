@@ -48,6 +48,7 @@ SIGNATURES = {
     "ds2_lookahead_ws_floats": (_l, [_i, _i, _i, _i]),
     "ds2_lookahead_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "ds2_softmax_rows": (_i, [_vp, _vp, _l, _i, _l, _l, _vp]),
+    "ds2_greedy_decode": (_i, [_vp, _l, _l, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "ds2_ctc_ws_floats": (_l, [_i, _i, _i, _i]),
     "ds2_ctc_loss_grad": (_i, [_vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _l, _vp, _vp]),
 }

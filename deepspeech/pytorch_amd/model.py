@@ -524,6 +524,46 @@ class _CtcFn(torch.autograd.Function):
         return dl * g, None, None, None, None, None, None, None
 
 
+class InferenceBatchSoftmax(nn.Module):  # model.py:72-77: identity in train mode, softmax over the classes in eval mode
+    def forward(self, input_):
+        if self.training:
+            return input_
+        if not input_.is_cuda:
+            raise Ds2HipError("InferenceBatchSoftmax (gfx950) needs a HIP tensor; there is no CPU fallback")
+        x = input_.float().contiguous()
+        return ops.softmax_rows(x.view(-1, x.shape[-1]), x.shape[-1]).view(x.shape)
+
+
+class CTCLossHip(nn.Module):
+    """``self.criterion`` of the reference (model.py:203: ``CTCLoss(blank, reduction='sum', zero_infinity=True)``) on the HIP
+    CTC kernels.  Called like the reference calls it (model.py:248): ``criterion(out (T',N,C), targets, output_sizes,
+    target_sizes)``; `out` may be log-probabilities or raw logits (the kernel applies log_softmax, which is the identity on
+    log-probabilities).  Differentiable with respect to `out`."""
+
+    def __init__(self, blank=0):
+        super().__init__()
+        self.blank, self.reduction, self.zero_infinity = blank, "sum", True
+
+    def forward(self, log_probs, targets, input_lengths, target_lengths):
+        Tp, N, Cc = log_probs.shape
+        if not log_probs.is_cuda:
+            raise Ds2HipError("CTCLossHip needs a HIP tensor; there is no CPU fallback")
+        x = torch.zeros((Tp * N, 32), dtype=torch.float32, device=log_probs.device)
+        x[:, :Cc] = log_probs.reshape(Tp * N, Cc).float()
+        loss = _CtcFn.apply(x, targets, input_lengths.to(log_probs.device, torch.int32), target_lengths, N, Tp, Cc, self.blank)
+        return loss
+
+
+def _reference_metrics(decoder):
+    """The reference's own torchmetrics classes (validation.py:48-132; they sync across DDP ranks) when its package and their
+    dependencies are importable, else the single-process stand-ins of .decoder."""
+    try:
+        from deepspeech_pytorch.validation import CharErrorRate, WordErrorRate
+    except Exception:
+        from .decoder import CharErrorRate, WordErrorRate
+    return (WordErrorRate(decoder=decoder, target_decoder=decoder), CharErrorRate(decoder=decoder, target_decoder=decoder))
+
+
 # ==================================================================================================================
 # the model
 # ==================================================================================================================
@@ -570,6 +610,12 @@ class DeepSpeech(_Base):
         fully_connected = nn.Sequential(nn.BatchNorm1d(H), nn.Linear(H, num_classes, bias=False))
         self.fc = nn.Sequential(SequenceWise(fully_connected))
         self.blank_index = self.labels.index('_')      # model.py:203
+        # model.py:202-212: the attributes validation_step / external callers use, with the reference's names
+        from .decoder import GreedyDecoder
+        self.inference_softmax = InferenceBatchSoftmax()
+        self.criterion = CTCLossHip(blank=self.blank_index)
+        self.evaluation_decoder = GreedyDecoder(self.labels, blank_index=self.blank_index)   # arg-max + collapse on the device
+        self.wer, self.cer = _reference_metrics(self.evaluation_decoder)
         self._cache = _WeightCache()
         self._side_streams = {}
         self._prep_done = None
@@ -724,24 +770,28 @@ class DeepSpeech(_Base):
         return _CtcFn.apply(logits, targets, lens_dev, target_sizes, N, Tp, len(self.labels), self.blank_index)
 
     def validation_step(self, batch, batch_idx):
-        # model.py:251-271: forward in eval mode + greedy decode + WER/CER.  The decoder / metric objects are the
-        # reference's own (out of the hot-path scope); attach them with `attach_evaluation(decoder, wer, cer)`.
+        # model.py:251-271, statement for statement.  The reference's `autocast(enabled=self.precision == 16)` is fp16
+        # autocast; the HIP path has bf16 and fp32 kernels, so a 16-bit precision selects bf16 storage (compute_dtype) and the
+        # autocast region is entered only to keep the dtype of any torch op a subclass adds consistent with the reference.
         inputs, targets, input_percentages, target_sizes = batch
         input_sizes = input_percentages.mul_(int(inputs.size(3))).int()
         inputs = inputs.to(self.device)
-        out, output_sizes, hs = self(inputs, input_sizes)
-        dec = getattr(self, "evaluation_decoder", None)
-        if dec is None:
-            return out, output_sizes
-        decoded_output, _ = dec.decode(out, output_sizes)
-        for metric, name in ((getattr(self, "wer", None), "wer"), (getattr(self, "cer", None), "cer")):
-            if metric is not None:
-                metric(preds=out, preds_sizes=output_sizes, targets=targets, target_sizes=target_sizes)
-                self.log(name, metric.compute(), prog_bar=True, on_epoch=True)
-        return decoded_output
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=str(self.precision) in ("16", "bf16", "16-mixed", "bf16-mixed")):
+            out, output_sizes, hs = self(inputs, input_sizes)
+        decoded_output, _ = self.evaluation_decoder.decode(out, output_sizes)
+        self.wer(preds=out, preds_sizes=output_sizes, targets=targets, target_sizes=target_sizes)
+        self.cer(preds=out, preds_sizes=output_sizes, targets=targets, target_sizes=target_sizes)
+        self.log('wer', self.wer.compute(), prog_bar=True, on_epoch=True)
+        self.log('cer', self.cer.compute(), prog_bar=True, on_epoch=True)
 
     def attach_evaluation(self, decoder, wer=None, cer=None):
-        self.evaluation_decoder, self.wer, self.cer = decoder, wer, cer
+        """Swap in other decoder / metric objects (e.g. the reference's beam decoder); any object with the reference's
+        ``decode(probs, sizes)`` / ``__call__(preds, preds_sizes, targets, target_sizes)`` + ``compute()`` interface."""
+        self.evaluation_decoder = decoder
+        if wer is not None:
+            self.wer = wer
+        if cer is not None:
+            self.cer = cer
 
     def configure_optimizers(self):  # model.py:273-297
         name = _cfg_type_name(self.optim_cfg)

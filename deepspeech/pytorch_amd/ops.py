@@ -324,6 +324,28 @@ def softmax_rows(logits, Cc):
     return out
 
 
+def greedy_decode(scores, sizes, blank):
+    """scores: (N, T', C) f32 CUDA tensor (any strides with a contiguous class dimension); sizes: [N] int tensor.
+    Returns host lists (tokens per sample, frame offsets per sample) -- reference decoder.py:164-181."""
+    if scores.dtype != torch.float32:
+        scores = scores.float()
+    if scores.stride(2) != 1:
+        scores = scores.contiguous()
+    N, T, Cc = scores.shape
+    dev = scores.device
+    sz = sizes.to(dev, torch.int32) if sizes is not None else None
+    buf = torch.empty((2, N, T), dtype=torch.int32, device=dev)
+    counts = torch.empty(N, dtype=torch.int32, device=dev)
+    call("ds2_greedy_decode", P(scores), scores.stride(0), scores.stride(1), N, T, Cc, P(sz), blank, P(buf[0]), P(buf[1]), P(counts),
+         S())
+    cnt = counts.cpu()
+    width = int(cnt.max().item()) if N > 0 else 0
+    host = buf[:, :, :max(width, 1)].cpu()           # only the surviving labels + offsets travel
+    toks = [host[0, i, :int(cnt[i])].tolist() for i in range(N)]
+    offs = [host[1, i, :int(cnt[i])] for i in range(N)]
+    return toks, offs
+
+
 def ctc_loss_grad(logits, targets_i32, target_offsets, input_lengths, target_lengths, Tp, N, Cc, blank, max_target_len,
                   ldg=32):
     """logits [Tp*N][ld] f32.  Returns (loss_sum [1], nll [N], dlogits [Tp*N][ldg] f32 with unit upstream gradient)."""

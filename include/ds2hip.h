@@ -157,6 +157,13 @@ int ds2_ctc_loss_grad(const float* logits, long ldl, const int* targets, const i
                       const int* target_lengths, int Tp, int N, int C, int blank, int max_target_len, float grad_scale,
                       float* nll, float* loss_sum, float* dlogits, long ldg, float* ws, ds2_stream_t stream);
 
+/* ---- greedy CTC decoding on the device (validation_step, model.py:256 -> GreedyDecoder.decode, decoder.py:164-181) -------
+ * x[n*stride_n + t*stride_t + c] f32 scores (probabilities or logits), C <= 64; sizes [N] int32 on the device (null = T).
+ * Per sample: arg-max per frame (first maximum), repeats collapsed, blanks dropped.  tokens / offsets [N][T] int32 (the first
+ * counts[n] entries of row n are valid: label index and its frame), counts [N]. */
+int ds2_greedy_decode(const float* x, long stride_n, long stride_t, int N, int T, int C, const int* sizes, int blank,
+                      int* tokens, int* offsets, int* counts, ds2_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,9 @@ def _install_stubs():
             def add_state(self, name, default, dist_reduce_fx=None):
                 setattr(self, name, default)
 
+            def forward(self, *a, **k):  # model.py:257-268: `self.wer(preds=...)` accumulates through update()
+                self.update(*a, **k)
+
         tm.Metric = Metric
         sys.modules["torchmetrics"] = tm
 

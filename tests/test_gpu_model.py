@@ -234,23 +234,32 @@ def test_librispeech_shape_matches_stock_torch_on_device():
     ref.backward()
     rl = float(ref.item())
     assert abs(losses[0] - rl) <= 2e-3 * abs(rl), (losses[0], rl)
-    # EVERY parameter gradient: relative L2 distance between the two bf16 pipelines (different summation orders and
-    # rounding points; the reference's own autocast run sits 2-7e-2 from its float64 run on the small fixtures)
+    # EVERY parameter gradient.  Truth at this size = the same stock op sequence in fp32 on the device (no autocast); both
+    # bf16 pipelines are measured against it: ours must be within FULL_SIZE_FACTOR x stock-bf16's own distance from fp32 (or
+    # the 3e-2 floor), for every parameter except the two conv biases in front of BatchNorm (zero in exact arithmetic).
+    port32 = TP.Port(cfg, state, DEV)
+    ref32 = port32.training_loss(mk())
+    ref32.backward()
     own = dict(m.named_parameters())
-    worst = ("", 0.0)
-    for k, p in port.P.items():
+    worst = ("", 0.0, 0.0, 0.0)
+    for k, p in port32.P.items():
         if k in ("conv.seq_module.0.bias", "conv.seq_module.3.bias") or p.grad is None:
             continue
-        a, b = own[k].grad.float().reshape(-1).double(), p.grad.float().reshape(-1).double()
+        t = p.grad.float().reshape(-1).double()
+        a = own[k].grad.float().reshape(-1).double()
+        b = port.P[k].grad.float().reshape(-1).double()
         assert torch.isfinite(a).all(), k
-        d = float((a - b).norm() / (b.norm() + 1e-30))
-        if d > worst[1]:
-            worst = (k, d)
-        assert d <= FULL_SIZE_GRAD_REL_L2, (k, d)
-    print("cfg3 full size vs stock PyTorch-ROCm: loss %.3f vs %.3f; worst gradient rel L2 %.3e (%s)" % (losses[0], rl, worst[1], worst[0]))
+        d_own, d_stock = float((a - t).norm() / (t.norm() + 1e-30)), float((b - t).norm() / (t.norm() + 1e-30))
+        bound = max(FULL_SIZE_FACTOR * d_stock, 3e-2)
+        assert d_own <= bound, "grad %s: rel L2 %.3e from the fp32 run > %.3e (stock bf16: %.3e)" % (k, d_own, bound, d_stock)
+        if d_own / bound > worst[1]:
+            worst = (k, d_own / bound, d_own, d_stock)
+    print("cfg3 full size: loss %.3f (stock bf16 %.3f, stock fp32 %.3f); worst gradient %s: rel L2 %.3e from fp32 (stock bf16: %.3e)" % (
+        losses[0], rl, float(ref32.item()), worst[0], worst[2], worst[3]))
+    assert abs(losses[0] - float(ref32.item())) <= 2e-3 * abs(float(ref32.item()))
 
 
-FULL_SIZE_GRAD_REL_L2 = 5e-2
+FULL_SIZE_FACTOR = 1.5
 
 
 def test_in_place_updates_without_version_bump_are_seen():
@@ -321,3 +330,75 @@ def test_step_on_a_non_default_stream_gives_the_same_gradients():
         worst = max(worst, d)
         assert d <= 1e-4, (k, d)
     print("worst relative gradient difference between streams: %.3g" % worst)
+
+
+# ---- validation path (reference model.py:251-271, decoder.py:164-181) -----------------------------------------------------
+def _py_greedy(scores, sizes, blank=0):
+    out = []
+    for n in range(scores.shape[0]):
+        am = scores[n, :sizes[n]].argmax(-1)
+        toks = [(int(t), int(v)) for t, v in enumerate(am) if v != blank and (t == 0 or v != am[t - 1])]
+        out.append(toks)
+    return out
+
+
+def test_greedy_decode_kernel_matches_argmax_collapse():
+    from deepspeech.pytorch_amd import ops
+    rs = np.random.RandomState(3)
+    N, T, C = 7, 203, 29
+    # peaky scores with long runs of repeats and blanks, sizes incl. 0, 1, a multiple of 64 and the full length
+    labels = rs.randint(0, 5, size=(N, T)) * rs.randint(0, 2, size=(N, T)) * rs.randint(1, 7)
+    labels = np.repeat(labels[:, ::3], 3, axis=1)[:, :T] % C
+    scores = rs.standard_normal((N, T, C)).astype(np.float32) * 0.1
+    for n in range(N):
+        scores[n, np.arange(T), labels[n]] += 3.0
+    sizes = np.array([203, 128, 65, 64, 1, 0, 200], dtype=np.int32)
+    x = torch.from_numpy(scores).to(DEV)
+    for view in (x, x.transpose(0, 1).contiguous().transpose(0, 1)):       # (N,T,C) contiguous and the (T,N,C)-backed view
+        toks, offs = ops.greedy_decode(view, torch.from_numpy(sizes), 0)
+        ref = _py_greedy(scores, sizes)
+        for n in range(N):
+            assert toks[n] == [v for _, v in ref[n]], n
+            assert offs[n].tolist() == [t for t, _ in ref[n]], n
+
+
+@pytest.mark.parametrize("name", ["gru_bi_mid", "lstm_uni_la", "gru_bi_1024"])
+def test_validation_step_decodes_on_device_and_logs_wer_cer(name):
+    from deepspeech.pytorch_amd import configs
+    fx = Fixture(name)
+    m = build(fx, 32).eval()
+    logged = {}
+    m.log = lambda k, v, **kw: logged.__setitem__(k, v)
+    inputs, targets, pct, tsz = fx.batch()
+    batch = (torch.from_numpy(inputs), torch.from_numpy(targets), torch.from_numpy(pct.copy()), torch.from_numpy(tsz))
+    with torch.no_grad():
+        assert m.validation_step(batch, 0) is None
+        probs, sizes, _ = m(batch[0].to(DEV), torch.from_numpy(fx.z["input_sizes"].copy()))
+        strings, offsets = m.evaluation_decoder.decode(probs, sizes)
+    got = [s[0] for s in strings]
+    assert got == fx.meta["transcripts"]                                  # north star: argmax transcripts identical
+    assert all(len(o[0]) == len(s[0]) for o, s in zip(offsets, strings))
+    # WER / CER of those transcripts against the targets, computed independently (validation.py:48-132 formulas)
+    from deepspeech.pytorch_amd.decoder import _edit_distance
+    tg, off = [], 0
+    for s_ in tsz:
+        tg.append(''.join(configs.LABELS[int(v)] for v in targets[off:off + int(s_)]))
+        off += int(s_)
+    cer = 100.0 * sum(_edit_distance(a.replace(' ', ''), b.replace(' ', '')) for a, b in zip(got, tg)) / \
+        sum(len(b.replace(' ', '')) for b in tg)
+    assert abs(logged["cer"] - cer) < 1e-9 and logged["wer"] > 0
+
+
+def test_criterion_attribute_equals_training_step_loss():
+    fx = Fixture("gru_bi_clamp_inf")                                      # contains an infeasible sample (zero_infinity)
+    m = build(fx, 32).train()
+    inputs, targets, pct, tsz = fx.batch()
+    x = torch.from_numpy(inputs).to(DEV)
+    loss = m.training_step((x, torch.from_numpy(targets), torch.from_numpy(pct.copy()), torch.from_numpy(tsz)), 0)
+    m2 = build(fx, 32).train()
+    out, out_sizes, _ = m2(x, torch.from_numpy(fx.z["input_sizes"].copy()))
+    lp = out.transpose(0, 1).log_softmax(-1)                              # model.py:245-246
+    l2 = m2.criterion(lp, torch.from_numpy(targets), out_sizes, torch.from_numpy(tsz))
+    assert abs(float(l2) - float(loss)) <= 1e-5 * abs(float(loss))
+    l2.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m2.parameters())

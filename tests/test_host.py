@@ -108,3 +108,67 @@ def test_product_path_does_not_import_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert "oracle" not in src.replace("CPU oracle", "").replace("the oracle", ""), fn
+
+
+# ---- validation_step boundary (reference model.py:202-212, 251-271) ------------------------------------------------------
+def test_model_carries_the_reference_evaluation_attributes():
+    fx = Fixture("gru_bi_tiny")
+    m = build_model(fx)
+    for attr in ("inference_softmax", "criterion", "evaluation_decoder", "wer", "cer"):
+        assert hasattr(m, attr), attr
+    assert m.criterion.blank == 0 and m.criterion.reduction == "sum" and m.criterion.zero_infinity is True
+    # none of them adds state: reference checkpoints still load strictly (test_state_dict_matches_reference_keys_and_shapes)
+    assert not any(k.startswith(("criterion", "inference_softmax", "wer", "cer")) for k in m.state_dict())
+
+
+def test_greedy_decoder_string_building_equals_the_reference():
+    """convert_to_strings / process_string (host side; the metrics use them for the TARGET strings) against the reference's
+    GreedyDecoder on random label sequences, with and without repeat removal."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import ref_harness
+    if not ref_harness.reference_available():
+        pytest.skip("reference tree not present")
+    ns = ref_harness.load_reference()
+    from deepspeech.pytorch_amd import configs
+    from deepspeech.pytorch_amd.decoder import GreedyDecoder
+    ref, own = ns.GreedyDecoder(ns.labels), GreedyDecoder(configs.LABELS)
+    assert configs.LABELS == ns.labels
+    rs = np.random.RandomState(0)
+    seqs = torch.from_numpy(rs.randint(0, 29, size=(6, 40)))
+    sizes = torch.tensor([40, 33, 21, 7, 1, 0])
+    for rr in (False, True):
+        a, ao = ref.convert_to_strings(seqs, sizes, remove_repetitions=rr, return_offsets=True)
+        b, bo = own.convert_to_strings(seqs, sizes, remove_repetitions=rr, return_offsets=True)
+        assert a == b
+        for x, y in zip(ao, bo):
+            assert torch.equal(x[0], y[0])
+
+
+def test_validation_step_drives_reference_decoder_and_metrics():
+    """validation_step with the REFERENCE's GreedyDecoder / WordErrorRate / CharErrorRate objects (through the stubs of
+    tests/golden/ref_harness.py) on the reference's own eval probabilities: same transcripts, WER / CER logged."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import ref_harness
+    if not ref_harness.reference_available():
+        pytest.skip("reference tree not present")
+    ns = ref_harness.load_reference()
+    from deepspeech_pytorch.validation import CharErrorRate, WordErrorRate
+    fx = Fixture("gru_bi_mid")
+    m = build_model(fx).eval()
+    from deepspeech.pytorch_amd import model as own_model
+    assert type(m.wer).__module__ == "deepspeech_pytorch.validation"      # the reference's classes are picked up when importable
+    dec = ns.GreedyDecoder(ns.labels)
+    m.attach_evaluation(dec, WordErrorRate(decoder=dec, target_decoder=dec), CharErrorRate(decoder=dec, target_decoder=dec))
+    probs = torch.from_numpy(fx.z["eval_probs"])
+    sizes = torch.from_numpy(fx.z["output_lengths"].copy())
+    m.forward = lambda x, lengths, hs=None: (probs, sizes, None)          # the HIP forward is covered by the -m gpu tests
+    logged = {}
+    m.log = lambda k, v, **kw: logged.__setitem__(k, v)
+    inputs, targets, pct, tsz = fx.batch()
+    out = m.validation_step((torch.from_numpy(inputs), torch.from_numpy(targets), torch.from_numpy(pct.copy()), torch.from_numpy(tsz)), 0)
+    assert out is None                                                     # model.py:251-271 returns nothing
+    assert set(logged) == {"wer", "cer"} and all(np.isfinite(v) and v > 0 for v in logged.values())
+    strings, _ = dec.decode(probs, sizes)
+    assert [s[0] for s in strings] == fx.meta["transcripts"]
