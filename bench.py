@@ -93,7 +93,13 @@ def run_native(args, rank, world, device):
     model = DeepSpeech(configs.LABELS, mc, "bf16" if dtype == "bf16" else 32, configs.AdamConfig(), configs.SpectConfig()).to(device)
     model.train()
     lengths, batch = build_batch(args.config, rank, device)
-    opt = model.configure_optimizers()[0][0]
+    opt = model.configure_optimizers()[0][0]       # FusedAdamW: clip + AdamW + next step's bf16 weight layouts on HIP kernels
+    fused_clip = hasattr(opt, "clip_grad_norm") and not args.torch_optimizer
+    if args.torch_optimizer:
+        opt = torch.optim.AdamW(model.parameters(), lr=model.optim_cfg.learning_rate, betas=tuple(model.optim_cfg.betas),
+                                eps=model.optim_cfg.eps, weight_decay=model.optim_cfg.weight_decay, fused=True)
+    if fused_clip:
+        opt.clip_grad_norm = 400.0                 # Lightning's gradient_clip_val: 400 (reference configs/*.yaml)
     step_mod = dsdist.wrap_data_parallel(dsdist.StepModule(model), device, world)
     params = [p for p in model.parameters()]
 
@@ -103,7 +109,8 @@ def run_native(args, rank, world, device):
         loss.backward()
         if finish_backward is not None:
             finish_backward()
-        torch.nn.utils.clip_grad_norm_(params, 400.0)
+        if not fused_clip:
+            torch.nn.utils.clip_grad_norm_(params, 400.0)
         opt.step()
         return loss
 
@@ -275,6 +282,7 @@ def main():
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--stock", action="store_true", help="time stock PyTorch-ROCm instead of the native path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--torch-optimizer", action="store_true", help="clip_grad_norm_ + torch AdamW(fused=True) instead of the HIP optimizer kernels")
     ap.add_argument("--cpu-clips", type=int, default=0, help="clips of the CPU sample (0 = the configuration's batch size)")
     ap.add_argument("--cpu-frames", type=int, default=301)
     ap.add_argument("--cpu-timeout", type=int, default=170)

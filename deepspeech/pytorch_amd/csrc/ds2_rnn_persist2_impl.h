@@ -124,47 +124,77 @@ __device__ __forceinline__ void item_decode<float>(int item, int p, int& mt, int
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
+// lane i of every 16-lane row <- lane (i + N) mod 16 (DPP row_ror:(16-N): data moves to higher lanes by 16-N)
+template <int N>
+__device__ __forceinline__ uint32_t row_from_plus(uint32_t v) {
+  static_assert(N > 0 && N < 16, "rotation");
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x120 + (16 - N), 0xf, 0xf, true);
+}
+__device__ __forceinline__ uint4 row_from_plus4(const uint4& a, int n) {   // n folds to a constant after unrolling
+  switch (n) {
+    case 4: return make_uint4(row_from_plus<4>(a.x), row_from_plus<4>(a.y), row_from_plus<4>(a.z), row_from_plus<4>(a.w));
+    case 8: return make_uint4(row_from_plus<8>(a.x), row_from_plus<8>(a.y), row_from_plus<8>(a.z), row_from_plus<8>(a.w));
+    case 12: return make_uint4(row_from_plus<12>(a.x), row_from_plus<12>(a.y), row_from_plus<12>(a.z), row_from_plus<12>(a.w));
+    default: return a;
+  }
+}
+
+// k-steps per gather chunk.  The loads of a chunk are all in flight together (the sweep is latency-bound: the deeper the
+// better) within a register budget: resident weights + accumulators + staging (8 registers per k-step, m-tile and buffer).
+constexpr int chunk2(int KSW, int MT, int RT, int SP) {
+  const int kpad = (KSW + SP - 1) / SP * SP;
+  const int budget = 440 - RT * KSW * 4 - MT * RT * 4 - 90;
+  int per_one = budget / (MT * 8);                       // k-steps per lane if ONE chunk covers the wave's slice
+  if (per_one * SP >= kpad) return kpad;                 // single chunk, no double buffer
+  int per = budget / (2 * MT * 8);                       // two buffers: the next chunk's loads fly under this chunk's MFMAs
+  per = per < 1 ? 1 : (per > 12 ? 12 : per);
+  return per * SP;
+}
+
 // Gathers this wave's k-steps [ks0, ks0 + cnt) of the exchanged vector (granules tagged `epoch`) for all MT m-tiles and
 // multiplies: acc[mt][rt] += A(mt: 16 samples x K-slice) * w[rt](16 rows x K-slice)^T.  Chunks of CH k-steps; the loads of
 // chunk c+1 are issued before the products of chunk c.
-template <typename T, int MT, int RT, int KSW, int CH, bool RAGGED>
+// SP > 1 (MT == 1, at most 16/SP samples in the group): the otherwise idle lanes of every 16-lane row share the loads --
+// lane (part, srow) = (li / (16/SP), li % (16/SP)) fetches k-steps part, part + SP, ... of each chunk for sample srow and
+// the fragment is rotated into place (DPP) before its MFMA: 1/SP of the load instructions per lane.
+template <typename T, int MT, int RT, int KSW, int SP, bool RAGGED>
 __device__ __forceinline__ void gather_mma2(ds2_f32x4 (&acc)[MT][RT], const uint4 (&w)[RT][KSW], __amdgpu_buffer_rsrc_t rsrc,
                                             int par_off, int ks0, int cnt, int lq, int li, int Ns, unsigned epoch, int* err,
                                             int* lerr, bool& dead) {
+  static_assert(SP == 1 || MT == 1, "lane sharing needs a single m-tile");
+  constexpr int CH = chunk2(KSW, MT, RT, SP);
+  constexpr int PER = CH / SP;
   constexpr int NCH = (KSW + CH - 1) / CH;
-  u32x4_t v[2][CH][MT][2];
+  constexpr int NB = NCH > 1 ? 2 : 1;
+  constexpr int W16 = 16 / SP;
+  u32x4_t v[NB][PER][MT][2];
+  const int srow = SP > 1 ? (li & (W16 - 1)) : li, part = SP > 1 ? li / W16 : 0;
   bool need[MT];
 #pragma unroll
-  for (int m = 0; m < MT; ++m) need[m] = m * 16 + li < Ns;
+  for (int m = 0; m < MT; ++m) need[m] = m * 16 + srow < Ns;
 #define DS2Q_LOAD(c, b)                                                                                                  \
-  _Pragma("unroll") for (int i = 0; i < CH; ++i) {                                                                      \
-    const int k_ = (c) * CH + i;                                                                                         \
-    if (k_ < KSW && (!RAGGED || k_ < cnt)) {                                                                             \
-      _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int q = 0; q < 2; ++q)                      \
-          v[b][i][m][q] = need[m] ? __builtin_amdgcn_raw_buffer_load_b128(rsrc, par_off + xunit2<MT>(ks0 + k_, m, q, lq, li), 0, 16 /* sc1 */) \
-                                  : u32x4_t{0u, epoch, 0u, epoch};                                                       \
-    }                                                                                                                    \
+  _Pragma("unroll") for (int i = 0; i < PER; ++i) {                                                                     \
+    const int k_ = (c) * CH + part + SP * i;                                                                             \
+    const bool kok = k_ < KSW && (!RAGGED || k_ < cnt);                                                                  \
+    _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int q = 0; q < 2; ++q)                        \
+        v[b][i][m][q] = (kok && need[m]) ? __builtin_amdgcn_raw_buffer_load_b128(rsrc, par_off + xunit2<MT>(ks0 + k_, m, q, lq, srow), 0, 16 /* sc1 */) \
+                                         : u32x4_t{0u, epoch, 0u, epoch};                                                \
   }
-#define DS2Q_CHECK(c, b, bad)                                                                                            \
+#define DS2Q_CHECK(b, bad)                                                                                               \
   bool bad = false;                                                                                                      \
-  _Pragma("unroll") for (int i = 0; i < CH; ++i) {                                                                      \
-    const int k_ = (c) * CH + i;                                                                                         \
-    if (k_ < KSW && (!RAGGED || k_ < cnt)) {                                                                             \
-      _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int q = 0; q < 2; ++q)                      \
-          bad |= (v[b][i][m][q][1] != epoch) | (v[b][i][m][q][3] != epoch);                                              \
-    }                                                                                                                    \
-  }
+  _Pragma("unroll") for (int i = 0; i < PER; ++i) _Pragma("unroll") for (int m = 0; m < MT; ++m)                        \
+      _Pragma("unroll") for (int q = 0; q < 2; ++q) bad |= (v[b][i][m][q][1] != epoch) | (v[b][i][m][q][3] != epoch);
   DS2Q_LOAD(0, 0)
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
-    const int b = c & 1;
-    DS2Q_CHECK(c, b, bad0)
+    const int b = NB > 1 ? (c & 1) : 0;
+    DS2Q_CHECK(b, bad0)
     if (__any(bad0) && !dead) {        // not all there yet: poll this chunk (bounded)
       unsigned spins = 0;
       for (;;) {
         __builtin_amdgcn_s_sleep(1);
         DS2Q_LOAD(c, b)
-        DS2Q_CHECK(c, b, bad1)
+        DS2Q_CHECK(b, bad1)
         if (!__any(bad1)) break;
         if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(lerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
           dead = true;
@@ -175,12 +205,14 @@ __device__ __forceinline__ void gather_mma2(ds2_f32x4 (&acc)[MT][RT], const uint
     }
     if (c + 1 < NCH) { DS2Q_LOAD(c + 1, b ^ 1) }
 #pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      const int k_ = c * CH + i;
+    for (int kk = 0; kk < CH; ++kk) {
+      const int k_ = c * CH + kk;                                  // compile-time after unrolling
       if (k_ < KSW && (!RAGGED || k_ < cnt)) {
+        const int i = kk / SP;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-          const uint4 a = make_uint4(v[b][i][m][0][0], v[b][i][m][0][2], v[b][i][m][1][0], v[b][i][m][1][2]);
+          uint4 a = make_uint4(v[b][i][m][0][0], v[b][i][m][0][2], v[b][i][m][1][0], v[b][i][m][1][2]);
+          if (SP > 1 && kk % SP) a = row_from_plus4(a, (kk % SP) * W16);   // the lanes of part kk % SP hold this k-step
 #pragma unroll
           for (int r = 0; r < RT; ++r) Mma<T>::mma16(acc[m][r], a, w[r][k_]);
         }
@@ -225,7 +257,7 @@ constexpr float QNAN = __builtin_nanf("");
 // ------------------------------------------------------------------------------------------------------------------
 // forward sweep
 // ------------------------------------------------------------------------------------------------------------------
-template <int CELL, typename T, int H, int MT>
+template <int CELL, typename T, int H, int MT, int SP>
 __global__ void __launch_bounds__(256, 1) k_rnn_persist2_fwd(QArgs a) {
   typedef XT<T> X;
   typedef typename X::raw raw_t;
@@ -233,7 +265,6 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_fwd(QArgs a) {
   constexpr int RT = G;                                  // 16-row tiles of the resident slice: tile g = gate g, 16 units
   constexpr int KSZ = X::KSZ, KT = H / KSZ, KSW = (KT + 3) / 4;
   constexpr bool RAGGED = KT % 4 != 0;
-  constexpr int CH = MT >= 4 ? 1 : (MT == 2 ? 2 : 4);
   constexpr int IT = Items<MT>::PER_THREAD;
   constexpr int PAR_BYTES = KT * MT * 2048;
   static_assert(H % KSZ == 0 && H % 16 == 0, "unsupported hidden size");
@@ -335,7 +366,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_fwd(QArgs a) {
 #pragma unroll
       for (int tt = 0; tt < RT; ++tt) acc[m][tt] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
     if (s > 0 || a.h0)
-      gather_mma2<T, MT, RT, KSW, CH, RAGGED>(acc, w, rsrc, (par ^ 1) * PAR_BYTES, ks0, cnt, lq, li, Ns, s > 0 ? (unsigned)s : TAG_INIT,
+      gather_mma2<T, MT, RT, KSW, SP, RAGGED>(acc, w, rsrc, (par ^ 1) * PAR_BYTES, ks0, cnt, lq, li, Ns, s > 0 ? (unsigned)s : TAG_INIT,
                                               a.err, a.lerr, dead);
     float* pp = part + par * PART_FLOATS;
     store_partials2<MT, RT>(pp, acc, wave, lane);
@@ -430,7 +461,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_fwd(QArgs a) {
 // BPTT sweep.  dh_t = dOut[t] + carry (elementwise part of dh from the step processed before) + dgates_{t'} * W_hh.
 // The workgroup owns W_hh^T rows of its 16 units (one 16-row tile), K = G*H.
 // ------------------------------------------------------------------------------------------------------------------
-template <int CELL, typename T, int H, int MT>
+template <int CELL, typename T, int H, int MT, int SP>
 __global__ void __launch_bounds__(256, 1) k_rnn_persist2_bwd(QArgs a) {
   typedef XT<T> X;
   typedef typename X::raw raw_t;
@@ -438,7 +469,6 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_bwd(QArgs a) {
   constexpr int RT = 1;
   constexpr int KSZ = X::KSZ, KT = G * H / KSZ, KSW = (KT + 3) / 4, KTH = H / KSZ;   // KTH: k-steps per gate
   constexpr bool RAGGED = KT % 4 != 0;
-  constexpr int CH = MT >= 4 ? 1 : (MT == 2 ? 2 : 4);
   constexpr int IT = Items<MT>::PER_THREAD;
   constexpr int PAR_BYTES = KT * MT * 2048;
   constexpr int GATE_BYTES = KTH * MT * 2048;            // exchange bytes of one gate's H elements
@@ -529,7 +559,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_bwd(QArgs a) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m][0] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
     if (s > 0)
-      gather_mma2<T, MT, RT, KSW, CH, RAGGED>(acc, w, rsrc, (par ^ 1) * PAR_BYTES, ks0, cnt, lq, li, Ns, (unsigned)s, a.err, a.lerr, dead);
+      gather_mma2<T, MT, RT, KSW, SP, RAGGED>(acc, w, rsrc, (par ^ 1) * PAR_BYTES, ks0, cnt, lq, li, Ns, (unsigned)s, a.err, a.lerr, dead);
     float* pp = part + par * PART_FLOATS;
     store_partials2<MT, RT>(pp, acc, wave, lane);
     __syncthreads();
@@ -630,20 +660,31 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_bwd(QArgs a) {
   }
 }
 
-template <int CELL, typename T, int H, int MT>
-int launch2(bool bwd, const QArgs& a, hipStream_t st) {
+template <int CELL, typename T, int H, int MT, int SP>
+int launch2_sp(bool bwd, const QArgs& a, hipStream_t st) {
   constexpr int G = CellInfo<CELL>::G;
   const int P = H / 16;
   const size_t shm = (size_t)2 * 4 * MT * (bwd ? 1 : G) * 256 * sizeof(float);
   static bool attr[2][DS2_MAX_DEVICES];
-  const void* fn = bwd ? (const void*)k_rnn_persist2_bwd<CELL, T, H, MT> : (const void*)k_rnn_persist2_fwd<CELL, T, H, MT>;
+  const void* fn = bwd ? (const void*)k_rnn_persist2_bwd<CELL, T, H, MT, SP> : (const void*)k_rnn_persist2_fwd<CELL, T, H, MT, SP>;
   if (ds2_first_use_on_device(attr[bwd ? 1 : 0])) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
   if (bwd)
-    hipLaunchKernelGGL((k_rnn_persist2_bwd<CELL, T, H, MT>), dim3(a.NG * P), dim3(256), shm, st, a);
+    hipLaunchKernelGGL((k_rnn_persist2_bwd<CELL, T, H, MT, SP>), dim3(a.NG * P), dim3(256), shm, st, a);
   else
-    hipLaunchKernelGGL((k_rnn_persist2_fwd<CELL, T, H, MT>), dim3(a.NG * P), dim3(256), shm, st, a);
+    hipLaunchKernelGGL((k_rnn_persist2_fwd<CELL, T, H, MT, SP>), dim3(a.NG * P), dim3(256), shm, st, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
+}
+
+// MT == 1: the lanes of absent sample rows share the gather loads (SP = 4 up to 4 samples per group, 2 up to 8)
+template <int CELL, typename T, int H, int MT>
+int launch2(bool bwd, const QArgs& a, hipStream_t st) {
+  if constexpr (MT == 1) {
+    const int ns = (a.N + a.gpd - 1) / a.gpd;
+    if (ns <= 4) return launch2_sp<CELL, T, H, 1, 4>(bwd, a, st);
+    if (ns <= 8) return launch2_sp<CELL, T, H, 1, 2>(bwd, a, st);
+  }
+  return launch2_sp<CELL, T, H, MT, 1>(bwd, a, st);
 }
 
 }  // namespace ds2q

@@ -137,8 +137,11 @@ class _WeightCache:
         hit = self._store.get(key)
         return hit is not None and hit[0] == self._ver(params)
 
-    def put(self, key, params, val):
-        self._store[key] = (self._ver(params), val)
+    def put(self, key, params, val, epoch=None):
+        ver = self._ver(params)
+        if epoch is not None:                       # stamped for a later epoch (the fused optimizer prepares the next step's layouts)
+            ver = (epoch,) + ver[1:]
+        self._store[key] = (ver, val)
 
     def clear(self):
         self._store.clear()
@@ -714,6 +717,10 @@ class DeepSpeech(_Base):
             # weight re-layouts for the RNN stack: second stream, hidden under the conv front-end
             main, side = torch.cuda.current_stream(), self._wgrad_stream(dev)
             side.wait_stream(main)
+            ready = getattr(self, "_layouts_ready", None)
+            if ready is not None:                # bf16 layouts written by the fused optimizer on ITS stream
+                side.wait_event(ready)
+                self._layouts_ready = None
             with torch.cuda.stream(side):
                 self._prep_rnn_weights(dtype, training and torch.is_grad_enabled())
             prep_done = torch.cuda.Event()
@@ -794,18 +801,20 @@ class DeepSpeech(_Base):
             self.cer = cer
 
     def configure_optimizers(self):  # model.py:273-297
+        # Same optimizers and hyper-parameters as the reference.  On a HIP device they are the subclasses of .optim whose
+        # step() runs the multi-tensor HIP kernels (same arithmetic, same state_dict; the recurrent weights' bf16 layouts for
+        # the next step are written in the same pass); a model still on the CPU gets the stock torch classes.
+        from .optim import FusedAdamW, FusedSGD
         name = _cfg_type_name(self.optim_cfg)
+        on_gpu = all(p.is_cuda for p in self.parameters())
         if name == "SGDConfig":
-            optimizer = torch.optim.SGD(params=self.parameters(), lr=self.optim_cfg.learning_rate,
-                                        momentum=self.optim_cfg.momentum, nesterov=True,
-                                        weight_decay=self.optim_cfg.weight_decay)
+            kw = dict(params=self.parameters(), lr=self.optim_cfg.learning_rate, momentum=self.optim_cfg.momentum, nesterov=True,
+                      weight_decay=self.optim_cfg.weight_decay)
+            optimizer = FusedSGD(model=self, **kw) if on_gpu else torch.optim.SGD(**kw)
         elif name == "AdamConfig":
-            # same optimizer and hyper-parameters as the reference (model.py:283-289); on a HIP device torch's own fused
-            # multi-tensor implementation is selected (one kernel per step instead of ~8 foreach passes; identical math)
-            on_gpu = all(p.is_cuda for p in self.parameters())
-            optimizer = torch.optim.AdamW(params=self.parameters(), lr=self.optim_cfg.learning_rate,
-                                          betas=tuple(self.optim_cfg.betas), eps=self.optim_cfg.eps,
-                                          weight_decay=self.optim_cfg.weight_decay, **({"fused": True} if on_gpu else {}))
+            kw = dict(params=self.parameters(), lr=self.optim_cfg.learning_rate, betas=tuple(self.optim_cfg.betas),
+                      eps=self.optim_cfg.eps, weight_decay=self.optim_cfg.weight_decay)
+            optimizer = FusedAdamW(model=self, **kw) if on_gpu else torch.optim.AdamW(**kw)
         else:
             raise ValueError("Optimizer has not been specified correctly.")
         scheduler = torch.optim.lr_scheduler.ExponentialLR(optimizer=optimizer, gamma=self.optim_cfg.learning_anneal)

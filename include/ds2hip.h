@@ -157,6 +157,21 @@ int ds2_ctc_loss_grad(const float* logits, long ldl, const int* targets, const i
                       const int* target_lengths, int Tp, int N, int C, int blank, int max_target_len, float grad_scale,
                       float* nll, float* loss_sum, float* dlogits, long ldg, float* ws, ds2_stream_t stream);
 
+/* ---- optimizer step (configure_optimizers, model.py:273-297; Lightning's gradient_clip_val, configs/an4.yaml:12) -----------
+ * ds2_clip_coef: out[0] = global L2 norm of `count` fp32 gradient tensors, out[1] = min(1, max_norm / (norm + 1e-6)) -- the
+ * coefficient torch.nn.utils.clip_grad_norm_ multiplies the gradients by; computed on the device, deterministic order.
+ * ds2_opt_multi / ds2_opt_matrix: mode 0 = AdamW, 1 = SGD with Nesterov momentum, fp32, torch's single-tensor arithmetic;
+ * hp[7] = {AdamW: 1-lr*wd, 1-beta1, beta2, 1-beta2, sqrt(1-beta2^t), eps, -lr/(1-beta1^t) | SGD: wd, momentum, 0, 0, 1, 0, -lr};
+ * first = 1 on SGD's first step; clip = out of ds2_clip_coef (device) or null; v is ignored for SGD.  ds2_opt_matrix also
+ * writes the bf16 copy / transpose of the updated matrix (same layout parameters as ds2_cast_transpose_bf16). */
+int ds2_opt_max_tensors(void);
+long ds2_clip_ws_floats(int count, const long* n);
+int ds2_clip_coef(int count, const float* const* g, const long* n, float max_norm, float* out, float* ws, ds2_stream_t stream);
+int ds2_opt_multi(int mode, int count, float* const* p, const float* const* g, float* const* m, float* const* v, const long* n,
+                  const float* hp, int first, const float* clip, ds2_stream_t stream);
+int ds2_opt_matrix(int mode, float* p, const float* g, float* m, float* v, int R, int C, int perm_c, int perm_f, int Cout,
+                   void* dst, long ldd, void* dstT, long lddT, const float* hp, int first, const float* clip, ds2_stream_t stream);
+
 /* ---- greedy CTC decoding on the device (validation_step, model.py:256 -> GreedyDecoder.decode, decoder.py:164-181) -------
  * x[n*stride_n + t*stride_t + c] f32 scores (probabilities or logits), C <= 64; sizes [N] int32 on the device (null = T).
  * Per sample: arg-max per frame (first maximum), repeats collapsed, blanks dropped.  tokens / offsets [N][T] int32 (the first
