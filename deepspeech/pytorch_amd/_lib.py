@@ -53,6 +53,9 @@ SIGNATURES = {
     "ds2_clip_coef": (_i, [_i, _vp, _vp, _f, _vp, _vp, _vp]),
     "ds2_opt_multi": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "ds2_opt_matrix": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _i, _vp, _vp]),
+    "ds2_spect_frames": (_i, [_i]),
+    "ds2_spect_ws_bytes": (_l, [_i, _i]),
+    "ds2_spectrogram": (_i, [_vp, _l, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "ds2_greedy_decode": (_i, [_vp, _l, _l, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "ds2_ctc_ws_floats": (_l, [_i, _i, _i, _i]),
     "ds2_ctc_loss_grad": (_i, [_vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _l, _vp, _vp]),

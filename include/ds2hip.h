@@ -172,6 +172,16 @@ int ds2_opt_multi(int mode, int count, float* const* p, const float* const* g, f
 int ds2_opt_matrix(int mode, float* p, const float* g, float* m, float* v, int R, int C, int perm_c, int perm_f, int Cout,
                    void* dst, long ldd, void* dstT, long lddT, const float* hp, int first, const float* clip, ds2_stream_t stream);
 
+/* ---- log-spectrogram front-end (SpectrogramParser.compute_spectrogram, loader/data_loader.py:73-94, + the padded batch layout
+ * of _collate_fn, :247-270).  wav [N][ldw] f32 waveforms (utterance n = first nsamples[n] entries of row n; nsamples on the
+ * device), n_fft 320 / hop 160 / center = True; basis [322][320] f32 = window-weighted cos rows then -sin rows; reflect: 0 zero
+ * centre padding (librosa >= 0.10), 1 reflection; normalize: (x - mean) / unbiased std per utterance.  out (N,1,161,Tmax) f32,
+ * Tmax = ds2_spect_frames(Lmax) = 1 + Lmax/160, zero beyond an utterance's own frames.  ws: ds2_spect_ws_bytes(N, Lmax). */
+int ds2_spect_frames(int nsamples);
+long ds2_spect_ws_bytes(int N, int Lmax);
+int ds2_spectrogram(const float* wav, long ldw, const int* nsamples, int N, int Lmax, const float* basis, int reflect,
+                    int normalize, float* out, void* ws, ds2_stream_t stream);
+
 /* ---- greedy CTC decoding on the device (validation_step, model.py:256 -> GreedyDecoder.decode, decoder.py:164-181) -------
  * x[n*stride_n + t*stride_t + c] f32 scores (probabilities or logits), C <= 64; sizes [N] int32 on the device (null = T).
  * Per sample: arg-max per frame (first maximum), repeats collapsed, blanks dropped.  tokens / offsets [N][T] int32 (the first

@@ -639,3 +639,37 @@ def greedy_decode(out, sizes, labels, blank=0):
             prev = k
         res.append(s)
     return res
+
+
+# ==================================================================================================================
+# spectrogram front-end (reference loader/data_loader.py:73-94)
+# ==================================================================================================================
+def spect_window(name="hamming", n=320):
+    """Periodic window (scipy.signal.get_window(name, n, fftbins=True), what librosa.stft uses for a window NAME)."""
+    k = np.arange(n, dtype=np.float64)
+    if name == "hamming":
+        return 0.54 - 0.46 * np.cos(2 * np.pi * k / n)
+    if name == "hann":
+        return 0.5 - 0.5 * np.cos(2 * np.pi * k / n)
+    raise ValueError(name)
+
+
+def log_spectrogram(y, sample_rate=16000, window_size=0.02, window_stride=0.01, window="hamming", normalize=True,
+                    pad_mode="constant"):
+    """compute_spectrogram (data_loader.py:73-94).  The STFT is librosa's (third-party, NOT vendored under /root/reference
+    and unpinned in requirements.txt:4 -- "parity unpinned" for this function): restated from its published algorithm --
+    centre padding of n_fft//2 samples on both sides (zeros in librosa >= 0.10, reflection before), frames of n_fft samples
+    every hop, periodic window, rfft; then magnitude (librosa.magphase), log1p, and (x - mean) / std with torch's UNBIASED std
+    over the whole utterance.  Returns float64 [n_fft/2 + 1][1 + len(y)//hop].  Cross-checked against scipy.signal.stft in
+    tests/test_oracle_vs_golden.py."""
+    y = np.asarray(y, dtype=np.float64)
+    n_fft = int(sample_rate * window_size)
+    hop = int(sample_rate * window_stride)
+    yp = np.pad(y, n_fft // 2, mode="reflect" if pad_mode == "reflect" else "constant")
+    T = 1 + len(y) // hop
+    w = spect_window(window, n_fft)
+    frames = np.stack([yp[t * hop:t * hop + n_fft] * w for t in range(T)], 1)          # [n_fft][T]
+    spect = np.log1p(np.abs(np.fft.rfft(frames, axis=0)))
+    if normalize:
+        spect = (spect - spect.mean()) / spect.std(ddof=1)
+    return spect

@@ -42,7 +42,7 @@ def test_fused_adamw_matches_torch_single_tensor(clip):
         ref.step()
         own.step()
         if clip is not None:
-            assert abs(float(own.last_grad_norm[own_p[0].device][0]) - float(total)) <= 1e-5 * float(total)
+            assert abs(float(own.last_grad_norm[own_p[0].device]) - float(total)) <= 1e-5 * float(total)
         for i, (p, q) in enumerate(zip(ref_p, own_p)):
             assert _close(q.detach().cpu().numpy(), p.detach().numpy(), 8 * (step + 1)), (step, i)
             assert _close(own.state[q]["exp_avg"].cpu().numpy(), ref.state[p]["exp_avg"].numpy(), 8 * (step + 1))

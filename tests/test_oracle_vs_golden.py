@@ -127,3 +127,21 @@ def test_hardtanh_boundary_flip_explains_the_gpu_deviation_of_rnn_bi_1024():
     wrong[k] = flipped[k] * 1.01
     with pytest.raises(AssertionError):
         check_grads_or_flip_variant(fx, wrong, lambda n: 1e-3)
+
+
+def test_log_spectrogram_oracle_against_scipy_stft():
+    """The front-end oracle (librosa.stft restated; librosa is absent and unpinned) against an independent published STFT:
+    scipy.signal.stft with the same framing (zero boundary extension of n_fft/2, hop 160, periodic hamming) is the same
+    transform up to scipy's 1/sum(window) scaling."""
+    import scipy.signal as ss
+    rs = np.random.RandomState(0)
+    y = rs.standard_normal(16000 + 37)
+    raw = O.log_spectrogram(y, normalize=False)
+    assert raw.shape == (161, 1 + len(y) // 160)
+    f, t, Z = ss.stft(y, fs=16000, window="hamming", nperseg=320, noverlap=160, nfft=320, boundary="zeros", padded=False)
+    mag = np.abs(Z) * ss.get_window("hamming", 320).sum()
+    n = min(mag.shape[1], raw.shape[1])
+    assert n >= raw.shape[1] - 1
+    assert np.abs(np.log1p(mag[:, :n]) - raw[:, :n]).max() < 1e-9
+    z = O.log_spectrogram(y)
+    assert abs(z.mean()) < 1e-12 and abs(z.std(ddof=1) - 1) < 1e-12
