@@ -69,7 +69,9 @@ class Port:
         return F.batch_norm(x, self.buf[prefix + "running_mean"], self.buf[prefix + "running_var"], self.P[prefix + "weight"],
                             self.P[prefix + "bias"], training=train, momentum=0.1, eps=1e-5)
 
-    def forward(self, x, lengths, train=True):
+    def forward(self, x, lengths, train=True, hs=None, return_hs=False):
+        """hs / return_hs: the hidden-state carry of reference model.py:224-230 (inference.py:86-96); with return_hs the
+        result is (softmax probabilities (N, T', C), lengths, new_hs) as the reference's eval-mode forward returns."""
         P = self.P
         ol = out_lengths(lengths)
         N = x.shape[0]
@@ -88,12 +90,14 @@ class Port:
             y = st(y)
             y = y.masked_fill(~keep, 0)
         y = y.reshape(N, y.shape[1] * y.shape[2], Tp).permute(2, 0, 1).contiguous()       # (T', N, 1312)
+        new_hs = []
         for l, rnn in enumerate(self.rnns):
             if l > 0:
                 T_, N_ = y.shape[0], y.shape[1]
                 y = self._bn(y.reshape(T_ * N_, -1), "rnns.%d.batch_norm.module." % l, train).view(T_, N_, -1)
             pk = pack_padded_sequence(y, ol)
-            o, _ = rnn(pk)
+            o, h_l = rnn(pk, hs[l] if hs is not None else None)
+            new_hs.append(h_l)
             y, _ = pad_packed_sequence(o, total_length=Tp)
             if self.bi:
                 y = y.view(y.shape[0], y.shape[1], 2, -1).sum(2)
@@ -106,6 +110,8 @@ class Port:
         T_, N_ = y.shape[0], y.shape[1]
         y = self._bn(y.reshape(T_ * N_, -1), "fc.0.module.0.", train)
         y = F.linear(y, P["fc.0.module.1.weight"]).view(T_, N_, -1)
+        if return_hs:
+            return y.transpose(0, 1).float().softmax(-1), ol, new_hs
         return y, ol                                                                         # logits (T', N, C)
 
     def training_loss(self, batch):

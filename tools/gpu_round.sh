@@ -22,4 +22,15 @@ if [ -n "$PROFILE" ]; then
   head -n 24 $out/kernel_stats_cfg3.md
   find $out/prof -size +20M -delete
 fi
+if [ -n "$PMC" ]; then   # HBM traffic counters: separate passes, kernel-trace only (MI355X_MICROARCH.md, rocprofv3 section)
+  here=$PWD; cd /tmp
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    timeout 600 rocprofv3 --kernel-trace --pmc $ctr -d $here/$out/pmc_$ctr -o cfg3 -- python $here/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $here/$out/pmc_$ctr.log 2>&1; echo "pmc $ctr rc=$?"
+    db=$(find $here/$out/pmc_$ctr -name "*.db" | head -n 1)
+    [ -n "$db" ] && python $here/tools/rocpd_pmc.py $db > $here/$out/pmc_$ctr.md 2>> $here/$out/pmc_$ctr.log
+    head -n 8 $here/$out/pmc_$ctr.md
+    find $here/$out/pmc_$ctr -size +20M -delete
+  done
+  cd $here
+fi
 if [ -n "$EXTRA" ]; then bash -c "$EXTRA" > $out/extra.log 2>&1; echo "extra rc=$?"; tail -n 40 $out/extra.log; fi
