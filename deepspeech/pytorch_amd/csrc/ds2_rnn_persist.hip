@@ -83,7 +83,8 @@ bool plan2(int dtype, int cell, int D, int N, int H, Plan2& pl) {
 long xbuf2_bytes(int dtype, int cell, int H, const Plan2& pl, bool bwd) {
   const int ksz = dtype == DS2_BF16 ? 32 : 16;
   const long kt = (bwd ? (long)gates(cell) * H : (long)H) / ksz;
-  return (long)pl.NG * 2 * kt * pl.MT * 2048;
+  // MT >= 2: tag-free payload (1024 B per k-step and m-tile) + 512 B of per-workgroup flags per group; else tagged granules
+  return pl.MT >= 2 ? (long)pl.NG * (2 * kt * pl.MT * 1024 + 512) : (long)pl.NG * 2 * kt * pl.MT * 2048;
 }
 
 }  // namespace
@@ -139,10 +140,14 @@ int ds2_rnn_persist_fwd(int dtype, int cell, int D, int N, int H, int Tp, const 
   return launch2_any(false, false, dtype, cell, H, pl.MT, a, st);
 }
 
-// Same contract as ds2_rnn_bwd (zero initial state).
+// BPTT sweep.  Inputs as ds2_rnn_bwd (zero initial state).  Outputs: dGI [Tp*N][D*G*H]; for GRU dQ [D][Tp][N][H] = dn * r, the
+// only slot of the hidden-side gate gradient that differs from dGI's (d(W_hh h + b_hh) = [dr, dz, dQ]); dBacc [D][N][NB*H] f32
+// (may be null) = per-sample sums over time of the gate-gradient planes as stored (NB = 4 for GRU: dr, dz, dn, dQ; G otherwise):
+// bias_ih.grad = sum over samples of planes 0..G-1, bias_hh.grad (GRU) = planes 0, 1, 3.
 int ds2_rnn_persist_bwd(int dtype, int cell, int D, int N, int H, int Tp, const int* lens, const void* dOut, const void* WhhT,
-                        const void* Hseq, long hseq_dstride, const void* S, void* dGI, void* dGH, void* ws, int* err,
+                        const void* Hseq, long hseq_dstride, const void* S, void* dGI, void* dQ, float* dBacc, void* ws, int* err,
                         ds2_stream_t st_) {
+  void* dGH = dQ;
   hipStream_t st = (hipStream_t)st_;
   DS2_REQUIRE(Tp > 0 && Tp < (int)TAG_INIT && ws && err, DS2_ERR_ARG);
   DS2_REQUIRE(cell != CELL_GRU || dGH != nullptr, DS2_ERR_ARG);
@@ -152,7 +157,7 @@ int ds2_rnn_persist_bwd(int dtype, int cell, int D, int N, int H, int Tp, const 
     PArgs a{};
     a.N = N; a.Tp = Tp; a.D = D; a.gpd = NGROUPS / D; a.lens = lens; a.W = (const bf16_t*)WhhT;
     a.Hseq = (bf16_t*)Hseq; a.hseq_dstride = hseq_dstride; a.S = (bf16_t*)S; a.dOut = (const bf16_t*)dOut;
-    a.dGI = (bf16_t*)dGI; a.dGH = (bf16_t*)dGH; a.xbuf = (u64*)((char*)ws + AUX_BYTES); a.err = err;
+    a.dGI = (bf16_t*)dGI; a.dGH = (bf16_t*)dGH; a.dBacc = dBacc; a.xbuf = (u64*)((char*)ws + AUX_BYTES); a.err = err;
     a.xcc = (u64*)((char*)ws + 1024); a.lerr = (int*)((char*)ws + 3072);
 #ifdef DS2_PROBE
     a.dbg = (unsigned long long*)ws;
@@ -167,7 +172,7 @@ int ds2_rnn_persist_bwd(int dtype, int cell, int D, int N, int H, int Tp, const 
   if (e != hipSuccess) return (int)e;
   ds2q::QArgs a{};
   a.N = N; a.Tp = Tp; a.D = D; a.gpd = pl.gpd; a.NG = pl.NG; a.lens = lens; a.W = WhhT; a.Hseq = (void*)Hseq;
-  a.hseq_dstride = hseq_dstride; a.S = (void*)S; a.dOut = dOut; a.dGI = dGI; a.dGH = dGH;
+  a.hseq_dstride = hseq_dstride; a.S = (void*)S; a.dOut = dOut; a.dGI = dGI; a.dGH = dGH; a.dBacc = dBacc;
   a.xbuf = (char*)ws + AUX_BYTES; a.xgroup_bytes = xb / pl.NG; a.err = err; a.lerr = (int*)((char*)ws + 3072);
   return launch2_any(false, true, dtype, cell, H, pl.MT, a, st);
 }

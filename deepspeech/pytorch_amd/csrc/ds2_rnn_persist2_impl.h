@@ -38,7 +38,8 @@ struct QArgs {
   float* cn;
   const void* dOut;         // bwd: [Tp][N][H]                                                 (T)
   void* dGI;                // bwd: [Tp*N][D*G*H]                                              (T)
-  void* dGH;                // bwd, GRU only: [D][Tp][N][3H]                                   (T)
+  void* dGH;                // bwd, GRU only: dQ [D][Tp][N][H] (the n-gate slot of the hidden-side gate gradient) (T)
+  float* dBacc;             // bwd: [D][N][NB*H] per-sample sums over time of the gate gradients (NB = 4 GRU: dr,dz,dn,dq; else G)
   char* xbuf;               // [NG][2 parities][PAR_BYTES], zeroed before the launch
   long xgroup_bytes;        // 2 * PAR_BYTES
   int* err;                 // sticky device word (the host reads it)
@@ -61,6 +62,7 @@ struct XT<bf16_t> {
   static __device__ __forceinline__ float hi(raw r) { return bf_hi(r); }
   static __device__ __forceinline__ float sig(float x) { return fsigmoid(x); }
   static __device__ __forceinline__ float tnh(float x) { return ftanh(x); }
+  static __device__ __forceinline__ float rnd(float x) { return bf_lo(cvt_pk_bf16(x, 0.f)); }   // x as stored
   // publish the pair (a, b) = elements (k, k+1), k even, tagged `tag`, at byte offset `off` of the parity buffer
   static __device__ __forceinline__ void publish(char* xpar, int off, unsigned tag, float a, float b) {
     g_store(reinterpret_cast<u64*>(xpar + off), ((u64)tag << 32) | cvt_pk_bf16(a, b));
@@ -79,6 +81,7 @@ struct XT<float> {
   static __device__ __forceinline__ float hi(raw r) { return r.y; }
   static __device__ __forceinline__ float sig(float x) { return sigmoid_acc(x); }   // full precision: the 1e-3 parity mode
   static __device__ __forceinline__ float tnh(float x) { return tanhf_(x); }
+  static __device__ __forceinline__ float rnd(float x) { return x; }
   static __device__ __forceinline__ void publish(char* xpar, int off, unsigned tag, float a, float b) {
     g_store(reinterpret_cast<u64*>(xpar + off), ((u64)tag << 32) | __float_as_uint(a));
     g_store(reinterpret_cast<u64*>(xpar + off + 8), ((u64)tag << 32) | __float_as_uint(b));
@@ -223,6 +226,95 @@ __device__ __forceinline__ void gather_mma2(ds2_f32x4 (&acc)[MT][RT], const uint
 #undef DS2Q_CHECK
 }
 
+// ---- flag exchange (MT >= 2, bf16): the large-batch regime is bound by the gathered BYTES (a workgroup reads N_s x K values per
+// step through one CU's vector-memory path), so the granule tags are dropped: payload = plain bf16 in A-fragment order
+// [k-step][m-tile][lq (4)][row (16)] x 16 bytes (ONE 16-byte load = one complete MFMA A fragment: half the bytes and half the load
+// instructions of the tagged form), completion = one flag word per producing workgroup (recipe R1 of the MI355X guide, section 6
+// G16: write-through payload stores -> vmcnt(0) -> workgroup barrier -> write-through flag; consumers poll the flags with sc1
+// loads, then read the payload with sc1 loads).  flag[p] = 1 after the initial state, s + 2 after time step s.
+template <int MT>
+__device__ __forceinline__ int xunitf(int kstep, int mt, int lq, int row) { return (((kstep * MT + mt) * 4 + lq) * 16 + row) * 16; }
+template <int MT>
+__device__ __forceinline__ int xpayf(int k, int mt, int row) {   // byte offset of the bf16 pair (k, k+1), k even
+  const int kk = k % 32;
+  return xunitf<MT>(k / 32, mt, kk / 8, row) + (kk % 8) * 2;
+}
+__device__ __forceinline__ void publish_pay(char* xpar, int off, float a, float b) {
+  __hip_atomic_store(reinterpret_cast<unsigned*>(xpar + off), cvt_pk_bf16(a, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// all stores of this workgroup have been acknowledged -> raise its flag
+__device__ __forceinline__ void raise_flag(unsigned* flag, unsigned value) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int KSW, int MT, int RT>
+constexpr int chunkf(int) {
+  const int budget = 440 - RT * KSW * 4 - MT * RT * 4 - 90;
+  int per_one = budget / (MT * 4);
+  if (per_one >= KSW) return KSW;
+  int per = budget / (2 * MT * 4);
+  return per < 1 ? 1 : (per > 16 ? 16 : per);
+}
+
+template <typename T, int MT, int RT, int KSW, int P, bool RAGGED>
+__device__ __forceinline__ void gather_mma2f(ds2_f32x4 (&acc)[MT][RT], const uint4 (&w)[RT][KSW], __amdgpu_buffer_rsrc_t rsrc,
+                                             int par_off, const unsigned* flags, int ks0, int cnt, int lq, int li, int Ns, unsigned need_flag,
+                                             int* err, int* lerr, bool& dead) {
+  static_assert(P <= 128, "flag poll covers two words per lane");
+  constexpr int CH = chunkf<KSW, MT, RT>(0);
+  constexpr int NCH = (KSW + CH - 1) / CH;
+  constexpr int NB = NCH > 1 ? 2 : 1;
+  const int lane = threadIdx.x & 63;
+  if (!dead) {   // wait until every producer of the group has published the step (bounded)
+    unsigned spins = 0;
+    for (;;) {
+      const unsigned f0 = lane < P ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need_flag;
+      const unsigned f1 = lane + 64 < P ? __hip_atomic_load(flags + lane + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need_flag;
+      if (__all(f0 >= need_flag && f1 >= need_flag)) break;
+      if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(lerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+        dead = true;
+        raise_err(err, lerr);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  u32x4_t v[NB][CH][MT];
+  bool need[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) need[m] = m * 16 + li < Ns;
+#define DS2Q_LOADF(c, b)                                                                                                 \
+  _Pragma("unroll") for (int i = 0; i < CH; ++i) {                                                                      \
+    const int k_ = (c) * CH + i;                                                                                         \
+    if (k_ < KSW && (!RAGGED || k_ < cnt)) {                                                                             \
+      _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                                     \
+          v[b][i][m] = need[m] ? __builtin_amdgcn_raw_buffer_load_b128(rsrc, par_off + xunitf<MT>(ks0 + k_, m, lq, li), 0, 16 /* sc1 */) \
+                               : u32x4_t{0u, 0u, 0u, 0u};                                                                \
+    }                                                                                                                    \
+  }
+  DS2Q_LOADF(0, 0)
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int b = NB > 1 ? (c & 1) : 0;
+    if (c + 1 < NCH) { DS2Q_LOADF(c + 1, b ^ 1) }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int k_ = c * CH + i;
+      if (k_ < KSW && (!RAGGED || k_ < cnt)) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const uint4 a = make_uint4(v[b][i][m][0], v[b][i][m][1], v[b][i][m][2], v[b][i][m][3]);
+#pragma unroll
+          for (int r = 0; r < RT; ++r) Mma<T>::mma16(acc[m][r], a, w[r][k_]);
+        }
+      }
+    }
+  }
+#undef DS2Q_LOADF
+}
+
 // partial sums of the 4 K-slices: part[wave][mt][rt][sample row][unit col]
 template <int MT, int RT>
 __device__ __forceinline__ void store_partials2(float* part, const ds2_f32x4 (&acc)[MT][RT], int wave, int lane) {
@@ -266,7 +358,9 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_fwd(QArgs a) {
   constexpr int KSZ = X::KSZ, KT = H / KSZ, KSW = (KT + 3) / 4;
   constexpr bool RAGGED = KT % 4 != 0;
   constexpr int IT = Items<MT>::PER_THREAD;
-  constexpr int PAR_BYTES = KT * MT * 2048;
+  constexpr bool FLAGS = MT >= 2;                          // large batch: tag-free payload + per-workgroup flags
+  static_assert(!FLAGS || sizeof(T) == 2, "the flag exchange is instantiated for bf16 storage");
+  constexpr int PAR_BYTES = KT * MT * (FLAGS ? 1024 : 2048);
   static_assert(H % KSZ == 0 && H % 16 == 0, "unsupported hidden size");
   extern __shared__ __attribute__((aligned(16))) float part[];       // [2][4][MT][RT][256]
   constexpr int PART_FLOATS = 4 * MT * RT * 256;
@@ -295,6 +389,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_fwd(QArgs a) {
   }
   char* xg = a.xbuf + (long)grp * a.xgroup_bytes;
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, 2 * PAR_BYTES, 0x00020000);
+  unsigned* flags = reinterpret_cast<unsigned*>(xg + 2 * PAR_BYTES);   // [P] (FLAGS only)
 
   // ---- gate items of this thread
   bool on[IT];
@@ -317,7 +412,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_fwd(QArgs a) {
     it_mt[it] = mt;
     it_j[it] = p * 16 + jo;
     it_n[it] = on[it] ? slice + a.gpd * gi_i : 0;
-    it_xoff[it] = xpair2<T, MT>(it_j[it], mt, row);
+    it_xoff[it] = FLAGS ? xpayf<MT>(it_j[it], mt, row) : xpair2<T, MT>(it_j[it], mt, row);
     it_len[it] = 0;
     hprev[it][0] = hprev[it][1] = cprev[it][0] = cprev[it][1] = 0.f;
 #pragma unroll
@@ -349,7 +444,11 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_fwd(QArgs a) {
   if (a.h0) {   // initial state as "step -1": parity 1, tag TAG_INIT
 #pragma unroll
     for (int it = 0; it < IT; ++it)
-      if (on[it]) X::publish(xg + PAR_BYTES, it_xoff[it], TAG_INIT, hprev[it][0], hprev[it][1]);
+      if (on[it]) {
+        if (FLAGS) publish_pay(xg + PAR_BYTES, it_xoff[it], hprev[it][0], hprev[it][1]);
+        else X::publish(xg + PAR_BYTES, it_xoff[it], TAG_INIT, hprev[it][0], hprev[it][1]);
+      }
+    if (FLAGS) raise_flag(flags + p, 1u);
   }
 
   for (int s = 0; s < Tp; ++s) {
@@ -365,9 +464,14 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_fwd(QArgs a) {
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int tt = 0; tt < RT; ++tt) acc[m][tt] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
-    if (s > 0 || a.h0)
-      gather_mma2<T, MT, RT, KSW, SP, RAGGED>(acc, w, rsrc, (par ^ 1) * PAR_BYTES, ks0, cnt, lq, li, Ns, s > 0 ? (unsigned)s : TAG_INIT,
-                                              a.err, a.lerr, dead);
+    if (s > 0 || a.h0) {
+      if constexpr (FLAGS)
+        gather_mma2f<T, MT, RT, KSW, H / 16, RAGGED>(acc, w, rsrc, (par ^ 1) * PAR_BYTES, flags, ks0, cnt, lq, li, Ns, (unsigned)s + 1u, a.err,
+                                                     a.lerr, dead);
+      else
+        gather_mma2<T, MT, RT, KSW, SP, RAGGED>(acc, w, rsrc, (par ^ 1) * PAR_BYTES, ks0, cnt, lq, li, Ns, s > 0 ? (unsigned)s : TAG_INIT,
+                                                a.err, a.lerr, dead);
+    }
     float* pp = part + par * PART_FLOATS;
     store_partials2<MT, RT>(pp, acc, wave, lane);
     __syncthreads();
@@ -431,7 +535,8 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_fwd(QArgs a) {
         }
         if (dead) hn0 = hn1 = hprev[it][0] = hprev[it][1] = QNAN;   // fail loudly downstream
         // publish the carried state first (inactive samples republish their unchanged state), then the bookkeeping stores
-        X::publish(xg + par * PAR_BYTES, it_xoff[it], (unsigned)(s + 1), hprev[it][0], hprev[it][1]);
+        if (FLAGS) publish_pay(xg + par * PAR_BYTES, it_xoff[it], hprev[it][0], hprev[it][1]);
+        else X::publish(xg + par * PAR_BYTES, it_xoff[it], (unsigned)(s + 1), hprev[it][0], hprev[it][1]);
         X::st(hs_ptr[it], hn0, hn1);
 #pragma unroll
         for (int q = 0; q < NS; ++q) X::st(sv_ptr[it] + (long)q * H, pl[q][0], pl[q][1]);
@@ -440,6 +545,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_fwd(QArgs a) {
       if (NS) sv_ptr[it] += sv_stride;
       hs_ptr[it] += hs_stride;
     }
+    if (FLAGS) raise_flag(flags + p, (unsigned)s + 2u);
   }
 #pragma unroll
   for (int it = 0; it < IT; ++it) {
@@ -470,8 +576,10 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_bwd(QArgs a) {
   constexpr int KSZ = X::KSZ, KT = G * H / KSZ, KSW = (KT + 3) / 4, KTH = H / KSZ;   // KTH: k-steps per gate
   constexpr bool RAGGED = KT % 4 != 0;
   constexpr int IT = Items<MT>::PER_THREAD;
-  constexpr int PAR_BYTES = KT * MT * 2048;
-  constexpr int GATE_BYTES = KTH * MT * 2048;            // exchange bytes of one gate's H elements
+  constexpr bool FLAGS = MT >= 2;
+  static_assert(!FLAGS || sizeof(T) == 2, "the flag exchange is instantiated for bf16 storage");
+  constexpr int PAR_BYTES = KT * MT * (FLAGS ? 1024 : 2048);
+  constexpr int GATE_BYTES = KTH * MT * (FLAGS ? 1024 : 2048);   // exchange bytes of one gate's H elements
   static_assert(H % KSZ == 0 && H % 16 == 0, "unsupported hidden size");
   extern __shared__ __attribute__((aligned(16))) float part[];       // [2][4][MT][1][256]
   constexpr int PART_FLOATS = 4 * MT * RT * 256;
@@ -497,10 +605,13 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_bwd(QArgs a) {
   }
   char* xg = a.xbuf + (long)grp * a.xgroup_bytes;
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, 2 * PAR_BYTES, 0x00020000);
+  unsigned* flags = reinterpret_cast<unsigned*>(xg + 2 * PAR_BYTES);
 
   bool on[IT];
   int it_row[IT], it_mt[IT], it_xoff[IT], it_j[IT], it_len[IT];
-  float car[IT][2], dc[IT][2];
+  constexpr int NB = CELL == CELL_GRU ? 4 : G;
+  int it_n[IT];
+  float car[IT][2], dc[IT][2], bsum[IT][NB][2];
   const T* do_ptr[IT];
   const T* sv_ptr[IT];
   const T* hs_ptr[IT];
@@ -521,14 +632,17 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_bwd(QArgs a) {
     it_mt[it] = mt;
     it_j[it] = p * 16 + jo;
     const int n = on[it] ? slice + a.gpd * gi_i : 0, j = it_j[it];
-    it_xoff[it] = xpair2<T, MT>(j, mt, row);
+    it_xoff[it] = FLAGS ? xpayf<MT>(j, mt, row) : xpair2<T, MT>(j, mt, row);
     it_len[it] = on[it] ? a.lens[n] : 0;
     car[it][0] = car[it][1] = dc[it][0] = dc[it][1] = 0.f;
+    it_n[it] = n;
+#pragma unroll
+    for (int g = 0; g < NB; ++g) bsum[it][g][0] = bsum[it][g][1] = 0.f;
     do_ptr[it] = (const T*)a.dOut + ((long)t_first * N + n) * H + j;
     sv_ptr[it] = NS ? (const T*)a.S + (((long)d * Tp + t_first) * N + n) * NSH_ + j : nullptr;
     hs_ptr[it] = (const T*)a.Hseq + (long)d * a.hseq_dstride + ((long)t_first * N + n) * H + j;   // h_t
     dgi_ptr[it] = (T*)a.dGI + ((long)t_first * N + n) * ldgi + (long)d * GH + j;
-    dgh_ptr[it] = a.dGH ? (T*)a.dGH + (((long)d * Tp + t_first) * N + n) * GH + j : nullptr;
+    dgh_ptr[it] = a.dGH ? (T*)a.dGH + (((long)d * Tp + t_first) * N + n) * H + j : nullptr;     // dQ
   }
   bool dead = false;
 
@@ -558,8 +672,13 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_bwd(QArgs a) {
     ds2_f32x4 acc[MT][RT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m][0] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
-    if (s > 0)
-      gather_mma2<T, MT, RT, KSW, SP, RAGGED>(acc, w, rsrc, (par ^ 1) * PAR_BYTES, ks0, cnt, lq, li, Ns, (unsigned)s, a.err, a.lerr, dead);
+    if (s > 0) {
+      if constexpr (FLAGS)
+        gather_mma2f<T, MT, RT, KSW, H / 16, RAGGED>(acc, w, rsrc, (par ^ 1) * PAR_BYTES, flags, ks0, cnt, lq, li, Ns, (unsigned)s + 1u, a.err,
+                                                     a.lerr, dead);
+      else
+        gather_mma2<T, MT, RT, KSW, SP, RAGGED>(acc, w, rsrc, (par ^ 1) * PAR_BYTES, ks0, cnt, lq, li, Ns, (unsigned)s, a.err, a.lerr, dead);
+    }
     float* pp = part + par * PART_FLOATS;
     store_partials2<MT, RT>(pp, acc, wave, lane);
     __syncthreads();
@@ -572,6 +691,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_bwd(QArgs a) {
         const float din0 = car[it][0] + mp.x, din1 = car[it][1] + mp.y;
         char* xo = xg + par * PAR_BYTES;
         const unsigned tag = (unsigned)(s + 1);
+#define DS2Q_PUB(off_, a_, b_) do { if (FLAGS) publish_pay(xo, (off_), (a_), (b_)); else X::publish(xo, (off_), tag, (a_), (b_)); } while (0)
         const int xo_ = it_xoff[it];
         T* dgi = dgi_ptr[it];
         constexpr int M = NS ? NS : 1;
@@ -595,16 +715,17 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_bwd(QArgs a) {
             car[it][1] = dh1 * z1;
           }
           if (dead) dr0 = dr1 = QNAN;
-          X::publish(xo, xo_, tag, dr0, dr1);                       // peers wait for these: first
-          X::publish(xo, xo_ + GATE_BYTES, tag, dz0, dz1);
-          X::publish(xo, xo_ + 2 * GATE_BYTES, tag, dq0, dq1);
-          T* dgh = dgh_ptr[it];
+          DS2Q_PUB(xo_, dr0, dr1);
+          DS2Q_PUB(xo_ + GATE_BYTES, dz0, dz1);
+          DS2Q_PUB(xo_ + 2 * GATE_BYTES, dq0, dq1);
           X::st(dgi, dr0, dr1);
           X::st(dgi + H, dz0, dz1);
           X::st(dgi + 2 * H, dn0, dn1);
-          X::st(dgh, dr0, dr1);
-          X::st(dgh + H, dz0, dz1);
-          X::st(dgh + 2 * H, dq0, dq1);
+          X::st(dgh_ptr[it], dq0, dq1);
+          bsum[it][0][0] += X::rnd(dr0); bsum[it][0][1] += X::rnd(dr1);
+          bsum[it][1 % NB][0] += X::rnd(dz0); bsum[it][1 % NB][1] += X::rnd(dz1);
+          bsum[it][2 % NB][0] += X::rnd(dn0); bsum[it][2 % NB][1] += X::rnd(dn1);
+          bsum[it][3 % NB][0] += X::rnd(dq0); bsum[it][3 % NB][1] += X::rnd(dq1);
         } else if (CELL == CELL_LSTM) {
           float di0 = 0.f, di1 = 0.f, df0 = 0.f, df1 = 0.f, dg0 = 0.f, dg1 = 0.f, do0 = 0.f, do1 = 0.f;
           car[it][0] = din0;
@@ -628,14 +749,18 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_bwd(QArgs a) {
             dc[it][1] = dcn1 * f1;
           }
           if (dead) di0 = di1 = QNAN;
-          X::publish(xo, xo_, tag, di0, di1);
-          X::publish(xo, xo_ + GATE_BYTES, tag, df0, df1);
-          X::publish(xo, xo_ + 2 * GATE_BYTES, tag, dg0, dg1);
-          X::publish(xo, xo_ + 3 * GATE_BYTES, tag, do0, do1);
+          DS2Q_PUB(xo_, di0, di1);
+          DS2Q_PUB(xo_ + GATE_BYTES, df0, df1);
+          DS2Q_PUB(xo_ + 2 * GATE_BYTES, dg0, dg1);
+          DS2Q_PUB(xo_ + 3 * GATE_BYTES, do0, do1);
           X::st(dgi, di0, di1);
           X::st(dgi + H, df0, df1);
           X::st(dgi + 2 * H, dg0, dg1);
           X::st(dgi + 3 * H, do0, do1);
+          bsum[it][0][0] += X::rnd(di0); bsum[it][0][1] += X::rnd(di1);
+          bsum[it][1 % NB][0] += X::rnd(df0); bsum[it][1 % NB][1] += X::rnd(df1);
+          bsum[it][2 % NB][0] += X::rnd(dg0); bsum[it][2 % NB][1] += X::rnd(dg1);
+          bsum[it][3 % NB][0] += X::rnd(do0); bsum[it][3 % NB][1] += X::rnd(do1);
         } else {
           float dg0 = 0.f, dg1 = 0.f;
           car[it][0] = din0;
@@ -647,15 +772,28 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_bwd(QArgs a) {
             car[it][0] = car[it][1] = 0.f;
           }
           if (dead) dg0 = dg1 = QNAN;
-          X::publish(xo, xo_, tag, dg0, dg1);
+          DS2Q_PUB(xo_, dg0, dg1);
           X::st(dgi, dg0, dg1);
+          bsum[it][0][0] += X::rnd(dg0); bsum[it][0][1] += X::rnd(dg1);
         }
       }
       do_ptr[it] += dstep * N * H;
       if (NS) sv_ptr[it] += dstep * N * NSH_;
       hs_ptr[it] += dstep * N * H;
       dgi_ptr[it] += dstep * N * ldgi;
-      if (CELL == CELL_GRU) dgh_ptr[it] += dstep * N * GH;
+      if (CELL == CELL_GRU) dgh_ptr[it] += dstep * N * H;
+    }
+#undef DS2Q_PUB
+    if (FLAGS) raise_flag(flags + p, (unsigned)s + 2u);
+  }
+  if (a.dBacc) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      if (on[it]) {
+        float* bo = a.dBacc + ((long)d * N + it_n[it]) * NB * H + it_j[it];
+#pragma unroll
+        for (int g = 0; g < NB; ++g) *reinterpret_cast<float2*>(bo + (long)g * H) = make_float2(bsum[it][g][0], bsum[it][g][1]);
+      }
     }
   }
 }

@@ -70,7 +70,10 @@ struct PArgs {
   float* cn;
   const bf16_t* dOut;       // bwd: [Tp][N][H]
   bf16_t* dGI;              // bwd: [Tp*N][D*G*H]
-  bf16_t* dGH;              // bwd, GRU only: [D][Tp][N][3H]
+  bf16_t* dGH;              // bwd, GRU only: dQ [D][Tp][N][H] = dn * r (the n-gate slot of d(W_hh h + b_hh); the r and z slots
+                            // equal dGI's and are not stored twice)
+  float* dBacc;             // bwd: [D][N][NB*H] per-sample sums over time of the gate gradients (NB planes: GRU dr,dz,dn,dq;
+                            // LSTM di,df,dg,do; RNN dg) -- the bias gradients are their sums over the samples
   u64* xbuf;                // [NGROUPS][2][MAXS][X/2] granules, zeroed before the launch
   int* err;                 // device word, set to 1 on a spin time-out (sticky: the host reads it)
   int* lerr;                // per-LAUNCH word in the zeroed scratch: lets the peers of a timed-out workgroup stop early
@@ -560,7 +563,11 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd(PArgs a) {
   const bf16_t* sv_ptr = NS ? a.S + (((long)d * Tp + t_first) * N + nn_) * NSH_ + j : nullptr;
   const bf16_t* hs_ptr = a.Hseq + (long)d * a.hseq_dstride + ((long)t_first * N + nn_) * H + j;   // h_t
   bf16_t* dgi_ptr = a.dGI + ((long)t_first * N + nn_) * ldgi + (long)d * GH + j;
-  bf16_t* dgh_ptr = a.dGH ? a.dGH + (((long)d * Tp + t_first) * N + nn_) * GH + j : nullptr;
+  bf16_t* dgh_ptr = a.dGH ? a.dGH + (((long)d * Tp + t_first) * N + nn_) * H + j : nullptr;   // dQ
+  constexpr int NB = CELL == CELL_GRU ? 4 : G;
+  float bsum[NB][2];        // bias-gradient accumulators of this thread's (sample, unit pair): sums over the time steps
+#pragma unroll
+  for (int g = 0; g < NB; ++g) bsum[g][0] = bsum[g][1] = 0.f;
   const long prev_off = d == 0 ? -1 : 1;                    // previous step in FORWARD order of this direction
   bool dead = false;
   const bool local = group_is_xcd_local(a.xcc + grp * 32, p, tid, a.err, a.lerr, dead);
@@ -634,15 +641,17 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd(PArgs a) {
         publish((u64*)(xo + xgranule_bytes<NROWS>(j, gi_i)), tag | pr, local);       // peers wait for these: first
         publish((u64*)(xo + xgranule_bytes<NROWS>(H + j, gi_i)), tag | pz, local);
         publish((u64*)(xo + xgranule_bytes<NROWS>(2 * H + j, gi_i)), tag | pq, local);
-        bf16_t* dgh = dgh_ptr;
         if (st_on) {
           *reinterpret_cast<uint32_t*>(dgi) = pr;
           *reinterpret_cast<uint32_t*>(dgi + H) = pz;
           *reinterpret_cast<uint32_t*>(dgi + 2 * H) = pn;
-          *reinterpret_cast<uint32_t*>(dgh) = pr;
-          *reinterpret_cast<uint32_t*>(dgh + H) = pz;
-          *reinterpret_cast<uint32_t*>(dgh + 2 * H) = pq;
+          *reinterpret_cast<uint32_t*>(dgh_ptr) = pq;
         }
+        // bias gradients: what the stored (bf16-rounded) planes sum to, so that they equal the column sums of dGI / dQ
+        bsum[0][0] += bf_lo(pr); bsum[0][1] += bf_hi(pr);
+        bsum[1 % NB][0] += bf_lo(pz); bsum[1 % NB][1] += bf_hi(pz);
+        bsum[2 % NB][0] += bf_lo(pn); bsum[2 % NB][1] += bf_hi(pn);
+        bsum[3 % NB][0] += bf_lo(pq); bsum[3 % NB][1] += bf_hi(pq);
       } else if (CELL == CELL_LSTM) {
         float di0 = 0.f, di1 = 0.f, df0 = 0.f, df1 = 0.f, dg0 = 0.f, dg1 = 0.f, do0 = 0.f, do1 = 0.f;
         car0 = din0;
@@ -676,6 +685,10 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd(PArgs a) {
         publish((u64*)(xo + xgranule_bytes<NROWS>(H + j, gi_i)), tag | pf, local);
         publish((u64*)(xo + xgranule_bytes<NROWS>(2 * H + j, gi_i)), tag | pg, local);
         publish((u64*)(xo + xgranule_bytes<NROWS>(3 * H + j, gi_i)), tag | po, local);
+        bsum[0][0] += bf_lo(pi); bsum[0][1] += bf_hi(pi);
+        bsum[1 % NB][0] += bf_lo(pf); bsum[1 % NB][1] += bf_hi(pf);
+        bsum[2 % NB][0] += bf_lo(pg); bsum[2 % NB][1] += bf_hi(pg);
+        bsum[3 % NB][0] += bf_lo(po); bsum[3 % NB][1] += bf_hi(po);
       } else {
         float dg0 = 0.f, dg1 = 0.f;
         car0 = din0;
@@ -690,13 +703,14 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd(PArgs a) {
         const uint32_t pg = pack_bf16x2(dg0, dg1);
         if (st_on) *reinterpret_cast<uint32_t*>(dgi) = pg;
         publish((u64*)(xo + xgranule_bytes<NROWS>(j, gi_i)), tag | pg, local);
+        bsum[0][0] += bf_lo(pg); bsum[0][1] += bf_hi(pg);
       }
     }
     do_ptr += dstep * N * H;
     if (NS) sv_ptr += dstep * N * NSH_;
     hs_ptr += dstep * N * H;
     dgi_ptr += dstep * N * ldgi;
-    if (CELL == CELL_GRU) dgh_ptr += dstep * N * GH;
+    if (CELL == CELL_GRU) dgh_ptr += dstep * N * H;
     DS2_PROBE_ONLY(const unsigned long long t3 = __builtin_readcyclecounter(); c_gather += t1 - t0; c_bar += t2 - t1; c_gate += t3 - t2;)
   }
 #ifdef DS2_PROBE
@@ -709,6 +723,11 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd(PArgs a) {
   }
 #endif
   (void)rounds;
+  if (gate_thread && a.dBacc) {
+    float* bo = a.dBacc + ((long)d * N + n) * NB * H + j;
+#pragma unroll
+    for (int g = 0; g < NB; ++g) *reinterpret_cast<float2*>(bo + (long)g * H) = make_float2(bsum[g][0], bsum[g][1]);
+  }
 }
 
 template <int CELL, int H, int P>

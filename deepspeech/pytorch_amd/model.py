@@ -333,7 +333,8 @@ class _RnnStackFn(torch.autograd.Function):
                 return w.t().to(dtype).contiguous()                                                             # [I][D*G*H]
             WihT = c.get(("wihT", li, dtype), list(wih), build_ihT)
             # ---- dependent chain (caller's stream): BPTT sweep -> dX -> BatchNorm backward
-            dGI, dGH = ops.rnn_bwd(kind, dout, WhhT, hext, Sv, lens_dev, D, N, H, Tp)
+            rg = ops.rnn_bwd(kind, dout, WhhT, hext, Sv, lens_dev, D, N, H, Tp)
+            dGI = rg.dGI
             dXh = ops.gemm_nt(dGI, WihT)                                # [R][I]
             if has_bn:
                 dX = torch.empty_like(dXh)
@@ -347,9 +348,8 @@ class _RnnStackFn(torch.autograd.Function):
             # ---- weight gradients (second stream, under the next layer's sweep): contraction over the T'*N rows
             with torch.cuda.stream(side):
                 side.wait_event(ready)
-                for t in (dGI, dGH, Xh, hext):
-                    if t is not None:
-                        t.record_stream(side)
+                for t in rg.tensors() + [Xh, hext]:
+                    t.record_stream(side)
                 dGI_T = ops.transpose(dGI)                              # [D*G*H][ldT]
                 Xh_T = ops.transpose(Xh)                                # [I][ldT]
                 ldT = dGI_T.shape[1]
@@ -358,19 +358,39 @@ class _RnnStackFn(torch.autograd.Function):
                 del Xh_T
                 if first:
                     dWih = torch.cat([_perm_cols_to_reference(dWih[d * GH:(d + 1) * GH]) for d in range(D)], 0)
-                dBih = ops.colsum(dGI)
+                # bias gradients: from the sweep's own per-sample sums (persistent kernels: a [N][NB*H] reduction instead of
+                # column sums over the T'*N rows of dGI / dGH), else column sums
+                bsum = None
+                if rg.bacc is not None:
+                    NB = rg.bacc.shape[2] // H
+                    bsum = [ops.colsum(rg.bacc[d]) for d in range(D)]                   # [NB*H] per direction
+                    dBih = torch.cat([b[:GH] for b in bsum], 0)
+                else:
+                    dBih = ops.colsum(dGI)
                 for d in range(D):
                     # h_{t-1} of the forward direction is slot t of the guarded buffer, h_{t+1} of the reverse direction slot t+2
                     hprev = hext[d, 0:Tp] if d == 0 else hext[d, 2:Tp + 2]
                     Hp_T = ops.transpose(hprev.reshape(R, H))           # [H][ldT]
-                    if kind == "gru":
-                        dGH_T = ops.transpose(dGH[d].reshape(R, GH))    # [G*H][ldT]
-                        dBhh = ops.colsum(dGH[d].reshape(R, GH))
+                    if kind == "gru" and rg.dQ is not None:
+                        # hidden-side gate gradient = [dr, dz (rows of dGI^T), dQ]: two GEMMs into the row blocks of dW_hh
+                        dQ_T = ops.transpose(rg.dQ[d].reshape(R, H))   # [H][ldT]
+                        sk = _wgrad_splitk(H, H, ldT)
+                        dWhh = (torch.zeros if sk > 1 else torch.empty)((GH, H), dtype=torch.float32, device=dGI.device)
+                        ops.gemm_nt(dGI_T[d * GH:d * GH + 2 * H], Hp_T, out_dtype=torch.float32, M=2 * H, N=H, K=ldT, lda=ldT, ldb=ldT,
+                                    out=dWhh, ldc=H, splitk=sk, coresident=True)
+                        ops.gemm_nt(dQ_T, Hp_T, out_dtype=torch.float32, M=H, N=H, K=ldT, lda=ldT, ldb=ldT, out=dWhh[2 * H:], ldc=H,
+                                    splitk=sk, coresident=True)
+                        dBhh = torch.cat([bsum[d][:2 * H], bsum[d][3 * H:4 * H]], 0) if bsum is not None else \
+                            torch.cat([dBih[d * GH:d * GH + 2 * H], ops.colsum(rg.dQ[d].reshape(R, H))], 0)
                     else:
-                        dGH_T = dGI_T[d * GH:(d + 1) * GH]
-                        dBhh = dBih[d * GH:(d + 1) * GH]
-                    dWhh = ops.gemm_nt(dGH_T, Hp_T, out_dtype=torch.float32, M=GH, N=H, K=ldT, lda=ldT, ldb=ldT,
-                                       splitk=_wgrad_splitk(GH, H, ldT), coresident=True)
+                        if kind == "gru":
+                            dGH_T = ops.transpose(rg.dGH[d].reshape(R, GH))    # [G*H][ldT]
+                            dBhh = ops.colsum(rg.dGH[d].reshape(R, GH))
+                        else:
+                            dGH_T = dGI_T[d * GH:(d + 1) * GH]
+                            dBhh = dBih[d * GH:(d + 1) * GH]
+                        dWhh = ops.gemm_nt(dGH_T, Hp_T, out_dtype=torch.float32, M=GH, N=H, K=ldT, lda=ldT, ldb=ldT,
+                                           splitk=_wgrad_splitk(GH, H, ldT), coresident=True)
                     grads[po + 4 * d:po + 4 * d + 4] = [dWih[d * GH:(d + 1) * GH].contiguous(), dWhh,
                                                         dBih[d * GH:(d + 1) * GH].contiguous(), dBhh.contiguous()]
                 del dGI_T

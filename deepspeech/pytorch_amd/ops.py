@@ -280,24 +280,40 @@ def rnn_fwd(kind, GI, Whh, bhh, lens, D, N, H, Tp, h0=None, c0=None, save=True):
     return hext, Sv, hn, cn
 
 
+class RnnGrads:
+    """What a BPTT sweep hands to the weight-gradient stage.  dGI [Tp*N][D*G*H]: gradient of the input projection (= of the
+    hidden-side pre-activations too, except the GRU's n slot).  GRU only: either dGH [D][Tp][N][3H] (per-time-step kernels: the
+    full hidden-side gradient [dr, dz, dQ]) or dQ [D][Tp][N][H] (persistent kernels: only the slot that differs from dGI).
+    bacc [D][N][NB*H] f32 or None: per-sample sums over time of the gate-gradient planes (persistent kernels)."""
+    __slots__ = ("dGI", "dGH", "dQ", "bacc")
+
+    def __init__(self, dGI, dGH=None, dQ=None, bacc=None):
+        self.dGI, self.dGH, self.dQ, self.bacc = dGI, dGH, dQ, bacc
+
+    def tensors(self):
+        return [t for t in (self.dGI, self.dGH, self.dQ, self.bacc) if t is not None]
+
+
 def rnn_bwd(kind, dOut, WhhT, hext, Sv, lens, D, N, H, Tp):
     dev, dtype = dOut.device, dOut.dtype
     G = GATES[kind]
     dGI = torch.empty((Tp * N, D * G * H), dtype=dtype, device=dev)
-    dGH = torch.empty((D, Tp, N, G * H), dtype=dtype, device=dev) if kind == "gru" else None
     if use_persistent(kind, dtype, D, N, H):
+        dQ = torch.empty((D, Tp, N, H), dtype=dtype, device=dev) if kind == "gru" else None
+        bacc = torch.empty((D, N, (4 if kind == "gru" else G) * H), dtype=torch.float32, device=dev)
         ws = torch.empty(query("ds2_rnn_persist_ws_bytes", dt(dtype), CELLS[kind], D, N, H), dtype=torch.uint8, device=dev)
         global LAST_PERSIST_WS
         LAST_PERSIST_WS = ws
         with _sweep_timer("rnn_bwd_persistent", Tp):
             call("ds2_rnn_persist_bwd", dt(dtype), CELLS[kind], D, N, H, Tp, P(lens), P(dOut), P(WhhT), P(hext[:, 1]), (Tp + 2) * N * H,
-                 P(Sv), P(dGI), P(dGH), P(ws), P(_persist_err(dev)), S())
-        return dGI, dGH
+                 P(Sv), P(dGI), P(dQ), P(bacc), P(ws), P(_persist_err(dev)), S())
+        return RnnGrads(dGI, dQ=dQ, bacc=bacc)
+    dGH = torch.empty((D, Tp, N, G * H), dtype=dtype, device=dev) if kind == "gru" else None
     state = torch.empty(query("ds2_rnn_state_bytes", D, N, H), dtype=torch.uint8, device=dev)
     with _sweep_timer("rnn_bwd", Tp):
         call("ds2_rnn_bwd", dt(dtype), CELLS[kind], D, N, H, Tp, P(lens), P(dOut), P(WhhT), P(hext[:, 1]), (Tp + 2) * N * H,
              P(Sv), P(dGI), P(dGH), P(state), S())
-    return dGI, dGH
+    return RnnGrads(dGI, dGH=dGH)
 
 
 # ---------------------------------------------------------------------------------------------------------------

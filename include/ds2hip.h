@@ -121,8 +121,11 @@ long ds2_rnn_persist_ws_bytes(int dtype, int cell, int D, int N, int H);
 int ds2_rnn_persist_fwd(int dtype, int cell, int D, int N, int H, int Tp, const int* lens, const void* GI, const void* Whh,
                         const float* bhh, const float* h0, const float* c0, void* Hseq, long hseq_dstride, void* S, float* hn,
                         float* cn, void* ws, int* err, ds2_stream_t stream);
+/* BPTT: dGI as ds2_rnn_bwd; GRU: dQ [D][Tp][N][H] = dn*r (the one slot of the hidden-side gate gradient [dr,dz,dQ] that differs
+ * from dGI's; null for LSTM / RNN); dBacc [D][N][NB*H] f32 (may be null): per-sample sums over time of the stored gate-gradient
+ * planes (NB = 4 for GRU: dr, dz, dn, dQ; G otherwise) -- the bias gradients are their sums over the samples. */
 int ds2_rnn_persist_bwd(int dtype, int cell, int D, int N, int H, int Tp, const int* lens, const void* dOut, const void* WhhT,
-                        const void* Hseq, long hseq_dstride, const void* S, void* dGI, void* dGH, void* ws, int* err,
+                        const void* Hseq, long hseq_dstride, const void* S, void* dGI, void* dQ, float* dBacc, void* ws, int* err,
                         ds2_stream_t stream);
 
 /* ---- small sequence ops ---------------------------------------------------------------------------------------------------

@@ -388,15 +388,23 @@ def _rnn_sweep_case(dtype, kind, D, N, H, Tp, wscale):
     dout = rs.standard_normal((Tp, N, H))
     dout_r = rnd(dout, dtype)
     WhhT = cu(Whh.transpose(0, 2, 1), dtype)
-    dGI, dGH = o.rnn_bwd(kind, cu(dout, dtype), WhhT, hext, Sv, lens_d, D, N, H, Tp)
-    dgi = np64(dGI).reshape(Tp, N, D, G * H)
+    rg = o.rnn_bwd(kind, cu(dout, dtype), WhhT, hext, Sv, lens_d, D, N, H, Tp)
+    dgi = np64(rg.dGI).reshape(Tp, N, D, G * H)
     for d in range(D):
         dx, dwi, dwh, dbi, dbh = O.rnn_dir_bwd(caches[d], dout_r, np.eye(G * H), Whh_r[d])
         # with W_ih = I the oracle's dx IS d loss / d GI
         scale = max(np.abs(dx).max(), 1e-6)
         assert np.abs(dgi[:, :, d] - dx).max() / scale < tol * (1 if dtype == torch.float32 else 3), (kind, d)
-        if kind == "gru":
-            assert relerr(np64(dGH[d]).reshape(Tp * N, G * H).sum(0), dbh) < tol * 4
+        # bias gradients: from the sweep's per-sample sums (persistent kernels) or the column sums of the stored planes
+        if rg.bacc is not None:
+            b = np64(rg.bacc[d]).sum(0)
+            assert relerr(b[:G * H], dbi) < tol * 4, (kind, d, "bias_ih")
+            got_bh = np.concatenate([b[:2 * H], b[3 * H:4 * H]]) if kind == "gru" else b[:G * H]
+            assert relerr(got_bh, dbh) < tol * 4, (kind, d, "bias_hh")
+            if kind == "gru":     # the stored dQ plane sums to the same thing
+                assert relerr(np64(rg.dQ[d]).reshape(Tp * N, H).sum(0), dbh[2 * H:]) < tol * 4
+        elif kind == "gru":
+            assert relerr(np64(rg.dGH[d]).reshape(Tp * N, G * H).sum(0), dbh) < tol * 4
     return got, np64(hn_d), dgi
 
 

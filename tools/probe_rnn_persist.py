@@ -47,7 +47,7 @@ for mask in masks:
       if it == 2:
           torch.cuda.synchronize()
           dbg("fwd")
-      dGI, dGH = ops.rnn_bwd(kind, dout, WhhT, hext, Sv, lens, D, N, H, Tp)
+      rg = ops.rnn_bwd(kind, dout, WhhT, hext, Sv, lens, D, N, H, Tp)
       e[2].record()
       torch.cuda.synchronize()
       print("iter %d: fwd %.3f ms (%.2f us/step)  bwd %.3f ms (%.2f us/step)" % (
