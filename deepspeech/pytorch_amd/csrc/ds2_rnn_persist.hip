@@ -83,8 +83,10 @@ bool plan2(int dtype, int cell, int D, int N, int H, Plan2& pl) {
 long xbuf2_bytes(int dtype, int cell, int H, const Plan2& pl, bool bwd) {
   const int ksz = dtype == DS2_BF16 ? 32 : 16;
   const long kt = (bwd ? (long)gates(cell) * H : (long)H) / ksz;
-  // MT >= 2: tag-free payload (1024 B per k-step and m-tile) + 512 B of per-workgroup flags per group; else tagged granules
-  return pl.MT >= 2 ? (long)pl.NG * (2 * kt * pl.MT * 1024 + 512) : (long)pl.NG * 2 * kt * pl.MT * 2048;
+  // large batch: tag-free payload (1024 B per k-step and m-tile) + 512 B of per-workgroup flags per group; else tagged granules
+  // (forward: from 4 m-tiles on, BPTT: from 2 -- must mirror FLAGS in ds2_rnn_persist2_impl.h)
+  const bool flags = bwd ? pl.MT >= 2 : pl.MT >= 4;
+  return flags ? (long)pl.NG * (2 * kt * pl.MT * 1024 + 512) : (long)pl.NG * 2 * kt * pl.MT * 2048;
 }
 
 }  // namespace

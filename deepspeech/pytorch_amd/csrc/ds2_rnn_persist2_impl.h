@@ -358,7 +358,8 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_fwd(QArgs a) {
   constexpr int KSZ = X::KSZ, KT = H / KSZ, KSW = (KT + 3) / 4;
   constexpr bool RAGGED = KT % 4 != 0;
   constexpr int IT = Items<MT>::PER_THREAD;
-  constexpr bool FLAGS = MT >= 2;                          // large batch: tag-free payload + per-workgroup flags
+  constexpr bool FLAGS = MT >= 4;                          // large batch: tag-free payload + per-workgroup flags (measured: with
+                                                           // 22 samples per group the forward is faster with tags, 5.0 vs 5.7 us per step)
   static_assert(!FLAGS || sizeof(T) == 2, "the flag exchange is instantiated for bf16 storage");
   constexpr int PAR_BYTES = KT * MT * (FLAGS ? 1024 : 2048);
   static_assert(H % KSZ == 0 && H % 16 == 0, "unsupported hidden size");
