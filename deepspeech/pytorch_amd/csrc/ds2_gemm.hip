@@ -342,13 +342,168 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16_glds(GemmArgs g) {
 }
 
 
+// ------------------------------------------------------------------------------------------------------------------
+// Large-tile variant of the DMA-staged kernel for the big GEMMs of the step (input projections, dX): TBM x TBN tile per
+// workgroup of 8 or 16 waves (WM x WN, each wave (TBM/WM) x (TBN/WN) = MI x NJ MFMA 32x32 accumulators), ONE workgroup
+// per CU, same two-stage global_load_lds pipeline and XOR-swizzled 128-byte rows.  Against the 128x128 tile: 2-4x the MFMA work
+// per staged byte (L2 -> LDS traffic per flop halves) and per barrier.  Same contract (K % 64 == 0, 16-byte aligned rows).
+// ------------------------------------------------------------------------------------------------------------------
+template <int TBM, int TBN, int WM, int WN>
+__global__ void __launch_bounds__(WM * WN * 64, WM * WN / 4) k_gemm_nt_bf16_big(GemmArgs g) {
+  constexpr int KT = 64, ROW = 128, NW = WM * WN;
+  constexpr int STAGE = (TBM + TBN) * ROW;
+  constexpr int MI = TBM / WM / 32, NJ = TBN / WN / 32;
+  constexpr int RA = TBM / NW, RB = TBN / NW;            // tile rows each wave stages (8 rows = 1 KiB per DMA instruction)
+  static_assert((NW == 8 || NW == 16) && RA % 8 == 0 && RB % 8 == 0 && MI >= 1 && NJ >= 1, "tile / wave decomposition");
+  __shared__ __attribute__((aligned(16))) unsigned char stage0[STAGE];
+  __shared__ __attribute__((aligned(16))) unsigned char stage1[STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int gx = gridDim.x, nblk = gridDim.x * gridDim.y;
+  int id = blockIdx.y * gx + blockIdx.x;
+  {
+    const int q = nblk / 8, r = nblk % 8, xcd = id % 8, k = id / 8;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int bx = id % gx, by = id / gx;
+  const int batch = blockIdx.z;
+  const bf16_t* A = (const bf16_t*)g.A + (long)batch * g.sA;
+  const bf16_t* B = (const bf16_t*)g.B + (long)batch * g.sB;
+  const int m0 = by * TBM, n0 = bx * TBN;
+  const int kt_end = g.K / KT;
+
+  ds2_f32x16 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int r_in = lane >> 3, slot = lane & 7;
+  // per-lane source offsets in ELEMENTS from the (uniform) operand base: 32-bit, half the registers of pointers (the host
+  // checks that the operands span < 2^31 elements)
+  int a_off[RA / 8], b_off[RB / 8];
+#pragma unroll
+  for (int j = 0; j < RA / 8; ++j) {
+    const int r = wave * RA + j * 8 + r_in;
+    a_off[j] = (int)((long)min(m0 + r, g.M - 1) * g.lda) + (slot ^ ((r >> 1) & 7)) * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < RB / 8; ++j) {
+    const int r = wave * RB + j * 8 + r_in;
+    b_off[j] = (int)((long)min(n0 + r, g.N - 1) * g.ldb) + (slot ^ ((r >> 1) & 7)) * 8;
+  }
+  auto dma = [&](unsigned char* st, int kt) {
+    unsigned char* sa = st + wave * RA * ROW;
+    unsigned char* sb = st + TBM * ROW + wave * RB * ROW;
+    const bf16_t* Ak = A + kt * KT;
+    const bf16_t* Bk = B + kt * KT;
+#pragma unroll
+    for (int j = 0; j < RA / 8; ++j) __builtin_amdgcn_global_load_lds((glb_ptr_t)(Ak + a_off[j]), (lds_ptr_t)(sa + j * 8 * ROW), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < RB / 8; ++j) __builtin_amdgcn_global_load_lds((glb_ptr_t)(Bk + b_off[j]), (lds_ptr_t)(sb + j * 8 * ROW), 16, 0, 0);
+  };
+  const int li = lane & 31, lq = lane >> 5;
+  const int key = (li >> 1) & 7;
+  auto compute = [&](const unsigned char* st) {
+    const unsigned char* sa = st + (wm * (TBM / WM) + li) * ROW;
+    const unsigned char* sb = st + TBM * ROW + (wn * (TBN / WN) + li) * ROW;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (MI * NJ >= 8 && c > 0) __builtin_amdgcn_sched_barrier(0);   // keep the fragment reads of one k-step at a time live (256-register cap)
+      const int off = ((2 * c + lq) ^ key) * 16;
+      uint4 a[MI], b[NJ];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const uint4*>(sa + i * 32 * ROW + off);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const uint4*>(sb + j * 32 * ROW + off);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) Mma<bf16_t>::mma32(acc[i][j], b[j], a[i]);   // operands swapped: see k_gemm_nt_bf16_glds
+    }
+  };
+  if (kt_end > 0) dma(stage0, 0);
+  for (int kt = 0; kt < kt_end;) {
+    __syncthreads();
+    if (kt + 1 < kt_end) dma(stage1, kt + 1);
+    compute(stage0);
+    if (++kt >= kt_end) break;
+    __syncthreads();
+    if (kt + 1 < kt_end) dma(stage0, kt + 1);
+    compute(stage1);
+    ++kt;
+  }
+
+  const float* bias = g.bias ? g.bias + (long)batch * g.sBias : nullptr;
+  const bool n_vec_ok = (g.ldc % 4 == 0);
+  // the epilogue's address arithmetic must not be hoisted above the K loop (it would sit in registers the accumulators need):
+  // route the lane coordinates through an opaque move after the loop
+  int eli = li, elq = lq;
+  asm volatile("" : "+v"(eli), "+v"(elq));
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int row = m0 + wm * (TBM / WM) + i * 32 + eli;
+    if (row >= g.M) continue;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = n0 + wn * (TBN / WN) + j * 32 + 8 * q + 4 * elq;
+        if (col >= g.N) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] + ((bias && col + e < g.N) ? bias[col + e] : 0.f);
+        const long off = (long)batch * g.sC + (long)row * g.ldc + col;
+        if (g.out_is_f32) {
+          float* cp = (float*)g.C + off;
+          if (col + 3 < g.N && n_vec_ok) {
+            *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (col + e < g.N) cp[e] = v[e];
+          }
+        } else {
+          bf16_t* cp = (bf16_t*)g.C + off;
+          if (col + 3 < g.N && n_vec_ok) {
+            uint2 pk;
+            pk.x = cvt_pk_bf16(v[0], v[1]);
+            pk.y = cvt_pk_bf16(v[2], v[3]);
+            *reinterpret_cast<uint2*>(cp) = pk;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (col + e < g.N) stf(cp + e, v[e]);
+          }
+        }
+      }
+    }
+  }
+}
+
+// tile choice for the large-tile kernel: 0 = use the 128x128 kernel.  (Measured on the step's shapes, tools/bench_gemm.py.)
+int big_tile_variant(int M, int N, int K) {
+  static int forced = -2;
+  if (forced == -2) {
+    const char* e = getenv("DS2_GEMM_TILE");    // tuning knob of tools/bench_gemm.py only: selects a kernel, never skips work
+    forced = e ? atoi(e) : -1;
+  }
+  if (forced >= 0) return forced;
+  if (M < 1024 || K < 256 || (long)M * K >= (1L << 31) || (long)N * K >= (1L << 31)) return 0;
+  if (N >= 2048) return 1;                       // 256 x 256
+  if (N >= 512) return 2;                        // 256 x 128
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
 
 // C (f32 if out_f32 else `dtype`) [M][ldc] = A[M][lda] * B[N][ldb]^T (+bias[N]); batched over `batch` with element strides.
-// K, lda, ldb must be multiples of 16 bytes / sizeof(T); A/B 16-byte aligned.  splitk>1 requires out_f32 and a
-// zero-initialised C (results are atomically accumulated).
+// K, lda, ldb must be multiples of 16 bytes / sizeof(T); A/B 16-byte aligned.  splitk>1 requires out_f32; C is zeroed here
+// (memset nodes on the stream) and the K-slices are atomically accumulated.
 static int gemm_nt_impl(int dtype, const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long lda,
                         long ldb, long ldc, int out_f32, int batch, long strideA, long strideB, long strideC, long strideBias,
                         int splitk, bool coresident, ds2_stream_t st_) {
@@ -362,6 +517,12 @@ static int gemm_nt_impl(int dtype, const void* A, const void* B, void* C, const 
   GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, strideA, strideB, strideC, strideBias, splitk, out_f32 || dtype == DS2_F32};
   dim3 grid(ds2_cdiv(N, BN), ds2_cdiv(M, BM), batch * splitk), blk(256);
   const size_t shm = 2 * STAGE_BYTES;
+  if (splitk > 1) {
+    for (int b = 0; b < batch; ++b) {
+      hipError_t e = hipMemset2DAsync((float*)C + (long)b * strideC, (size_t)ldc * 4, 0, (size_t)N * 4, (size_t)M, st);
+      if (e != hipSuccess) return (int)e;
+    }
+  }
   if (dtype == DS2_F32) {
     static bool attr_f[DS2_MAX_DEVICES];
     if (ds2_first_use_on_device(attr_f)) (void)hipFuncSetAttribute((const void*)k_gemm_nt<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
@@ -369,7 +530,12 @@ static int gemm_nt_impl(int dtype, const void* A, const void* B, void* C, const 
   } else if (splitk == 1 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0) {
     // (split-K accumulates with atomics: the register-staged kernel below keeps them coalesced along n)
     g.out_is_f32 = out_f32;
-    if (coresident) {
+    const int big = coresident ? 0 : big_tile_variant(M, N, K);
+    if (big == 1) {
+      hipLaunchKernelGGL((k_gemm_nt_bf16_big<256, 256, 2, 4>), dim3(ds2_cdiv(N, 256), ds2_cdiv(M, 256), batch), dim3(512), 0, st, g);
+    } else if (big == 2) {
+      hipLaunchKernelGGL((k_gemm_nt_bf16_big<256, 128, 4, 2>), dim3(ds2_cdiv(N, 128), ds2_cdiv(M, 256), batch), dim3(512), 0, st, g);
+    } else if (coresident) {
       static bool attr_lr[DS2_MAX_DEVICES];
       const size_t shm_lr = 2 * (BM + BN) * 128;
       if (ds2_first_use_on_device(attr_lr))

@@ -442,6 +442,13 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_fwd(QArgs a) {
   }
   const long gi_stride = dstep * N * ldgi, sv_stride = dstep * N * NSH_, hs_stride = dstep * N * H;
   bool dead = false;
+#pragma unroll
+  for (int it = 0; it < IT; ++it)
+    if (on[it]) {   // zero guard slots of the state sequence at t = -1 and t = T' ("previous h" reads are unconditional)
+      T* hb = (T*)a.Hseq + (long)d * a.hseq_dstride + (long)it_n[it] * H + it_j[it];
+      X::st(hb - (long)N * H, 0.f, 0.f);
+      X::st(hb + (long)Tp * N * H, 0.f, 0.f);
+    }
   if (a.h0) {   // initial state as "step -1": parity 1, tag TAG_INIT
 #pragma unroll
     for (int it = 0; it < IT; ++it)

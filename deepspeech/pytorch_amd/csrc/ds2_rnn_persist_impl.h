@@ -370,6 +370,11 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd(PArgs a) {
   const long hs_stride = dstep * N * H;
   bool dead = false;
   const bool local = group_is_xcd_local(a.xcc + grp * 32, p, tid, a.err, a.lerr, dead);
+  if (gate_thread) {         // zero guard slots of the state sequence at t = -1 and t = T' ("previous h" reads are unconditional)
+    bf16_t* hb = a.Hseq + (long)d * a.hseq_dstride + (long)n * H + j;
+    *reinterpret_cast<uint32_t*>(hb - (long)N * H) = 0u;
+    *reinterpret_cast<uint32_t*>(hb + (long)Tp * N * H) = 0u;
+  }
   if (gate_thread && a.h0)   // initial state as "step -1": parity 1, tag TAG_INIT
     publish((u64*)((char*)xg + PAR_BYTES + xgranule_bytes<NROWS>(j, gi_i)), ((u64)TAG_INIT << 32) | pack_bf16x2(hprev0, hprev1), local);
   unsigned rounds = 0;

@@ -195,6 +195,65 @@ __global__ void __launch_bounds__(256) k_cast_transpose(const float* __restrict_
   o[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
+// Kernel layouts of the small weights, all in one launch (what the conv / head stages need every step after the optimizer moved
+// the fp32 parameters): conv1 tap-major, conv2 tap-major (forward) and the two flipped row-parity sub-kernels (dgrad), the head
+// weight zero-padded to 32 classes and its transpose.  Flat index over the concatenated outputs.
+struct SmallLayouts {
+  const float *w1, *w2, *wfc;     // conv.seq_module.0.weight (32,1,41,11), conv.seq_module.3.weight (32,32,21,11), fc weight (C,H)
+  int C, H;
+  float* w1k;                     // [451][32] f32: w1k[k][c] = w1[c][k]
+  void* w2t;                      // [21][11][32 co][32 ci]  (T)
+  void* w2d0;                     // [11][11][32 ci][32 co]  (T): rows kh = 0,2,..,20 flipped, columns flipped
+  void* w2d1;                     // [10][11][32 ci][32 co]  (T): rows kh = 1,3,..,19 flipped
+  void* wfcp;                     // [32][H] (T), rows >= C zero
+  void* wfcT;                     // [H][32] (T)
+};
+template <typename T>
+__global__ void __launch_bounds__(256) k_small_layouts(SmallLayouts a) {
+  const long n1 = 451 * 32, n2 = 231L * 1024, n3 = 121L * 1024, n4 = 110L * 1024, n5 = 32L * a.H, n6 = 32L * a.H;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n1 + n2 + n3 + n4 + n5 + n6; i += (long)gridDim.x * 256) {
+    long e = i;
+    if (e < n1) {
+      const int k = (int)(e / 32), c = (int)(e % 32);
+      a.w1k[e] = a.w1[c * 451 + k];
+      continue;
+    }
+    e -= n1;
+    if (e < n2) {
+      const int ci = (int)(e % 32), co = (int)((e / 32) % 32), tap = (int)(e / 1024);     // tap = kh*11 + kw
+      stf((T*)a.w2t + e, a.w2[((long)co * 32 + ci) * 231 + tap]);
+      continue;
+    }
+    e -= n2;
+    if (e < n3 + n4) {
+      const int q = e < n3 ? 0 : 1;
+      const long f = q ? e - n3 : e;
+      const int KHq = q ? 10 : 11;
+      const int co = (int)(f % 32), ci = (int)((f / 32) % 32), b = (int)((f / 1024) % 11), r = (int)(f / (1024 * 11));
+      const int kh = q + 2 * (KHq - 1 - r), kw = 10 - b;
+      stf((T*)(q ? a.w2d1 : a.w2d0) + f, a.w2[((long)co * 32 + ci) * 231 + kh * 11 + kw]);
+      continue;
+    }
+    e -= n3 + n4;
+    if (e < n5) {
+      const int c = (int)(e / a.H), h = (int)(e % a.H);
+      stf((T*)a.wfcp + e, c < a.C ? a.wfc[(long)c * a.H + h] : 0.f);
+      continue;
+    }
+    e -= n5;
+    {
+      const int h = (int)(e / 32), c = (int)(e % 32);
+      stf((T*)a.wfcT + e, c < a.C ? a.wfc[(long)c * a.H + h] : 0.f);
+    }
+  }
+}
+
+// x[i] *= *s  (upstream gradient of the summed CTC loss, model.py:248, applied to the gradient computed with the loss)
+__global__ void __launch_bounds__(256) k_scale_by(float* __restrict__ x, const float* __restrict__ s, long n) {
+  const float v = *s;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) x[i] *= v;
+}
+
 inline int ew_grid(long n) {
   long g = (n + 255) / 256;
   if (g > 2048) g = 2048;
@@ -255,6 +314,29 @@ int ds2_cast_transpose_bf16(const float* src, long lds_, int R, int C, int perm_
   if (dstT != nullptr) DS2_REQUIRE(lddT >= R && lddT % 8 == 0 && ((uintptr_t)dstT & 15) == 0, DS2_ERR_ALIGN);
   hipLaunchKernelGGL(k_cast_transpose, dim3(ds2_cdiv(Cout, 64), ds2_cdiv(R, 64)), dim3(256), 0, st, src, lds_, R, C, perm_c,
                      perm_f, Cout, (uint16_t*)dst, ldd, (uint16_t*)dstT, lddT);
+  DS2_CHECK_LAUNCH();
+  return 0;
+}
+
+int ds2_small_weight_layouts(int dtype, const float* w1, const float* w2, const float* wfc, int C, int H, float* w1k, void* w2t,
+                             void* w2d0, void* w2d1, void* wfcp, void* wfcT, ds2_stream_t st_) {
+  hipStream_t st = (hipStream_t)st_;
+  DS2_REQUIRE(dtype == DS2_F32 || dtype == DS2_BF16, DS2_ERR_DTYPE);
+  DS2_REQUIRE(w1 && w2 && wfc && w1k && w2t && w2d0 && w2d1 && wfcp && wfcT && C > 0 && C <= 32 && H > 0, DS2_ERR_ARG);
+  SmallLayouts a{w1, w2, wfc, C, H, w1k, w2t, w2d0, w2d1, wfcp, wfcT};
+  const long total = 451 * 32 + 231L * 1024 + 231L * 1024 + 64L * H;
+  if (dtype == DS2_F32)
+    hipLaunchKernelGGL(k_small_layouts<float>, dim3(ew_grid(total)), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(k_small_layouts<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, st, a);
+  DS2_CHECK_LAUNCH();
+  return 0;
+}
+
+int ds2_scale_by(float* x, const float* s, long n, ds2_stream_t st_) {
+  hipStream_t st = (hipStream_t)st_;
+  DS2_REQUIRE(x && s && n > 0, DS2_ERR_ARG);
+  hipLaunchKernelGGL(k_scale_by, dim3(ew_grid(n)), dim3(256), 0, st, x, s, n);
   DS2_CHECK_LAUNCH();
   return 0;
 }

@@ -264,8 +264,7 @@ class _RnnStackFn(torch.autograd.Function):
                 return w.to(dtype).contiguous()
             Wih = c.get(("wih", li, dtype), wih, build_ih)
             Whh = c.get(("whh", li, dtype), whh, lambda whh=whh: torch.stack([p.detach() for p in whh], 0).to(dtype).contiguous())
-            Bih = c.get(("bih", li), bih, lambda bih=bih: torch.cat([p.detach() for p in bih], 0).contiguous())
-            Bhh = c.get(("bhh", li), bhh, lambda bhh=bhh: torch.stack([p.detach() for p in bhh], 0).contiguous())
+            Bih, Bhh = mod._bias_views(li)
             sv, Xh = None, X
             if has_bn:
                 bn = layer.batch_norm.module
@@ -375,7 +374,7 @@ class _RnnStackFn(torch.autograd.Function):
                         # hidden-side gate gradient = [dr, dz (rows of dGI^T), dQ]: two GEMMs into the row blocks of dW_hh
                         dQ_T = ops.transpose(rg.dQ[d].reshape(R, H))   # [H][ldT]
                         sk = _wgrad_splitk(H, H, ldT)
-                        dWhh = (torch.zeros if sk > 1 else torch.empty)((GH, H), dtype=torch.float32, device=dGI.device)
+                        dWhh = torch.empty((GH, H), dtype=torch.float32, device=dGI.device)
                         ops.gemm_nt(dGI_T[d * GH:d * GH + 2 * H], Hp_T, out_dtype=torch.float32, M=2 * H, N=H, K=ldT, lda=ldT, ldb=ldT,
                                     out=dWhh, ldc=H, splitk=sk, coresident=True)
                         ops.gemm_nt(dQ_T, Hp_T, out_dtype=torch.float32, M=H, N=H, K=ldT, lda=ldT, ldb=ldT, out=dWhh[2 * H:], ldc=H,
@@ -536,15 +535,18 @@ class _CtcFn(torch.autograd.Function):
         if N > 1:
             offs[1:] = torch.cumsum(tsz, 0)[:-1]
         max_tl = int(tsz.max().item()) if N > 0 else 0
-        loss, nll, dl = ops.ctc_loss_grad(logits, targets.to(dev, torch.int32), offs.to(dev, torch.int32), out_lens_dev,
-                                          tsz.to(dev, torch.int32), Tp, N, Cc, blank, max_tl)
+        # one host staging buffer, one host-to-device copy: [target offsets | target sizes | targets] as int32
+        tg = targets.cpu() if targets.is_cuda else targets
+        meta = torch.cat([offs.to(torch.int32), tsz.to(torch.int32), tg.reshape(-1).to(torch.int32)]).to(dev, non_blocking=True)
+        loss, nll, dl = ops.ctc_loss_grad(logits, meta[2 * N:], meta[:N], out_lens_dev, meta[N:2 * N], Tp, N, Cc, blank, max_tl)
         ctx.save_for_backward(dl)
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, g):
         (dl,) = ctx.saved_tensors
-        return dl * g, None, None, None, None, None, None, None
+        # the gradient was computed with the loss for a unit upstream gradient; scale it in place (backward runs once per forward)
+        return ops.scale_by_(dl, g.detach().float()), None, None, None, None, None, None, None
 
 
 class InferenceBatchSoftmax(nn.Module):  # model.py:72-77: identity in train mode, softmax over the classes in eval mode
@@ -640,6 +642,7 @@ class DeepSpeech(_Base):
         self.evaluation_decoder = GreedyDecoder(self.labels, blank_index=self.blank_index)   # arg-max + collapse on the device
         self.wer, self.cer = _reference_metrics(self.evaluation_decoder)
         self._cache = _WeightCache()
+        self._flat_bias = {}
         self._side_streams = {}
         self._prep_done = None
         self._weights_dirty = False
@@ -689,12 +692,47 @@ class DeepSpeech(_Base):
                 return _perm_cols_to_internal(w) if first else w
             c.get(("wih", li, dtype), wih, lambda: cat_ih().to(dtype).contiguous())
             c.get(("whh", li, dtype), whh, lambda whh=whh: torch.stack([q.detach() for q in whh], 0).to(dtype).contiguous())
-            c.get(("bih", li), bih, lambda bih=bih: torch.cat([q.detach() for q in bih], 0).contiguous())
-            c.get(("bhh", li), bhh, lambda bhh=bhh: torch.stack([q.detach() for q in bhh], 0).contiguous())
+            self._bias_views(li)
             if need_backward:
                 c.get(("whhT", li, dtype), list(whh),
                       lambda whh=whh: torch.stack([q.detach().t() for q in whh], 0).to(dtype).contiguous())
                 c.get(("wihT", li, dtype), list(wih), lambda: cat_ih().t().to(dtype).contiguous())
+
+    def _bias_views(self, li):
+        """(bias_ih of all directions [D*G*H], bias_hh [D][G*H]) as VIEWS of the parameters: the directions' bias vectors of a
+        layer share one flat storage (set up here, like nn.RNNBase.flatten_parameters does for cuDNN/MIOpen; re-done if a
+        .to() / load replaced the tensors), so no per-step concatenation is needed and in-place optimizer updates are seen."""
+        layer = self.rnns[li]
+        p, D = layer.rnn, layer.num_directions
+        sufs = [""] + (["_reverse"] if D == 2 else [])
+        out = []
+        for name in ("bias_ih_l0", "bias_hh_l0"):
+            ps = [getattr(p, name + s_) for s_ in sufs]
+            n = ps[0].numel()
+            key = (li, name)
+            flat = self._flat_bias.get(key)
+            ok = flat is not None and all(q.data_ptr() == flat.data_ptr() + 4 * n * i and q.is_contiguous() for i, q in enumerate(ps))
+            if not ok:
+                with torch.no_grad():
+                    flat = torch.cat([q.detach().reshape(-1) for q in ps]).contiguous()
+                    for i, q in enumerate(ps):
+                        q.data = flat[i * n:(i + 1) * n]
+                self._flat_bias[key] = flat
+            out.append(flat)
+        return out[0], out[1].view(D, -1)
+
+    def _prep_small_weights(self, dtype):
+        """conv / head weights in kernel layout: one launch when the parameters changed (every training step)."""
+        c = self._cache
+        sm, fcw = self.conv.seq_module, self.fc[0].module[1].weight
+        w1, w2 = sm[0].weight, sm[3].weight
+        keys = (("w1k", [w1]), (("w2t", dtype), [w2]), (("w2d", dtype), [w2]), (("wfc", dtype), [fcw]), (("wfcT", dtype), [fcw]))
+        if all(c.valid(k, ps) for k, ps in keys):
+            return
+        with torch.no_grad():
+            vals = ops.small_weight_layouts(w1.detach().contiguous(), w2.detach().contiguous(), fcw.detach().contiguous(), dtype)
+        for (k, ps), v in zip(keys, vals):
+            c.put(k, ps, v)
 
     def _wgrad_stream(self, device):
         """Second HIP stream of this module on `device` (weight-gradient work of the RNN stack's backward)."""
@@ -735,6 +773,7 @@ class DeepSpeech(_Base):
         sm = self.conv.seq_module
         with torch.autocast("cuda", enabled=False):
             # weight re-layouts for the RNN stack: second stream, hidden under the conv front-end
+            self._prep_small_weights(dtype)
             main, side = torch.cuda.current_stream(), self._wgrad_stream(dev)
             side.wait_stream(main)
             ready = getattr(self, "_layouts_ready", None)

@@ -87,7 +87,7 @@ def gemm_nt(A, B, bias=None, out_dtype=None, M=None, N=None, K=None, lda=None, l
     out_dtype = out_dtype or A.dtype
     if out is None:
         shape = (batch, M, N) if batch > 1 else (M, N)
-        out = (torch.zeros if splitk > 1 else torch.empty)(shape, dtype=out_dtype, device=A.device)
+        out = torch.empty(shape, dtype=out_dtype, device=A.device)       # split-K: the entry zeroes C itself
         ldc = N
         sC = M * N
     out_f32 = 1 if out.dtype == torch.float32 else 0
@@ -124,6 +124,25 @@ def cast_transpose_bf16(src, dst=None, ldd=0, dstT=None, lddT=0, perm=None, cout
     pc, pf = perm if perm is not None else (0, 0)
     call("ds2_cast_transpose_bf16", PF(src), src.stride(0), R, Cc, pc, pf, Cc if cout is None else cout,
          P(dst) if dst is not None else None, ldd, P(dstT) if dstT is not None else None, lddT, S())
+
+
+def small_weight_layouts(w1, w2, wfc, dtype):
+    """(w1k, w2t, [w2d_even, w2d_odd], wfc_padded, wfcT) in kernel layout from the fp32 parameters -- one launch."""
+    dev, Cc, H = w1.device, wfc.shape[0], wfc.shape[1]
+    w1k = torch.empty((451, 32), dtype=torch.float32, device=dev)
+    w2t = torch.empty((21, 11, 32, 32), dtype=dtype, device=dev)
+    w2d0 = torch.empty((11, 11, 32, 32), dtype=dtype, device=dev)
+    w2d1 = torch.empty((10, 11, 32, 32), dtype=dtype, device=dev)
+    wp = torch.empty((32, H), dtype=dtype, device=dev)
+    wpT = torch.empty((H, 32), dtype=dtype, device=dev)
+    call("ds2_small_weight_layouts", dt(dtype), PF(w1), PF(w2), PF(wfc), Cc, H, P(w1k), P(w2t), P(w2d0), P(w2d1), P(wp), P(wpT), S())
+    return w1k, w2t, [w2d0, w2d1], wp, wpT
+
+
+def scale_by_(x, s):
+    """x *= s[0] in place (x f32 contiguous, s a device scalar tensor)."""
+    call("ds2_scale_by", P(x), PF(s.reshape(1)), x.numel(), S())
+    return x
 
 
 def add2(a, b):
@@ -259,13 +278,15 @@ def rnn_fwd(kind, GI, Whh, bhh, lens, D, N, H, Tp, h0=None, c0=None, save=True):
     """Returns (HseqExt [D][Tp+2][N][H] with zero guard slots, S, hn [D,N,H] f32, cn or None)."""
     dev, dtype = GI.device, GI.dtype
     hext = torch.empty((D, Tp + 2, N, H), dtype=dtype, device=dev)
-    hext[:, 0].zero_()
-    hext[:, Tp + 1].zero_()
+    persistent = use_persistent(kind, dtype, D, N, H)
+    if not persistent:                    # the persistent kernels zero the guard slots themselves
+        hext[:, 0].zero_()
+        hext[:, Tp + 1].zero_()
     ns = SAVED_PLANES[kind]
     Sv = torch.empty((D, Tp, N, max(ns, 1) * H) if ns else (1,), dtype=dtype, device=dev)
     hn = torch.empty((D, N, H), dtype=torch.float32, device=dev)
     cn = torch.empty((D, N, H), dtype=torch.float32, device=dev) if kind == "lstm" else None
-    if use_persistent(kind, dtype, D, N, H):
+    if persistent:
         ws = torch.empty(query("ds2_rnn_persist_ws_bytes", dt(dtype), CELLS[kind], D, N, H), dtype=torch.uint8, device=dev)
         global LAST_PERSIST_WS
         LAST_PERSIST_WS = ws

@@ -141,6 +141,14 @@ int ds2_transpose(int dtype, const void* src, void* dst, long R, int C, long lds
  * kernels' [f][c] order; the reference flattens [c][f], model.py:219-220); columns [C, Cout) are zero.  R % 16 == 0. */
 int ds2_cast_transpose_bf16(const float* src, long lds, int R, int C, int perm_c, int perm_f, int Cout, void* dst, long ldd,
                             void* dstT, long lddT, ds2_stream_t stream);
+/* Kernel layouts of the small weights in one launch (the per-step re-layout of conv.seq_module.{0,3}.weight and fc weight after
+ * the optimizer step; model.py:158,161,197): w1k [451][32] f32 = conv1 weight tap-major; w2t [21][11][co][ci] (T) conv2 forward;
+ * w2d0 [11][11][ci][co] / w2d1 [10][11][ci][co] (T) = the flipped even / odd kernel-row sub-kernels of the conv2 data gradient;
+ * wfcp [32][H] (T) = head weight zero-padded to 32 classes, wfcT [H][32] (T) its transpose.
+ * ds2_scale_by: x[i] *= *s (s on the device) -- the upstream gradient of the summed CTC loss. */
+int ds2_small_weight_layouts(int dtype, const float* w1, const float* w2, const float* wfc, int C, int H, float* w1k, void* w2t,
+                             void* w2d0, void* w2d1, void* wfcp, void* wfcT, ds2_stream_t stream);
+int ds2_scale_by(float* x, const float* s, long n, ds2_stream_t stream);
 int ds2_lookahead_fwd(int dtype, const void* x, const float* w, void* y, void* pre, int Tp, int N, int H, int ctx,
                       ds2_stream_t stream);
 long ds2_lookahead_ws_floats(int Tp, int N, int H, int ctx);
