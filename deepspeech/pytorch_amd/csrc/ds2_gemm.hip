@@ -411,7 +411,6 @@ __global__ void __launch_bounds__(WM * WN * 64, WM * WN / 4) k_gemm_nt_bf16_big(
     const unsigned char* sb = st + TBM * ROW + (wn * (TBN / WN) + li) * ROW;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      if (MI * NJ >= 8 && c > 0) __builtin_amdgcn_sched_barrier(0);   // keep the fragment reads of one k-step at a time live (256-register cap)
       const int off = ((2 * c + lq) ^ key) * 16;
       uint4 a[MI], b[NJ];
 #pragma unroll
@@ -483,18 +482,13 @@ __global__ void __launch_bounds__(WM * WN * 64, WM * WN / 4) k_gemm_nt_bf16_big(
   }
 }
 
-// tile choice for the large-tile kernel: 0 = use the 128x128 kernel.  (Measured on the step's shapes, tools/bench_gemm.py.)
+// 1 = use the 256x128 tile.  Measured on the step's shapes (tools/bench_gemm.py, profiles/r02c_gemm_tiles.txt): input projections
+// (M = 24032, N = 6144) 616-660 vs 573-597 TFLOP/s with the 128x128 tile; narrow outputs (N = 1024: dX, weight gradients) are
+// faster on the 128x128 tile (more workgroups in the tail); a 256x256 tile needs 128 accumulator registers per wave, which hipcc
+// duplicates across the two-stage loop (spills) -- rejected.
 int big_tile_variant(int M, int N, int K) {
-  static int forced = -2;
-  if (forced == -2) {
-    const char* e = getenv("DS2_GEMM_TILE");    // tuning knob of tools/bench_gemm.py only: selects a kernel, never skips work
-    forced = e ? atoi(e) : -1;
-  }
-  if (forced >= 0) return forced;
-  if (M < 1024 || K < 256 || (long)M * K >= (1L << 31) || (long)N * K >= (1L << 31)) return 0;
-  if (N >= 2048) return 1;                       // 256 x 256
-  if (N >= 512) return 2;                        // 256 x 128
-  return 0;
+  if (M < 4096 || N < 2048 || K < 256 || (long)M * K >= (1L << 31) || (long)N * K >= (1L << 31)) return 0;
+  return 1;
 }
 
 }  // namespace
@@ -532,8 +526,6 @@ static int gemm_nt_impl(int dtype, const void* A, const void* B, void* C, const 
     g.out_is_f32 = out_f32;
     const int big = coresident ? 0 : big_tile_variant(M, N, K);
     if (big == 1) {
-      hipLaunchKernelGGL((k_gemm_nt_bf16_big<256, 256, 2, 4>), dim3(ds2_cdiv(N, 256), ds2_cdiv(M, 256), batch), dim3(512), 0, st, g);
-    } else if (big == 2) {
       hipLaunchKernelGGL((k_gemm_nt_bf16_big<256, 128, 4, 2>), dim3(ds2_cdiv(N, 128), ds2_cdiv(M, 256), batch), dim3(512), 0, st, g);
     } else if (coresident) {
       static bool attr_lr[DS2_MAX_DEVICES];
