@@ -20,6 +20,7 @@ SIGNATURES = {
     "ds2_error_string": (C.c_char_p, [_i]),
     "ds2_gemm_nt": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _l, _l, _l, _i, _i, _l, _l, _l, _l, _i, _vp]),
     "ds2_gemm_nt_coresident": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _l, _l, _l, _i, _i, _l, _l, _l, _l, _i, _vp]),
+    "ds2_gemm_nt_rows2": (_i, [_i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _l, _l, _l, _i, _i, _i, _vp]),
     "ds2_norm_partials": (_i, [_l]),
     "ds2_bn_fwd": (_i, [_i, _i, _i, _vp, _vp, _l, _i, _l, _l, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp,
                         _vp, _vp, _vp, _vp]),

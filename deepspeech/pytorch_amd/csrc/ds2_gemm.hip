@@ -29,6 +29,8 @@ struct GemmArgs {
   long sA, sB, sC, sBias;  // batch strides (elements)
   int splitk;              // >1: K is split over blockIdx.z % splitk and results are atomically added (f32 C only)
   int out_is_f32;
+  const void* A2;          // optional second block of A rows: rows m >= m_split are A2[m - m_split][.] (same lda); null = none
+  int m_split;
 };
 
 template <typename T>
@@ -76,7 +78,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt(GemmArgs g) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = ld_row + i * 32;
-    a_row[i] = A + (long)min(m0 + row, g.M - 1) * g.lda;
+    const int ar = min(m0 + row, g.M - 1);
+    a_row[i] = (g.A2 && ar >= g.m_split) ? (const T*)g.A2 + (long)batch * g.sA + (long)(ar - g.m_split) * g.lda : A + (long)ar * g.lda;
     b_row[i] = B + (long)min(n0 + row, g.N - 1) * g.ldb;
   }
 #define DS2_MASK4(r, m) r.x &= m; r.y &= m; r.z &= m; r.w &= m;
@@ -236,7 +239,9 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16_glds(GemmArgs g) {
   for (int j = 0; j < 4; ++j) {
     const int r = wave * 32 + j * 8 + r_in;
     const int chunk = slot ^ ((r >> 1) & 7);
-    a_src[j] = A + (long)min(m0 + r, g.M - 1) * g.lda + chunk * 8;
+    const int ar = min(m0 + r, g.M - 1);
+    a_src[j] = ((g.A2 && ar >= g.m_split) ? (const bf16_t*)g.A2 + (long)batch * g.sA + (long)(ar - g.m_split) * g.lda : A + (long)ar * g.lda) +
+               chunk * 8;
     b_src[j] = B + (long)min(n0 + r, g.N - 1) * g.ldb + chunk * 8;
   }
   auto dma = [&](unsigned char* st, int kt) {
@@ -498,7 +503,7 @@ extern "C" {
 // C (f32 if out_f32 else `dtype`) [M][ldc] = A[M][lda] * B[N][ldb]^T (+bias[N]); batched over `batch` with element strides.
 // K, lda, ldb must be multiples of 16 bytes / sizeof(T); A/B 16-byte aligned.  splitk>1 requires out_f32; C is zeroed here
 // (memset nodes on the stream) and the K-slices are atomically accumulated.
-static int gemm_nt_impl(int dtype, const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long lda,
+static int gemm_nt_impl(int dtype, const void* A, const void* A2, int m_split, const void* B, void* C, const float* bias, int M, int N, int K, long lda,
                         long ldb, long ldc, int out_f32, int batch, long strideA, long strideB, long strideC, long strideBias,
                         int splitk, bool coresident, ds2_stream_t st_) {
   hipStream_t st = (hipStream_t)st_;
@@ -508,7 +513,8 @@ static int gemm_nt_impl(int dtype, const void* A, const void* B, void* C, const 
   DS2_REQUIRE(K % V == 0 && lda % V == 0 && ldb % V == 0 && strideA % V == 0 && strideB % V == 0, DS2_ERR_ALIGN);
   DS2_REQUIRE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)B) & 15) == 0, DS2_ERR_ALIGN);
   DS2_REQUIRE(splitk == 1 || out_f32, DS2_ERR_ARG);
-  GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, strideA, strideB, strideC, strideBias, splitk, out_f32 || dtype == DS2_F32};
+  GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, strideA, strideB, strideC, strideBias, splitk, out_f32 || dtype == DS2_F32, A2, m_split};
+  DS2_REQUIRE(A2 == nullptr || (m_split > 0 && m_split < M && (((uintptr_t)A2) & 15) == 0), DS2_ERR_ARG);
   dim3 grid(ds2_cdiv(N, BN), ds2_cdiv(M, BM), batch * splitk), blk(256);
   const size_t shm = 2 * STAGE_BYTES;
   if (splitk > 1) {
@@ -524,7 +530,7 @@ static int gemm_nt_impl(int dtype, const void* A, const void* B, void* C, const 
   } else if (splitk == 1 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0) {
     // (split-K accumulates with atomics: the register-staged kernel below keeps them coalesced along n)
     g.out_is_f32 = out_f32;
-    const int big = coresident ? 0 : big_tile_variant(M, N, K);
+    const int big = (coresident || A2) ? 0 : big_tile_variant(M, N, K);
     if (big == 1) {
       hipLaunchKernelGGL((k_gemm_nt_bf16_big<256, 128, 4, 2>), dim3(ds2_cdiv(N, 128), ds2_cdiv(M, 256), batch), dim3(512), 0, st, g);
     } else if (coresident) {
@@ -548,7 +554,7 @@ static int gemm_nt_impl(int dtype, const void* A, const void* B, void* C, const 
 int ds2_gemm_nt(int dtype, const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long lda, long ldb,
                 long ldc, int out_f32, int batch, long strideA, long strideB, long strideC, long strideBias, int splitk,
                 ds2_stream_t st) {
-  return gemm_nt_impl(dtype, A, B, C, bias, M, N, K, lda, ldb, ldc, out_f32, batch, strideA, strideB, strideC, strideBias, splitk,
+  return gemm_nt_impl(dtype, A, nullptr, 0, B, C, bias, M, N, K, lda, ldb, ldc, out_f32, batch, strideA, strideB, strideC, strideBias, splitk,
                       false, st);
 }
 
@@ -557,8 +563,15 @@ int ds2_gemm_nt(int dtype, const void* A, const void* B, void* C, const float* b
 int ds2_gemm_nt_coresident(int dtype, const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long lda,
                            long ldb, long ldc, int out_f32, int batch, long strideA, long strideB, long strideC, long strideBias,
                            int splitk, ds2_stream_t st) {
-  return gemm_nt_impl(dtype, A, B, C, bias, M, N, K, lda, ldb, ldc, out_f32, batch, strideA, strideB, strideC, strideBias, splitk,
+  return gemm_nt_impl(dtype, A, nullptr, 0, B, C, bias, M, N, K, lda, ldb, ldc, out_f32, batch, strideA, strideB, strideC, strideBias, splitk,
                       true, st);
+}
+
+// A given as two row blocks: rows [0, m_split) from A, rows [m_split, M) from A2 (same lda) -- the GRU's hidden-side gate gradient
+// [dr, dz | dQ] lives in two buffers (ds2_rnn_persist_bwd).  coresident != 0 selects the low-register kernel.
+int ds2_gemm_nt_rows2(int dtype, const void* A, const void* A2, int m_split, const void* B, void* C, int M, int N, int K, long lda,
+                      long ldb, long ldc, int out_f32, int splitk, int coresident, ds2_stream_t st) {
+  return gemm_nt_impl(dtype, A, A2, m_split, B, C, nullptr, M, N, K, lda, ldb, ldc, out_f32, 1, 0, 0, 0, 0, splitk, coresident != 0, st);
 }
 
 }  // extern "C"

@@ -371,14 +371,10 @@ class _RnnStackFn(torch.autograd.Function):
                     hprev = hext[d, 0:Tp] if d == 0 else hext[d, 2:Tp + 2]
                     Hp_T = ops.transpose(hprev.reshape(R, H))           # [H][ldT]
                     if kind == "gru" and rg.dQ is not None:
-                        # hidden-side gate gradient = [dr, dz (rows of dGI^T), dQ]: two GEMMs into the row blocks of dW_hh
+                        # hidden-side gate gradient = [dr, dz (rows of dGI^T) | dQ^T]: one GEMM whose A operand is two row blocks
                         dQ_T = ops.transpose(rg.dQ[d].reshape(R, H))   # [H][ldT]
-                        sk = _wgrad_splitk(H, H, ldT)
-                        dWhh = torch.empty((GH, H), dtype=torch.float32, device=dGI.device)
-                        ops.gemm_nt(dGI_T[d * GH:d * GH + 2 * H], Hp_T, out_dtype=torch.float32, M=2 * H, N=H, K=ldT, lda=ldT, ldb=ldT,
-                                    out=dWhh, ldc=H, splitk=sk, coresident=True)
-                        ops.gemm_nt(dQ_T, Hp_T, out_dtype=torch.float32, M=H, N=H, K=ldT, lda=ldT, ldb=ldT, out=dWhh[2 * H:], ldc=H,
-                                    splitk=sk, coresident=True)
+                        dWhh = ops.gemm_nt_rows2(dGI_T[d * GH:d * GH + 2 * H], dQ_T, 2 * H, Hp_T, GH, H, ldT, ldT, ldT,
+                                                 splitk=_wgrad_splitk(GH, H, ldT), coresident=True)
                         dBhh = torch.cat([bsum[d][:2 * H], bsum[d][3 * H:4 * H]], 0) if bsum is not None else \
                             torch.cat([dBih[d * GH:d * GH + 2 * H], ops.colsum(rg.dQ[d].reshape(R, H))], 0)
                     else:

@@ -96,6 +96,13 @@ def gemm_nt(A, B, bias=None, out_dtype=None, M=None, N=None, K=None, lda=None, l
     return out
 
 
+def gemm_nt_rows2(A, A2, m_split, B, M, N, K, lda, ldb, splitk=1, coresident=False):
+    """C[M][N] f32 = [A rows 0..m_split-1 ; A2 rows 0..M-m_split-1][.][K] * B[N][K]^T: the A operand split over two buffers."""
+    out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    call("ds2_gemm_nt_rows2", dt(A), P(A), P(A2), m_split, P(B), P(out), M, N, K, lda, ldb, N, 1, splitk, 1 if coresident else 0, S())
+    return out
+
+
 def colsum(X, R=None, Cc=None, ld=None, scale=1.0):
     R = X.shape[0] if R is None else R
     Cc = X.shape[1] if Cc is None else Cc
@@ -268,10 +275,24 @@ def poll_persistent_error(dev):
 PERSIST_ENABLED = True   # tests flip this to run the per-time-step kernels on shapes the persistent kernels cover
 
 
+_WARNED_CUS = set()
+
+
 def use_persistent(kind, dtype, D, N, H):
     if not PERSIST_ENABLED:
         return False
-    return bool(query("ds2_rnn_persist_supported", dt(dtype), CELLS[kind], D, N, H))
+    ok = bool(query("ds2_rnn_persist_supported", dt(dtype), CELLS[kind], D, N, H))
+    if not ok:
+        # never silent: a device that does not expose all 256 CUs (partition / CU-mask modes) cannot host the persistent sweeps
+        # (one workgroup per CU, all co-resident) and runs the launch-per-time-step kernels instead (several times slower)
+        dev = torch.cuda.current_device()
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        if cus < 256 and dev not in _WARNED_CUS:
+            _WARNED_CUS.add(dev)
+            import warnings
+            warnings.warn("ds2hip: device %d exposes %d compute units (< 256): the persistent recurrent kernels are disabled, the "
+                          "recurrent sweeps use one launch per time step" % (dev, cus))
+    return ok
 
 
 def rnn_fwd(kind, GI, Whh, bhh, lens, D, N, H, Tp, h0=None, c0=None, save=True):

@@ -54,6 +54,9 @@ int ds2_gemm_nt(int dtype, const void* A, const void* B, void* C, const float* b
 
 /* same contract as ds2_gemm_nt; selects the low-register kernel variant whose waves can share a CU with the persistent
  * recurrent kernels (weight-gradient GEMMs issued on a second stream while a sweep runs). */
+/* A as two row blocks (rows [0,m_split) from A, the rest from A2, same lda); coresident != 0: the low-register kernel. */
+int ds2_gemm_nt_rows2(int dtype, const void* A, const void* A2, int m_split, const void* B, void* C, int M, int N, int K, long lda,
+                      long ldb, long ldc, int out_f32, int splitk, int coresident, ds2_stream_t stream);
 int ds2_gemm_nt_coresident(int dtype, const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long lda,
                            long ldb, long ldc, int out_f32, int batch, long strideA, long strideB, long strideC, long strideBias,
                            int splitk, ds2_stream_t stream);

@@ -56,6 +56,20 @@ def test_gemm_nt(dtype, M, N, K):
     assert relerr(np64(got_c), ref) < TOL[dtype]
 
 
+@pytest.mark.parametrize("coresident", [False, True])
+@pytest.mark.parametrize("M,ms,N,K,sk", [(3072, 2048, 1024, 1536, 1), (192, 128, 96, 640, 1), (160, 96, 64, 4096, 4)])
+def test_gemm_nt_rows2(coresident, M, ms, N, K, sk):
+    """A operand given as two row blocks in separate buffers (the GRU's [dr, dz | dQ] hidden-side gradient)."""
+    rs = np.random.RandomState(M + N + K)
+    A, B = rs.standard_normal((M, K)), rs.standard_normal((N, K))
+    ref = rnd(A, torch.bfloat16) @ rnd(B, torch.bfloat16).T
+    o = ops()
+    Ad = cu(A, torch.bfloat16)
+    a1, a2 = Ad[:ms].contiguous(), Ad[ms:].contiguous()
+    got = o.gemm_nt_rows2(a1, a2, ms, cu(B, torch.bfloat16), M, N, K, K, K, splitk=sk, coresident=coresident)
+    assert relerr(np64(got), ref) < 1e-4
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_nt_transposed_operands_and_splitk(dtype):
     """A asymmetric, non-square: catches row/col swaps of the MFMA C layout (cdna guide: always test asymmetric)."""
