@@ -117,8 +117,8 @@ class _FusedStep:
             ldd = lddT = 0
             if emit:
                 layer = m.rnns[li]
-                L = self._layout_buffers(li, D, GH, layer.hidden_size, Io if kind == "ih" else plan[id(getattr(layer.rnn, "weight_ih_l0"))][5],
-                                         dev)
+                io_layer = plan[id(layer.rnn.weight_ih_l0)][5]          # padded input width of this layer's W_ih layouts
+                L = self._layout_buffers(li, D, GH, layer.hidden_size, io_layer, dev)
                 if kind == "ih":
                     dst, ldd, dstT, lddT = L["Wih"][d * GH:], L["Wih"].shape[1], L["WihT"][:, d * GH:], D * GH
                 else:

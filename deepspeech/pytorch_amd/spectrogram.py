@@ -67,10 +67,12 @@ class SpectrogramFrontEnd:
             raise Ds2HipError("SpectrogramFrontEnd needs the waveforms on a HIP device; there is no CPU path")
         wav = wav.float().contiguous()
         N, Lmax = wav.shape
-        ns = torch.as_tensor(nsamples, dtype=torch.int32)
-        if int(ns.max()) != Lmax and int(ns.max()) > Lmax:
-            raise ValueError("nsamples exceeds the waveform buffer")
+        ns = torch.as_tensor(nsamples, dtype=torch.int32).cpu()
+        if ns.numel() != N or int(ns.min()) < 1:
+            raise ValueError("nsamples must hold one positive sample count per waveform row")
         Lm = int(ns.max())
+        if Lm > Lmax:
+            raise ValueError("nsamples exceeds the waveform buffer")
         Tmax = 1 + Lm // HOP
         out = torch.empty((N, 1, N_BIN, Tmax), dtype=torch.float32, device=wav.device)
         ws = torch.empty(query("ds2_spect_ws_bytes", N, Lm), dtype=torch.uint8, device=wav.device)

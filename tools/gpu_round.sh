@@ -22,14 +22,17 @@ if [ -n "$PROFILE" ]; then
   head -n 24 $out/kernel_stats_cfg3.md
   find $out/prof -size +20M -delete
 fi
-if [ -n "$PMC" ]; then   # HBM traffic counters: separate passes, kernel-trace only (MI355X_MICROARCH.md, rocprofv3 section)
+if [ -n "$PMC" ]; then   # PMC counters: separate passes, kernel-trace only (MI355X_MICROARCH.md, rocprofv3 section)
   here=$PWD; cd /tmp
-  for ctr in FETCH_SIZE WRITE_SIZE; do
-    timeout 600 rocprofv3 --kernel-trace --pmc $ctr -d $here/$out/pmc_$ctr -o cfg3 -- python $here/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $here/$out/pmc_$ctr.log 2>&1; echo "pmc $ctr rc=$?"
-    db=$(find $here/$out/pmc_$ctr -name "*.db" | head -n 1)
-    [ -n "$db" ] && python $here/tools/rocpd_pmc.py $db > $here/$out/pmc_$ctr.md 2>> $here/$out/pmc_$ctr.log
-    head -n 8 $here/$out/pmc_$ctr.md
-    find $here/$out/pmc_$ctr -size +20M -delete
+  IFS=';' read -ra sets <<< "${PMC_SETS:-FETCH_SIZE;WRITE_SIZE;SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE}"
+  i=0
+  for ctrs in "${sets[@]}"; do
+    i=$((i+1)); tag2=pmc$i
+    timeout 600 rocprofv3 --kernel-trace --pmc $ctrs -d $here/$out/$tag2 -o cfg3 -- python $here/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $here/$out/$tag2.log 2>&1; echo "pmc [$ctrs] rc=$?"
+    db=$(find $here/$out/$tag2 -name "*.db" | head -n 1)
+    [ -n "$db" ] && python $here/tools/rocpd_pmc.py $db > $here/$out/$tag2.md 2>> $here/$out/$tag2.log
+    head -n 8 $here/$out/$tag2.md
+    find $here/$out/$tag2 -size +20M -delete
   done
   cd $here
 fi
