@@ -60,7 +60,17 @@ __global__ void __launch_bounds__(256) k_sumsq(SumsqTable t, float* __restrict__
   const float* g = t.g[i] + off;
   const long n = min((long)CHUNK, t.n[i] - off);
   float s = 0.f;
-  for (long e = threadIdx.x; e < n; e += 256) s += g[e] * g[e];
+  if ((((uintptr_t)g) & 15) == 0) {               // 16-byte loads (chunks start at multiples of 16384 elements)
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    const long n4 = n >> 2;
+    for (long e = threadIdx.x; e < n4; e += 256) {
+      const float4 x = g4[e];
+      s += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
+    }
+    for (long e = (n4 << 2) + threadIdx.x; e < n; e += 256) s += g[e] * g[e];
+  } else {
+    for (long e = threadIdx.x; e < n; e += 256) s += g[e] * g[e];
+  }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
@@ -166,6 +176,73 @@ __global__ void __launch_bounds__(256) k_opt_matrix(float* __restrict__ p, const
   o[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
+// Vectorised form for the un-permuted matrices (C % 4 == 0, Cout == C): a thread owns a 4-row x 4-column patch of the 64x64
+// tile -- 16-byte loads / stores of p, g, m, v, 8-byte stores of the bf16 copy, the same LDS image for the transpose.
+__global__ void __launch_bounds__(256) k_opt_matrix4(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                     float* __restrict__ v, int R, int C, uint16_t* __restrict__ dst, long ldd,
+                                                     uint16_t* __restrict__ dstT, long lddT, Hyper h) {
+  __shared__ uint32_t tileT[64 * 33];
+  const int tid = threadIdx.x, cx = tid & 15, ry = tid >> 4;         // 16 column quads x 16 row quads
+  const int c0 = blockIdx.x * 64 + cx * 4, r0 = blockIdx.y * 64 + ry * 4;
+  const float cs = h.clip ? h.clip[1] : 1.f;
+  float val[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) val[i][e] = 0.f;
+  if (c0 < C) {
+    float4 pv[4], gv[4], mv[4], vv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long o = (long)min(r0 + i, R - 1) * C + c0;
+      pv[i] = *reinterpret_cast<const float4*>(p + o);
+      gv[i] = *reinterpret_cast<const float4*>(g + o);
+      mv[i] = *reinterpret_cast<const float4*>(m + o);
+      vv[i] = h.mode == 0 ? *reinterpret_cast<const float4*>(v + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (r0 + i >= R) continue;
+      float* pe = reinterpret_cast<float*>(&pv[i]);
+      float* ge = reinterpret_cast<float*>(&gv[i]);
+      float* me = reinterpret_cast<float*>(&mv[i]);
+      float* ve = reinterpret_cast<float*>(&vv[i]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        update(h, cs, pe[e], ge[e], me[e], ve[e]);
+        val[i][e] = pe[e];
+      }
+      const long o = (long)(r0 + i) * C + c0;
+      *reinterpret_cast<float4*>(p + o) = pv[i];
+      *reinterpret_cast<float4*>(m + o) = mv[i];
+      if (h.mode == 0) *reinterpret_cast<float4*>(v + o) = vv[i];
+      if (dst != nullptr) {
+        uint2 pk;
+        pk.x = cvt_pk_bf16(val[i][0], val[i][1]);
+        pk.y = cvt_pk_bf16(val[i][2], val[i][3]);
+        *reinterpret_cast<uint2*>(dst + (long)(r0 + i) * ldd + c0) = pk;
+      }
+    }
+  }
+  if (dstT == nullptr) return;
+  // LDS image: tileT[column][row pair] (bf16 x 2 packed along the rows), the layout the transposed 32-byte stores read
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    tileT[(cx * 4 + e) * 33 + ry * 2] = cvt_pk_bf16(val[0][e], val[1][e]);
+    tileT[(cx * 4 + e) * 33 + ry * 2 + 1] = cvt_pk_bf16(val[2][e], val[3][e]);
+  }
+  __syncthreads();
+  const int col = tid >> 2, part = tid & 3;
+  const int jo = blockIdx.x * 64 + col, ro = blockIdx.y * 64 + part * 16;
+  if (jo >= C || ro >= R) return;
+  uint32_t w[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) w[k] = tileT[col * 33 + part * 8 + k];
+  uint4* o = reinterpret_cast<uint4*>(dstT + (long)jo * lddT + ro);
+  o[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
 Hyper make_hyper(int mode, const float* hp, int first, const float* clip) {
   Hyper h{};
   h.mode = mode;
@@ -247,8 +324,14 @@ int ds2_opt_matrix(int mode, float* p, const float* g, float* m, float* v, int R
   DS2_REQUIRE(perm_c == 0 || perm_c * perm_f == C, DS2_ERR_ARG);
   DS2_REQUIRE(dstT == nullptr || (lddT % 8 == 0 && (((uintptr_t)dstT) & 15) == 0), DS2_ERR_ALIGN);
   const Hyper h = make_hyper(mode, hp, first, clip);
-  hipLaunchKernelGGL(k_opt_matrix, dim3(ds2_cdiv(Cout, 64), ds2_cdiv(R, 64)), dim3(256), 0, st, p, g, m, v, R, C, perm_c, perm_f,
-                     Cout, (uint16_t*)dst, ldd, (uint16_t*)dstT, lddT, h);
+  const bool vec = perm_c == 0 && Cout == C && C % 4 == 0 && (dst == nullptr || ldd % 4 == 0) && (((uintptr_t)p | (uintptr_t)g |
+                    (uintptr_t)m | (uintptr_t)(mode == 0 ? v : p) | (uintptr_t)dst) & 15) == 0;
+  if (vec)
+    hipLaunchKernelGGL(k_opt_matrix4, dim3(ds2_cdiv(C, 64), ds2_cdiv(R, 64)), dim3(256), 0, st, p, g, m, v, R, C, (uint16_t*)dst, ldd,
+                       (uint16_t*)dstT, lddT, h);
+  else
+    hipLaunchKernelGGL(k_opt_matrix, dim3(ds2_cdiv(Cout, 64), ds2_cdiv(R, 64)), dim3(256), 0, st, p, g, m, v, R, C, perm_c, perm_f,
+                       Cout, (uint16_t*)dst, ldd, (uint16_t*)dstT, lddT, h);
   DS2_CHECK_LAUNCH();
   return 0;
 }

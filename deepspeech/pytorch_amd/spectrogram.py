@@ -76,7 +76,10 @@ class SpectrogramFrontEnd:
         Tmax = 1 + Lm // HOP
         out = torch.empty((N, 1, N_BIN, Tmax), dtype=torch.float32, device=wav.device)
         ws = torch.empty(query("ds2_spect_ws_bytes", N, Lm), dtype=torch.uint8, device=wav.device)
-        call("ds2_spectrogram", ops.P(wav), wav.stride(0), ops.P(ns.to(wav.device)), N, Lm, ops.P(self._basis_on(wav.device)),
+        basis = self._basis_on(wav.device)
+        ns_dev = ns.to(wav.device)       # held in a local until the launch is enqueued (a temporary would be freed -- and its block
+        #                                  possibly re-used by the basis upload -- before the kernels read it)
+        call("ds2_spectrogram", ops.P(wav), wav.stride(0), ops.P(ns_dev), N, Lm, ops.P(basis),
              1 if self.reflect else 0, 1 if self.normalize else 0, ops.P(out), ops.P(ws), ops.S())
         frames = 1 + ns.to(torch.int64) // HOP
         pct = (frames.to(torch.float64) / float(Tmax)).to(torch.float32)      # _collate_fn: seq_length / float(max_seqlength)
