@@ -234,19 +234,24 @@ __device__ __forceinline__ bool load_gated(const T* __restrict__ G, const T* __r
                                            const float* __restrict__ rstd, const RowMap& rm, const int* __restrict__ lens,
                                            int N, float (&g)[Vec16<T>::N], float (&xh)[Vec16<T>::N]) {
   constexpr int V = Vec16<T>::N;
-  int n = 0, t = 0;
-  if (CONV) {
-    rm.nt(r, n, t);
-    if (t >= lens[n]) return false;
+  int n = 0, t = 0, f = 0;
+  if (CONV) {   // row -> (n, f, t) in 32-bit arithmetic (N*F*T' < 2^31: checked by the entry)
+    const unsigned ur = (unsigned)r, q = ur / (unsigned)rm.Tp;
+    t = (int)(ur - q * (unsigned)rm.Tp);
+    n = (int)(q / (unsigned)rm.F);
+    f = (int)(q - (unsigned)n * (unsigned)rm.F);
   }
+  // all three loads are issued unconditionally and together (a masked row's values are discarded): a load of lens[n] that
+  // gates the other two is two dependent memory round trips per row
+  const int len = CONV ? lens[n] : 0;
   float x[V];
   Vec16<T>::load(X + r * ldx + c0, x);
   if (SEQ_IN) {
-    int f = (int)((r / rm.Tp) % rm.F);
     Vec16<T>::load(G + ((long)t * N + n) * ldg + (long)f * C + c0, g);
   } else {
     Vec16<T>::load(G + r * ldg + c0, g);
   }
+  if (CONV && t >= len) return false;
 #pragma unroll
   for (int i = 0; i < V; ++i) {
     if (CONV) {
@@ -335,9 +340,14 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-inline int norm_grid_y(long R) {
+// Row-blocks (= partial sums per column) of a column reduction.  The reductions are latency-bound on their loads (one 16-byte
+// load per thread and iteration in flight): ~1024 workgroups in total -- 4 per CU -- instead of 256 took the 125-250 MB conv
+// tensors (C = 32: a single column block) from 1-2 to 3 TB/s; wide matrices already get their workgroups from the column blocks.
+inline int norm_grid_y(long R, int col_blocks = 1) {
   long gy = (R + NORM_RY - 1) / NORM_RY;
-  if (gy > 256) gy = 256;
+  long cap = 1024 / (col_blocks < 1 ? 1 : col_blocks);
+  if (cap < 256) cap = 256;
+  if (gy > cap) gy = cap;
   if (gy < 1) gy = 1;
   return (int)gy;
 }
@@ -347,7 +357,7 @@ int colstats_impl(const void* X, long R, int C, long ld, float* psum, float* psq
   constexpr int V = Vec16<T>::N;
   DS2_REQUIRE(C % V == 0 && ld % V == 0, DS2_ERR_ALIGN);
   dim3 blk(NORM_CX, NORM_RY);
-  dim3 grd(ds2_cdiv(C / V, NORM_CX), norm_grid_y(R));
+  dim3 grd(ds2_cdiv(C / V, NORM_CX), norm_grid_y(R, ds2_cdiv(C / V, NORM_CX)));
   if (psq)
     hipLaunchKernelGGL((k_colstats<T, true>), grd, blk, 0, st, (const T*)X, R, C, ld, psum, psq);
   else
@@ -392,10 +402,11 @@ int ds2_bn_fwd(int dtype, int mode, int training, const void* X, void* Y, long R
   hipStream_t st = (hipStream_t)st_;
   DS2_REQUIRE(dtype == DS2_F32 || dtype == DS2_BF16, DS2_ERR_DTYPE);
   DS2_REQUIRE(mode >= 0 && mode <= 2, DS2_ERR_ARG);
+  DS2_REQUIRE(mode == 0 || R < (1L << 31), DS2_ERR_ARG);      // conv rows are decomposed in 32-bit arithmetic
   int rc, P = 0;
   if (training) {
     float* psum = ws;
-    float* psq = ws + (long)norm_grid_y(R) * C;
+    float* psq = ws + (long)norm_grid_y(R) * C;          // sized for the largest partial count (ds2_norm_partials)
     rc = dtype == DS2_F32 ? colstats_impl<float>(X, R, C, ldx, psum, psq, &P, st)
                           : colstats_impl<bf16_t>(X, R, C, ldx, psum, psq, &P, st);
     if (rc) return rc;
@@ -437,10 +448,11 @@ int ds2_bn_bwd(int dtype, int mode, const void* G, const void* X, void* DX, long
   hipStream_t st = (hipStream_t)st_;
   DS2_REQUIRE(dtype == DS2_F32 || dtype == DS2_BF16, DS2_ERR_DTYPE);
   DS2_REQUIRE(mode >= 0 && mode <= 2, DS2_ERR_ARG);
+  DS2_REQUIRE(mode == 0 || R < (1L << 31), DS2_ERR_ARG);      // conv rows are decomposed in 32-bit arithmetic
   const int V = dtype == DS2_F32 ? 4 : 8;
   DS2_REQUIRE(C % V == 0 && ldx % V == 0 && ldg % V == 0 && lddx % V == 0, DS2_ERR_ALIGN);
   RowMap rm{F, Tp};
-  const int P = norm_grid_y(R);
+  const int P = norm_grid_y(R, ds2_cdiv(C / V, NORM_CX));
   float* ps = ws;
   float* pq = ws + (long)P * C;
   float* c1 = pq + (long)P * C;

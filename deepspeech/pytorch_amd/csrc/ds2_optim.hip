@@ -243,6 +243,87 @@ __global__ void __launch_bounds__(256) k_opt_matrix4(float* __restrict__ p, cons
   o[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
+// Permuted form (rnns.0 weight_ih: output column j = f*perm_c + c <- source column c*perm_f + f, zero columns [C, Cout)): tiles run
+// over the SOURCE columns so that the 28 B/element of fp32 traffic (p, g, m, v) stays in 16-byte coalesced accesses; only the bf16
+// copy is scattered (2-byte stores), the transpose leaves through LDS as 32-byte runs.  C % 4 == 0.
+__global__ void __launch_bounds__(256) k_opt_matrix_perm(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                         float* __restrict__ v, int R, int C, int perm_c, int perm_f, int Cout,
+                                                         uint16_t* __restrict__ dst, long ldd, uint16_t* __restrict__ dstT, long lddT,
+                                                         Hyper h) {
+  __shared__ uint32_t tileT[64 * 33];
+  const int tid = threadIdx.x, cx = tid & 15, ry = tid >> 4;
+  const int s0 = blockIdx.x * 64 + cx * 4, r0 = blockIdx.y * 64 + ry * 4;     // source column quad, row quad
+  const float cs = h.clip ? h.clip[1] : 1.f;
+  float val[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) val[i][e] = 0.f;
+  if (s0 < C) {
+    float4 pv[4], gv[4], mv[4], vv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long o = (long)min(r0 + i, R - 1) * C + s0;
+      pv[i] = *reinterpret_cast<const float4*>(p + o);
+      gv[i] = *reinterpret_cast<const float4*>(g + o);
+      mv[i] = *reinterpret_cast<const float4*>(m + o);
+      vv[i] = h.mode == 0 ? *reinterpret_cast<const float4*>(v + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    int jcol[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) jcol[e] = ((s0 + e) % perm_f) * perm_c + (s0 + e) / perm_f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (r0 + i >= R) continue;
+      float* pe = reinterpret_cast<float*>(&pv[i]);
+      float* ge = reinterpret_cast<float*>(&gv[i]);
+      float* me = reinterpret_cast<float*>(&mv[i]);
+      float* ve = reinterpret_cast<float*>(&vv[i]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        update(h, cs, pe[e], ge[e], me[e], ve[e]);
+        val[i][e] = pe[e];
+      }
+      const long o = (long)(r0 + i) * C + s0;
+      *reinterpret_cast<float4*>(p + o) = pv[i];
+      *reinterpret_cast<float4*>(m + o) = mv[i];
+      if (h.mode == 0) *reinterpret_cast<float4*>(v + o) = vv[i];
+      if (dst != nullptr) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[(long)(r0 + i) * ldd + jcol[e]] = (uint16_t)cvt_pk_bf16(val[i][e], 0.f);
+      }
+    }
+  }
+  // zero pad columns [C, Cout) of the rows of this tile row (done by the first column block)
+  if (blockIdx.x == 0 && Cout > C) {
+    const int npad = Cout - C;
+    for (int e = tid; e < 64 * npad; e += 256) {
+      const int r = blockIdx.y * 64 + e / npad, j = C + e % npad;
+      if (r < R) {
+        if (dst != nullptr) dst[(long)r * ldd + j] = 0;
+        if (dstT != nullptr) dstT[(long)j * lddT + r] = 0;
+      }
+    }
+  }
+  if (dstT == nullptr) return;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    tileT[(cx * 4 + e) * 33 + ry * 2] = cvt_pk_bf16(val[0][e], val[1][e]);
+    tileT[(cx * 4 + e) * 33 + ry * 2 + 1] = cvt_pk_bf16(val[2][e], val[3][e]);
+  }
+  __syncthreads();
+  const int col = tid >> 2, part = tid & 3;
+  const int sc = blockIdx.x * 64 + col, ro = blockIdx.y * 64 + part * 16;
+  if (sc >= C || ro >= R) return;
+  const int jo = (sc % perm_f) * perm_c + sc / perm_f;
+  uint32_t w[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) w[k] = tileT[col * 33 + part * 8 + k];
+  uint4* o = reinterpret_cast<uint4*>(dstT + (long)jo * lddT + ro);
+  o[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
 Hyper make_hyper(int mode, const float* hp, int first, const float* clip) {
   Hyper h{};
   h.mode = mode;
@@ -329,6 +410,9 @@ int ds2_opt_matrix(int mode, float* p, const float* g, float* m, float* v, int R
   if (vec)
     hipLaunchKernelGGL(k_opt_matrix4, dim3(ds2_cdiv(C, 64), ds2_cdiv(R, 64)), dim3(256), 0, st, p, g, m, v, R, C, (uint16_t*)dst, ldd,
                        (uint16_t*)dstT, lddT, h);
+  else if (perm_c > 0 && C % 4 == 0 && (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)(mode == 0 ? v : p)) & 15) == 0)
+    hipLaunchKernelGGL(k_opt_matrix_perm, dim3(ds2_cdiv(C, 64), ds2_cdiv(R, 64)), dim3(256), 0, st, p, g, m, v, R, C, perm_c, perm_f,
+                       Cout, (uint16_t*)dst, ldd, (uint16_t*)dstT, lddT, h);
   else
     hipLaunchKernelGGL(k_opt_matrix, dim3(ds2_cdiv(Cout, 64), ds2_cdiv(R, 64)), dim3(256), 0, st, p, g, m, v, R, C, perm_c, perm_f,
                        Cout, (uint16_t*)dst, ldd, (uint16_t*)dstT, lddT, h);
