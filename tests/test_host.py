@@ -172,3 +172,37 @@ def test_validation_step_drives_reference_decoder_and_metrics():
     assert set(logged) == {"wer", "cer"} and all(np.isfinite(v) and v > 0 for v in logged.values())
     strings, _ = dec.decode(probs, sizes)
     assert [s[0] for s in strings] == fx.meta["transcripts"]
+
+
+# ---- spectrogram front-end host side (window / DFT basis builders) ---------------------------------------------------------
+@pytest.mark.parametrize("name", ["hamming", "hann", "blackman", "bartlett"])
+def test_spectrogram_windows_equal_scipy(name):
+    """SpectConfig.window names (reference enums.py:8-14) -> the periodic windows scipy.signal.get_window / librosa produce."""
+    import scipy.signal as ss
+    from deepspeech.pytorch_amd.spectrogram import window_values
+    assert np.abs(window_values(name) - ss.get_window(name, 320, fftbins=True)).max() < 1e-12
+
+
+def test_dft_basis_reproduces_rfft_of_windowed_frames():
+    from deepspeech.pytorch_amd.spectrogram import dft_basis, window_values
+    rs = np.random.RandomState(0)
+    frames = rs.standard_normal((5, 320))
+    B = dft_basis("hamming").astype(np.float64)               # [322][320]: cos rows then -sin rows
+    out = frames @ B.T
+    ref = np.fft.rfft(frames * window_values("hamming"), axis=1)
+    assert np.abs(out[:, :161] - ref.real).max() < 1e-4 and np.abs(out[:, 161:] - ref.imag).max() < 1e-4
+
+
+def test_bench_frame_arithmetic_equals_get_seq_lens():
+    """bench.out_frames (valid output frames, incl. the float32 percentage round trip of model.py:243) == the class's
+    get_seq_lens applied to training_step's input_sizes, for random length sets."""
+    import bench
+    fx = Fixture("gru_bi_tiny")
+    m = build_model(fx)
+    rs = np.random.RandomState(1)
+    for _ in range(20):
+        lengths = np.sort(rs.randint(41, 1502, size=rs.randint(1, 40)))[::-1].copy()
+        tmax = int(lengths.max())
+        pct = torch.from_numpy((lengths / float(tmax)).astype(np.float32))
+        sizes = pct.mul_(tmax).int()
+        assert m.get_seq_lens(sizes).tolist() == bench.out_frames(lengths).tolist()
