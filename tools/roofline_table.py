@@ -35,7 +35,7 @@ ROWS = [
     ("k_opt_matrix", "AdamW + bf16 layouts of a recurrent weight matrix", "hbm", None, 8e12),
 ]
 BYTES = {"k_transpose": (R * D * GH * 2 * 2 + R * H * 2 * 2 + 2 * 2 * (R * H * 2 * 2)) * 1.0 / 6,   # dGI, Xh, 2 x (h_prev, dQ): read + write
-         "k_opt_matrix": (D * GH * H * 2) * 32.0 / (4 * D) * 1.0}                                    # ~32 B per parameter
+         "k_opt_matrix": GH * H * 32.0}                                                             # 32 B per parameter of a [3H][H] matrix
 
 
 def main():
