@@ -59,6 +59,9 @@ CASES = [
          lookahead_context=20, lengths=[111, 96, 83], data_seed=20, param_seed=110, stride=1009),
     dict(name="rnn_bi_1024", rnn_type="rnn", hidden_size=1024, hidden_layers=2, bidirectional=True,
          lengths=[101, 88, 61, 45, 33], data_seed=21, param_seed=111, stride=1009),
+    # the reference's DEFAULT model family (configs/train_config.py:46-50: bidirectional LSTM, hidden 1024) at its own width
+    dict(name="lstm_bi_1024", rnn_type="lstm", hidden_size=1024, hidden_layers=2, bidirectional=True,
+         lengths=[127, 111, 94, 80, 52], data_seed=26, param_seed=116, stride=1009),
     # ---- BASELINE.json configurations at their own size / width (round 2) -------------------------------------
     # configs[1] (AN4 shape) at FULL size: 5 x BiGRU-800, 8 clips of 2.01 ... 1.01 s, fp32
     dict(name="cfg2_full", rnn_type="gru", hidden_size=800, hidden_layers=5, bidirectional=True,

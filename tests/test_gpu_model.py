@@ -108,7 +108,7 @@ def test_fp32_logits_eval_transcripts_and_carry(name):
     assert np.abs(hl.cpu().numpy() - fx.z["carry_h_last"]).max() <= 1e-4
 
 
-BF16_CASES = ["gru_bi_tiny", "lstm_bi_tiny", "gru_uni_la", "gru_bi_mid", "gru_bi_1024", "lstm_uni_1024_la", "rnn_bi_1024",
+BF16_CASES = ["gru_bi_tiny", "lstm_bi_tiny", "gru_uni_la", "gru_bi_mid", "gru_bi_1024", "lstm_uni_1024_la", "rnn_bi_1024", "lstm_bi_1024",
               "cfg2_full", "lstm_bi_1280", "lstm_uni_1280_la", "gru_bi_1024_l5_n32"]
 # Stated bf16 bounds.  The comparator is the REFERENCE ITSELF under torch.autocast(bfloat16) (fixture keys loss_ac /
 # logits_ac / grad_ac.* / acnoise.*, tests/golden/make_golden.py leg C) next to the reference in float64:
