@@ -549,3 +549,22 @@ def test_cpu_tensor_is_refused():
     from deepspeech.pytorch_amd import _lib
     with pytest.raises(_lib.Ds2HipError):
         ops().add2(torch.zeros(8), torch.zeros(8))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_small_weight_layouts_equal_the_torch_expressions(dtype):
+    """ds2_small_weight_layouts (one launch) against the tensor expressions that define the kernel layouts of the conv / head
+    weights: conv1 tap-major, conv2 tap-major, the flipped row-parity sub-kernels of the conv2 data gradient, the zero-padded head
+    weight and its transpose."""
+    rs = np.random.RandomState(9)
+    H, Cc = 96, 29
+    w1 = torch.from_numpy(rs.standard_normal((32, 1, 41, 11)).astype(np.float32)).to(DEV)
+    w2 = torch.from_numpy(rs.standard_normal((32, 32, 21, 11)).astype(np.float32)).to(DEV)
+    wf = torch.from_numpy(rs.standard_normal((Cc, H)).astype(np.float32)).to(DEV)
+    w1k, w2t, w2d, wp, wpT = ops().small_weight_layouts(w1, w2, wf, dtype)
+    assert torch.equal(w1k, w1.reshape(32, 451).t().contiguous())
+    assert torch.equal(w2t, w2.permute(2, 3, 0, 1).contiguous().to(dtype))
+    for q in (0, 1):
+        assert torch.equal(w2d[q], w2[:, :, q::2, :].flip(2, 3).permute(2, 3, 1, 0).contiguous().to(dtype))
+    ref = torch.cat([wf, torch.zeros(32 - Cc, H, device=DEV)], 0).to(dtype)
+    assert torch.equal(wp, ref) and torch.equal(wpT, ref.t().contiguous())
