@@ -28,7 +28,17 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, probe=False):
+    """probe=True: the instrumented library for tools/probe_rnn_persist.py (-DDS2_PROBE: in-kernel cycle counters and the
+    DS2_PERSIST_DBG work-skipping masks) as libds2hip_probe.so -- never loaded by the product."""
+    global OBJ, LIB
+    obj_dir, lib_path, flags = OBJ, LIB, FLAGS
+    if probe:
+        obj_dir, lib_path, flags = OBJ + "_probe", LIB.replace("libds2hip.so", "libds2hip_probe.so"), FLAGS + ["-DDS2_PROBE"]
+    return _build(obj_dir, lib_path, flags, force, verbose)
+
+
+def _build(OBJ, LIB, FLAGS, force, verbose):
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, "ds2_common.h"), os.path.join(CSRC, "ds2_rnn_persist_impl.h"), os.path.join(CSRC, "ds2_rnn_persist2_impl.h"),
                os.path.join(HERE, "..", "..", "include", "ds2hip.h")]
@@ -59,4 +69,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, probe="--probe" in sys.argv))

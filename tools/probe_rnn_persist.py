@@ -8,6 +8,9 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from deepspeech.pytorch_amd import _lib, build  # noqa: E402
+
+_lib.LIB_PATH = build.build(probe=True, verbose=False)      # the instrumented (-DDS2_PROBE) library, not the shipping one
 from deepspeech.pytorch_amd import ops  # noqa: E402
 
 kind = sys.argv[1] if len(sys.argv) > 1 else "gru"
