@@ -506,6 +506,190 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd(PArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// forward sweep, <= 8 samples per group, gate phase on ALL four waves: one hidden unit per thread.
+// The probe build shows where a step goes when the group is small (cfg3, cycles per step): gather + MFMA ~3700 (of which ~300 are
+// MFMAs: the rest is the exchange), partial sums + barrier ~400, gate phase ~1200 -- and the gate phase is a single wave per SIMD
+// executing ~130 dependent-latency-exposed instructions for its two hidden units.  Giving every thread ONE unit (256 items =
+// 8 samples x 32 units) halves that chain; the two lanes of a unit pair meet through a DPP quad permute and the even lane
+// publishes the granule and stores the packed planes, so the memory instructions stay 4 and 8 bytes wide.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dpp_xor1(float v) {      // value of the neighbouring lane (lane ^ 1)
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true));
+}
+
+template <int CELL, int H, int P>
+__global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd4(PArgs a) {
+  constexpr int G = CellInfo<CELL>::G, NS = CellInfo<CELL>::NS;
+  constexpr int SPLIT = 2, NROWS = 8;
+  constexpr int U = H / P;
+  constexpr int TILES = G * U / 16;
+  constexpr int KS = H / 128;
+  constexpr int X2 = H / 2;
+  static_assert(U == 32 && H % 128 == 0, "the one-unit-per-thread gate map assumes 32 hidden units per workgroup");
+  __shared__ __attribute__((aligned(16))) float part[2][4 * TILES * 256];
+  __builtin_amdgcn_s_setprio(3);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = blockIdx.x % NGROUPS, p = blockIdx.x / NGROUPS;
+  const int d = grp / a.gpd, slice = grp % a.gpd;
+  const int N = a.N, Tp = a.Tp;
+  const int Ns = (N - slice + a.gpd - 1) / a.gpd;
+  const int li = lane & 15, lq = lane >> 4;
+  constexpr long GH = (long)G * H;
+  const long ldgi = (long)a.D * GH;
+
+  uint4 w[TILES][KS];
+  {
+    const bf16_t* Wd = a.W + (long)d * GH * H;
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+      const int r = 16 * t + li;
+      const bf16_t* row = Wd + ((long)(r / U) * H + p * U + (r % U)) * H + wave * (H / 4) + lq * 8;
+#pragma unroll
+      for (int k = 0; k < KS; ++k) w[t][k] = *reinterpret_cast<const uint4*>(row + 32 * k);
+    }
+  }
+  u64* xg = a.xbuf + (long)grp * 2 * MAXS * X2;
+  const int srow = li & 7, half = li >> 3;
+  const bool need = srow < Ns;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, 2 * MAXS * X2 * 8, 0x00020000);
+  constexpr int PAR_BYTES = MAXS * X2 * 8;
+
+  // ---- gate identity: thread bits = (e: unit of the pair, pos, sample row (3), lq (2), q) -- the pair index (tid >> 1) has the
+  // bit order of the exchange layout, so the even lanes of a wave publish one contiguous run
+  const int e = tid & 1, pid = tid >> 1;
+  const int gi_i = (pid >> 1) & 7;
+  const int up = ((pid >> 4) & 3) * 4 + ((pid >> 6) & 1) * 2 + (pid & 1);
+  const bool gate_thread = gi_i < Ns;
+  const int n = slice + a.gpd * gi_i;
+  const int j = p * U + 2 * up;              // first unit of the pair
+  const int ju = j + e;                      // this thread's unit
+  int len = 0;
+  float hprev = 0.f, cprev = 0.f;
+  float bh[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) bh[g] = 0.f;
+  if (gate_thread) {
+    len = a.lens[n];
+    const long so = ((long)d * N + n) * H + ju;
+    if (a.h0) hprev = a.h0[so];
+    if (CELL == CELL_LSTM && a.c0) cprev = a.c0[so];
+#pragma unroll
+    for (int g = 0; g < G; ++g) bh[g] = a.bhh[(long)d * GH + (long)g * H + ju];
+  }
+  const long dstep = d == 0 ? 1 : -1;
+  const int t_first = d == 0 ? 0 : Tp - 1;
+  const int nn_ = gate_thread ? n : 0;
+  const uint16_t* gi_ptr = reinterpret_cast<const uint16_t*>(a.GI + ((long)t_first * N + nn_) * ldgi + (long)d * GH + ju);
+  const long gi_stride = dstep * N * ldgi;
+  constexpr long NSH_ = (long)(NS ? NS : 1) * H;
+  bf16_t* sv_ptr = NS ? a.S + (((long)d * Tp + t_first) * N + nn_) * NSH_ + j : nullptr;     // pair base (even lane stores)
+  const long sv_stride = dstep * N * NSH_;
+  bf16_t* hs_ptr = a.Hseq + (long)d * a.hseq_dstride + ((long)t_first * N + nn_) * H + j;
+  const long hs_stride = dstep * N * H;
+  bool dead = false;
+  const bool local = group_is_xcd_local(a.xcc + grp * 32, p, tid, a.err, a.lerr, dead);
+  if (gate_thread && e == 0) {   // zero guard slots of the state sequence at t = -1 and t = T'
+    bf16_t* hb = a.Hseq + (long)d * a.hseq_dstride + (long)n * H + j;
+    *reinterpret_cast<uint32_t*>(hb - (long)N * H) = 0u;
+    *reinterpret_cast<uint32_t*>(hb + (long)Tp * N * H) = 0u;
+  }
+  if (a.h0) {                    // initial state as "step -1": parity 1, tag TAG_INIT
+    const float other = dpp_xor1(hprev);
+    if (gate_thread && e == 0)
+      publish((u64*)((char*)xg + PAR_BYTES + xgranule_bytes<NROWS>(j, gi_i)), ((u64)TAG_INIT << 32) | pack_bf16x2(hprev, other), local);
+  }
+  unsigned rounds = 0;
+  // partial-sum address of this thread's unit in tile coordinates: gate g -> local row g*U + 2*up + e
+  int pidx[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const int r = g * U + 2 * up + e;
+    pidx[g] = ((r / 16) * 16 + gi_i) * 16 + (r % 16);
+  }
+
+  for (int s = 0; s < Tp; ++s) {
+    const int t = d == 0 ? s : Tp - 1 - s;
+    const int par = s & 1;
+    float gi[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) gi[g] = 0.f;
+    if (gate_thread) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) gi[g] = __uint_as_float((uint32_t)gi_ptr[(long)g * H] << 16);
+    }
+    ds2_f32x4 acc[TILES];
+#pragma unroll
+    for (int tt = 0; tt < TILES; ++tt) acc[tt] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
+    if (s > 0 || a.h0)
+      gather_mma<TILES, KS, SPLIT>(acc, w, rsrc, (par ^ 1) * PAR_BYTES, wave * KS, lq, srow, half, need, s > 0 ? (unsigned)s : TAG_INIT,
+                                   a.err, a.lerr, dead, rounds);
+    store_partials<TILES>(part[par], acc, wave, lane);
+    __syncthreads();
+    float hn = 0.f;                 // emitted h_t (0 when inactive)
+    float pl[NS ? NS : 1];
+#pragma unroll
+    for (int q = 0; q < (NS ? NS : 1); ++q) pl[q] = 0.f;
+    if (gate_thread) {
+      const bool act = t < len;
+      float gh[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float* pp = part[par] + pidx[g];
+        gh[g] = (pp[0] + pp[TILES * 256]) + (pp[2 * TILES * 256] + pp[3 * TILES * 256]);
+      }
+      if (act) {
+        if (CELL == CELL_GRU) {
+          const float q = gh[2 % G] + bh[2 % G];
+          const float r = fsigmoid(gi[0] + gh[0] + bh[0]);
+          const float z = fsigmoid(gi[1 % G] + gh[1 % G] + bh[1 % G]);
+          const float nn = ftanh(gi[2 % G] + r * q);
+          hn = (1.f - z) * nn + z * hprev;
+          hprev = hn;
+          pl[0] = r; pl[1 % (NS ? NS : 1)] = z; pl[2 % (NS ? NS : 1)] = nn; pl[3 % (NS ? NS : 1)] = q;
+        } else if (CELL == CELL_LSTM) {
+          const float ig = fsigmoid(gi[0] + gh[0] + bh[0]);
+          const float fg = fsigmoid(gi[1 % G] + gh[1 % G] + bh[1 % G]);
+          const float gg = ftanh(gi[2 % G] + gh[2 % G] + bh[2 % G]);
+          const float og = fsigmoid(gi[3 % G] + gh[3 % G] + bh[3 % G]);
+          const float c = fg * cprev + ig * gg;
+          hn = og * ftanh(c);
+          cprev = c;
+          hprev = hn;
+          pl[0] = ig; pl[1 % (NS ? NS : 1)] = fg; pl[2 % (NS ? NS : 1)] = gg; pl[3 % (NS ? NS : 1)] = og; pl[4 % (NS ? NS : 1)] = c;
+        } else {
+          hn = ftanh(gi[0] + gh[0] + bh[0]);
+          hprev = hn;
+        }
+      }
+      if (dead) hn = hprev = __uint_as_float(0x7fc00000u);
+    }
+    // the pair meets: the even lane publishes the carried state of both units, then stores the packed planes
+    {
+      const float hp_o = dpp_xor1(hprev), hn_o = dpp_xor1(hn);
+      float pl_o[NS ? NS : 1];
+#pragma unroll
+      for (int q = 0; q < (NS ? NS : 1); ++q) pl_o[q] = dpp_xor1(pl[q]);
+      if (gate_thread && e == 0) {
+        publish((u64*)((char*)xg + par * PAR_BYTES + xgranule_bytes<NROWS>(j, gi_i)), ((u64)(unsigned)(s + 1) << 32) | pack_bf16x2(hprev, hp_o),
+                local);
+        *reinterpret_cast<uint32_t*>(hs_ptr) = pack_bf16x2(hn, hn_o);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) *reinterpret_cast<uint32_t*>(sv_ptr + (long)q * H) = pack_bf16x2(pl[q], pl_o[q]);
+      }
+    }
+    gi_ptr += gi_stride;
+    if (NS) sv_ptr += sv_stride;
+    hs_ptr += hs_stride;
+  }
+  (void)rounds;
+  if (gate_thread) {
+    const long so = ((long)d * N + n) * H + ju;
+    if (a.hn) a.hn[so] = hprev;
+    if (CELL == CELL_LSTM && a.cn) a.cn[so] = cprev;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // BPTT sweep.  dh_t = dOut[t] + carry (elementwise part of dh from the step processed before) + dgh_{t'} * W_hh.
 // ------------------------------------------------------------------------------------------------------------------
 template <int CELL, int H, int P, int SPLIT>
@@ -735,17 +919,208 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd(PArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// BPTT sweep, <= 8 samples per group, gate phase on all four waves (one hidden unit per thread): see k_rnn_persist_fwd4.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ld_bf16(const bf16_t* p) { return __uint_as_float((uint32_t)p->v << 16); }
+
+template <int CELL, int H, int P>
+__global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd4(PArgs a) {
+  constexpr int G = CellInfo<CELL>::G, NS = CellInfo<CELL>::NS;
+  constexpr int SPLIT = 2, NROWS = 8;
+  constexpr int U = H / P;
+  constexpr int TILES = U / 16;
+  constexpr int KS = G * H / 128;
+  constexpr int X2 = G * H / 2;
+  static_assert(U == 32 && (G * H) % 128 == 0, "the one-unit-per-thread gate map assumes 32 hidden units per workgroup");
+  __shared__ __attribute__((aligned(16))) float part[2][4 * TILES * 256];
+  __builtin_amdgcn_s_setprio(3);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = blockIdx.x % NGROUPS, p = blockIdx.x / NGROUPS;
+  const int d = grp / a.gpd, slice = grp % a.gpd;
+  const int N = a.N, Tp = a.Tp;
+  const int Ns = (N - slice + a.gpd - 1) / a.gpd;
+  const int li = lane & 15, lq = lane >> 4;
+  constexpr long GH = (long)G * H;
+  const long ldgi = (long)a.D * GH;
+
+  uint4 w[TILES][KS];
+  {
+    const bf16_t* WT = a.W + (long)d * H * GH;
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+      const bf16_t* row = WT + (long)(p * U + 16 * t + li) * GH + wave * (GH / 4) + lq * 8;
+#pragma unroll
+      for (int k = 0; k < KS; ++k) w[t][k] = *reinterpret_cast<const uint4*>(row + 32 * k);
+    }
+  }
+  u64* xg = a.xbuf + (long)grp * 2 * MAXS * X2;
+  const int srow = li & 7, half = li >> 3;
+  const bool need = srow < Ns;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, 2 * MAXS * X2 * 8, 0x00020000);
+  constexpr int PAR_BYTES = MAXS * X2 * 8;
+
+  const int e = tid & 1, pid = tid >> 1;
+  const int gi_i = (pid >> 1) & 7;
+  const int up = ((pid >> 4) & 3) * 4 + ((pid >> 6) & 1) * 2 + (pid & 1);
+  const bool gate_thread = gi_i < Ns;
+  const int n = slice + a.gpd * gi_i;
+  const int j = p * U + 2 * up, ju = j + e;
+  int len = 0;
+  if (gate_thread) len = a.lens[n];
+  float car = 0.f, dc = 0.f;                                // carried dh (elementwise part) and dc of this thread's unit
+  const long dstep = d == 0 ? -1 : 1;
+  const int t_first = d == 0 ? Tp - 1 : 0;
+  const int nn_ = gate_thread ? n : 0;
+  constexpr long NSH_ = (long)(NS ? NS : 1) * H;
+  const bf16_t* do_ptr = a.dOut + ((long)t_first * N + nn_) * H + ju;
+  const bf16_t* sv_ptr = NS ? a.S + (((long)d * Tp + t_first) * N + nn_) * NSH_ + ju : nullptr;
+  const bf16_t* hs_ptr = a.Hseq + (long)d * a.hseq_dstride + ((long)t_first * N + nn_) * H + ju;   // h_t
+  bf16_t* dgi_ptr = a.dGI + ((long)t_first * N + nn_) * ldgi + (long)d * GH + j;                     // pair base (even lane stores)
+  bf16_t* dgh_ptr = a.dGH ? a.dGH + (((long)d * Tp + t_first) * N + nn_) * H + j : nullptr;         // dQ, pair base
+  constexpr int NB = CELL == CELL_GRU ? 4 : G;
+  float bsum[NB];
+#pragma unroll
+  for (int g = 0; g < NB; ++g) bsum[g] = 0.f;
+  const long prev_off = d == 0 ? -1 : 1;
+  bool dead = false;
+  const bool local = group_is_xcd_local(a.xcc + grp * 32, p, tid, a.err, a.lerr, dead);
+  unsigned rounds = 0;
+  const int pidx = (((2 * up + e) / 16) * 16 + gi_i) * 16 + ((2 * up + e) % 16);
+
+  for (int s = 0; s < Tp; ++s) {
+    const int t = d == 0 ? Tp - 1 - s : s;
+    const int par = s & 1;
+    // ---- prefetch everything the gate phase needs (2-byte loads of this thread's unit)
+    float dout = 0.f, sp[NS ? NS : 1], hp = 0.f, cp = 0.f;
+#pragma unroll
+    for (int q = 0; q < (NS ? NS : 1); ++q) sp[q] = 0.f;
+    if (gate_thread) {
+      dout = ld_bf16(do_ptr);
+#pragma unroll
+      for (int q = 0; q < NS; ++q) sp[q] = ld_bf16(sv_ptr + (long)q * H);
+      hp = ld_bf16(hs_ptr + prev_off * N * H);          // guard slots / inactive frames hold zeros: unconditional
+      if (CELL == CELL_LSTM) {
+        const bool has_prev = d == 0 ? (t > 0) : (t + 1 < len);
+        if (has_prev) cp = ld_bf16(sv_ptr + prev_off * N * NSH_ + 4 * H);
+      }
+      if (CELL == CELL_RNN) hp = ld_bf16(hs_ptr);
+    }
+    ds2_f32x4 acc[TILES];
+#pragma unroll
+    for (int tt = 0; tt < TILES; ++tt) acc[tt] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
+    if (s > 0)
+      gather_mma<TILES, KS, SPLIT>(acc, w, rsrc, (par ^ 1) * PAR_BYTES, wave * KS, lq, srow, half, need, (unsigned)s, a.err, a.lerr, dead,
+                                   rounds);
+    store_partials<TILES>(part[par], acc, wave, lane);
+    __syncthreads();
+    // gate gradients of this thread's unit (zeros when inactive); gq[] = what is exchanged, gs[] = what is stored in dGI
+    constexpr int M = NS ? NS : 1;
+    float gx[G], gn = 0.f, gq = 0.f;        // gx: the G exchanged planes; GRU: gx = {dr, dz, dq}, gn = dn (stored), gq = dq
+#pragma unroll
+    for (int g = 0; g < G; ++g) gx[g] = 0.f;
+    if (gate_thread) {
+      const bool act = t < len;
+      const float* pp = part[par] + pidx;
+      const float din = car + ((pp[0] + pp[TILES * 256]) + (pp[2 * TILES * 256] + pp[3 * TILES * 256]));
+      car = din;
+      if (CELL == CELL_GRU) {
+        if (act) {
+          const float r = sp[0], z = sp[1 % M], nn = sp[2 % M], q = sp[3 % M];
+          const float dh = dout + din;
+          gn = dh * (1.f - z) * (1.f - nn * nn);
+          gx[1 % G] = dh * (hp - nn) * z * (1.f - z);
+          gx[0] = gn * q * r * (1.f - r);
+          gx[2 % G] = gn * r;
+          car = dh * z;
+        }
+        if (dead) gx[0] = __uint_as_float(0x7fc00000u);
+      } else if (CELL == CELL_LSTM) {
+        if (act) {
+          const float ig = sp[0], fg = sp[1 % M], gg = sp[2 % M], og = sp[3 % M];
+          const float tc = ftanh(sp[4 % M]);
+          const float dh = dout + din;
+          const float dcn = dc + dh * og * (1.f - tc * tc);
+          gx[0] = dcn * gg * ig * (1.f - ig);
+          gx[1 % G] = dcn * cp * fg * (1.f - fg);
+          gx[2 % G] = dcn * ig * (1.f - gg * gg);
+          gx[3 % G] = dh * tc * og * (1.f - og);
+          car = 0.f;
+          dc = dcn * fg;
+        }
+        if (dead) gx[0] = __uint_as_float(0x7fc00000u);
+      } else {
+        if (act) {
+          gx[0] = (dout + din) * (1.f - hp * hp);
+          car = 0.f;
+        }
+        if (dead) gx[0] = __uint_as_float(0x7fc00000u);
+      }
+    }
+    // the pair meets: the even lane publishes and stores the packed values; both lanes accumulate their own bias sums from
+    // the ROUNDED values (= the column sums of the stored planes)
+    {
+      float go[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) go[g] = dpp_xor1(gx[g]);
+      const float gn_o = dpp_xor1(gn);
+      uint32_t pk[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) pk[g] = e == 0 ? pack_bf16x2(gx[g], go[g]) : pack_bf16x2(go[g], gx[g]);
+      const uint32_t pkn = e == 0 ? pack_bf16x2(gn, gn_o) : pack_bf16x2(gn_o, gn);
+      if (gate_thread) {
+        char* xo = (char*)xg + par * PAR_BYTES;
+        const u64 tag = (u64)(unsigned)(s + 1) << 32;
+        if (e == 0) {
+#pragma unroll
+          for (int g = 0; g < G; ++g) publish((u64*)(xo + xgranule_bytes<NROWS>(g * H + j, gi_i)), tag | pk[g], local);
+          if (CELL == CELL_GRU) {
+            *reinterpret_cast<uint32_t*>(dgi_ptr) = pk[0];
+            *reinterpret_cast<uint32_t*>(dgi_ptr + H) = pk[1 % G];
+            *reinterpret_cast<uint32_t*>(dgi_ptr + 2 * H) = pkn;
+            *reinterpret_cast<uint32_t*>(dgh_ptr) = pk[2 % G];
+          } else {
+#pragma unroll
+            for (int g = 0; g < G; ++g) *reinterpret_cast<uint32_t*>(dgi_ptr + (long)g * H) = pk[g];
+          }
+        }
+        // own unit's rounded values: low half of the pair word on the even lane, high half on the odd lane
+        if (CELL == CELL_GRU) {
+          bsum[0] += e == 0 ? bf_lo(pk[0]) : bf_hi(pk[0]);
+          bsum[1 % NB] += e == 0 ? bf_lo(pk[1 % G]) : bf_hi(pk[1 % G]);
+          bsum[2 % NB] += e == 0 ? bf_lo(pkn) : bf_hi(pkn);
+          bsum[3 % NB] += e == 0 ? bf_lo(pk[2 % G]) : bf_hi(pk[2 % G]);
+        } else {
+#pragma unroll
+          for (int g = 0; g < G; ++g) bsum[g % NB] += e == 0 ? bf_lo(pk[g]) : bf_hi(pk[g]);
+        }
+      }
+    }
+    do_ptr += dstep * N * H;
+    if (NS) sv_ptr += dstep * N * NSH_;
+    hs_ptr += dstep * N * H;
+    dgi_ptr += dstep * N * ldgi;
+    if (CELL == CELL_GRU) dgh_ptr += dstep * N * H;
+  }
+  (void)rounds;
+  if (gate_thread && a.dBacc) {
+    float* bo = a.dBacc + ((long)d * N + n) * NB * H + ju;
+#pragma unroll
+    for (int g = 0; g < NB; ++g) bo[(long)g * H] = bsum[g];
+  }
+}
+
 template <int CELL, int H, int P>
 int launch(bool bwd, const PArgs& a, hipStream_t st) {
   const bool split = (a.N + a.gpd - 1) / a.gpd <= 8;   // <= 8 samples per group: lane pairs share the gather
   if (bwd) {
     if (split)
-      hipLaunchKernelGGL((k_rnn_persist_bwd<CELL, H, P, 2>), dim3(NGROUPS * P), dim3(256), 0, st, a);
+      hipLaunchKernelGGL((k_rnn_persist_bwd4<CELL, H, P>), dim3(NGROUPS * P), dim3(256), 0, st, a);
     else
       hipLaunchKernelGGL((k_rnn_persist_bwd<CELL, H, P, 1>), dim3(NGROUPS * P), dim3(256), 0, st, a);
   } else {
     if (split)
-      hipLaunchKernelGGL((k_rnn_persist_fwd<CELL, H, P, 2>), dim3(NGROUPS * P), dim3(256), 0, st, a);
+      hipLaunchKernelGGL((k_rnn_persist_fwd4<CELL, H, P>), dim3(NGROUPS * P), dim3(256), 0, st, a);
     else
       hipLaunchKernelGGL((k_rnn_persist_fwd<CELL, H, P, 1>), dim3(NGROUPS * P), dim3(256), 0, st, a);
   }
