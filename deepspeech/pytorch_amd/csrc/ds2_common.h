@@ -174,6 +174,15 @@ __device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + ex
     if (e__ != hipSuccess) return (int)e__;            \
   } while (0)
 
+// compute units of the CURRENT device (cached per device; 256 when the query fails)
+static inline int ds2_cu_count() {
+  static int n[64];
+  int dev = 0, v = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (n[dev] == 0) n[dev] = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0 ? v : 256;
+  return n[dev];
+}
+
 #define DS2_REQUIRE(cond, code) \
   do {                          \
     if (!(cond)) return (code); \

@@ -154,6 +154,211 @@ __global__ void __launch_bounds__(C1W_THREADS) k_conv1_wgrad(const float* __rest
 }
 
 // ============================================================================================================
+// conv1 on the matrix pipes (bf16 storage): what torch.autocast does with this layer (bf16 input and weight, fp32 sums)
+// ============================================================================================================
+// One workgroup block = 9 output rows x 128 output frames of one sample (81 = 9 x 9 rows: no ragged row block); wave w owns
+// the 32 frames [32w, 32w+32).  The input patch (57 rows x 272 columns, column u <-> input frame 2*t0 - 5 + u) is staged in
+// LDS as bf16.  The contraction index of one MFMA is the kernel's time tap kt padded from 11 to 16 (zero weights), one MFMA
+// per kernel row kf: the operand of input row rho = 2*fl + kf is the same for every (output row fl, kernel row kf) pair on
+// that input row, so it is read from LDS ONCE and multiplied into up to 9 accumulators -- 6.5 MFMAs per 1 KB LDS read,
+// which is what takes this layer off the LDS roof (one read per MFMA = LDS-bound at half rate).
+constexpr int M1_FB = 9, M1_TB = 128;
+constexpr int M1_PR = 2 * (M1_FB - 1) + K1F;   // 57 input rows
+constexpr int M1_PC = 2 * M1_TB + 16;          // 272 input columns
+constexpr int M1_RSB = M1_PC * 2;              // LDS bytes per patch row
+constexpr int M1_PATCH_BYTES = M1_PR * M1_RSB; // 31008
+static_assert(F1 == 9 * M1_FB, "conv1 MFMA kernels assume 81 output rows");
+
+template <int BATCH>
+__device__ __forceinline__ void conv1_stage_bf16(unsigned char* patch, const float* __restrict__ xn, int T, int f_base, int t_base,
+                                                 int tid) {
+  // column pairs -> one packed dword.  Straight-line batches of BATCH pairs per thread: all 2*BATCH loads of a batch are in flight
+  // together (a rolled loop pays one L2 round trip per iteration, which was 80 % of this kernel).
+  constexpr int NP = M1_PC / 2, TOTAL = M1_PR * NP, ITER = (TOTAL + 255) / 256;
+#pragma unroll
+  for (int b0 = 0; b0 < ITER; b0 += BATCH) {
+    float v0[BATCH], v1[BATCH];
+#pragma unroll
+    for (int it = 0; it < BATCH; ++it) {
+      const int i = tid + (b0 + it) * 256;
+      v0[it] = v1[it] = 0.f;
+      if (b0 + it < ITER && i < TOTAL) {
+        const int pr = i / NP, pc = 2 * (i - pr * NP);
+        const int fi = f_base + pr, t0 = t_base + pc, t1 = t0 + 1;
+        const bool okf = fi >= 0 && fi < F0;
+        const int ro = min(max(fi, 0), F0 - 1) * T;                 // 32-bit offsets: one sample is 161 * T floats
+        const float a = xn[ro + min(max(t0, 0), T - 1)], b = xn[ro + min(max(t1, 0), T - 1)];
+        v0[it] = okf && t0 >= 0 && t0 < T ? a : 0.f;
+        v1[it] = okf && t1 >= 0 && t1 < T ? b : 0.f;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < BATCH; ++it) {
+      const int i = tid + (b0 + it) * 256;
+      if (b0 + it < ITER && i < TOTAL) {
+        const int pr = i / NP, pc = 2 * (i - pr * NP);
+        *reinterpret_cast<uint32_t*>(patch + pr * M1_RSB + pc * 2) = cvt_pk_bf16(v0[it], v1[it]);
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256, 1) k_conv1_fwd_mfma(const float* __restrict__ x, const float* __restrict__ w1k,
+                                                           const float* __restrict__ b1, const int* __restrict__ lens,
+                                                           bf16_t* __restrict__ y1, int N, int Tin, int Tp, int ntb) {
+  __shared__ __attribute__((aligned(16))) unsigned char patch[M1_PATCH_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int pos = lane & 31, h = lane >> 5;
+  // the weights as A fragments, resident for the whole launch: lane (channel = lane & 31, k-block h) holds kt = 8h .. 8h+7 of row kf
+  uint4 A[K1F];
+#pragma unroll
+  for (int kf = 0; kf < K1F; ++kf) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int kt = 8 * h + i;
+      const float wv = w1k[(kf * K1T + min(kt, K1T - 1)) * CH + pos];
+      v[i] = kt < K1T ? wv : 0.f;
+    }
+    A[kf] = make_uint4(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]), cvt_pk_bf16(v[4], v[5]), cvt_pk_bf16(v[6], v[7]));
+  }
+  float bias[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bias[r] = b1[mma32_row(r, lane)];
+  const unsigned char* bp = patch + wave * 128 + pos * 4 + h * 16;
+  const int total = N * ntb * 9;
+  for (int blk = blockIdx.x; blk < total; blk += gridDim.x) {
+    const int fb = blk % 9, tb = (blk / 9) % ntb, n = blk / (9 * ntb);
+    __syncthreads();
+    conv1_stage_bf16<8>(patch, x + (long)n * F0 * Tin, Tin, 18 * fb - 20, 256 * tb - 5, tid);
+    __syncthreads();
+    ds2_f32x16 acc[M1_FB];
+#pragma unroll
+    for (int fl = 0; fl < M1_FB; ++fl)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[fl][r] = bias[r];
+#pragma unroll
+    for (int rho = 0; rho < M1_PR; ++rho) {
+      const uint32_t* q = reinterpret_cast<const uint32_t*>(bp + rho * M1_RSB);
+      const uint4 b = make_uint4(q[0], q[1], q[2], q[3]);
+#pragma unroll
+      for (int fl = 0; fl < M1_FB; ++fl) {
+        const int kf = rho - 2 * fl;
+        if (kf >= 0 && kf < K1F) Mma<bf16_t>::mma32(acc[fl], A[kf], b);
+      }
+    }
+    const int t = tb * M1_TB + wave * 32 + pos;
+    if (t < Tp) {
+      const bool live = t < lens[n];
+#pragma unroll
+      for (int fl = 0; fl < M1_FB; ++fl) {
+        bf16_t* dst = y1 + (((long)n * F1 + 9 * fb + fl) * Tp + t) * CH + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          uint2 o = make_uint2(cvt_pk_bf16(acc[fl][4 * g], acc[fl][4 * g + 1]), cvt_pk_bf16(acc[fl][4 * g + 2], acc[fl][4 * g + 3]));
+          if (!live) o = make_uint2(0u, 0u);
+          *reinterpret_cast<uint2*>(dst + 8 * g) = o;
+        }
+      }
+    }
+  }
+}
+
+// Weight gradient: contraction over the frames (32 per MFMA 16x16x32), A = input taps [16 kt x 32 frames] gathered from the
+// staged patch (stride-2 columns), B = the output gradient transposed through LDS [32 frames x 16 channels].  Wave w owns the
+// 64 frames [64*(w>>1), +64) and the channel half w & 1, and keeps its 41 accumulator tiles dW[kf][kt][16 channels] in
+// registers; as in the forward the tap operand of input row rho serves every (fl, kf) pair on that row.
+constexpr int M1_DYS = 72;                                   // frames per channel row of the transposed tile (64 + pad: conflict-free b128)
+constexpr int M1_DYT_WAVE = M1_FB * 16 * M1_DYS * 2;         // 20736 bytes per wave
+constexpr int M1_PATCH_PAD = 31232;                          // patch rounded up to 256 bytes
+constexpr int M1W_SMEM = M1_PATCH_PAD + 4 * M1_DYT_WAVE;     // 114176
+static_assert(K1F * K1T * CH * 4 <= M1W_SMEM, "reduction buffer aliases the staging area");
+
+__global__ void __launch_bounds__(256, 1) k_conv1_wgrad_mfma(const float* __restrict__ x, const bf16_t* __restrict__ dy1,
+                                                             float* __restrict__ partial, int N, int Tin, int Tp, int ntb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem1[];
+  unsigned char* patch = smem1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int pair = wave >> 1, hh = wave & 1;
+  uint16_t* dyT = reinterpret_cast<uint16_t*>(smem1 + M1_PATCH_PAD + wave * M1_DYT_WAVE);
+  const int kt = lane & 15, q = lane >> 4;
+  ds2_f32x4 acc[K1F];
+#pragma unroll
+  for (int kf = 0; kf < K1F; ++kf) acc[kf] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
+  // byte offset of this lane's first tap inside a patch row: column u = 2 * (64*pair + 32*c + 8*q + i) + kt
+  const unsigned char* xp = patch + (2 * (64 * pair + 8 * q) + kt) * 2;
+  const int total = N * ntb * 9;
+  for (int blk = blockIdx.x; blk < total; blk += gridDim.x) {
+    const int fb = blk % 9, tb = (blk / 9) % ntb, n = blk / (9 * ntb);
+    __syncthreads();
+    conv1_stage_bf16<16>(patch, x + (long)n * F0 * Tin, Tin, 18 * fb - 20, 256 * tb - 5, tid);
+    {  // this wave's output-gradient tile, transposed: dyT[fl][channel of the half][frame]
+      const int t0 = tb * M1_TB + 64 * pair, piece = lane & 1;
+#pragma unroll
+      for (int fl = 0; fl < M1_FB; ++fl)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int tl = 32 * j + (lane >> 1), t = t0 + tl;
+          uint4 v = make_uint4(0u, 0u, 0u, 0u);
+          if (t < Tp) v = *reinterpret_cast<const uint4*>(dy1 + (((long)n * F1 + 9 * fb + fl) * Tp + t) * CH + 16 * hh + 8 * piece);
+          uint16_t* d = dyT + (fl * 16 + 8 * piece) * M1_DYS + tl;
+          d[0 * M1_DYS] = (uint16_t)v.x;
+          d[1 * M1_DYS] = (uint16_t)(v.x >> 16);
+          d[2 * M1_DYS] = (uint16_t)v.y;
+          d[3 * M1_DYS] = (uint16_t)(v.y >> 16);
+          d[4 * M1_DYS] = (uint16_t)v.z;
+          d[5 * M1_DYS] = (uint16_t)(v.z >> 16);
+          d[6 * M1_DYS] = (uint16_t)v.w;
+          d[7 * M1_DYS] = (uint16_t)(v.w >> 16);
+        }
+    }
+    __syncthreads();
+    uint4 dyb[M1_FB][2];
+#pragma unroll
+    for (int fl = 0; fl < M1_FB; ++fl)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) dyb[fl][c] = *reinterpret_cast<const uint4*>(dyT + (fl * 16 + kt) * M1_DYS + 32 * c + 8 * q);
+#pragma unroll
+    for (int rho = 0; rho < M1_PR; ++rho) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const uint16_t* xr = reinterpret_cast<const uint16_t*>(xp + rho * M1_RSB + c * 128);
+        uint4 xa;
+        xa.x = (uint32_t)xr[0] | ((uint32_t)xr[2] << 16);
+        xa.y = (uint32_t)xr[4] | ((uint32_t)xr[6] << 16);
+        xa.z = (uint32_t)xr[8] | ((uint32_t)xr[10] << 16);
+        xa.w = (uint32_t)xr[12] | ((uint32_t)xr[14] << 16);
+#pragma unroll
+        for (int fl = 0; fl < M1_FB; ++fl) {
+          const int kf = rho - 2 * fl;
+          if (kf >= 0 && kf < K1F) Mma<bf16_t>::mma16(acc[kf], xa, dyb[fl][c]);
+        }
+      }
+    }
+  }
+  // the two frame halves' sums in a fixed order, then one partial per workgroup: partial[blockIdx.x][451][32]
+  float* red = reinterpret_cast<float*>(smem1);
+  for (int w = 0; w < 2; ++w) {
+    __syncthreads();
+    if (pair == w) {
+#pragma unroll
+      for (int kf = 0; kf < K1F; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = 4 * q + r;                 // 16x16 D layout: row = 4*(lane>>4) + r (tap), column = lane & 15 (channel)
+          if (k < K1T) {
+            float* e = red + (kf * K1T + k) * CH + 16 * hh + kt;
+            *e = w == 0 ? acc[kf][r] : *e + acc[kf][r];
+          }
+        }
+    }
+  }
+  __syncthreads();
+  float* dst = partial + (long)blockIdx.x * (K1F * K1T * CH);
+  for (int e = tid; e < K1F * K1T * CH; e += 256) dst[e] = red[e];
+}
+
+// ============================================================================================================
 // conv2 forward / dgrad: MFMA tap-GEMM
 // ============================================================================================================
 constexpr int CT_UB = 4, CT_TB = 32;          // output tile: 4 rows (one per wave) x 32 positions
@@ -531,10 +736,15 @@ int ds2_conv1_fwd(int dtype, const float* x, const float* w1k, const float* b1, 
   DS2_REQUIRE(dtype == DS2_F32 || dtype == DS2_BF16, DS2_ERR_DTYPE);
   DS2_REQUIRE(N > 0 && T > 0 && Tp == (T + 2 * 5 - 10 - 1) / 2 + 1, DS2_ERR_ARG);
   dim3 grid(ds2_cdiv(Tp, C1_TB), ds2_cdiv(F1, C1_FB), N);
-  if (dtype == DS2_F32)
+  if (dtype == DS2_F32) {
     hipLaunchKernelGGL(k_conv1_fwd<float>, grid, dim3(256), 0, st, x, w1k, b1, lens, (float*)y1, N, T, Tp);
-  else
-    hipLaunchKernelGGL(k_conv1_fwd<bf16_t>, grid, dim3(256), 0, st, x, w1k, b1, lens, (bf16_t*)y1, N, T, Tp);
+  } else {   // matrix pipes: persistent workgroups over the (sample, frame block, row block) tiles
+    const int ntb = ds2_cdiv(Tp, M1_TB);
+    const long total = (long)N * ntb * 9;
+    const int cus = ds2_cu_count();
+    hipLaunchKernelGGL(k_conv1_fwd_mfma, dim3((unsigned)(total < cus ? total : cus)), dim3(256), 0, st, x, w1k, b1, lens, (bf16_t*)y1, N,
+                       T, Tp, ntb);
+  }
   DS2_CHECK_LAUNCH();
   return 0;
 }
@@ -542,6 +752,11 @@ int ds2_conv1_fwd(int dtype, const float* x, const float* w1k, const float* b1, 
 static int conv1_wgrad_blocks(int N, int Tp) {
   long total = (long)N * ds2_cdiv(F1, C1_FB) * ds2_cdiv(Tp, C1_TB);
   return (int)(total < C1W_MAXBLOCKS ? total : C1W_MAXBLOCKS);
+}
+static int conv1_wgrad_mfma_blocks(int N, int Tp) {   // never more than conv1_wgrad_blocks (the workspace is sized for that)
+  const long total = (long)N * ds2_cdiv(Tp, M1_TB) * 9;
+  const int cus = ds2_cu_count();
+  return (int)(total < cus ? total : cus);
 }
 long ds2_conv1_wgrad_ws_floats(int N, int Tp) {
   const long P = conv1_wgrad_blocks(N, Tp);
@@ -551,12 +766,17 @@ int ds2_conv1_wgrad(int dtype, const float* x, const void* dy1, float* dw1k, int
                     ds2_stream_t st_) {
   hipStream_t st = (hipStream_t)st_;
   DS2_REQUIRE(dtype == DS2_F32 || dtype == DS2_BF16, DS2_ERR_DTYPE);
-  const int P = conv1_wgrad_blocks(N, Tp);
+  int P = conv1_wgrad_blocks(N, Tp);
   const int ncf = ds2_cdiv(F1, C1_FB), nct = ds2_cdiv(Tp, C1_TB);
-  if (dtype == DS2_F32)
+  if (dtype == DS2_F32) {
     hipLaunchKernelGGL(k_conv1_wgrad<float>, dim3(P), dim3(C1W_THREADS), 0, st, x, (const float*)dy1, ws, N, T, Tp, nct, ncf);
-  else
-    hipLaunchKernelGGL(k_conv1_wgrad<bf16_t>, dim3(P), dim3(C1W_THREADS), 0, st, x, (const bf16_t*)dy1, ws, N, T, Tp, nct, ncf);
+  } else {
+    static bool attr[DS2_MAX_DEVICES];
+    if (ds2_first_use_on_device(attr))
+      (void)hipFuncSetAttribute((const void*)k_conv1_wgrad_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, M1W_SMEM);
+    P = conv1_wgrad_mfma_blocks(N, Tp) < P ? conv1_wgrad_mfma_blocks(N, Tp) : P;
+    hipLaunchKernelGGL(k_conv1_wgrad_mfma, dim3(P), dim3(256), M1W_SMEM, st, x, (const bf16_t*)dy1, ws, N, T, Tp, ds2_cdiv(Tp, M1_TB));
+  }
   DS2_CHECK_LAUNCH();
   const int C = K1F * K1T * CH;
   return ds2_colsum(DS2_F32, ws, P, C, C, dw1k, 1.0f, ws + (long)P * C, st_);

@@ -39,7 +39,9 @@ int dispatch(bool bwd, int cell, int H, const PArgs& a, hipStream_t st) {
 }
 
 // scratch head: [0,1024) cycle counters (-DDS2_PROBE builds only), [1024,3072) XCC-id handshake slots, [3072] the per-launch
-// error word; the exchange buffer follows.  All of it is zeroed before every launch.
+// error word; the exchange buffer follows.  All of it is reset before every launch: to zeros for the general kernels, to 0xFF
+// bytes for the tuned ones (their tag-free exchange uses the all-ones dword as "not published yet"; an all-ones tag never
+// equals a step index, an all-ones handshake slot is not a signature, and the error word counts as raised only when it is 1).
 constexpr long AUX_BYTES = 4096;
 
 int gates(int cell) { return cell == CELL_GRU ? 3 : cell == CELL_LSTM ? 4 : 1; }
@@ -117,7 +119,7 @@ int ds2_rnn_persist_fwd(int dtype, int cell, int D, int N, int H, int Tp, const 
   hipStream_t st = (hipStream_t)st_;
   DS2_REQUIRE(Tp > 0 && Tp < (int)TAG_INIT && ws && err, DS2_ERR_ARG);
   if (tuned_ok(dtype, cell, D, N, H)) {
-    hipError_t e = hipMemsetAsync(ws, 0, AUX_BYTES + xbuf_bytes(cell, H, false), st);
+    hipError_t e = hipMemsetAsync(ws, 0xff, AUX_BYTES + xbuf_bytes(cell, H, false), st);   // 0xFF: see gather_mma_tf
     if (e != hipSuccess) return (int)e;
     PArgs a{};
     a.N = N; a.Tp = Tp; a.D = D; a.gpd = NGROUPS / D; a.lens = lens; a.W = (const bf16_t*)Whh; a.bhh = bhh;
@@ -154,7 +156,7 @@ int ds2_rnn_persist_bwd(int dtype, int cell, int D, int N, int H, int Tp, const 
   DS2_REQUIRE(Tp > 0 && Tp < (int)TAG_INIT && ws && err, DS2_ERR_ARG);
   DS2_REQUIRE(cell != CELL_GRU || dGH != nullptr, DS2_ERR_ARG);
   if (tuned_ok(dtype, cell, D, N, H)) {
-    hipError_t e = hipMemsetAsync(ws, 0, AUX_BYTES + xbuf_bytes(cell, H, true), st);
+    hipError_t e = hipMemsetAsync(ws, 0xff, AUX_BYTES + xbuf_bytes(cell, H, true), st);
     if (e != hipSuccess) return (int)e;
     PArgs a{};
     a.N = N; a.Tp = Tp; a.D = D; a.gpd = NGROUPS / D; a.lens = lens; a.W = (const bf16_t*)WhhT;

@@ -240,7 +240,7 @@ __device__ __forceinline__ void gather_mma(ds2_f32x4 (&acc)[TILES], const uint4 
           if (!__any(bad2)) break;
           // give up after the spin limit, or early when a peer of THIS launch already did (the per-launch word lives in the
           // scratch that is zeroed before every launch: a time-out of an earlier launch never shortens this one's patience)
-          if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(lerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(lerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1)) {
             dead = true;
             raise_err(err, lerr);
             break;
@@ -252,6 +252,106 @@ __device__ __forceinline__ void gather_mma(ds2_f32x4 (&acc)[TILES], const uint4 
 #undef DS2_GATHER_LOAD
 #undef DS2_GATHER_MMA
 #undef DS2_GATHER_CHECK
+    if (KS != CH) {
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) acc[t] += part[t];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Tag-free exchange (groups of <= 8 samples: k_rnn_persist_fwd4 / bwd4).  The tagged granules spend half of every gathered byte
+// -- and half of the load instructions, which is what a step is priced in -- on tags.  Here the payload alone travels:
+//   * the buffer is FOUR slots (step e publishes into slot e & 3), each in MFMA A-fragment order
+//     [k-step][lq (4)][sample row (8)] x 16 bytes = the 8 bf16 k-values 32*kstep + 8*lq .. +7 of one row: ONE 16-byte load is
+//     one A fragment;
+//   * "not there yet" is the dword 0xFFFFFFFF (two bf16 NaNs with all mantissa bits set, which no published pair is: a pair
+//     that would be is published as two canonical NaNs).  The host fills the buffer with 0xFF bytes; a dword is written by
+//     exactly one thread with one 4-byte store, so it is either the sentinel or complete data;
+//   * every publisher re-arms its own dwords: at step s, after its gather, it writes the sentinel into slot (s + 2) & 3.
+//     That slot last held step s-2's data, which every peer finished reading before it published step s-1's (and those
+//     publishes are what this workgroup's gather of step s just consumed).  The re-arm is acknowledged before this wave
+//     publishes step s+1 (its gather of step s+1 waits on vmcnt, which retires in order), and a peer polls the slot for step
+//     s+2's data only after it has seen this workgroup's step s+1 data: it can never read the stale step s-2 values.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t XSENT = 0xffffffffu;
+__device__ __forceinline__ int xtf_unit_bytes(int kstep, int lq, int row) { return ((kstep * 4 + lq) * 8 + row) * 16; }
+// byte offset of the dword that carries elements (k, k+1), k even, of sample row `row`
+__device__ __forceinline__ int xtf_pair_bytes(int k, int row) {
+  const int kk = k & 31;
+  return xtf_unit_bytes(k >> 5, kk >> 3, row) + ((kk & 7) >> 1) * 4;
+}
+__device__ __forceinline__ uint32_t xtf_word(uint32_t pk) { return pk == XSENT ? 0x7fc07fc0u : pk; }
+__device__ __forceinline__ void publish32(void* p, uint32_t v, bool local) {
+  if (local)
+    __builtin_nontemporal_store(v, (uint32_t*)p);
+  else
+    __hip_atomic_store((uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int TILES, int KS>
+__device__ __forceinline__ void gather_mma_tf(ds2_f32x4 (&acc)[TILES], const uint4 (&w)[TILES][KS], __amdgpu_buffer_rsrc_t rsrc,
+                                              int slot_off, int kstep0, int lq, int srow, int half, bool need, int* err, int* lerr,
+                                              bool& dead, unsigned& rounds) {
+  constexpr int CH = chunk_ksteps(KS, 2);
+  constexpr int PER = CH / 2;       // k-steps a lane loads per chunk (the other half arrives by the DPP row rotate)
+  static_assert(KS % CH == 0 && CH % 2 == 0, "k-steps per wave must tile into poll chunks");
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+#pragma unroll
+  for (int c = 0; c < KS / CH; ++c) {
+    u32x4 v[PER];
+    ds2_f32x4 part_[KS == CH ? 1 : TILES];
+    ds2_f32x4 (&part)[TILES] = *reinterpret_cast<ds2_f32x4 (*)[TILES]>(KS == CH ? &acc[0] : &part_[0]);
+#define DS2_TF_LOAD()                                                                                                  \
+    if (need) {                                                                                                        \
+      _Pragma("unroll") for (int i = 0; i < PER; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(                    \
+          rsrc, slot_off + xtf_unit_bytes(kstep0 + c * CH + half * PER + i, lq, srow), 0, 16 /* sc1 */);               \
+    }
+#define DS2_TF_MMA()                                                                                                   \
+    _Pragma("unroll") for (int t = 0; t < TILES; ++t) part[t] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};                        \
+    _Pragma("unroll") for (int k = 0; k < CH; ++k) {                                                                   \
+      const int i = k % PER;                                                                                           \
+      uint4 a = make_uint4(0, 0, 0, 0);                                                                                \
+      if (need) a = make_uint4(v[i][0], v[i][1], v[i][2], v[i][3]);                                                    \
+      if (k >= PER) a = make_uint4(ror8(a.x), ror8(a.y), ror8(a.z), ror8(a.w));                                        \
+      _Pragma("unroll") for (int t = 0; t < TILES; ++t) Mma<bf16_t>::mma16(part[t], a, w[t][c * CH + k]);              \
+    }
+#define DS2_TF_CHECK(bad)                                                                                              \
+    bool bad = false;                                                                                                  \
+    if (need) {                                                                                                        \
+      uint32_t m = 0;                                                                                                  \
+      _Pragma("unroll") for (int i = 0; i < PER; ++i) m = max(max(m, max(v[i][0], v[i][1])), max(v[i][2], v[i][3]));   \
+      bad = m == XSENT;                                                                                                \
+    }
+    DS2_TF_LOAD()
+    DS2_TF_MMA()              // speculative: runs k-step by k-step as the loads land
+    DS2_TF_CHECK(bad0)
+    if (__any(bad0) && !dead) {
+      __builtin_amdgcn_s_sleep(1);
+      ++rounds;
+      DS2_TF_LOAD()
+      DS2_TF_MMA()
+      DS2_TF_CHECK(bad1)
+      if (__any(bad1)) {
+        unsigned spins = 0;
+        for (;;) {
+          __builtin_amdgcn_s_sleep(1);
+          ++rounds;
+          DS2_TF_LOAD()
+          DS2_TF_CHECK(bad2)
+          if (!__any(bad2)) break;
+          if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(lerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1)) {
+            dead = true;
+            raise_err(err, lerr);
+            break;
+          }
+        }
+        DS2_TF_MMA()
+      }
+    }
+#undef DS2_TF_LOAD
+#undef DS2_TF_MMA
+#undef DS2_TF_CHECK
     if (KS != CH) {
 #pragma unroll
       for (int t = 0; t < TILES; ++t) acc[t] += part[t];
@@ -520,7 +620,6 @@ __device__ __forceinline__ float dpp_xor1(float v) {      // value of the neighb
 template <int CELL, int H, int P>
 __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd4(PArgs a) {
   constexpr int G = CellInfo<CELL>::G, NS = CellInfo<CELL>::NS;
-  constexpr int SPLIT = 2, NROWS = 8;
   constexpr int U = H / P;
   constexpr int TILES = G * U / 16;
   constexpr int KS = H / 128;
@@ -548,17 +647,19 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd4(PArgs a) {
       for (int k = 0; k < KS; ++k) w[t][k] = *reinterpret_cast<const uint4*>(row + 32 * k);
     }
   }
-  u64* xg = a.xbuf + (long)grp * 2 * MAXS * X2;
+  // tag-free exchange: 4 slots of [H/32 k-steps][4][8 rows] x 16 bytes inside this group's share of the scratch
+  constexpr int SLOT_BYTES = (H / 32) * 512;
+  static_assert(4 * SLOT_BYTES <= 2 * MAXS * X2 * 8, "four payload slots fit where the two tagged parities lived");
+  char* xg = (char*)(a.xbuf + (long)grp * 2 * MAXS * X2);
   const int srow = li & 7, half = li >> 3;
   const bool need = srow < Ns;
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, 2 * MAXS * X2 * 8, 0x00020000);
-  constexpr int PAR_BYTES = MAXS * X2 * 8;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, 4 * SLOT_BYTES, 0x00020000);
 
-  // ---- gate identity: thread bits = (e: unit of the pair, pos, sample row (3), lq (2), q) -- the pair index (tid >> 1) has the
-  // bit order of the exchange layout, so the even lanes of a wave publish one contiguous run
+  // ---- gate identity: thread bits = (e: unit of the pair, pair within the 16-byte unit (2), sample row (3), lq (2)) -- the pair
+  // index (tid >> 1) has the bit order of the exchange layout, so the even lanes of a wave publish one contiguous 128-byte run
   const int e = tid & 1, pid = tid >> 1;
-  const int gi_i = (pid >> 1) & 7;
-  const int up = ((pid >> 4) & 3) * 4 + ((pid >> 6) & 1) * 2 + (pid & 1);
+  const int gi_i = (pid >> 2) & 7;
+  const int up = ((pid >> 5) & 3) * 4 + (pid & 3);
   const bool gate_thread = gi_i < Ns;
   const int n = slice + a.gpd * gi_i;
   const int j = p * U + 2 * up;              // first unit of the pair
@@ -593,10 +694,10 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd4(PArgs a) {
     *reinterpret_cast<uint32_t*>(hb - (long)N * H) = 0u;
     *reinterpret_cast<uint32_t*>(hb + (long)Tp * N * H) = 0u;
   }
-  if (a.h0) {                    // initial state as "step -1": parity 1, tag TAG_INIT
+  const int xoff = xtf_pair_bytes(j, gi_i);     // this pair's dword inside a slot
+  if (a.h0) {                    // initial state as "step -1": slot 3
     const float other = dpp_xor1(hprev);
-    if (gate_thread && e == 0)
-      publish((u64*)((char*)xg + PAR_BYTES + xgranule_bytes<NROWS>(j, gi_i)), ((u64)TAG_INIT << 32) | pack_bf16x2(hprev, other), local);
+    if (gate_thread && e == 0) publish32(xg + 3 * SLOT_BYTES + xoff, xtf_word(pack_bf16x2(hprev, other)), local);
   }
   unsigned rounds = 0;
   // partial-sum address of this thread's unit in tile coordinates: gate g -> local row g*U + 2*up + e
@@ -621,8 +722,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd4(PArgs a) {
 #pragma unroll
     for (int tt = 0; tt < TILES; ++tt) acc[tt] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
     if (s > 0 || a.h0)
-      gather_mma<TILES, KS, SPLIT>(acc, w, rsrc, (par ^ 1) * PAR_BYTES, wave * KS, lq, srow, half, need, s > 0 ? (unsigned)s : TAG_INIT,
-                                   a.err, a.lerr, dead, rounds);
+      gather_mma_tf<TILES, KS>(acc, w, rsrc, ((s + 3) & 3) * SLOT_BYTES, wave * KS, lq, srow, half, need, a.err, a.lerr, dead, rounds);
     store_partials<TILES>(part[par], acc, wave, lane);
     __syncthreads();
     float hn = 0.f;                 // emitted h_t (0 when inactive)
@@ -670,8 +770,8 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd4(PArgs a) {
 #pragma unroll
       for (int q = 0; q < (NS ? NS : 1); ++q) pl_o[q] = dpp_xor1(pl[q]);
       if (gate_thread && e == 0) {
-        publish((u64*)((char*)xg + par * PAR_BYTES + xgranule_bytes<NROWS>(j, gi_i)), ((u64)(unsigned)(s + 1) << 32) | pack_bf16x2(hprev, hp_o),
-                local);
+        publish32(xg + (s & 3) * SLOT_BYTES + xoff, xtf_word(pack_bf16x2(hprev, hp_o)), local);
+        publish32(xg + ((s + 2) & 3) * SLOT_BYTES + xoff, XSENT, local);        // re-arm the slot of step s + 2
         *reinterpret_cast<uint32_t*>(hs_ptr) = pack_bf16x2(hn, hn_o);
 #pragma unroll
         for (int q = 0; q < NS; ++q) *reinterpret_cast<uint32_t*>(sv_ptr + (long)q * H) = pack_bf16x2(pl[q], pl_o[q]);
@@ -927,7 +1027,6 @@ __device__ __forceinline__ float ld_bf16(const bf16_t* p) { return __uint_as_flo
 template <int CELL, int H, int P>
 __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd4(PArgs a) {
   constexpr int G = CellInfo<CELL>::G, NS = CellInfo<CELL>::NS;
-  constexpr int SPLIT = 2, NROWS = 8;
   constexpr int U = H / P;
   constexpr int TILES = U / 16;
   constexpr int KS = G * H / 128;
@@ -954,15 +1053,17 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd4(PArgs a) {
       for (int k = 0; k < KS; ++k) w[t][k] = *reinterpret_cast<const uint4*>(row + 32 * k);
     }
   }
-  u64* xg = a.xbuf + (long)grp * 2 * MAXS * X2;
+  // tag-free exchange (see gather_mma_tf): 4 slots of [G*H/32 k-steps][4][8 rows] x 16 bytes
+  constexpr int SLOT_BYTES = (G * H / 32) * 512;
+  static_assert(4 * SLOT_BYTES <= 2 * MAXS * X2 * 8, "four payload slots fit where the two tagged parities lived");
+  char* xg = (char*)(a.xbuf + (long)grp * 2 * MAXS * X2);
   const int srow = li & 7, half = li >> 3;
   const bool need = srow < Ns;
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, 2 * MAXS * X2 * 8, 0x00020000);
-  constexpr int PAR_BYTES = MAXS * X2 * 8;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, 4 * SLOT_BYTES, 0x00020000);
 
-  const int e = tid & 1, pid = tid >> 1;
-  const int gi_i = (pid >> 1) & 7;
-  const int up = ((pid >> 4) & 3) * 4 + ((pid >> 6) & 1) * 2 + (pid & 1);
+  const int e = tid & 1, pid = tid >> 1;      // thread bits as in k_rnn_persist_fwd4
+  const int gi_i = (pid >> 2) & 7;
+  const int up = ((pid >> 5) & 3) * 4 + (pid & 3);
   const bool gate_thread = gi_i < Ns;
   const int n = slice + a.gpd * gi_i;
   const int j = p * U + 2 * up, ju = j + e;
@@ -987,6 +1088,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd4(PArgs a) {
   const bool local = group_is_xcd_local(a.xcc + grp * 32, p, tid, a.err, a.lerr, dead);
   unsigned rounds = 0;
   const int pidx = (((2 * up + e) / 16) * 16 + gi_i) * 16 + ((2 * up + e) % 16);
+  const int xoff = xtf_pair_bytes(j, gi_i);     // this pair's dword of gate 0 inside a slot
 
   for (int s = 0; s < Tp; ++s) {
     const int t = d == 0 ? Tp - 1 - s : s;
@@ -1009,9 +1111,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd4(PArgs a) {
     ds2_f32x4 acc[TILES];
 #pragma unroll
     for (int tt = 0; tt < TILES; ++tt) acc[tt] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
-    if (s > 0)
-      gather_mma<TILES, KS, SPLIT>(acc, w, rsrc, (par ^ 1) * PAR_BYTES, wave * KS, lq, srow, half, need, (unsigned)s, a.err, a.lerr, dead,
-                                   rounds);
+    if (s > 0) gather_mma_tf<TILES, KS>(acc, w, rsrc, ((s + 3) & 3) * SLOT_BYTES, wave * KS, lq, srow, half, need, a.err, a.lerr, dead, rounds);
     store_partials<TILES>(part[par], acc, wave, lane);
     __syncthreads();
     // gate gradients of this thread's unit (zeros when inactive); gq[] = what is exchanged, gs[] = what is stored in dGI
@@ -1069,11 +1169,13 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd4(PArgs a) {
       for (int g = 0; g < G; ++g) pk[g] = e == 0 ? pack_bf16x2(gx[g], go[g]) : pack_bf16x2(go[g], gx[g]);
       const uint32_t pkn = e == 0 ? pack_bf16x2(gn, gn_o) : pack_bf16x2(gn_o, gn);
       if (gate_thread) {
-        char* xo = (char*)xg + par * PAR_BYTES;
-        const u64 tag = (u64)(unsigned)(s + 1) << 32;
         if (e == 0) {
+          char* xo = xg + (s & 3) * SLOT_BYTES + xoff;         // gate g, units (j, j+1): element k = g*H + j -> k-step 32*g + p
+          char* xr = xg + ((s + 2) & 3) * SLOT_BYTES + xoff;   // re-armed for step s + 2
 #pragma unroll
-          for (int g = 0; g < G; ++g) publish((u64*)(xo + xgranule_bytes<NROWS>(g * H + j, gi_i)), tag | pk[g], local);
+          for (int g = 0; g < G; ++g) publish32(xo + g * (H / 32) * 512, xtf_word(pk[g]), local);
+#pragma unroll
+          for (int g = 0; g < G; ++g) publish32(xr + g * (H / 32) * 512, XSENT, local);
           if (CELL == CELL_GRU) {
             *reinterpret_cast<uint32_t*>(dgi_ptr) = pk[0];
             *reinterpret_cast<uint32_t*>(dgi_ptr + H) = pk[1 % G];
