@@ -172,34 +172,39 @@ static_assert(F1 == 9 * M1_FB, "conv1 MFMA kernels assume 81 output rows");
 template <int BATCH>
 __device__ __forceinline__ void conv1_stage_bf16(unsigned char* patch, const float* __restrict__ xn, int T, int f_base, int t_base,
                                                  int tid) {
-  // column pairs -> one packed dword.  Straight-line batches of BATCH pairs per thread: all 2*BATCH loads of a batch are in flight
-  // together (a rolled loop pays one L2 round trip per iteration, which was 80 % of this kernel).
+  // column pairs -> one packed dword.  Branch-free straight-line batches of BATCH pairs per thread, so that all 2*BATCH loads
+  // of a batch are in flight together (with a branch per element the compiler waits for every load before it issues the
+  // next: one L2 round trip per element).  Every thread runs the same ITER iterations; indices past the end are clamped to the
+  // last pair, which is then simply written more than once with the same value.
   constexpr int NP = M1_PC / 2, TOTAL = M1_PR * NP, ITER = (TOTAL + 255) / 256;
 #pragma unroll
   for (int b0 = 0; b0 < ITER; b0 += BATCH) {
     float v0[BATCH], v1[BATCH];
 #pragma unroll
     for (int it = 0; it < BATCH; ++it) {
-      const int i = tid + (b0 + it) * 256;
-      v0[it] = v1[it] = 0.f;
-      if (b0 + it < ITER && i < TOTAL) {
+      if (b0 + it < ITER) {
+        const int i = min(tid + (b0 + it) * 256, TOTAL - 1);
+        const int pr = i / NP, pc = 2 * (i - pr * NP);
+        const int t0 = t_base + pc;
+        const int ro = min(max(f_base + pr, 0), F0 - 1) * T;        // 32-bit offsets: one sample is 161 * T floats
+        v0[it] = xn[ro + min(max(t0, 0), T - 1)];
+        v1[it] = xn[ro + min(max(t0 + 1, 0), T - 1)];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);   // loads above, selects and LDS stores below: the scheduler must not sink each load to its use
+#pragma unroll
+    for (int it = 0; it < BATCH; ++it) {
+      if (b0 + it < ITER) {
+        const int i = min(tid + (b0 + it) * 256, TOTAL - 1);
         const int pr = i / NP, pc = 2 * (i - pr * NP);
         const int fi = f_base + pr, t0 = t_base + pc, t1 = t0 + 1;
         const bool okf = fi >= 0 && fi < F0;
-        const int ro = min(max(fi, 0), F0 - 1) * T;                 // 32-bit offsets: one sample is 161 * T floats
-        const float a = xn[ro + min(max(t0, 0), T - 1)], b = xn[ro + min(max(t1, 0), T - 1)];
-        v0[it] = okf && t0 >= 0 && t0 < T ? a : 0.f;
-        v1[it] = okf && t1 >= 0 && t1 < T ? b : 0.f;
+        const float a = okf && t0 >= 0 && t0 < T ? v0[it] : 0.f;
+        const float b = okf && t1 >= 0 && t1 < T ? v1[it] : 0.f;
+        *reinterpret_cast<uint32_t*>(patch + pr * M1_RSB + pc * 2) = cvt_pk_bf16(a, b);
       }
     }
-#pragma unroll
-    for (int it = 0; it < BATCH; ++it) {
-      const int i = tid + (b0 + it) * 256;
-      if (b0 + it < ITER && i < TOTAL) {
-        const int pr = i / NP, pc = 2 * (i - pr * NP);
-        *reinterpret_cast<uint32_t*>(patch + pr * M1_RSB + pc * 2) = cvt_pk_bf16(v0[it], v1[it]);
-      }
-    }
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -237,10 +242,15 @@ __global__ void __launch_bounds__(256, 1) k_conv1_fwd_mfma(const float* __restri
     for (int fl = 0; fl < M1_FB; ++fl)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[fl][r] = bias[r];
+    auto frag = [&](int rho) {
+      const uint32_t* q = reinterpret_cast<const uint32_t*>(bp + rho * M1_RSB);
+      return make_uint4(q[0], q[1], q[2], q[3]);
+    };
+    uint4 bn = frag(0);
 #pragma unroll
     for (int rho = 0; rho < M1_PR; ++rho) {
-      const uint32_t* q = reinterpret_cast<const uint32_t*>(bp + rho * M1_RSB);
-      const uint4 b = make_uint4(q[0], q[1], q[2], q[3]);
+      const uint4 b = bn;
+      if (rho + 1 < M1_PR) bn = frag(rho + 1);      // the next row's operand is read under this row's MFMAs
 #pragma unroll
       for (int fl = 0; fl < M1_FB; ++fl) {
         const int kf = rho - 2 * fl;
@@ -294,13 +304,22 @@ __global__ void __launch_bounds__(256, 1) k_conv1_wgrad_mfma(const float* __rest
     conv1_stage_bf16<16>(patch, x + (long)n * F0 * Tin, Tin, 18 * fb - 20, 256 * tb - 5, tid);
     {  // this wave's output-gradient tile, transposed: dyT[fl][channel of the half][frame]
       const int t0 = tb * M1_TB + 64 * pair, piece = lane & 1;
+      uint4 dv[M1_FB][2];
+#pragma unroll
+      for (int fl = 0; fl < M1_FB; ++fl)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {      // unconditional loads from a clamped frame, zeroed by a select: all 18 in flight together
+          const int t = t0 + 32 * j + (lane >> 1);
+          const uint4 v = *reinterpret_cast<const uint4*>(dy1 + (((long)n * F1 + 9 * fb + fl) * Tp + min(t, Tp - 1)) * CH + 16 * hh + 8 * piece);
+          dv[fl][j] = t < Tp ? v : make_uint4(0u, 0u, 0u, 0u);
+        }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int fl = 0; fl < M1_FB; ++fl)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const int tl = 32 * j + (lane >> 1), t = t0 + tl;
-          uint4 v = make_uint4(0u, 0u, 0u, 0u);
-          if (t < Tp) v = *reinterpret_cast<const uint4*>(dy1 + (((long)n * F1 + 9 * fb + fl) * Tp + t) * CH + 16 * hh + 8 * piece);
+          const int tl = 32 * j + (lane >> 1);
+          const uint4 v = dv[fl][j];
           uint16_t* d = dyT + (fl * 16 + 8 * piece) * M1_DYS + tl;
           d[0 * M1_DYS] = (uint16_t)v.x;
           d[1 * M1_DYS] = (uint16_t)(v.x >> 16);
@@ -318,21 +337,28 @@ __global__ void __launch_bounds__(256, 1) k_conv1_wgrad_mfma(const float* __rest
     for (int fl = 0; fl < M1_FB; ++fl)
 #pragma unroll
       for (int c = 0; c < 2; ++c) dyb[fl][c] = *reinterpret_cast<const uint4*>(dyT + (fl * 16 + kt) * M1_DYS + 32 * c + 8 * q);
+    // the 8 strided taps of one operand as raw 16-bit reads; they are issued one operand AHEAD of the MFMAs that consume them
+    // (read right before use they cost four exposed LDS round trips per operand: 5x the MFMA time of the block)
+    uint16_t xn[8];
+    auto taps = [&](int it) {      // it = 2 * rho + c
+      const uint16_t* xr = reinterpret_cast<const uint16_t*>(xp + (it >> 1) * M1_RSB + (it & 1) * 128);
 #pragma unroll
-    for (int rho = 0; rho < M1_PR; ++rho) {
+      for (int i = 0; i < 8; ++i) xn[i] = xr[2 * i];
+    };
+    taps(0);
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const uint16_t* xr = reinterpret_cast<const uint16_t*>(xp + rho * M1_RSB + c * 128);
-        uint4 xa;
-        xa.x = (uint32_t)xr[0] | ((uint32_t)xr[2] << 16);
-        xa.y = (uint32_t)xr[4] | ((uint32_t)xr[6] << 16);
-        xa.z = (uint32_t)xr[8] | ((uint32_t)xr[10] << 16);
-        xa.w = (uint32_t)xr[12] | ((uint32_t)xr[14] << 16);
+    for (int it = 0; it < 2 * M1_PR; ++it) {
+      const int rho = it >> 1, c = it & 1;
+      uint4 xa;
+      xa.x = (uint32_t)xn[0] | ((uint32_t)xn[1] << 16);
+      xa.y = (uint32_t)xn[2] | ((uint32_t)xn[3] << 16);
+      xa.z = (uint32_t)xn[4] | ((uint32_t)xn[5] << 16);
+      xa.w = (uint32_t)xn[6] | ((uint32_t)xn[7] << 16);
+      if (it + 1 < 2 * M1_PR) taps(it + 1);
 #pragma unroll
-        for (int fl = 0; fl < M1_FB; ++fl) {
-          const int kf = rho - 2 * fl;
-          if (kf >= 0 && kf < K1F) Mma<bf16_t>::mma16(acc[kf], xa, dyb[fl][c]);
-        }
+      for (int fl = 0; fl < M1_FB; ++fl) {
+        const int kf = rho - 2 * fl;
+        if (kf >= 0 && kf < K1F) Mma<bf16_t>::mma16(acc[kf], xa, dyb[fl][c]);
       }
     }
   }

@@ -39,9 +39,9 @@ int dispatch(bool bwd, int cell, int H, const PArgs& a, hipStream_t st) {
 }
 
 // scratch head: [0,1024) cycle counters (-DDS2_PROBE builds only), [1024,3072) XCC-id handshake slots, [3072] the per-launch
-// error word; the exchange buffer follows.  All of it is reset before every launch: to zeros for the general kernels, to 0xFF
-// bytes for the tuned ones (their tag-free exchange uses the all-ones dword as "not published yet"; an all-ones tag never
-// equals a step index, an all-ones handshake slot is not a signature, and the error word counts as raised only when it is 1).
+// error word; the exchange buffer follows.  All of it is reset to 0xFF bytes before every launch: the payload-only exchanges use
+// the all-ones dword as "not published yet"; an all-ones tag never equals a step index, an all-ones handshake slot is not a
+// signature, and the error word counts as raised only when it is 1.
 constexpr long AUX_BYTES = 4096;
 
 int gates(int cell) { return cell == CELL_GRU ? 3 : cell == CELL_LSTM ? 4 : 1; }
@@ -85,10 +85,8 @@ bool plan2(int dtype, int cell, int D, int N, int H, Plan2& pl) {
 long xbuf2_bytes(int dtype, int cell, int H, const Plan2& pl, bool bwd) {
   const int ksz = dtype == DS2_BF16 ? 32 : 16;
   const long kt = (bwd ? (long)gates(cell) * H : (long)H) / ksz;
-  // large batch: tag-free payload (1024 B per k-step and m-tile) + 512 B of per-workgroup flags per group; else tagged granules
-  // (forward: from 4 m-tiles on, BPTT: from 2 -- must mirror FLAGS in ds2_rnn_persist2_impl.h)
-  const bool flags = bwd ? pl.MT >= 2 : pl.MT >= 4;
-  return flags ? (long)pl.NG * (2 * kt * pl.MT * 1024 + 512) : (long)pl.NG * 2 * kt * pl.MT * 2048;
+  // two parities of tagged granules (2048 B per k-step and m-tile) or four payload-only slots (1024 B): the same bytes
+  return (long)pl.NG * 2 * kt * pl.MT * 2048;
 }
 
 }  // namespace
@@ -111,7 +109,7 @@ long ds2_rnn_persist_ws_bytes(int dtype, int cell, int D, int N, int H) {
   return AUX_BYTES + xbuf2_bytes(dtype, cell, H, pl, true);
 }
 
-// Same contract as ds2_rnn_fwd (ds2_rnn.hip); ws = ds2_rnn_persist_ws_bytes() bytes (zeroed here).
+// Same contract as ds2_rnn_fwd (ds2_rnn.hip); ws = ds2_rnn_persist_ws_bytes() bytes (reset here).
 // err: one device int, set to 1 if a workgroup gave up waiting (outputs are then NaN-poisoned).
 int ds2_rnn_persist_fwd(int dtype, int cell, int D, int N, int H, int Tp, const int* lens, const void* GI, const void* Whh,
                         const float* bhh, const float* h0, const float* c0, void* Hseq, long hseq_dstride, void* S, float* hn,
@@ -135,7 +133,7 @@ int ds2_rnn_persist_fwd(int dtype, int cell, int D, int N, int H, int Tp, const 
   Plan2 pl;
   DS2_REQUIRE(plan2(dtype, cell, D, N, H, pl), DS2_ERR_ARG);
   const long xb = xbuf2_bytes(dtype, cell, H, pl, false);
-  hipError_t e = hipMemsetAsync(ws, 0, AUX_BYTES + xb, st);
+  hipError_t e = hipMemsetAsync(ws, 0xff, AUX_BYTES + xb, st);
   if (e != hipSuccess) return (int)e;
   ds2q::QArgs a{};
   a.N = N; a.Tp = Tp; a.D = D; a.gpd = pl.gpd; a.NG = pl.NG; a.lens = lens; a.W = Whh; a.bhh = bhh; a.GI = GI; a.Hseq = Hseq;
@@ -172,7 +170,7 @@ int ds2_rnn_persist_bwd(int dtype, int cell, int D, int N, int H, int Tp, const 
   Plan2 pl;
   DS2_REQUIRE(plan2(dtype, cell, D, N, H, pl), DS2_ERR_ARG);
   const long xb = xbuf2_bytes(dtype, cell, H, pl, true);
-  hipError_t e = hipMemsetAsync(ws, 0, AUX_BYTES + xb, st);
+  hipError_t e = hipMemsetAsync(ws, 0xff, AUX_BYTES + xb, st);
   if (e != hipSuccess) return (int)e;
   ds2q::QArgs a{};
   a.N = N; a.Tp = Tp; a.D = D; a.gpd = pl.gpd; a.NG = pl.NG; a.lens = lens; a.W = WhhT; a.Hseq = (void*)Hseq;

@@ -40,10 +40,10 @@ struct QArgs {
   void* dGI;                // bwd: [Tp*N][D*G*H]                                              (T)
   void* dGH;                // bwd, GRU only: dQ [D][Tp][N][H] (the n-gate slot of the hidden-side gate gradient) (T)
   float* dBacc;             // bwd: [D][N][NB*H] per-sample sums over time of the gate gradients (NB = 4 GRU: dr,dz,dn,dq; else G)
-  char* xbuf;               // [NG][2 parities][PAR_BYTES], zeroed before the launch
+  char* xbuf;               // [NG][2 parities or 4 slots][PAR_BYTES], filled with 0xFF bytes before the launch
   long xgroup_bytes;        // 2 * PAR_BYTES
   int* err;                 // sticky device word (the host reads it)
-  int* lerr;                // per-launch word in the zeroed scratch
+  int* lerr;                // per-launch word in the scratch (reset before the launch; raised == 1)
 };
 
 // ---- storage-type traits: pair access, granule packing, gate math --------------------------------------------------
@@ -199,7 +199,7 @@ __device__ __forceinline__ void gather_mma2(ds2_f32x4 (&acc)[MT][RT], const uint
         DS2Q_LOAD(c, b)
         DS2Q_CHECK(b, bad1)
         if (!__any(bad1)) break;
-        if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(lerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+        if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(lerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1)) {
           dead = true;
           raise_err(err, lerr);
           break;
@@ -226,12 +226,13 @@ __device__ __forceinline__ void gather_mma2(ds2_f32x4 (&acc)[MT][RT], const uint
 #undef DS2Q_CHECK
 }
 
-// ---- flag exchange (MT >= 2, bf16): the large-batch regime is bound by the gathered BYTES (a workgroup reads N_s x K values per
-// step through one CU's vector-memory path), so the granule tags are dropped: payload = plain bf16 in A-fragment order
+// ---- payload-only exchange (MT >= 2, bf16): the large-batch regime is bound by the gathered BYTES (a workgroup reads N_s x K
+// values per step through one CU's vector-memory path), so the granule tags are dropped: payload = plain bf16 in A-fragment order
 // [k-step][m-tile][lq (4)][row (16)] x 16 bytes (ONE 16-byte load = one complete MFMA A fragment: half the bytes and half the load
-// instructions of the tagged form), completion = one flag word per producing workgroup (recipe R1 of the MI355X guide, section 6
-// G16: write-through payload stores -> vmcnt(0) -> workgroup barrier -> write-through flag; consumers poll the flags with sc1
-// loads, then read the payload with sc1 loads).  flag[p] = 1 after the initial state, s + 2 after time step s.
+// instructions of the tagged form).  Completion is carried by the data itself: a dword that still holds the all-ones sentinel
+// has not been published (gather_mma2f).  Until round 2d this form used one flag word per producing workgroup instead (payload
+// stores -> vmcnt(0) -> barrier -> flag store; consumers polled the flags, then loaded the payload): three dependent round trips
+// and an extra workgroup barrier per step.
 template <int MT>
 __device__ __forceinline__ int xunitf(int kstep, int mt, int lq, int row) { return (((kstep * MT + mt) * 4 + lq) * 16 + row) * 16; }
 template <int MT>
@@ -239,14 +240,13 @@ __device__ __forceinline__ int xpayf(int k, int mt, int row) {   // byte offset 
   const int kk = k % 32;
   return xunitf<MT>(k / 32, mt, kk / 8, row) + (kk % 8) * 2;
 }
-__device__ __forceinline__ void publish_pay(char* xpar, int off, float a, float b) {
-  __hip_atomic_store(reinterpret_cast<unsigned*>(xpar + off), cvt_pk_bf16(a, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+constexpr uint32_t XSENT2 = 0xffffffffu;   // "not published yet": see gather_mma_tf in ds2_rnn_persist_impl.h (same protocol)
+__device__ __forceinline__ void publish_pay(char* xslot, int off, float a, float b) {
+  const uint32_t pk = cvt_pk_bf16(a, b);
+  __hip_atomic_store(reinterpret_cast<unsigned*>(xslot + off), pk == XSENT2 ? 0x7fc07fc0u : pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// all stores of this workgroup have been acknowledged -> raise its flag
-__device__ __forceinline__ void raise_flag(unsigned* flag, unsigned value) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ void rearm_pay(char* xslot, int off) {
+  __hip_atomic_store(reinterpret_cast<unsigned*>(xslot + off), XSENT2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int KSW, int MT, int RT>
@@ -258,29 +258,17 @@ constexpr int chunkf(int) {
   return per < 1 ? 1 : (per > 16 ? 16 : per);
 }
 
-template <typename T, int MT, int RT, int KSW, int P, bool RAGGED>
+// Payload-only gather: FOUR slots (step e publishes into slot e & 3), the all-ones dword marks "not published yet", every
+// publisher re-arms its dwords of slot (s + 2) & 3 at step s (the protocol and its ordering argument: gather_mma_tf in
+// ds2_rnn_persist_impl.h).  One round trip per step where the flag form needed three (payload acknowledged -> barrier -> flag
+// store -> flag poll -> payload load).  The loads of chunk c+1 are in flight while chunk c is checked and multiplied; a chunk
+// with a sentinel in it is re-polled (bounded) before its MFMAs -- no speculative products, nothing to undo.
+template <typename T, int MT, int RT, int KSW, bool RAGGED>
 __device__ __forceinline__ void gather_mma2f(ds2_f32x4 (&acc)[MT][RT], const uint4 (&w)[RT][KSW], __amdgpu_buffer_rsrc_t rsrc,
-                                             int par_off, const unsigned* flags, int ks0, int cnt, int lq, int li, int Ns, unsigned need_flag,
-                                             int* err, int* lerr, bool& dead) {
-  static_assert(P <= 128, "flag poll covers two words per lane");
+                                             int slot_off, int ks0, int cnt, int lq, int li, int Ns, int* err, int* lerr, bool& dead) {
   constexpr int CH = chunkf<KSW, MT, RT>(0);
   constexpr int NCH = (KSW + CH - 1) / CH;
   constexpr int NB = NCH > 1 ? 2 : 1;
-  const int lane = threadIdx.x & 63;
-  if (!dead) {   // wait until every producer of the group has published the step (bounded)
-    unsigned spins = 0;
-    for (;;) {
-      const unsigned f0 = lane < P ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need_flag;
-      const unsigned f1 = lane + 64 < P ? __hip_atomic_load(flags + lane + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need_flag;
-      if (__all(f0 >= need_flag && f1 >= need_flag)) break;
-      if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(lerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-        dead = true;
-        raise_err(err, lerr);
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-  }
   u32x4_t v[NB][CH][MT];
   bool need[MT];
 #pragma unroll
@@ -290,15 +278,43 @@ __device__ __forceinline__ void gather_mma2f(ds2_f32x4 (&acc)[MT][RT], const uin
     const int k_ = (c) * CH + i;                                                                                         \
     if (k_ < KSW && (!RAGGED || k_ < cnt)) {                                                                             \
       _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                                     \
-          v[b][i][m] = need[m] ? __builtin_amdgcn_raw_buffer_load_b128(rsrc, par_off + xunitf<MT>(ks0 + k_, m, lq, li), 0, 16 /* sc1 */) \
+          v[b][i][m] = need[m] ? __builtin_amdgcn_raw_buffer_load_b128(rsrc, slot_off + xunitf<MT>(ks0 + k_, m, lq, li), 0, 16 /* sc1 */) \
                                : u32x4_t{0u, 0u, 0u, 0u};                                                                \
     }                                                                                                                    \
+  }
+#define DS2Q_CHECKF(c, b, bad)                                                                                           \
+  bool bad;                                                                                                              \
+  {                                                                                                                      \
+    uint32_t mx = 0;                                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < CH; ++i) {                                                                    \
+      const int k_ = (c) * CH + i;                                                                                       \
+      if (k_ < KSW && (!RAGGED || k_ < cnt)) {                                                                           \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                                   \
+            mx = max(max(mx, max(v[b][i][m][0], v[b][i][m][1])), max(v[b][i][m][2], v[b][i][m][3]));                     \
+      }                                                                                                                  \
+    }                                                                                                                    \
+    bad = mx == XSENT2;   /* rows that are not loaded hold zeros */                                                      \
   }
   DS2Q_LOADF(0, 0)
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int b = NB > 1 ? (c & 1) : 0;
     if (c + 1 < NCH) { DS2Q_LOADF(c + 1, b ^ 1) }
+    DS2Q_CHECKF(c, b, bad0)
+    if (__any(bad0) && !dead) {
+      unsigned spins = 0;
+      for (;;) {
+        __builtin_amdgcn_s_sleep(1);
+        DS2Q_LOADF(c, b)
+        DS2Q_CHECKF(c, b, bad1)
+        if (!__any(bad1)) break;
+        if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(lerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1)) {
+          dead = true;
+          raise_err(err, lerr);
+          break;
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       const int k_ = c * CH + i;
@@ -313,6 +329,7 @@ __device__ __forceinline__ void gather_mma2f(ds2_f32x4 (&acc)[MT][RT], const uin
     }
   }
 #undef DS2Q_LOADF
+#undef DS2Q_CHECKF
 }
 
 // partial sums of the 4 K-slices: part[wave][mt][rt][sample row][unit col]
@@ -358,10 +375,8 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_fwd(QArgs a) {
   constexpr int KSZ = X::KSZ, KT = H / KSZ, KSW = (KT + 3) / 4;
   constexpr bool RAGGED = KT % 4 != 0;
   constexpr int IT = Items<MT>::PER_THREAD;
-  constexpr bool FLAGS = MT >= 4;                          // large batch: tag-free payload + per-workgroup flags (measured: with
-                                                           // 22 samples per group the forward is faster with tags, 5.0 vs 5.7 us per step)
-  static_assert(!FLAGS || sizeof(T) == 2, "the flag exchange is instantiated for bf16 storage");
-  constexpr int PAR_BYTES = KT * MT * (FLAGS ? 1024 : 2048);
+  constexpr bool FLAGS = sizeof(T) == 2 && MT >= 2;        // > 16 samples per group, bf16: payload-only exchange in four slots
+  constexpr int PAR_BYTES = KT * MT * (FLAGS ? 1024 : 2048);   // one slot (payload-only) / one parity (tagged granules)
   static_assert(H % KSZ == 0 && H % 16 == 0, "unsupported hidden size");
   extern __shared__ __attribute__((aligned(16))) float part[];       // [2][4][MT][RT][256]
   constexpr int PART_FLOATS = 4 * MT * RT * 256;
@@ -389,8 +404,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_fwd(QArgs a) {
     }
   }
   char* xg = a.xbuf + (long)grp * a.xgroup_bytes;
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, 2 * PAR_BYTES, 0x00020000);
-  unsigned* flags = reinterpret_cast<unsigned*>(xg + 2 * PAR_BYTES);   // [P] (FLAGS only)
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, (FLAGS ? 4 : 2) * PAR_BYTES, 0x00020000);
 
   // ---- gate items of this thread
   bool on[IT];
@@ -453,10 +467,9 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_fwd(QArgs a) {
 #pragma unroll
     for (int it = 0; it < IT; ++it)
       if (on[it]) {
-        if (FLAGS) publish_pay(xg + PAR_BYTES, it_xoff[it], hprev[it][0], hprev[it][1]);
+        if (FLAGS) publish_pay(xg + 3 * PAR_BYTES, it_xoff[it], hprev[it][0], hprev[it][1]);     // "step -1": slot 3
         else X::publish(xg + PAR_BYTES, it_xoff[it], TAG_INIT, hprev[it][0], hprev[it][1]);
       }
-    if (FLAGS) raise_flag(flags + p, 1u);
   }
 
   for (int s = 0; s < Tp; ++s) {
@@ -474,8 +487,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_fwd(QArgs a) {
       for (int tt = 0; tt < RT; ++tt) acc[m][tt] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
     if (s > 0 || a.h0) {
       if constexpr (FLAGS)
-        gather_mma2f<T, MT, RT, KSW, H / 16, RAGGED>(acc, w, rsrc, (par ^ 1) * PAR_BYTES, flags, ks0, cnt, lq, li, Ns, (unsigned)s + 1u, a.err,
-                                                     a.lerr, dead);
+        gather_mma2f<T, MT, RT, KSW, RAGGED>(acc, w, rsrc, ((s + 3) & 3) * PAR_BYTES, ks0, cnt, lq, li, Ns, a.err, a.lerr, dead);
       else
         gather_mma2<T, MT, RT, KSW, SP, RAGGED>(acc, w, rsrc, (par ^ 1) * PAR_BYTES, ks0, cnt, lq, li, Ns, s > 0 ? (unsigned)s : TAG_INIT,
                                                 a.err, a.lerr, dead);
@@ -543,8 +555,12 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_fwd(QArgs a) {
         }
         if (dead) hn0 = hn1 = hprev[it][0] = hprev[it][1] = QNAN;   // fail loudly downstream
         // publish the carried state first (inactive samples republish their unchanged state), then the bookkeeping stores
-        if (FLAGS) publish_pay(xg + par * PAR_BYTES, it_xoff[it], hprev[it][0], hprev[it][1]);
-        else X::publish(xg + par * PAR_BYTES, it_xoff[it], (unsigned)(s + 1), hprev[it][0], hprev[it][1]);
+        if (FLAGS) {
+          publish_pay(xg + (s & 3) * PAR_BYTES, it_xoff[it], hprev[it][0], hprev[it][1]);
+          rearm_pay(xg + ((s + 2) & 3) * PAR_BYTES, it_xoff[it]);
+        } else {
+          X::publish(xg + par * PAR_BYTES, it_xoff[it], (unsigned)(s + 1), hprev[it][0], hprev[it][1]);
+        }
         X::st(hs_ptr[it], hn0, hn1);
 #pragma unroll
         for (int q = 0; q < NS; ++q) X::st(sv_ptr[it] + (long)q * H, pl[q][0], pl[q][1]);
@@ -553,7 +569,6 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_fwd(QArgs a) {
       if (NS) sv_ptr[it] += sv_stride;
       hs_ptr[it] += hs_stride;
     }
-    if (FLAGS) raise_flag(flags + p, (unsigned)s + 2u);
   }
 #pragma unroll
   for (int it = 0; it < IT; ++it) {
@@ -584,8 +599,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_bwd(QArgs a) {
   constexpr int KSZ = X::KSZ, KT = G * H / KSZ, KSW = (KT + 3) / 4, KTH = H / KSZ;   // KTH: k-steps per gate
   constexpr bool RAGGED = KT % 4 != 0;
   constexpr int IT = Items<MT>::PER_THREAD;
-  constexpr bool FLAGS = MT >= 2;
-  static_assert(!FLAGS || sizeof(T) == 2, "the flag exchange is instantiated for bf16 storage");
+  constexpr bool FLAGS = sizeof(T) == 2 && MT >= 2;        // payload-only exchange in four slots (see the forward kernel)
   constexpr int PAR_BYTES = KT * MT * (FLAGS ? 1024 : 2048);
   constexpr int GATE_BYTES = KTH * MT * (FLAGS ? 1024 : 2048);   // exchange bytes of one gate's H elements
   static_assert(H % KSZ == 0 && H % 16 == 0, "unsupported hidden size");
@@ -612,8 +626,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_bwd(QArgs a) {
       w[0][k] = (!RAGGED || k < cnt) ? *reinterpret_cast<const uint4*>(row + (long)(ks0 + k) * KSZ) : make_uint4(0, 0, 0, 0);
   }
   char* xg = a.xbuf + (long)grp * a.xgroup_bytes;
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, 2 * PAR_BYTES, 0x00020000);
-  unsigned* flags = reinterpret_cast<unsigned*>(xg + 2 * PAR_BYTES);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, (FLAGS ? 4 : 2) * PAR_BYTES, 0x00020000);
 
   bool on[IT];
   int it_row[IT], it_mt[IT], it_xoff[IT], it_j[IT], it_len[IT];
@@ -682,8 +695,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_bwd(QArgs a) {
     for (int m = 0; m < MT; ++m) acc[m][0] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
     if (s > 0) {
       if constexpr (FLAGS)
-        gather_mma2f<T, MT, RT, KSW, H / 16, RAGGED>(acc, w, rsrc, (par ^ 1) * PAR_BYTES, flags, ks0, cnt, lq, li, Ns, (unsigned)s + 1u, a.err,
-                                                     a.lerr, dead);
+        gather_mma2f<T, MT, RT, KSW, RAGGED>(acc, w, rsrc, ((s + 3) & 3) * PAR_BYTES, ks0, cnt, lq, li, Ns, a.err, a.lerr, dead);
       else
         gather_mma2<T, MT, RT, KSW, SP, RAGGED>(acc, w, rsrc, (par ^ 1) * PAR_BYTES, ks0, cnt, lq, li, Ns, (unsigned)s, a.err, a.lerr, dead);
     }
@@ -697,9 +709,18 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_bwd(QArgs a) {
         const int jo = it_j[it] - p * 16;
         const float2 mp = load_partials2<MT, RT>(pp, it_mt[it], 0, it_row[it], jo);
         const float din0 = car[it][0] + mp.x, din1 = car[it][1] + mp.y;
-        char* xo = xg + par * PAR_BYTES;
+        char* xo = xg + (FLAGS ? (s & 3) : par) * PAR_BYTES;
+        char* xr = xg + ((s + 2) & 3) * PAR_BYTES;      // payload-only form: the slot re-armed for step s + 2
         const unsigned tag = (unsigned)(s + 1);
-#define DS2Q_PUB(off_, a_, b_) do { if (FLAGS) publish_pay(xo, (off_), (a_), (b_)); else X::publish(xo, (off_), tag, (a_), (b_)); } while (0)
+#define DS2Q_PUB(off_, a_, b_)                                \
+  do {                                                        \
+    if (FLAGS) {                                              \
+      publish_pay(xo, (off_), (a_), (b_));                    \
+      rearm_pay(xr, (off_));                                  \
+    } else {                                                  \
+      X::publish(xo, (off_), tag, (a_), (b_));                \
+    }                                                         \
+  } while (0)
         const int xo_ = it_xoff[it];
         T* dgi = dgi_ptr[it];
         constexpr int M = NS ? NS : 1;
@@ -792,7 +813,6 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_bwd(QArgs a) {
       if (CELL == CELL_GRU) dgh_ptr[it] += dstep * N * H;
     }
 #undef DS2Q_PUB
-    if (FLAGS) raise_flag(flags + p, (unsigned)s + 2u);
   }
   if (a.dBacc) {
 #pragma unroll

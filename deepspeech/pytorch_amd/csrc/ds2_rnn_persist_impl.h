@@ -74,10 +74,10 @@ struct PArgs {
                             // equal dGI's and are not stored twice)
   float* dBacc;             // bwd: [D][N][NB*H] per-sample sums over time of the gate gradients (NB planes: GRU dr,dz,dn,dq;
                             // LSTM di,df,dg,do; RNN dg) -- the bias gradients are their sums over the samples
-  u64* xbuf;                // [NGROUPS][2][MAXS][X/2] granules, zeroed before the launch
+  u64* xbuf;                // [NGROUPS][2][MAXS][X/2] granules (or four payload-only slots), filled with 0xFF bytes before the launch
   int* err;                 // device word, set to 1 on a spin time-out (sticky: the host reads it)
-  int* lerr;                // per-LAUNCH word in the zeroed scratch: lets the peers of a timed-out workgroup stop early
-  u64* xcc;                 // [NGROUPS][32] start-up exchange of the workgroups' XCC ids, zeroed before the launch
+  int* lerr;                // per-LAUNCH word in the scratch (reset before the launch, raised == 1): lets the peers of a timed-out workgroup stop early
+  u64* xcc;                 // [NGROUPS][32] start-up exchange of the workgroups' XCC ids, reset (0xFF bytes) before the launch
 #ifdef DS2_PROBE            // tools/probe_rnn_persist.py builds its own library with -DDS2_PROBE; the shipping kernels carry none of it
   unsigned long long* dbg;  // [NGROUPS][8] cycle counters of workgroup 0 of each group
   int dbgmask;              // 1 skip GI/dOut/S prefetch loads, 2 skip output stores, 8 skip the gather (no exchange)
@@ -239,7 +239,7 @@ __device__ __forceinline__ void gather_mma(ds2_f32x4 (&acc)[TILES], const uint4 
           DS2_GATHER_CHECK(bad2)
           if (!__any(bad2)) break;
           // give up after the spin limit, or early when a peer of THIS launch already did (the per-launch word lives in the
-          // scratch that is zeroed before every launch: a time-out of an earlier launch never shortens this one's patience)
+          // scratch that is reset before every launch: a time-out of an earlier launch never shortens this one's patience)
           if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(lerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1)) {
             dead = true;
             raise_err(err, lerr);
@@ -275,6 +275,16 @@ __device__ __forceinline__ void gather_mma(ds2_f32x4 (&acc)[TILES], const uint4 
 //     s+2's data only after it has seen this workgroup's step s+1 data: it can never read the stale step s-2 values.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr uint32_t XSENT = 0xffffffffu;
+constexpr int chunk_ksteps_tf(int KS) {
+#ifdef DS2_CHUNK
+  return (KS % DS2_CHUNK == 0 && DS2_CHUNK % 2 == 0) ? DS2_CHUNK : KS;
+#else
+  // measured on cfg3 inside the training step (tools/bench_with_lib.py, us per time step forward / BPTT): chunks of 2: 2.55 / 5.38,
+  // 4: 2.18 / 4.04, 6: - / 3.66, 8: 1.90 / 3.51, 12: - / 3.41, 24: - / 2.85 -- but the 24-k-step form holds 409 registers and
+  // locks the weight-gradient GEMMs out of the CU (116 registers: they then run after the sweep, +2 ms per step), 12 holds 340
+  return KS <= 8 ? KS : (KS % 12 == 0 ? 12 : 8);
+#endif
+}
 __device__ __forceinline__ int xtf_unit_bytes(int kstep, int lq, int row) { return ((kstep * 4 + lq) * 8 + row) * 16; }
 // byte offset of the dword that carries elements (k, k+1), k even, of sample row `row`
 __device__ __forceinline__ int xtf_pair_bytes(int k, int row) {
@@ -293,7 +303,7 @@ template <int TILES, int KS>
 __device__ __forceinline__ void gather_mma_tf(ds2_f32x4 (&acc)[TILES], const uint4 (&w)[TILES][KS], __amdgpu_buffer_rsrc_t rsrc,
                                               int slot_off, int kstep0, int lq, int srow, int half, bool need, int* err, int* lerr,
                                               bool& dead, unsigned& rounds) {
-  constexpr int CH = chunk_ksteps(KS, 2);
+  constexpr int CH = chunk_ksteps_tf(KS);
   constexpr int PER = CH / 2;       // k-steps a lane loads per chunk (the other half arrives by the DPP row rotate)
   static_assert(KS % CH == 0 && CH % 2 == 0, "k-steps per wave must tile into poll chunks");
   typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
