@@ -29,7 +29,8 @@ SIGNATURES = {
     "ds2_conv1_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "ds2_conv1_wgrad_ws_floats": (_l, [_i, _i]),
     "ds2_conv1_wgrad": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
-    "ds2_conv2_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "ds2_conv2_fwd_ws_bytes": (_l, [_i, _i, _i]),
+    "ds2_conv2_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "ds2_conv2_dgrad": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "ds2_conv2_wgrad_ws_floats": (_l, [_i, _i]),
     "ds2_conv2_wgrad": (_i, [_i, _vp, _vp, _vp, _i, _i, _vp, _vp]),

@@ -189,6 +189,7 @@ static inline int ds2_cu_count() {
   } while (0)
 
 static inline int ds2_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+__device__ __forceinline__ int ds2_cdiv_dev(int a, int b) { return (a + b - 1) / b; }
 
 // Per-DEVICE one-time set-up (kernel attributes are per device, a process may drive several): returns true the first time
 // it is called with `flags` on the current device.  A benign race (two threads both see "first") only repeats an idempotent call.

@@ -727,6 +727,193 @@ __global__ void __launch_bounds__(256, 1) k_conv2_wgrad_bf16(const bf16_t* __res
   }
 }
 
+// ============================================================================================================
+// conv2 forward / dgrad for bf16 storage with the TAPS RESIDENT IN REGISTERS.
+// k_conv_tap above is LDS-bound: every MFMA reads a fresh weight fragment and a fresh activation fragment (2 KB of LDS per
+// 32-cycle MFMA, four waves per CU).  Here a launch is a stride-1 correlation with at most 11 x 11 taps (the forward is the sum
+// of two such correlations over the even / odd input rows -- kf = 2m + q reads input row 2(u + m - 5) + q -- and the dgrad
+// already is two of them), and its 121 x [32 x 32] weights are split over the four waves by contraction item (kernel column kt,
+// channel half): <= 6 items x 11 kernel rows = 66 A fragments = 264 registers per wave, loaded ONCE per workgroup, which then
+// walks over its tiles (4 output rows x 32 frames).  Per tile a wave reads each activation fragment of its items once per INPUT
+// row and multiplies it into every output row that uses that input row (fl = rho - m): 84 LDS fragment reads for 264 MFMAs.
+// The waves' partial sums over their items meet in LDS once per tile (fixed order), wave w finishing output row w; the next
+// tile's input patch travels global -> registers during the MFMAs and registers -> LDS after them (two patch buffers).
+// ============================================================================================================
+struct RTapArgs {
+  const bf16_t* X;    // [N][Fin][Tp][32]
+  const bf16_t* W;    // [rows*11][32 m][32 k]: kernel row m of this launch is row m*WSF + WQ of the tensor
+  const float* bias;  // [32] or null
+  const int* lens;    // [N] or null (time mask on the output)
+  const float* Pin;   // fp32 partial sums [N][U][Tp][32] to add, or null
+  float* Pout;        // write fp32 partial sums [N][U][Tp][32] instead of Y, or null
+  bf16_t* Y;          // [N][Fout][Tp][32]
+  int N, Tp, Fin, Fout;
+  int KF, WSF, WQ;    // kernel rows (<= 11) and their place in W
+  int ISF, IQ, PF;    // input row of (u, m) = (u + m - PF) * ISF + IQ
+  int U, OSF, OQ;     // output rows handled: f_out = u*OSF + OQ, u in [0, U)
+};
+constexpr int RT_FB = 4, RT_TB = 32, RT_PC = RT_TB + K2T - 1;        // tile: 4 output rows x 32 frames; 42 patch columns
+constexpr int RT_KFM = 11, RT_PR = RT_FB - 1 + RT_KFM;               // <= 11 kernel rows -> <= 14 patch rows
+constexpr int RT_PATCH = RT_PR * RT_PC * CT_POSB;                    // 47040 bytes (80-byte positions: conflict-free b128 reads)
+constexpr int RT_RED = 4 * RT_FB * 4096;                             // partial sums [wave][row][4][64 lanes] x 16 bytes
+constexpr int RT_SMEM = 2 * RT_PATCH + RT_RED;                       // 159616
+constexpr int RT_NLOAD = (RT_PR * RT_PC * 4 + 255) / 256;            // 16-byte patch chunks per thread: 10
+
+template <int KF>   // kernel rows of the launch (11 or 10): compile-time, so that the MFMA loop is straight-line code
+__global__ void __launch_bounds__(256, 1) k_conv_rtap(RTapArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
+  float* red = reinterpret_cast<float*>(rsm + 2 * RT_PATCH);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lq = lane >> 5;
+  // contraction items of this wave: item = 2*kt + channel half; waves 0,1 own 6, waves 2,3 own 5 and run a sixth with zero
+  // weights (they would wait for waves 0,1 at the tile's barrier anyway; a wave-dependent trip count would put a branch around
+  // every MFMA group)
+  const int i0 = wave < 2 ? 6 * wave : 12 + 5 * (wave - 2), icnt = wave < 2 ? 6 : 5;
+  uint4 A[KF][6];
+  int boff[6];                                   // byte offset of item j's activation fragment inside a patch row
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int item = i0 + min(j, icnt - 1), kt = item >> 1, half = item & 1;
+    boff[j] = (li + kt) * CT_POSB + half * 32 + lq * 16;
+#pragma unroll
+    for (int m = 0; m < KF; ++m) {
+      const uint4 wv = *reinterpret_cast<const uint4*>(a.W + (((long)(m * a.WSF + a.WQ) * K2T + kt) * CH + li) * CH + half * 16 + lq * 8);
+      A[m][j] = j < icnt ? wv : make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+  constexpr int PR = RT_FB - 1 + KF;
+  const int nub = ds2_cdiv_dev(a.U, RT_FB), ntb = ds2_cdiv_dev(a.Tp, RT_TB);
+  const int total = a.N * nub * ntb;
+
+  // ---- patch prefetch: chunk i = tid + 256*it -> (position i>>2, 16-byte chunk i&3); the validity bits travel with the data
+  uint4 pf[RT_NLOAD];
+  unsigned pmask = 0;
+  auto issue = [&](int tile) {
+    const int tb = tile % ntb, ub = (tile / ntb) % nub, n = tile / (ntb * nub);
+    const bf16_t* Xn = a.X + (long)n * a.Fin * a.Tp * CH;
+    pmask = 0;
+#pragma unroll
+    for (int it = 0; it < RT_NLOAD; ++it) {
+      const int i = min(tid + it * 256, RT_PR * RT_PC * 4 - 1);
+      const int v = i & 3, pos = i >> 2;
+      const int pr = pos / RT_PC, pc = pos - pr * RT_PC;
+      const int fi = (ub * RT_FB + pr - a.PF) * a.ISF + a.IQ, ti = tb * RT_TB - 5 + pc;
+      const bool ok = fi >= 0 && fi < a.Fin && ti >= 0 && ti < a.Tp;
+      pmask |= ok ? (1u << it) : 0u;
+      pf[it] = *reinterpret_cast<const uint4*>(Xn + ((long)min(max(fi, 0), a.Fin - 1) * a.Tp + min(max(ti, 0), a.Tp - 1)) * CH + v * 8);
+    }
+  };
+  auto commit = [&](unsigned char* patch) {
+#pragma unroll
+    for (int it = 0; it < RT_NLOAD; ++it) {
+      const int i = min(tid + it * 256, RT_PR * RT_PC * 4 - 1);
+      const uint32_t mk = (pmask >> it) & 1u ? 0xffffffffu : 0u;
+      uint4 val = pf[it];
+      val.x &= mk; val.y &= mk; val.z &= mk; val.w &= mk;
+      *reinterpret_cast<uint4*>(patch + (i >> 2) * CT_POSB + (i & 3) * 16) = val;
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < total) {
+    issue(tile);
+    __builtin_amdgcn_sched_barrier(0);
+    commit(rsm);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (; tile < total; tile += gridDim.x, buf ^= 1) {
+    const int tb = tile % ntb, ub = (tile / ntb) % nub, n = tile / (ntb * nub);
+    const int next = tile + gridDim.x;
+    if (next < total) issue(next);                       // global -> registers, in flight under the MFMAs below
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned char* patch = rsm + buf * RT_PATCH;
+    ds2_f32x16 acc[RT_FB];
+#pragma unroll
+    for (int fl = 0; fl < RT_FB; ++fl)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[fl][r] = 0.f;
+#pragma unroll
+    for (int rho = 0; rho < PR; ++rho) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const uint4 b = *reinterpret_cast<const uint4*>(patch + rho * RT_PC * CT_POSB + boff[j]);
+#pragma unroll
+        for (int fl = 0; fl < RT_FB; ++fl) {
+          const int m = rho - fl;
+          if (m >= 0 && m < KF) Mma<bf16_t>::mma32(acc[fl], A[m][j], b);
+        }
+      }
+    }
+    // ---- the four waves' partial sums meet: red[wave][row][g][lane] x 16 bytes
+#pragma unroll
+    for (int fl = 0; fl < RT_FB; ++fl)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(red + (((wave * RT_FB + fl) * 4 + g) * 64 + lane) * 4) =
+            make_float4(acc[fl][4 * g], acc[fl][4 * g + 1], acc[fl][4 * g + 2], acc[fl][4 * g + 3]);
+    __syncthreads();
+    {
+      const int u = ub * RT_FB + wave, t = tb * RT_TB + li;       // wave w finishes output row w of the tile
+      float o[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 s4 = *reinterpret_cast<const float4*>(red + (((0 * RT_FB + wave) * 4 + g) * 64 + lane) * 4);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+          const float4 q4 = *reinterpret_cast<const float4*>(red + (((w * RT_FB + wave) * 4 + g) * 64 + lane) * 4);
+          s4.x += q4.x; s4.y += q4.y; s4.z += q4.z; s4.w += q4.w;
+        }
+        o[4 * g] = s4.x; o[4 * g + 1] = s4.y; o[4 * g + 2] = s4.z; o[4 * g + 3] = s4.w;
+      }
+      if (u < a.U && t < a.Tp) {
+        // lane (frame li, lq) holds channels 8g + 4lq .. +3 (the 32x32 D layout with the weights as the row operand)
+        const long pidx = (((long)n * a.U + u) * a.Tp + t) * CH + 4 * lq;
+        if (a.Pin) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 q4 = *reinterpret_cast<const float4*>(a.Pin + pidx + 8 * g);
+            o[4 * g] += q4.x; o[4 * g + 1] += q4.y; o[4 * g + 2] += q4.z; o[4 * g + 3] += q4.w;
+          }
+        }
+        if (a.Pout) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(a.Pout + pidx + 8 * g) = make_float4(o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]);
+        } else {
+          const bool live = a.lens ? (t < a.lens[n]) : true;
+          bf16_t* dst = a.Y + (((long)n * a.Fout + u * a.OSF + a.OQ) * a.Tp + t) * CH + 4 * lq;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float e[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) e[c] = live ? o[4 * g + c] + (a.bias ? a.bias[8 * g + 4 * lq + c] : 0.f) : 0.f;
+            *reinterpret_cast<uint2*>(dst + 8 * g) = make_uint2(cvt_pk_bf16(e[0], e[1]), cvt_pk_bf16(e[2], e[3]));
+          }
+        }
+      }
+    }
+    if (next < total) commit(rsm + (buf ^ 1) * RT_PATCH);   // registers -> the other patch buffer (last read two tiles ago)
+    __syncthreads();
+  }
+}
+
+template <int KF>
+int conv_rtap_launch_kf(const RTapArgs& a, hipStream_t st) {
+  static bool attr[DS2_MAX_DEVICES];
+  if (ds2_first_use_on_device(attr)) (void)hipFuncSetAttribute((const void*)k_conv_rtap<KF>, hipFuncAttributeMaxDynamicSharedMemorySize, RT_SMEM);
+  const long total = (long)a.N * ds2_cdiv(a.U, RT_FB) * ds2_cdiv(a.Tp, RT_TB);
+  const int cus = ds2_cu_count();
+  hipLaunchKernelGGL(k_conv_rtap<KF>, dim3((unsigned)(total < cus ? total : cus)), dim3(256), RT_SMEM, st, a);
+  DS2_CHECK_LAUNCH();
+  return 0;
+}
+int conv_rtap_launch(const RTapArgs& a, hipStream_t st) {
+  if (a.KF == 11) return conv_rtap_launch_kf<11>(a, st);
+  if (a.KF == 10) return conv_rtap_launch_kf<10>(a, st);
+  return DS2_ERR_ARG;
+}
+
 template <typename T, int NT>
 int conv_tap_launch_nt(const ConvTapArgs& a, hipStream_t st) {
   const int PR = (CT_UB - 1) * a.SF + a.KF, PC = CT_TB * NT + K2T - 1;
@@ -808,13 +995,24 @@ int ds2_conv1_wgrad(int dtype, const float* x, const void* dy1, float* dw1k, int
   return ds2_colsum(DS2_F32, ws, P, C, C, dw1k, 1.0f, ws + (long)P * C, st_);
 }
 
-int ds2_conv2_fwd(int dtype, const void* a1, const void* w2t, const float* b2, const int* lens, void* y2, int N, int Tp,
+// scratch of ds2_conv2_fwd: bf16 storage runs the layer as two register-resident tap correlations (even / odd kernel rows)
+// whose fp32 partial sums [N][41][Tp][32] pass through it; fp32 storage needs none
+long ds2_conv2_fwd_ws_bytes(int dtype, int N, int Tp) { return dtype == DS2_BF16 ? (long)N * F2 * Tp * CH * 4 : 0; }
+int ds2_conv2_fwd(int dtype, const void* a1, const void* w2t, const float* b2, const int* lens, void* y2, int N, int Tp, void* ws,
                   ds2_stream_t st_) {
   hipStream_t st = (hipStream_t)st_;
   DS2_REQUIRE(dtype == DS2_F32 || dtype == DS2_BF16, DS2_ERR_DTYPE);
   DS2_REQUIRE(N > 0 && Tp > 0, DS2_ERR_ARG);
-  ConvTapArgs a{a1, w2t, b2, lens, y2, N, Tp, F1, F2, K2F, 2, 10, F2, 1, 0};
-  return dtype == DS2_F32 ? conv_tap_launch<float>(a, st) : conv_tap_launch<bf16_t>(a, st);
+  if (dtype == DS2_F32) {
+    ConvTapArgs a{a1, w2t, b2, lens, y2, N, Tp, F1, F2, K2F, 2, 10, F2, 1, 0};
+    return conv_tap_launch<float>(a, st);
+  }
+  DS2_REQUIRE(ws != nullptr, DS2_ERR_ARG);
+  // kernel rows kf = 2m (11 of them), then kf = 2m + 1 (10): input row of (u, m) = 2*(u + m - 5) + q
+  RTapArgs e{(const bf16_t*)a1, (const bf16_t*)w2t, nullptr, nullptr, nullptr, (float*)ws, nullptr, N, Tp, F1, F2, 11, 2, 0, 2, 0, 5, F2, 1, 0};
+  RTapArgs o{(const bf16_t*)a1, (const bf16_t*)w2t, b2, lens, (const float*)ws, nullptr, (bf16_t*)y2, N, Tp, F1, F2, 10, 2, 1, 2, 1, 5, F2, 1, 0};
+  const int rc = conv_rtap_launch(e, st);
+  return rc ? rc : conv_rtap_launch(o, st);
 }
 
 // da1[n][f][t][ci] = sum_{co,kf,kt} w2[co][ci][kf][kt] * dy2[n][(f+10-kf)/2][t+5-kt][co]   (only even f+10-kf)
@@ -826,11 +1024,16 @@ int ds2_conv2_dgrad(int dtype, const void* dy2, const void* w2d_even, const void
   hipStream_t st = (hipStream_t)st_;
   DS2_REQUIRE(dtype == DS2_F32 || dtype == DS2_BF16, DS2_ERR_DTYPE);
   DS2_REQUIRE(N > 0 && Tp > 0, DS2_ERR_ARG);
+  if (dtype == DS2_BF16) {
+    RTapArgs e{(const bf16_t*)dy2, (const bf16_t*)w2d_even, nullptr, nullptr, nullptr, nullptr, (bf16_t*)da1, N, Tp, F2, F1, 11, 1, 0, 1, 0, 5, 41, 2, 0};
+    RTapArgs o{(const bf16_t*)dy2, (const bf16_t*)w2d_odd, nullptr, nullptr, nullptr, nullptr, (bf16_t*)da1, N, Tp, F2, F1, 10, 1, 0, 1, 0, 4, 40, 2, 1};
+    const int rc = conv_rtap_launch(e, st);
+    return rc ? rc : conv_rtap_launch(o, st);
+  }
   ConvTapArgs e{dy2, w2d_even, nullptr, nullptr, da1, N, Tp, F2, F1, 11, 1, 5, 41, 2, 0};
   ConvTapArgs o{dy2, w2d_odd, nullptr, nullptr, da1, N, Tp, F2, F1, 10, 1, 4, 40, 2, 1};
-  int rc = dtype == DS2_F32 ? conv_tap_launch<float>(e, st) : conv_tap_launch<bf16_t>(e, st);
-  if (rc) return rc;
-  return dtype == DS2_F32 ? conv_tap_launch<float>(o, st) : conv_tap_launch<bf16_t>(o, st);
+  const int rc = conv_tap_launch<float>(e, st);
+  return rc ? rc : conv_tap_launch<float>(o, st);
 }
 
 long ds2_conv2_wgrad_ws_floats(int N, int Tp) {

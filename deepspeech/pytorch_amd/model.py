@@ -211,26 +211,6 @@ class _ConvStackFn(torch.autograd.Function):
         R1, R2 = N * 81 * Tp, N * 41 * Tp
         dy2 = torch.empty_like(y2)
         dg2, dbe2 = ops.bn_bwd(dx0, y2, dy2, 2, sv2, R2, 32, RNN_INPUT_LD, 32, 32, F=41, Tp=Tp, N=N, lens=lens_dev)
-
-        def conv2_param_grads():
-            db2 = ops.colsum(dy2.view(R2, 32))
-            dw2t = ops.conv2_wgrad(dy2, a1)
-            return db2, dw2t.view(21, 11, 32, 32).permute(2, 3, 0, 1).contiguous()
-        side = getattr(ctx, "side", None)
-        if side is None:
-            db2, dw2 = conv2_param_grads()
-        else:
-            # off the dependent chain (dgrad -> BatchNorm backward -> conv1 weight gradient): second stream, behind the layer-0
-            # weight-gradient GEMMs of the RNN stack; the caller joins the streams and owns the hand-over of db2 / dw2
-            main = torch.cuda.current_stream()
-            ready = torch.cuda.Event()
-            ready.record(main)
-            with torch.cuda.stream(side):
-                side.wait_event(ready)
-                dy2.record_stream(side)
-                a1.record_stream(side)
-                db2, dw2 = conv2_param_grads()
-            ctx.side_grads = [db2, dw2]
         w2d = c.get(("w2d", dtype), [w2], lambda: [
             w2.detach()[:, :, q::2, :].flip(2, 3).permute(2, 3, 1, 0).contiguous().to(dtype) for q in (0, 1)])
         da1 = ops.conv2_dgrad(dy2, w2d[0], w2d[1])
@@ -239,6 +219,10 @@ class _ConvStackFn(torch.autograd.Function):
         db1 = ops.colsum(dy1.view(R1, 32))
         dw1k = ops.conv1_wgrad(x, dy1, Tp)
         dw1 = dw1k.t().reshape(32, 1, 41, 11).contiguous()
+        # conv2's parameter gradients are off the dependent chain (dgrad -> BatchNorm backward -> conv1 weight gradient), so last;
+        # on this stream: the second one is busy with the layer-0 weight-gradient GEMMs of the RNN stack for longer than this one
+        db2 = ops.colsum(dy2.view(R2, 32))
+        dw2 = ops.conv2_wgrad(dy2, a1).view(21, 11, 32, 32).permute(2, 3, 0, 1).contiguous()
         return (None, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, None, None, None, None, None)
 
 
@@ -473,10 +457,8 @@ class _FrontFn(torch.autograd.Function):
         c2.defer_join = True
         r = _RnnStackFn.backward(c2, dout)
         rnn_grads = r[8 + 2 * L:]
-        main, side, grads, mod = c2.pending
-        c1.side = side
         cg = _ConvStackFn.backward(c1, r[0])
-        _join_side(main, side, list(grads) + c1.side_grads, mod)
+        _join_side(*c2.pending)
         ctx.c1 = ctx.c2 = None
         return (None,) * 8 + tuple(cg[1:9]) + (None,) * (2 * L) + tuple(rnn_grads)
 

@@ -204,7 +204,9 @@ def conv1_wgrad(x, dy1, Tp):
 def conv2_fwd(a1, w2t, b2, lens):
     N, _, Tp, _ = a1.shape
     y2 = torch.empty((N, 41, Tp, 32), dtype=a1.dtype, device=a1.device)
-    call("ds2_conv2_fwd", dt(a1), P(a1), P(w2t), PF(b2), P(lens), P(y2), N, Tp, S())
+    nws = query("ds2_conv2_fwd_ws_bytes", dt(a1), N, Tp)
+    ws = torch.empty(nws, dtype=torch.uint8, device=a1.device) if nws else None
+    call("ds2_conv2_fwd", dt(a1), P(a1), P(w2t), PF(b2), P(lens), P(y2), N, Tp, P(ws), S())
     return y2
 
 

@@ -93,7 +93,10 @@ int ds2_conv1_fwd(int dtype, const float* x, const float* w1k, const float* b1, 
 long ds2_conv1_wgrad_ws_floats(int N, int Tp);
 int ds2_conv1_wgrad(int dtype, const float* x, const void* dy1, float* dw1k, int N, int T, int Tp, float* ws,
                     ds2_stream_t stream);
-int ds2_conv2_fwd(int dtype, const void* a1, const void* w2t, const float* b2, const int* lens, void* y2, int N, int Tp,
+/* ws: ds2_conv2_fwd_ws_bytes(dtype,N,Tp) bytes (bf16 storage: fp32 partial sums of the even-kernel-row half of the layer pass
+ * through it; 0 and ws may be NULL for fp32 storage). */
+long ds2_conv2_fwd_ws_bytes(int dtype, int N, int Tp);
+int ds2_conv2_fwd(int dtype, const void* a1, const void* w2t, const float* b2, const int* lens, void* y2, int N, int Tp, void* ws,
                   ds2_stream_t stream);
 int ds2_conv2_dgrad(int dtype, const void* dy2, const void* w2d_even, const void* w2d_odd, void* da1, int N, int Tp,
                     ds2_stream_t stream);
