@@ -11,6 +11,8 @@
 //          (a stride-2 transposed conv is two stride-1 convs); wgrad contracts over positions with the exact-fp32
 //          MFMA 32x32x2 (one element per lane: no K-contiguity requirement on the position axis).
 // Layouts: x (N,1,161,T) f32 as given by the loader; activations NFTC [N][F][T'][32] in storage type T.
+#include <type_traits>
+
 #include "ds2_common.h"
 
 namespace {
@@ -596,6 +598,7 @@ __global__ void __launch_bounds__(256, 1) k_conv2_wgrad(const T* __restrict__ dY
 constexpr int CWB_DY_LD = 136;          // bf16 per channel row of the dY^T tile (128 positions + pad)
 constexpr int CWB_X_POS = 144;          // staged X positions: t0-8 .. t0+135
 constexpr int CWB_X_LD = 152;
+constexpr int CWB_DEPTH = 3;           // work items in flight (register prefetch ring)
 
 __device__ __forceinline__ uint32_t cw_pair_lo(uint32_t a, uint32_t b) { return (a & 0xffffu) | (b << 16); }      // even channel of (t, t+1)
 __device__ __forceinline__ uint32_t cw_pair_hi(uint32_t a, uint32_t b) { return (a >> 16) | (b & 0xffff0000u); }  // odd channel
@@ -643,10 +646,14 @@ __global__ void __launch_bounds__(256, 1) k_conv2_wgrad_bf16(const bf16_t* __res
   const int x_pp0 = tid % 72, x_v0 = tid / 72;              // tid < 256 -> v0 in 0..3 (tid 216..255 -> v0 = 3)
   const int x_pp1 = (tid + 256) % 72, x_v1 = (tid + 256) / 72;
   const bool x_has1 = tid + 256 < 72 * 4;
-  uint4 g[6];
-  uint32_t gm[6];   // masks (all ones / zero) for out-of-range positions
+  // Prefetch ring: the tiles of the next CWB_DEPTH work items travel global -> registers while the current ones are multiplied.
+  // One item is only ~1.5k cycles of work (22 MFMAs per wave between two barriers), an L2 / HBM round trip is 2-4k: with a
+  // single item in flight (round 1) the kernel sat at 19 % of the MFMA rate waiting for its loads.
+  uint4 g[CWB_DEPTH][6];
+  uint32_t gm[CWB_DEPTH][6];   // masks (all ones / zero) for out-of-range positions
 
-  auto issue = [&](long wk) {
+  auto issue = [&](auto dc, long wk) {
+    constexpr int d = decltype(dc)::value;
     const int r = (int)(wk / ntiles), t0 = (int)(wk % ntiles) * CW_TB;
     const int n = r / nvalid, fo = fo_lo + r % nvalid, fi = 2 * fo - 10 + kf;
     const bf16_t* dyrow = dY + ((long)n * F2 + fo) * Tp * CH;
@@ -654,54 +661,49 @@ __global__ void __launch_bounds__(256, 1) k_conv2_wgrad_bf16(const bf16_t* __res
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int t = t0 + 2 * dy_pp + h;
-      gm[h] = t < Tp ? 0xffffffffu : 0u;
-      g[h] = *reinterpret_cast<const uint4*>(dyrow + (long)min(t, Tp - 1) * CH + dy_v * 8);
+      gm[d][h] = t < Tp ? 0xffffffffu : 0u;
+      g[d][h] = *reinterpret_cast<const uint4*>(dyrow + (long)min(t, Tp - 1) * CH + dy_v * 8);
       const int tx = t0 - 8 + 2 * x_pp0 + h;
-      gm[2 + h] = (tx >= 0 && tx < Tp) ? 0xffffffffu : 0u;
-      g[2 + h] = *reinterpret_cast<const uint4*>(xrow + (long)min(max(tx, 0), Tp - 1) * CH + x_v0 * 8);
+      gm[d][2 + h] = (tx >= 0 && tx < Tp) ? 0xffffffffu : 0u;
+      g[d][2 + h] = *reinterpret_cast<const uint4*>(xrow + (long)min(max(tx, 0), Tp - 1) * CH + x_v0 * 8);
       const int ty = t0 - 8 + 2 * x_pp1 + h;
-      gm[4 + h] = (x_has1 && ty >= 0 && ty < Tp) ? 0xffffffffu : 0u;
-      g[4 + h] = *reinterpret_cast<const uint4*>(xrow + (long)min(max(ty, 0), Tp - 1) * CH + (x_has1 ? x_v1 : 0) * 8);
+      gm[d][4 + h] = (x_has1 && ty >= 0 && ty < Tp) ? 0xffffffffu : 0u;
+      g[d][4 + h] = *reinterpret_cast<const uint4*>(xrow + (long)min(max(ty, 0), Tp - 1) * CH + (x_has1 ? x_v1 : 0) * 8);
     }
   };
-  auto stage = [&]() {
+  auto stage = [&](auto dc) {
+    constexpr int d = decltype(dc)::value;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      g[i].x &= gm[i]; g[i].y &= gm[i]; g[i].z &= gm[i]; g[i].w &= gm[i];
+      g[d][i].x &= gm[d][i]; g[d][i].y &= gm[d][i]; g[d][i].z &= gm[d][i]; g[d][i].w &= gm[d][i];
     }
     {
       uint32_t* row = reinterpret_cast<uint32_t*>(sdy + (dy_v * 8) * CWB_DY_LD + 2 * dy_pp);
       constexpr int LD = CWB_DY_LD / 2;
-      row[0 * LD] = cw_pair_lo(g[0].x, g[1].x); row[1 * LD] = cw_pair_hi(g[0].x, g[1].x);
-      row[2 * LD] = cw_pair_lo(g[0].y, g[1].y); row[3 * LD] = cw_pair_hi(g[0].y, g[1].y);
-      row[4 * LD] = cw_pair_lo(g[0].z, g[1].z); row[5 * LD] = cw_pair_hi(g[0].z, g[1].z);
-      row[6 * LD] = cw_pair_lo(g[0].w, g[1].w); row[7 * LD] = cw_pair_hi(g[0].w, g[1].w);
+      row[0 * LD] = cw_pair_lo(g[d][0].x, g[d][1].x); row[1 * LD] = cw_pair_hi(g[d][0].x, g[d][1].x);
+      row[2 * LD] = cw_pair_lo(g[d][0].y, g[d][1].y); row[3 * LD] = cw_pair_hi(g[d][0].y, g[d][1].y);
+      row[4 * LD] = cw_pair_lo(g[d][0].z, g[d][1].z); row[5 * LD] = cw_pair_hi(g[d][0].z, g[d][1].z);
+      row[6 * LD] = cw_pair_lo(g[d][0].w, g[d][1].w); row[7 * LD] = cw_pair_hi(g[d][0].w, g[d][1].w);
     }
     constexpr int LX = CWB_X_LD / 2;
     {
       uint32_t* row = reinterpret_cast<uint32_t*>(sx + (x_v0 * 8) * CWB_X_LD + 2 * x_pp0);
-      row[0 * LX] = cw_pair_lo(g[2].x, g[3].x); row[1 * LX] = cw_pair_hi(g[2].x, g[3].x);
-      row[2 * LX] = cw_pair_lo(g[2].y, g[3].y); row[3 * LX] = cw_pair_hi(g[2].y, g[3].y);
-      row[4 * LX] = cw_pair_lo(g[2].z, g[3].z); row[5 * LX] = cw_pair_hi(g[2].z, g[3].z);
-      row[6 * LX] = cw_pair_lo(g[2].w, g[3].w); row[7 * LX] = cw_pair_hi(g[2].w, g[3].w);
+      row[0 * LX] = cw_pair_lo(g[d][2].x, g[d][3].x); row[1 * LX] = cw_pair_hi(g[d][2].x, g[d][3].x);
+      row[2 * LX] = cw_pair_lo(g[d][2].y, g[d][3].y); row[3 * LX] = cw_pair_hi(g[d][2].y, g[d][3].y);
+      row[4 * LX] = cw_pair_lo(g[d][2].z, g[d][3].z); row[5 * LX] = cw_pair_hi(g[d][2].z, g[d][3].z);
+      row[6 * LX] = cw_pair_lo(g[d][2].w, g[d][3].w); row[7 * LX] = cw_pair_hi(g[d][2].w, g[d][3].w);
     }
     if (x_has1) {
       uint32_t* row = reinterpret_cast<uint32_t*>(sx + (x_v1 * 8) * CWB_X_LD + 2 * x_pp1);
-      row[0 * LX] = cw_pair_lo(g[4].x, g[5].x); row[1 * LX] = cw_pair_hi(g[4].x, g[5].x);
-      row[2 * LX] = cw_pair_lo(g[4].y, g[5].y); row[3 * LX] = cw_pair_hi(g[4].y, g[5].y);
-      row[4 * LX] = cw_pair_lo(g[4].z, g[5].z); row[5 * LX] = cw_pair_hi(g[4].z, g[5].z);
-      row[6 * LX] = cw_pair_lo(g[4].w, g[5].w); row[7 * LX] = cw_pair_hi(g[4].w, g[5].w);
+      row[0 * LX] = cw_pair_lo(g[d][4].x, g[d][5].x); row[1 * LX] = cw_pair_hi(g[d][4].x, g[d][5].x);
+      row[2 * LX] = cw_pair_lo(g[d][4].y, g[d][5].y); row[3 * LX] = cw_pair_hi(g[d][4].y, g[d][5].y);
+      row[4 * LX] = cw_pair_lo(g[d][4].z, g[d][5].z); row[5 * LX] = cw_pair_hi(g[d][4].z, g[d][5].z);
+      row[6 * LX] = cw_pair_lo(g[d][4].w, g[d][5].w); row[7 * LX] = cw_pair_hi(g[d][4].w, g[d][5].w);
     }
   };
 
-  long wk = split;
-  if (wk < nwork) issue(wk);
-  for (; wk < nwork; wk += gridDim.y) {
-    __syncthreads();            // previous tile's fragment reads are done
-    stage();
-    __syncthreads();
-    const long nxt = wk + gridDim.y;
-    if (nxt < nwork) issue(nxt);   // in flight during the MFMAs below
+  const long stride = gridDim.y;
+  auto multiply = [&]() {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int ks = wave + 4 * kk;
@@ -715,6 +717,23 @@ __global__ void __launch_bounds__(256, 1) k_conv2_wgrad_bf16(const bf16_t* __res
       cw_tap<6>(acc, a, q0, q1, q2); cw_tap<7>(acc, a, q0, q1, q2); cw_tap<8>(acc, a, q0, q1, q2);
       cw_tap<9>(acc, a, q0, q1, q2); cw_tap<10>(acc, a, q0, q1, q2);
     }
+  };
+  auto step = [&](auto dc, long w) {
+    if (w >= nwork) return;
+    __syncthreads();            // previous tile's fragment reads are done
+    stage(dc);
+    __syncthreads();
+    if (w + CWB_DEPTH * stride < nwork) issue(dc, w + CWB_DEPTH * stride);   // in flight during the next CWB_DEPTH items' MFMAs
+    multiply();
+  };
+  static_assert(CWB_DEPTH == 3, "the ring below is written out for three buffers");
+  if (split < nwork) issue(std::integral_constant<int, 0>{}, split);
+  if (split + stride < nwork) issue(std::integral_constant<int, 1>{}, split + stride);
+  if (split + 2 * stride < nwork) issue(std::integral_constant<int, 2>{}, split + 2 * stride);
+  for (long wk = split; wk < nwork; wk += CWB_DEPTH * stride) {
+    step(std::integral_constant<int, 0>{}, wk);
+    step(std::integral_constant<int, 1>{}, wk + stride);
+    step(std::integral_constant<int, 2>{}, wk + 2 * stride);
   }
   float* red = reinterpret_cast<float*>(smem);
   float* out = partial + ((long)split * (K2F * K2T) + (long)kf * K2T) * (CH * CH);
