@@ -277,7 +277,7 @@ def cpu_baseline(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=150, help="timed steps (default: a >= 5 s timed region on cfg3)")
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (default: a >= 5 s timed region on cfg3: 200 x ~30 ms)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--stock", action="store_true", help="time stock PyTorch-ROCm instead of the native path")

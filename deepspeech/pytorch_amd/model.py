@@ -345,7 +345,9 @@ class _RnnStackFn(torch.autograd.Function):
             # with the next layer's sweep: the dependent chain never competes with them for the CUs
             ready = torch.cuda.Event()
             ready.record(main)
-            # ---- weight gradients (second stream, under the next layer's sweep): contraction over the T'*N rows
+            # ---- weight gradients (second stream, under the next layer's sweep): contraction over the T'*N rows.  Layer 0's run
+            # under the conv backward instead, where no persistent sweep needs most of every CU's registers: the full-size tiles
+            cores = li > 0
             with torch.cuda.stream(side):
                 side.wait_event(ready)
                 for t in rg.tensors() + [Xh, hext]:
@@ -354,7 +356,7 @@ class _RnnStackFn(torch.autograd.Function):
                 Xh_T = ops.transpose(Xh)                                # [I][ldT]
                 ldT = dGI_T.shape[1]
                 dWih = ops.gemm_nt(dGI_T, Xh_T, out_dtype=torch.float32, splitk=_wgrad_splitk(dGI_T.shape[0], Xh_T.shape[0], ldT),
-                                   coresident=True)
+                                   coresident=cores)
                 del Xh_T
                 if first:
                     dWih = torch.cat([_perm_cols_to_reference(dWih[d * GH:(d + 1) * GH]) for d in range(D)], 0)
@@ -375,7 +377,7 @@ class _RnnStackFn(torch.autograd.Function):
                         # hidden-side gate gradient = [dr, dz (rows of dGI^T) | dQ^T]: one GEMM whose A operand is two row blocks
                         dQ_T = ops.transpose(rg.dQ[d].reshape(R, H))   # [H][ldT]
                         dWhh = ops.gemm_nt_rows2(dGI_T[d * GH:d * GH + 2 * H], dQ_T, 2 * H, Hp_T, GH, H, ldT, ldT, ldT,
-                                                 splitk=_wgrad_splitk(GH, H, ldT), coresident=True)
+                                                 splitk=_wgrad_splitk(GH, H, ldT), coresident=cores)
                         dBhh = torch.cat([bsum[d][:2 * H], bsum[d][3 * H:4 * H]], 0) if bsum is not None else \
                             torch.cat([dBih[d * GH:d * GH + 2 * H], ops.colsum(rg.dQ[d].reshape(R, H))], 0)
                     else:
@@ -386,7 +388,7 @@ class _RnnStackFn(torch.autograd.Function):
                             dGH_T = dGI_T[d * GH:(d + 1) * GH]
                             dBhh = dBih[d * GH:(d + 1) * GH]
                         dWhh = ops.gemm_nt(dGH_T, Hp_T, out_dtype=torch.float32, M=GH, N=H, K=ldT, lda=ldT, ldb=ldT,
-                                           splitk=_wgrad_splitk(GH, H, ldT), coresident=True)
+                                           splitk=_wgrad_splitk(GH, H, ldT), coresident=cores)
                     grads[po + 4 * d:po + 4 * d + 4] = [dWih[d * GH:(d + 1) * GH].contiguous(), dWhh,
                                                         dBih[d * GH:(d + 1) * GH].contiguous(), dBhh.contiguous()]
                 del dGI_T

@@ -26,11 +26,14 @@ ROWS = [
     ("k_gemm_nt_bf16_big", "input projections X*W_ih^T (256x128 tile)", "mfma", sum(i2h) / L, 2.5e15),
     ("k_gemm_nt_bf16_glds<true>", "weight gradients dW_ih, dW_hh (co-resident with the BPTT sweeps)", "mfma", (sum(wih) + 2 * L * whh) / (3 * L), 2.5e15),
     ("k_gemm_nt_bf16_glds<false>", "dX = dGI*W_ih (5 of 6 launches per step; + head)", "mfma", sum(i2h) / L * 5 / 6, 2.5e15),
-    ("k_conv_tap<bf16_t, 1>", "conv2 forward (tap GEMM, one position tile per wave)", "mfma", conv2, 2.5e15),
-    ("k_conv_tap<bf16_t, 2>", "conv2 data gradient (two row-parity launches)", "mfma", conv2 / 2, 2.5e15),
+    ("k_conv_rtap", "conv2 forward and data gradient (two 11x11 / 10x11 tap correlations each, taps in registers)", "mfma", conv2 / 2, 2.5e15),
+    ("k_conv_tap<bf16_t, 1>", "conv2 forward (tap GEMM, one position tile per wave; before round 2e)", "mfma", conv2, 2.5e15),
+    ("k_conv_tap<bf16_t, 2>", "conv2 data gradient (two row-parity launches; before round 2e)", "mfma", conv2 / 2, 2.5e15),
     ("k_conv2_wgrad_bf16", "conv2 weight gradient", "mfma", conv2, 2.5e15),
-    ("k_conv1_fwd", "conv1 forward (Cin = 1: VALU)", "valu fp32", conv1, 157.3e12),
-    ("k_conv1_wgrad", "conv1 weight gradient (VALU)", "valu fp32", conv1, 157.3e12),
+    ("k_conv1_fwd_mfma", "conv1 forward (MFMA, time taps padded 11 -> 16: 69 % useful flops, counted as algorithmic)", "mfma", conv1, 2.5e15),
+    ("k_conv1_wgrad_mfma", "conv1 weight gradient (MFMA)", "mfma", conv1, 2.5e15),
+    ("k_conv1_fwd<", "conv1 forward (Cin = 1: VALU; fp32 storage and before round 2e)", "valu fp32", conv1, 157.3e12),
+    ("k_conv1_wgrad<", "conv1 weight gradient (VALU; fp32 storage and before round 2e)", "valu fp32", conv1, 157.3e12),
     ("k_transpose", "operand transposes of the weight-gradient GEMMs", "hbm", None, 8e12),
     ("k_opt_matrix", "AdamW + bf16 layouts of a recurrent weight matrix", "hbm", None, 8e12),
 ]
