@@ -718,13 +718,20 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd4(PArgs a) {
     pidx[g] = ((r / 16) * 16 + gi_i) * 16 + (r % 16);
   }
 
+  DS2_PROBE_ONLY(unsigned long long c_gather = 0, c_bar = 0, c_gate = 0;)
+  // The hoisted input projection of a step is loaded at the top of the step, IN FRONT of the gather.  vmcnt retires in order,
+  // so these loads (2-byte reads walking through a 295 MB tensor: HBM latency) hold the gather's waits up -- the probe build
+  // runs at 1.66 instead of 1.97 us per step without them -- but moving them behind the gather (one or two steps ahead, three
+  // rotating register sets) was slower in the training step, 2.05 vs 1.90: the gather then returns before every peer has
+  // published (0.65 instead of 0.02 re-polls per step, each a full L2 round trip), i.e. the slow loads also pace the group.
   for (int s = 0; s < Tp; ++s) {
+    DS2_PROBE_ONLY(const unsigned long long t0 = __builtin_readcyclecounter();)
     const int t = d == 0 ? s : Tp - 1 - s;
     const int par = s & 1;
     float gi[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) gi[g] = 0.f;
-    if (gate_thread) {
+    if (gate_thread && !DS2_DBG(a, 1)) {
 #pragma unroll
       for (int g = 0; g < G; ++g) gi[g] = __uint_as_float((uint32_t)gi_ptr[(long)g * H] << 16);
     }
@@ -733,8 +740,10 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd4(PArgs a) {
     for (int tt = 0; tt < TILES; ++tt) acc[tt] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
     if (s > 0 || a.h0)
       gather_mma_tf<TILES, KS>(acc, w, rsrc, ((s + 3) & 3) * SLOT_BYTES, wave * KS, lq, srow, half, need, a.err, a.lerr, dead, rounds);
+    DS2_PROBE_ONLY(const unsigned long long t1 = __builtin_readcyclecounter();)
     store_partials<TILES>(part[par], acc, wave, lane);
     __syncthreads();
+    DS2_PROBE_ONLY(const unsigned long long t2 = __builtin_readcyclecounter();)
     float hn = 0.f;                 // emitted h_t (0 when inactive)
     float pl[NS ? NS : 1];
 #pragma unroll
@@ -790,7 +799,17 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd4(PArgs a) {
     gi_ptr += gi_stride;
     if (NS) sv_ptr += sv_stride;
     hs_ptr += hs_stride;
+    DS2_PROBE_ONLY(const unsigned long long t3 = __builtin_readcyclecounter(); c_gather += t1 - t0; c_bar += t2 - t1; c_gate += t3 - t2;)
   }
+#ifdef DS2_PROBE
+  if (a.dbg && p == 0 && (tid == 0 || tid == 255)) {
+    const int o = grp * 8 + (tid == 0 ? 0 : 4);
+    a.dbg[o + 0] = c_gather;
+    a.dbg[o + 1] = c_bar;
+    a.dbg[o + 2] = c_gate;
+    a.dbg[o + 3] = rounds;
+  }
+#endif
   (void)rounds;
   if (gate_thread) {
     const long so = ((long)d * N + n) * H + ju;
@@ -1100,32 +1119,62 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd4(PArgs a) {
   const int pidx = (((2 * up + e) / 16) * 16 + gi_i) * 16 + ((2 * up + e) % 16);
   const int xoff = xtf_pair_bytes(j, gi_i);     // this pair's dword of gate 0 inside a slot
 
-  for (int s = 0; s < Tp; ++s) {
-    const int t = d == 0 ? Tp - 1 - s : s;
-    const int par = s & 1;
-    // ---- prefetch everything the gate phase needs (2-byte loads of this thread's unit)
-    float dout = 0.f, sp[NS ? NS : 1], hp = 0.f, cp = 0.f;
+  DS2_PROBE_ONLY(unsigned long long c_gather = 0, c_bar = 0, c_gate = 0;)
+  // Everything the gate phase of a step needs (2-byte loads of this thread's unit: dOut, the saved planes, h_prev, c_prev) is
+  // loaded TWO STEPS AHEAD, right after a gather has returned: loads that are still on their way from HBM when the gather's loads
+  // come back hold the gather up (vmcnt retires in order; probe build: 2.78 -> 2.09 us per step without them).  Unlike in the
+  // forward sweep (see k_rnn_persist_fwd4) this pays in the training step, a little: 3.40 -> 3.33 us.  Raw 16-bit values (a
+  // conversion at load time would wait right there) in three rotating register sets.
+  constexpr int M = NS ? NS : 1;
+  struct Pre {
+    uint32_t dout, sp[M], hp, cp;
+  };
+  auto prefetch = [&](Pre& r, int s, long off) {     // the loads of step s, `off` steps ahead of the running pointers
+    r.dout = 0u; r.hp = 0u; r.cp = 0u;
 #pragma unroll
-    for (int q = 0; q < (NS ? NS : 1); ++q) sp[q] = 0.f;
-    if (gate_thread) {
-      dout = ld_bf16(do_ptr);
+    for (int q = 0; q < M; ++q) r.sp[q] = 0u;
+    if (gate_thread && !DS2_DBG(a, 1)) {
+      const int t = d == 0 ? Tp - 1 - s : s;
+      const bf16_t* dop = do_ptr + off * dstep * N * H;
+      const bf16_t* svp = NS ? sv_ptr + off * dstep * N * NSH_ : nullptr;
+      const bf16_t* hsp = hs_ptr + off * dstep * N * H;
+      r.dout = dop->v;
 #pragma unroll
-      for (int q = 0; q < NS; ++q) sp[q] = ld_bf16(sv_ptr + (long)q * H);
-      hp = ld_bf16(hs_ptr + prev_off * N * H);          // guard slots / inactive frames hold zeros: unconditional
+      for (int q = 0; q < NS; ++q) r.sp[q] = (svp + (long)q * H)->v;
+      r.hp = (hsp + prev_off * N * H)->v;              // guard slots / inactive frames hold zeros: unconditional
       if (CELL == CELL_LSTM) {
         const bool has_prev = d == 0 ? (t > 0) : (t + 1 < len);
-        if (has_prev) cp = ld_bf16(sv_ptr + prev_off * N * NSH_ + 4 * H);
+        if (has_prev) r.cp = (svp + prev_off * N * NSH_ + 4 * H)->v;
       }
-      if (CELL == CELL_RNN) hp = ld_bf16(hs_ptr);
+      if (CELL == CELL_RNN) r.hp = hsp->v;
     }
+  };
+  Pre pra, prb, prc;
+  prefetch(pra, 0, 0);
+  prefetch(prb, Tp > 1 ? 1 : 0, Tp > 1 ? 1 : 0);
+  prefetch(prc, 0, 0);            // defined contents for the set that is filled from step 2 on
+  auto body = [&](int s, Pre& pu, Pre& pn) {
+    DS2_PROBE_ONLY(const unsigned long long t0 = __builtin_readcyclecounter();)
+    const int t = d == 0 ? Tp - 1 - s : s;
+    const int par = s & 1;
     ds2_f32x4 acc[TILES];
 #pragma unroll
     for (int tt = 0; tt < TILES; ++tt) acc[tt] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
     if (s > 0) gather_mma_tf<TILES, KS>(acc, w, rsrc, ((s + 3) & 3) * SLOT_BYTES, wave * KS, lq, srow, half, need, a.err, a.lerr, dead, rounds);
+    // this step's values first (loaded two steps ago; the gather has just drained vmcnt), THEN the new loads: converted after
+    // them, the compiler's wait-count bookkeeping across the rotated loop would wait for the new loads as well
+    const float dout = __uint_as_float(pu.dout << 16), hp = __uint_as_float(pu.hp << 16), cp = __uint_as_float(pu.cp << 16);
+    float sp[M];
+#pragma unroll
+    for (int q = 0; q < M; ++q) sp[q] = __uint_as_float(pu.sp[q] << 16);
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 2 < Tp) prefetch(pn, s + 2, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    DS2_PROBE_ONLY(const unsigned long long t1 = __builtin_readcyclecounter();)
     store_partials<TILES>(part[par], acc, wave, lane);
     __syncthreads();
+    DS2_PROBE_ONLY(const unsigned long long t2 = __builtin_readcyclecounter();)
     // gate gradients of this thread's unit (zeros when inactive); gq[] = what is exchanged, gs[] = what is stored in dGI
-    constexpr int M = NS ? NS : 1;
     float gx[G], gn = 0.f, gq = 0.f;        // gx: the G exchanged planes; GRU: gx = {dr, dz, dq}, gn = dn (stored), gq = dq
 #pragma unroll
     for (int g = 0; g < G; ++g) gx[g] = 0.f;
@@ -1213,7 +1262,22 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd4(PArgs a) {
     hs_ptr += dstep * N * H;
     dgi_ptr += dstep * N * ldgi;
     if (CELL == CELL_GRU) dgh_ptr += dstep * N * H;
+    DS2_PROBE_ONLY(const unsigned long long t3 = __builtin_readcyclecounter(); c_gather += t1 - t0; c_bar += t2 - t1; c_gate += t3 - t2;)
+  };
+  for (int s = 0; s < Tp; s += 3) {
+    body(s, pra, prc);
+    if (s + 1 < Tp) body(s + 1, prb, pra);
+    if (s + 2 < Tp) body(s + 2, prc, prb);
   }
+#ifdef DS2_PROBE
+  if (a.dbg && p == 0 && (tid == 0 || tid == 255)) {
+    const int o = grp * 8 + (tid == 0 ? 0 : 4);
+    a.dbg[o + 0] = c_gather;
+    a.dbg[o + 1] = c_bar;
+    a.dbg[o + 2] = c_gate;
+    a.dbg[o + 3] = rounds;
+  }
+#endif
   (void)rounds;
   if (gate_thread && a.dBacc) {
     float* bo = a.dBacc + ((long)d * N + n) * NB * H + ju;
