@@ -1,18 +1,19 @@
 // Conv front-end of MaskConv (reference model.py:53-69 over the Sequential at model.py:157-164).
 //
-//   conv1  Conv2d(1,32,(41,11),s=(2,2),p=(20,5))   Cin = 1: no contraction over channels, low arithmetic intensity ->
-//          VALU kernels with the 32 output channels as per-thread accumulators and the weights (fwd) / the output
+//   conv1  Conv2d(1,32,(41,11),s=(2,2),p=(20,5))   Cin = 1: no contraction over channels.
+//          fp32 storage: VALU kernels with the 32 output channels as per-thread accumulators and the weights (fwd) / the output
 //          gradient (wgrad) as wave-uniform scalar operands (s_load + v_fmac with an SGPR source), input patch in LDS.
+//          bf16 storage: MFMA kernels whose contraction is the kernel's TIME tap (k_conv1_fwd_mfma / k_conv1_wgrad_mfma below).
 //   conv2  Conv2d(32,32,(21,11),s=(2,1),p=(10,5))   implicit GEMM on MFMA 32x32: for every kernel tap a
 //          [32 out] x [32 in] x [32 positions] product; activations are NFTC (channel fastest) so the K operand is a
-//          contiguous 64-byte channel vector of one position; the input patch of a 4-row x 32-position output tile and
-//          the 11 taps of one kernel row are staged in LDS (80-byte position stride = conflict-free ds_read_b128).
-//          dgrad is the SAME kernel run once per output-row parity with the flipped, parity-subsampled weights
-//          (a stride-2 transposed conv is two stride-1 convs); wgrad contracts over positions with the exact-fp32
-//          MFMA 32x32x2 (one element per lane: no K-contiguity requirement on the position axis).
+//          contiguous 64-byte channel vector of one position.
+//          fp32 storage: k_conv_tap (input patch of a 4-row x 32-position output tile and the 11 taps of one kernel row staged in
+//          LDS, 80-byte position stride = conflict-free ds_read_b128); dgrad is the SAME kernel run once per output-row parity
+//          with the flipped, parity-subsampled weights (a stride-2 transposed conv is two stride-1 convs); wgrad contracts over
+//          positions with the exact-fp32 MFMA 32x32x2.
+//          bf16 storage: k_conv_rtap (forward and dgrad: taps resident in registers) and k_conv2_wgrad_bf16r (several kernel
+//          rows per workgroup, taps split over the waves).
 // Layouts: x (N,1,161,T) f32 as given by the loader; activations NFTC [N][F][T'][32] in storage type T.
-#include <type_traits>
-
 #include "ds2_common.h"
 
 namespace {
@@ -598,7 +599,6 @@ __global__ void __launch_bounds__(256, 1) k_conv2_wgrad(const T* __restrict__ dY
 constexpr int CWB_DY_LD = 136;          // bf16 per channel row of the dY^T tile (128 positions + pad)
 constexpr int CWB_X_POS = 144;          // staged X positions: t0-8 .. t0+135
 constexpr int CWB_X_LD = 152;
-constexpr int CWB_DEPTH = 3;           // work items in flight (register prefetch ring)
 
 __device__ __forceinline__ uint32_t cw_pair_lo(uint32_t a, uint32_t b) { return (a & 0xffffu) | (b << 16); }      // even channel of (t, t+1)
 __device__ __forceinline__ uint32_t cw_pair_hi(uint32_t a, uint32_t b) { return (a >> 16) | (b & 0xffff0000u); }  // odd channel
@@ -612,138 +612,169 @@ __device__ __forceinline__ uint4 cw_window(const uint4& lo, const uint4& hi) {
                     __builtin_amdgcn_alignbyte(d[o + 3], d[o + 2], 2), __builtin_amdgcn_alignbyte(d[o + 4], d[o + 3], 2));
 }
 
-template <int KT>
-__device__ __forceinline__ void cw_tap(ds2_f32x16 (&acc)[K2T], const uint4& a, const uint4& q0, const uint4& q1, const uint4& q2) {
-  constexpr int e = KT + 3;   // element offset of tap KT inside the three staged 8-element chunks
-  const uint4 b = e < 8 ? cw_window<e % 8>(q0, q1) : cw_window<e % 8>(q1, q2);
-  Mma<bf16_t>::mma32(acc[KT], a, b);
+// ------------------------------------------------------------------------------------------------------------
+// conv2 weight gradient, SEVERAL kernel rows per workgroup and the TAPS split over the waves.
+// Until round 2e (k_conv2_wgrad_bf16, in the history) every wave had all 11 taps of one kernel row (176 accumulator registers) and a
+// quarter of the positions: 22 MFMAs per wave between two barriers, and a work item was bound by what surrounds them (the
+// transposing stage, the barriers, the tap windows on the VALU): 0.96 ms, 19 % of the MFMA rate.  Here wave w owns the taps kt = w, w + 4, w + 8 of R kernel rows kf0, kf0 + 2, ... of
+// one parity -- they read the SAME input row fi = 2 j - 10 + kf0 against the output rows j, j - 1, ... -- and walks over all 128
+// positions of the tile: 3 R accumulator tiles per wave (no cross-wave reduction at the end), one staged input tile and one set of
+// tap windows per k-step for 3 R MFMAs.  Six row groups (R = 4) cover the 21 kernel rows: {0,2,4,6} {8,..,14} {16,18,20,-} {1,..,7}
+// {9,..,15} {17,19,-,-}.  Work item = (sample, j in [0, 40 + R - 1], 128-frame tile); an output or kernel row that does not exist
+// is staged as zeros (branch-free).
+// ------------------------------------------------------------------------------------------------------------
+// One tile: wave `wave` multiplies its taps kt = wave + 4 i (i = 0..2; wave 3's third tap does not exist: its products land
+// in an accumulator that is never written out) of the R kernel rows against all 8 k-steps.  The tap window of element offset
+// e = kt + 3 inside the 24 staged positions is dwords (e >> 1) .. +3 of q0|q1|q2, shifted by one element when e is odd: with
+// e = wave + 3 + 4 i the dword offset is (1 + 2 i) + ((wave + 1) >> 1) and the parity that of wave + 1 -- wave-uniform values, so
+// the windows are selections + v_alignbyte with a register shift and the code is the same for the four waves (a switch over
+// per-wave instantiations made hipcc keep several copies of the accumulators: spills).
+template <int R>
+__device__ __forceinline__ void cwr_multiply(ds2_f32x16 (&acc)[R][3], const uint16_t* sdy, const uint16_t* sx, int li, int lq, int wave) {
+  const int delta = (wave + 1) >> 1;
+  const uint32_t sh = (wave & 1) ? 0u : 2u;
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    const uint16_t* xb = sx + li * CWB_X_LD + (2 * ks + lq) * 8;
+    const uint4 q0 = *reinterpret_cast<const uint4*>(xb);
+    const uint4 q1 = *reinterpret_cast<const uint4*>(xb + 8);
+    const uint4 q2 = *reinterpret_cast<const uint4*>(xb + 16);
+    const uint32_t D[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+    uint4 w[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int b = 1 + 2 * i;
+      uint32_t X[5];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const uint32_t c2 = b + j + 2 < 12 ? D[b + j + 2] : 0u;      // only read for delta = 2, j = 4, i = 2: the non-existent tap
+        X[j] = delta == 0 ? D[b + j] : (delta == 1 ? D[b + j + 1] : c2);
+      }
+      w[i] = make_uint4(__builtin_amdgcn_alignbyte(X[1], X[0], sh), __builtin_amdgcn_alignbyte(X[2], X[1], sh),
+                        __builtin_amdgcn_alignbyte(X[3], X[2], sh), __builtin_amdgcn_alignbyte(X[4], X[3], sh));
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const uint4 a = *reinterpret_cast<const uint4*>(sdy + (r * CH + li) * CWB_DY_LD + 16 * ks + 8 * lq);
+      Mma<bf16_t>::mma32(acc[r][0], a, w[0]);
+      Mma<bf16_t>::mma32(acc[r][1], a, w[1]);
+      Mma<bf16_t>::mma32(acc[r][2], a, w[2]);
+    }
+  }
 }
 
-__global__ void __launch_bounds__(256, 1) k_conv2_wgrad_bf16(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ A1,
-                                                              float* __restrict__ partial, int N, int Tp) {
-  constexpr int TILE_BYTES = CH * (CWB_DY_LD + CWB_X_LD) * 2;   // 8704 + 9728
-  __shared__ __attribute__((aligned(16))) unsigned char smem[TILE_BYTES > 4 * 1024 * 4 ? TILE_BYTES : 4 * 1024 * 4];   // reused by the reduction
+constexpr int CWR_SPLITS = 85;     // 6 row groups x 85 = 510 workgroups: two rounds of 256 CUs
+
+template <int R>
+__global__ void __launch_bounds__(256, 1) k_conv2_wgrad_bf16r(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ A1,
+                                                               float* __restrict__ partial, int N, int Tp) {
+  // row group of this workgroup: kernel rows kf0 + 2 r, r < 4, that exist ({16,18,20} and {17,19} are short: their missing rows
+  // are staged as zeros and not written out)
+  const int kf0 = blockIdx.y < 3 ? 8 * blockIdx.y : 1 + 8 * (blockIdx.y - 3);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[CH * (R * CWB_DY_LD + CWB_X_LD) * 2];   // R dY^T tiles + one X tile
   uint16_t* sdy = reinterpret_cast<uint16_t*>(smem);
-  uint16_t* sx = sdy + CH * CWB_DY_LD;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint16_t* sx = sdy + R * CH * CWB_DY_LD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lq = lane >> 5;
-  const int kf = blockIdx.x, split = blockIdx.y;
-  ds2_f32x16 acc[K2T];
+  const int split = blockIdx.x;
+  ds2_f32x16 acc[R][3];
 #pragma unroll
-  for (int k = 0; k < K2T; ++k)
+  for (int r = 0; r < R; ++r)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
-
-  // rows (n, fo) whose input row fi = 2 fo - 10 + kf exists
-  const int fo_lo = kf >= 10 ? 0 : (10 - kf + 1) / 2;
-  const int fo_hi = min(F2 - 1, (F1 - 1 + 10 - kf) / 2);
-  const int nvalid = fo_hi - fo_lo + 1;
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[r][i][e] = 0.f;
   const int ntiles = (Tp + CW_TB - 1) / CW_TB;
-  const long nwork = (long)N * nvalid * ntiles;
-
-  // staging identity: dY item = (position pair tid % 64, channel group tid / 64); X items tid and tid + 256 (< 288)
+  constexpr int NJ = F2 + R - 1;             // j = 0 .. 40 + R - 1: kernel row r pairs with output row j - r
+  const long nwork = (long)N * NJ * ntiles;
+  auto decode = [&](long wk, int& n, int& j, int& t0) {
+    const int q = (int)(wk / ntiles);
+    t0 = (int)(wk % ntiles) * CW_TB;
+    n = q / NJ;
+    j = q % NJ;
+  };
+  auto next_live = [&](long wk) {            // skip the items whose input row does not exist
+    for (; wk < nwork; wk += gridDim.x) {
+      int n, j, t0;
+      decode(wk, n, j, t0);
+      const int fi = 2 * j - 10 + kf0;
+      if (fi >= 0 && fi < F1) break;
+    }
+    return wk;
+  };
+  // staging identity: dY item = (position pair tid % 64, channel group tid / 64); X items tid, tid + 256 (< 288)
   const int dy_pp = tid & 63, dy_v = tid >> 6;
-  const int x_pp0 = tid % 72, x_v0 = tid / 72;              // tid < 256 -> v0 in 0..3 (tid 216..255 -> v0 = 3)
+  const int x_pp0 = tid % 72, x_v0 = tid / 72;
   const int x_pp1 = (tid + 256) % 72, x_v1 = (tid + 256) / 72;
   const bool x_has1 = tid + 256 < 72 * 4;
-  // Prefetch ring: the tiles of the next CWB_DEPTH work items travel global -> registers while the current ones are multiplied.
-  // One item is only ~1.5k cycles of work (22 MFMAs per wave between two barriers), an L2 / HBM round trip is 2-4k: with a
-  // single item in flight (round 1) the kernel sat at 19 % of the MFMA rate waiting for its loads.
-  uint4 g[CWB_DEPTH][6];
-  uint32_t gm[CWB_DEPTH][6];   // masks (all ones / zero) for out-of-range positions
-
-  auto issue = [&](auto dc, long wk) {
-    constexpr int d = decltype(dc)::value;
-    const int r = (int)(wk / ntiles), t0 = (int)(wk % ntiles) * CW_TB;
-    const int n = r / nvalid, fo = fo_lo + r % nvalid, fi = 2 * fo - 10 + kf;
-    const bf16_t* dyrow = dY + ((long)n * F2 + fo) * Tp * CH;
+  uint4 g[2 * R + 4];
+  uint32_t gm[2 * R + 4];
+  auto issue = [&](long wk) {
+    int n, j, t0;
+    decode(wk, n, j, t0);
+    const int fi = 2 * j - 10 + kf0;
     const bf16_t* xrow = A1 + ((long)n * F1 + fi) * Tp * CH;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int t = t0 + 2 * dy_pp + h;
-      gm[d][h] = t < Tp ? 0xffffffffu : 0u;
-      g[d][h] = *reinterpret_cast<const uint4*>(dyrow + (long)min(t, Tp - 1) * CH + dy_v * 8);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int fo = j - r;
+        gm[2 * r + h] = (t < Tp && fo >= 0 && fo < F2 && kf0 + 2 * r < K2F) ? 0xffffffffu : 0u;
+        g[2 * r + h] = *reinterpret_cast<const uint4*>(dY + (((long)n * F2 + min(max(fo, 0), F2 - 1)) * Tp + min(t, Tp - 1)) * CH + dy_v * 8);
+      }
       const int tx = t0 - 8 + 2 * x_pp0 + h;
-      gm[d][2 + h] = (tx >= 0 && tx < Tp) ? 0xffffffffu : 0u;
-      g[d][2 + h] = *reinterpret_cast<const uint4*>(xrow + (long)min(max(tx, 0), Tp - 1) * CH + x_v0 * 8);
+      gm[2 * R + h] = (tx >= 0 && tx < Tp) ? 0xffffffffu : 0u;
+      g[2 * R + h] = *reinterpret_cast<const uint4*>(xrow + (long)min(max(tx, 0), Tp - 1) * CH + x_v0 * 8);
       const int ty = t0 - 8 + 2 * x_pp1 + h;
-      gm[d][4 + h] = (x_has1 && ty >= 0 && ty < Tp) ? 0xffffffffu : 0u;
-      g[d][4 + h] = *reinterpret_cast<const uint4*>(xrow + (long)min(max(ty, 0), Tp - 1) * CH + (x_has1 ? x_v1 : 0) * 8);
+      gm[2 * R + 2 + h] = (x_has1 && ty >= 0 && ty < Tp) ? 0xffffffffu : 0u;
+      g[2 * R + 2 + h] = *reinterpret_cast<const uint4*>(xrow + (long)min(max(ty, 0), Tp - 1) * CH + (x_has1 ? x_v1 : 0) * 8);
     }
   };
-  auto stage = [&](auto dc) {
-    constexpr int d = decltype(dc)::value;
+  auto put = [&](uint16_t* base, int ld, int v, int pp, const uint4& a, const uint4& b) {   // 8 channels x 2 positions, transposed
+    uint32_t* row = reinterpret_cast<uint32_t*>(base + (v * 8) * ld + 2 * pp);
+    const int L = ld / 2;
+    row[0 * L] = cw_pair_lo(a.x, b.x); row[1 * L] = cw_pair_hi(a.x, b.x);
+    row[2 * L] = cw_pair_lo(a.y, b.y); row[3 * L] = cw_pair_hi(a.y, b.y);
+    row[4 * L] = cw_pair_lo(a.z, b.z); row[5 * L] = cw_pair_hi(a.z, b.z);
+    row[6 * L] = cw_pair_lo(a.w, b.w); row[7 * L] = cw_pair_hi(a.w, b.w);
+  };
+  auto stage = [&]() {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      g[d][i].x &= gm[d][i]; g[d][i].y &= gm[d][i]; g[d][i].z &= gm[d][i]; g[d][i].w &= gm[d][i];
+    for (int i = 0; i < 2 * R + 4; ++i) {
+      g[i].x &= gm[i]; g[i].y &= gm[i]; g[i].z &= gm[i]; g[i].w &= gm[i];
     }
-    {
-      uint32_t* row = reinterpret_cast<uint32_t*>(sdy + (dy_v * 8) * CWB_DY_LD + 2 * dy_pp);
-      constexpr int LD = CWB_DY_LD / 2;
-      row[0 * LD] = cw_pair_lo(g[d][0].x, g[d][1].x); row[1 * LD] = cw_pair_hi(g[d][0].x, g[d][1].x);
-      row[2 * LD] = cw_pair_lo(g[d][0].y, g[d][1].y); row[3 * LD] = cw_pair_hi(g[d][0].y, g[d][1].y);
-      row[4 * LD] = cw_pair_lo(g[d][0].z, g[d][1].z); row[5 * LD] = cw_pair_hi(g[d][0].z, g[d][1].z);
-      row[6 * LD] = cw_pair_lo(g[d][0].w, g[d][1].w); row[7 * LD] = cw_pair_hi(g[d][0].w, g[d][1].w);
-    }
-    constexpr int LX = CWB_X_LD / 2;
-    {
-      uint32_t* row = reinterpret_cast<uint32_t*>(sx + (x_v0 * 8) * CWB_X_LD + 2 * x_pp0);
-      row[0 * LX] = cw_pair_lo(g[d][2].x, g[d][3].x); row[1 * LX] = cw_pair_hi(g[d][2].x, g[d][3].x);
-      row[2 * LX] = cw_pair_lo(g[d][2].y, g[d][3].y); row[3 * LX] = cw_pair_hi(g[d][2].y, g[d][3].y);
-      row[4 * LX] = cw_pair_lo(g[d][2].z, g[d][3].z); row[5 * LX] = cw_pair_hi(g[d][2].z, g[d][3].z);
-      row[6 * LX] = cw_pair_lo(g[d][2].w, g[d][3].w); row[7 * LX] = cw_pair_hi(g[d][2].w, g[d][3].w);
-    }
-    if (x_has1) {
-      uint32_t* row = reinterpret_cast<uint32_t*>(sx + (x_v1 * 8) * CWB_X_LD + 2 * x_pp1);
-      row[0 * LX] = cw_pair_lo(g[d][4].x, g[d][5].x); row[1 * LX] = cw_pair_hi(g[d][4].x, g[d][5].x);
-      row[2 * LX] = cw_pair_lo(g[d][4].y, g[d][5].y); row[3 * LX] = cw_pair_hi(g[d][4].y, g[d][5].y);
-      row[4 * LX] = cw_pair_lo(g[d][4].z, g[d][5].z); row[5 * LX] = cw_pair_hi(g[d][4].z, g[d][5].z);
-      row[6 * LX] = cw_pair_lo(g[d][4].w, g[d][5].w); row[7 * LX] = cw_pair_hi(g[d][4].w, g[d][5].w);
-    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) put(sdy + r * CH * CWB_DY_LD, CWB_DY_LD, dy_v, dy_pp, g[2 * r], g[2 * r + 1]);
+    put(sx, CWB_X_LD, x_v0, x_pp0, g[2 * R], g[2 * R + 1]);
+    if (x_has1) put(sx, CWB_X_LD, x_v1, x_pp1, g[2 * R + 2], g[2 * R + 3]);
   };
 
-  const long stride = gridDim.y;
-  auto multiply = [&]() {
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int ks = wave + 4 * kk;
-      const uint4 a = *reinterpret_cast<const uint4*>(sdy + li * CWB_DY_LD + 16 * ks + 8 * lq);
-      const uint16_t* xb = sx + li * CWB_X_LD + (2 * ks + lq) * 8;
-      const uint4 q0 = *reinterpret_cast<const uint4*>(xb);
-      const uint4 q1 = *reinterpret_cast<const uint4*>(xb + 8);
-      const uint4 q2 = *reinterpret_cast<const uint4*>(xb + 16);
-      cw_tap<0>(acc, a, q0, q1, q2); cw_tap<1>(acc, a, q0, q1, q2); cw_tap<2>(acc, a, q0, q1, q2);
-      cw_tap<3>(acc, a, q0, q1, q2); cw_tap<4>(acc, a, q0, q1, q2); cw_tap<5>(acc, a, q0, q1, q2);
-      cw_tap<6>(acc, a, q0, q1, q2); cw_tap<7>(acc, a, q0, q1, q2); cw_tap<8>(acc, a, q0, q1, q2);
-      cw_tap<9>(acc, a, q0, q1, q2); cw_tap<10>(acc, a, q0, q1, q2);
-    }
-  };
-  auto step = [&](auto dc, long w) {
-    if (w >= nwork) return;
+  long wk = next_live(split);
+  if (wk < nwork) issue(wk);
+  while (wk < nwork) {
     __syncthreads();            // previous tile's fragment reads are done
-    stage(dc);
+    stage();
     __syncthreads();
-    if (w + CWB_DEPTH * stride < nwork) issue(dc, w + CWB_DEPTH * stride);   // in flight during the next CWB_DEPTH items' MFMAs
-    multiply();
-  };
-  static_assert(CWB_DEPTH == 3, "the ring below is written out for three buffers");
-  if (split < nwork) issue(std::integral_constant<int, 0>{}, split);
-  if (split + stride < nwork) issue(std::integral_constant<int, 1>{}, split + stride);
-  if (split + 2 * stride < nwork) issue(std::integral_constant<int, 2>{}, split + 2 * stride);
-  for (long wk = split; wk < nwork; wk += CWB_DEPTH * stride) {
-    step(std::integral_constant<int, 0>{}, wk);
-    step(std::integral_constant<int, 1>{}, wk + stride);
-    step(std::integral_constant<int, 2>{}, wk + 2 * stride);
+    const long nxt = next_live(wk + gridDim.x);
+    if (nxt < nwork) issue(nxt);   // in flight during the MFMAs below
+    cwr_multiply<R>(acc, sdy, sx, li, lq, wave);
+    wk = nxt;
   }
-  float* red = reinterpret_cast<float*>(smem);
-  float* out = partial + ((long)split * (K2F * K2T) + (long)kf * K2T) * (CH * CH);
-  for (int kt = 0; kt < K2T; ++kt) {
-    __syncthreads();
+  // every wave owns its taps: straight to partial[split][kf][kt][co][ci]
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[wave * 1024 + mma32_row(r, lane) * 32 + li] = acc[kt][r];
-    __syncthreads();
-    for (int e = tid; e < 1024; e += 256) out[(long)kt * 1024 + e] = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
-  }
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int kt = wave + 4 * i;
+      if (kt < K2T && kf0 + 2 * r < K2F) {
+        float* out = partial + (((long)split * K2F + (kf0 + 2 * r)) * K2T + kt) * (CH * CH);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) out[mma32_row(e, lane) * 32 + li] = acc[r][i][e];
+      }
+    }
 }
 
 // ============================================================================================================
@@ -1058,19 +1089,22 @@ int ds2_conv2_dgrad(int dtype, const void* dy2, const void* w2d_even, const void
 long ds2_conv2_wgrad_ws_floats(int N, int Tp) {
   (void)N; (void)Tp;
   const long C = (long)K2F * K2T * CH * CH;
-  return (long)CW_SPLITS * C + (long)ds2_norm_partials(CW_SPLITS) * C;
+  static_assert(CWR_SPLITS >= CW_SPLITS, "sized for the larger split count of the two kernels");
+  return (long)CWR_SPLITS * C + (long)ds2_norm_partials(CWR_SPLITS) * C;
 }
 int ds2_conv2_wgrad(int dtype, const void* dy2, const void* a1, float* dw2t, int N, int Tp, float* ws, ds2_stream_t st_) {
   hipStream_t st = (hipStream_t)st_;
   DS2_REQUIRE(dtype == DS2_F32 || dtype == DS2_BF16, DS2_ERR_DTYPE);
   dim3 grid(K2F, CW_SPLITS);
-  if (dtype == DS2_F32)
+  if (dtype == DS2_F32) {
     hipLaunchKernelGGL(k_conv2_wgrad<float>, grid, dim3(256), 0, st, (const float*)dy2, (const float*)a1, ws, N, Tp);
-  else
-    hipLaunchKernelGGL(k_conv2_wgrad_bf16, grid, dim3(256), 0, st, (const bf16_t*)dy2, (const bf16_t*)a1, ws, N, Tp);
+  } else {
+    hipLaunchKernelGGL(k_conv2_wgrad_bf16r<4>, dim3(CWR_SPLITS, 6), dim3(256), 0, st, (const bf16_t*)dy2, (const bf16_t*)a1, ws, N, Tp);
+  }
   DS2_CHECK_LAUNCH();
   const int C = K2F * K2T * CH * CH;
-  return ds2_colsum(DS2_F32, ws, CW_SPLITS, C, C, dw2t, 1.0f, ws + (long)CW_SPLITS * C, st_);
+  const int splits = dtype == DS2_F32 ? CW_SPLITS : CWR_SPLITS;
+  return ds2_colsum(DS2_F32, ws, splits, C, C, dw2t, 1.0f, ws + (long)splits * C, st_);
 }
 
 }  // extern "C"
