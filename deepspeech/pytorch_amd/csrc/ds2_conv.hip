@@ -643,8 +643,6 @@ __device__ __forceinline__ void cwr_multiply(ds2_f32x16 (&acc)[R][3], const uint
     uint4 w[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      constexpr int dummy = 0;
-      (void)dummy;
       const int b = 1 + 2 * i;
       uint32_t X[5];
 #pragma unroll
