@@ -47,7 +47,7 @@ const char* ds2_error_string(int code);
 
 /* ---- dense contraction (MFMA): C[M][ldc] = A[M][lda] * B[N][ldb]^T (+ bias[N]) -------------------------------------
  * Replaces the GEMMs inside torch's GRU/LSTM input projection (model.py:97-99), nn.Linear of the head (model.py:197)
- * and their autograd backward.  out_f32 != 0 -> C is float regardless of dtype.  splitk > 1: C must be zeroed, f32. */
+ * and their autograd backward.  out_f32 != 0 -> C is float regardless of dtype.  splitk > 1: C is f32 and is zeroed by the call (memset nodes on `stream`). */
 int ds2_gemm_nt(int dtype, const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long lda, long ldb,
                 long ldc, int out_f32, int batch, long strideA, long strideB, long strideC, long strideBias, int splitk,
                 ds2_stream_t stream);
@@ -116,11 +116,12 @@ int ds2_rnn_bwd(int dtype, int cell, int D, int N, int H, int Tp, const int* len
                 const void* Hseq, long hseq_dstride, const void* S, void* dGI, void* dGH, void* state, ds2_stream_t stream);
 
 /* Persistent variant (csrc/ds2_rnn_persist.hip): one launch per sweep, all time steps inside the kernel, W_hh resident in
- * registers, h exchanged between the workgroups of a group through tagged 8-byte granules; same buffer contract as
+ * registers, h exchanged between the workgroups of a group through a polled exchange buffer inside ws (pure payload in four
+ * slots with an all-ones "not published yet" dword, or tagged 8-byte granules: csrc/ds2_rnn_persist_impl.h); same buffer contract as
  * ds2_rnn_fwd / ds2_rnn_bwd.  Covered (ds2_rnn_persist_supported): bf16 with H = 1024 (any cell, <= 16 samples per group of an
  * 8-group chip: BASELINE config 3), and GRU / LSTM with bf16 H in {800, 1280} or fp32 H in {800, 1024} (configs 2 and 5, the
  * 1e-3 parity mode; up to 64 samples per group for bf16 H = 1280, 16 otherwise); everything else runs ds2_rnn_fwd / _bwd.
- * ws: ds2_rnn_persist_ws_bytes() bytes of scratch; err: one device int that the kernel sets to 1 if a workgroup gave up
+ * ws: ds2_rnn_persist_ws_bytes() bytes of scratch (reset by every call on `stream`); err: one device int that the kernel sets to 1 if a workgroup gave up
  * waiting for its peers (its outputs are then NaN). */
 int ds2_rnn_persist_supported(int dtype, int cell, int D, int N, int H);
 long ds2_rnn_persist_ws_bytes(int dtype, int cell, int D, int N, int H);
