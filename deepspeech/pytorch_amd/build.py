@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libds2hip.so")
-SOURCES = ["ds2_norm.hip", "ds2_gemm.hip", "ds2_rnn.hip", "ds2_rnn_persist.hip", "ds2_rnn_persist_gru.hip", "ds2_rnn_persist_lstm.hip",
+SOURCES = ["ds2_norm.hip", "ds2_gemm.hip", "ds2_gemm8.hip", "ds2_rnn.hip", "ds2_rnn_persist.hip", "ds2_rnn_persist_gru.hip", "ds2_rnn_persist_lstm.hip",
            "ds2_rnn_persist_rnn.hip", "ds2_rnn_persist2_bf16_800.hip", "ds2_rnn_persist2_bf16_1280.hip", "ds2_rnn_persist2_f32_800.hip",
            "ds2_rnn_persist2_f32_1024.hip", "ds2_conv.hip", "ds2_ctc.hip", "ds2_seqops.hip", "ds2_decode.hip", "ds2_optim.hip", "ds2_spect.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -8,7 +8,7 @@
 // log_softmax backward  dlogit = g - softmax * sum_c g.  Infeasible samples (ll = -inf): loss 0, gradient 0.
 //
 // Four launches on the caller's stream, split by what bounds each stage:
-//   k_ctc_logsoftmax  one thread per frame; bytes: logits once -> log-prob scratch [N][Tp][32].
+//   k_ctc_logsoftmax  one thread per frame; bytes: logits once -> log-prob scratch [N][Tp][CP] (CP = 32 for <= 32 classes).
 //   k_ctc_recursion   grid (N, 2): the alpha and the beta recursion of a sample are independent workgroups of 4 waves.  T'
 //                     dependent steps, pure latency: the step is branch-free (operand addresses and transition masks are
 //                     fixed per thread before the loop), the frames' log-probs are staged in LDS a chunk ahead, and the
@@ -23,7 +23,8 @@
 namespace {
 
 constexpr int REC_THREADS = 256;  // one recursion: <= 4 states per thread (fast path) for targets up to 511 labels
-constexpr int CP = 32;            // padded class stride of the log-prob scratch
+// CP (template parameter of the kernels below): padded class stride of the log-prob scratch -- 32, 64, 128 or 256, the smallest
+// that holds the model's classes (the reference takes any labels file, model.py:154-155; the English set has 29)
 constexpr int LP_CHUNK = 8;       // recursion steps whose log-prob rows are staged in LDS together
 constexpr int NS_FAST = 4;        // extended-label states per thread the branch-free recursion keeps in registers
 constexpr int GRAD_WAVES = 4;     // waves (= frames in flight) per workgroup of the gradient pass
@@ -42,6 +43,7 @@ __device__ __forceinline__ float lse3(float a, float b, float c) {
   return ms + __logf(__expf(a - ms) + __expf(b - ms) + __expf(c - ms));
 }
 
+template <int CP>
 __global__ void __launch_bounds__(256) k_ctc_logsoftmax(const float* __restrict__ logits, long ldl,
                                                         const int* __restrict__ in_len, int Tp, int N, int C,
                                                         float* __restrict__ ws_lp) {
@@ -50,25 +52,35 @@ __global__ void __launch_bounds__(256) k_ctc_logsoftmax(const float* __restrict_
   const int t = (int)(i / N), n = (int)(i % N);
   if (t >= in_len[n]) return;
   const float* x = logits + i * ldl;
-  float v[CP];
-  float m = -INFINITY;
-#pragma unroll
-  for (int c = 0; c < CP; ++c) {
-    v[c] = x[c < C ? c : 0];
-    if (c < C) m = fmaxf(m, v[c]);
-  }
-  float sum = 0.f;
-#pragma unroll
-  for (int c = 0; c < CP; ++c)
-    if (c < C) sum += expf(v[c] - m);
-  const float lz = m + logf(sum);
   float* lp = ws_lp + ((long)n * Tp + t) * CP;
+  if constexpr (CP == 32) {
+    float v[CP];
+    float m = -INFINITY;
 #pragma unroll
-  for (int c = 0; c < CP; ++c)
-    if (c < C) lp[c] = v[c] - lz;
+    for (int c = 0; c < CP; ++c) {
+      v[c] = x[c < C ? c : 0];
+      if (c < C) m = fmaxf(m, v[c]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < CP; ++c)
+      if (c < C) sum += expf(v[c] - m);
+    const float lz = m + logf(sum);
+#pragma unroll
+    for (int c = 0; c < CP; ++c)
+      if (c < C) lp[c] = v[c] - lz;
+  } else {                                             // larger label sets: three passes over the row (L1 / L2 resident)
+    float m = -INFINITY;
+    for (int c = 0; c < C; ++c) m = fmaxf(m, x[c]);
+    float sum = 0.f;
+    for (int c = 0; c < C; ++c) sum += expf(x[c] - m);
+    const float lz = m + logf(sum);
+    for (int c = 0; c < C; ++c) lp[c] = x[c] - lz;
+  }
 }
 
 // blockIdx.x = sample, blockIdx.y = 0: alpha (t = 0 .. Ti-1), 1: beta (t = Ti-1 .. 0)
+template <int CP>
 __global__ void __launch_bounds__(REC_THREADS) k_ctc_recursion(const int* __restrict__ targets, const int* __restrict__ toff,
                                                                const int* __restrict__ in_len, const int* __restrict__ tg_len,
                                                                int Tp, int blank, int Lmax, float* __restrict__ nll_out,
@@ -97,9 +109,11 @@ __global__ void __launch_bounds__(REC_THREADS) k_ctc_recursion(const int* __rest
   const float* lp = ws_lp + (long)n * Tp * CP;                               // [Tp][CP] of this sample
   float* dst = (is_beta ? ws_beta : ws_alpha) + (long)n * Tp * Lmax;         // [Tp][Lmax]
   for (int s = tid; s < L; s += REC_THREADS) ext[s] = (s & 1) ? tg[s >> 1] : blank;
-  static_assert(REC_THREADS == LP_CHUNK * CP, "one prefetch element per thread");
-  const int prow = tid / CP, pcol = tid % CP;        // element of a chunk this thread stages
-  {
+  constexpr int PE = LP_CHUNK * CP / REC_THREADS;    // elements of a chunk [LP_CHUNK][CP] each thread stages (1 for CP = 32)
+  static_assert(PE * REC_THREADS == LP_CHUNK * CP, "whole prefetch elements per thread");
+#pragma unroll
+  for (int j = 0; j < PE; ++j) {
+    const int e = tid + j * REC_THREADS, prow = e / CP, pcol = e % CP;
     const int i = prow < Ti ? prow : Ti - 1;
     lpl[prow * CP + pcol] = lp[(long)(is_beta ? Ti - 1 - i : i) * CP + pcol];
   }
@@ -142,9 +156,14 @@ __global__ void __launch_bounds__(REC_THREADS) k_ctc_recursion(const int* __rest
   float* cur = row1;
   for (int i0 = 0; i0 < Ti; i0 += LP_CHUNK) {
     const float* lpc = lpl + ((i0 / LP_CHUNK) & 1) * LP_CHUNK * CP;
-    int pi = i0 + LP_CHUNK + prow;                   // step whose row goes into the other chunk buffer
-    if (pi > Ti - 1) pi = Ti - 1;
-    const float nxt = lp[(long)(is_beta ? Ti - 1 - pi : pi) * CP + pcol];
+    float nxt[PE];                                   // the rows of the steps that go into the other chunk buffer
+#pragma unroll
+    for (int j = 0; j < PE; ++j) {
+      const int e = tid + j * REC_THREADS;
+      int pi = i0 + LP_CHUNK + e / CP;
+      if (pi > Ti - 1) pi = Ti - 1;
+      nxt[j] = lp[(long)(is_beta ? Ti - 1 - pi : pi) * CP + e % CP];
+    }
     const int kend = Ti - i0 < LP_CHUNK ? Ti - i0 : LP_CHUNK;
     for (int k = 0; k < kend; ++k) {
       const int i = i0 + k;
@@ -196,7 +215,8 @@ __global__ void __launch_bounds__(REC_THREADS) k_ctc_recursion(const int* __rest
       prev = cur;
       cur = tmp;
     }
-    lpl[(((i0 / LP_CHUNK) + 1) & 1) * LP_CHUNK * CP + prow * CP + pcol] = nxt;
+#pragma unroll
+    for (int j = 0; j < PE; ++j) lpl[(((i0 / LP_CHUNK) + 1) & 1) * LP_CHUNK * CP + tid + j * REC_THREADS] = nxt[j];
     lds_barrier();
   }
   if (!is_beta && tid == 0) {
@@ -215,6 +235,7 @@ __global__ void __launch_bounds__(REC_THREADS) k_ctc_recursion(const int* __rest
 
 // grid (ceil(Tp / GRAD_FRAMES), N); one wave per frame.  Writes EVERY row of dlogits of its frames (zeros past the
 // sample's length and for infeasible samples).
+template <int CP>
 __global__ void __launch_bounds__(GRAD_WAVES * 64) k_ctc_gradient(const int* __restrict__ targets, const int* __restrict__ toff,
                                                                   const int* __restrict__ in_len,
                                                                   const int* __restrict__ tg_len, int Tp, int N, int C,
@@ -238,13 +259,13 @@ __global__ void __launch_bounds__(GRAD_WAVES * 64) k_ctc_gradient(const int* __r
   for (int t = blockIdx.x * GRAD_FRAMES + wave; t < t_end; t += GRAD_WAVES) {
     float* dl = dlogits + ((long)t * N + n) * ldg;
     if (!live || t >= Ti) {                          // wave-uniform
-      if (lane < ldg) dl[lane] = 0.f;
+      for (int c = lane; c < ldg; c += 64) dl[c] = 0.f;
       continue;
     }
     const float* lpt = ws_lp + ((long)n * Tp + t) * CP;
     const float* al = ws_alpha + ((long)n * Tp + t) * Lmax;
     const float* be = ws_beta + ((long)n * Tp + t) * Lmax;
-    if (lane < CP) wacc[lane] = 0.f;
+    for (int c = lane; c < CP; c += 64) wacc[c] = 0.f;
     __builtin_amdgcn_wave_barrier();
     float blank_part = 0.f;
     for (int s = lane; s < L; s += 64) {
@@ -256,18 +277,30 @@ __global__ void __launch_bounds__(GRAD_WAVES * 64) k_ctc_gradient(const int* __r
     }
     blank_part = wave_sum(blank_part);
     __builtin_amdgcn_wave_barrier();
-    float g = 0.f, y = 0.f;
-    if (lane < C) {
-      float a = wacc[lane];
-      if (lane == blank) a += blank_part;
-      y = expf(lpt[lane]);
-      g = a > 0.f ? -a / y : 0.f;
+    constexpr int CL = (CP + 63) / 64;                 // classes per lane
+    float g[CL], y[CL], gpart = 0.f;
+#pragma unroll
+    for (int j = 0; j < CL; ++j) {
+      const int c = lane + 64 * j;
+      g[j] = y[j] = 0.f;
+      if (c < C) {
+        float a = wacc[c];
+        if (c == blank) a += blank_part;
+        y[j] = expf(lpt[c]);
+        g[j] = a > 0.f ? -a / y[j] : 0.f;
+      }
+      gpart += g[j];
     }
-    const float gs = wave_sum(g);
-    if (lane < C)
-      dl[lane] = (g - y * gs) * grad_scale;
-    else if (lane < ldg)
-      dl[lane] = 0.f;
+    const float gs = wave_sum(gpart);
+#pragma unroll
+    for (int j = 0; j < CL; ++j) {
+      const int c = lane + 64 * j;
+      if (c < C)
+        dl[c] = (g[j] - y[j] * gs) * grad_scale;
+      else if (c < ldg)
+        dl[c] = 0.f;
+    }
+    for (int c = lane + 64 * CL; c < ldg; c += 64) dl[c] = 0.f;
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -283,43 +316,53 @@ __global__ void k_sum_small(const float* __restrict__ v, int n, float* __restric
 
 extern "C" {
 
+static int ctc_class_stride(int C) { return C <= 32 ? 32 : C <= 64 ? 64 : C <= 128 ? 128 : 256; }
+
 long ds2_ctc_ws_floats(int Tp, int N, int C, int max_target_len) {
-  (void)C;
   const long Lmax = 2L * max_target_len + 1;
-  return (long)N * Tp * CP + 2L * N * Tp * Lmax + N;
+  return (long)N * Tp * ctc_class_stride(C) + 2L * N * Tp * Lmax + N;
 }
 
 int ds2_ctc_loss_grad(const float* logits, long ldl, const int* targets, const int* target_offsets, const int* input_lengths,
                       const int* target_lengths, int Tp, int N, int C, int blank, int max_target_len, float grad_scale,
                       float* nll, float* loss_sum, float* dlogits, long ldg, float* ws, ds2_stream_t st_) {
   hipStream_t st = (hipStream_t)st_;
-  DS2_REQUIRE(Tp > 0 && N > 0 && C > 0 && C <= CP && blank >= 0 && blank < C && max_target_len >= 0, DS2_ERR_ARG);
-  DS2_REQUIRE(ldg >= C && ldg <= 64 && ldl >= C, DS2_ERR_ARG);
+  DS2_REQUIRE(Tp > 0 && N > 0 && C > 0 && C <= 256 && blank >= 0 && blank < C && max_target_len >= 0, DS2_ERR_ARG);
+  DS2_REQUIRE(ldg >= C && ldl >= C, DS2_ERR_ARG);
+  const int CP = ctc_class_stride(C);
   const int Lmax = 2 * max_target_len + 1;
   const size_t shm = (size_t)Lmax * 12 + 2 * LP_CHUNK * CP * 4;
   DS2_REQUIRE(shm <= 160 * 1024, DS2_ERR_ARG);
-  static size_t attr[DS2_MAX_DEVICES];           // per device: the attribute belongs to the device's copy of the kernel
   int dev = 0;
   (void)hipGetDevice(&dev);
   dev = dev >= 0 && dev < DS2_MAX_DEVICES ? dev : 0;
-  if (attr[dev] < shm) {
-    (void)hipFuncSetAttribute((const void*)k_ctc_recursion, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    attr[dev] = shm;
-  }
   float* ws_lp = ws;
   float* ws_alpha = ws + (long)N * Tp * CP;
   float* ws_beta = ws_alpha + (long)N * Tp * Lmax;
   float* ws_ll = ws_beta + (long)N * Tp * Lmax;
-  hipLaunchKernelGGL(k_ctc_logsoftmax, dim3(ds2_cdiv((long)Tp * N, 256)), dim3(256), 0, st, logits, ldl, input_lengths, Tp, N,
-                     C, ws_lp);
-  DS2_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_ctc_recursion, dim3(N, 2), dim3(REC_THREADS), shm, st, targets, target_offsets, input_lengths,
-                     target_lengths, Tp, blank, Lmax, nll, ws_lp, ws_alpha, ws_beta, ws_ll);
-  DS2_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_ctc_gradient, dim3(ds2_cdiv(Tp, GRAD_FRAMES), N), dim3(GRAD_WAVES * 64), 0, st, targets, target_offsets,
-                     input_lengths, target_lengths, Tp, N, C, blank, Lmax, grad_scale, dlogits, ldg, ws_lp, ws_alpha, ws_beta,
-                     ws_ll);
-  DS2_CHECK_LAUNCH();
+#define DS2_CTC_LAUNCH(CPT, SLOT)                                                                                                   \
+  {                                                                                                                                 \
+    static size_t attr[DS2_MAX_DEVICES]; /* per device: the attribute belongs to the device's copy of the kernel */                 \
+    if (attr[dev] < shm) {                                                                                                          \
+      (void)hipFuncSetAttribute((const void*)k_ctc_recursion<CPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);           \
+      attr[dev] = shm;                                                                                                              \
+    }                                                                                                                               \
+    hipLaunchKernelGGL(k_ctc_logsoftmax<CPT>, dim3(ds2_cdiv((long)Tp * N, 256)), dim3(256), 0, st, logits, ldl, input_lengths, Tp, \
+                       N, C, ws_lp);                                                                                                \
+    DS2_CHECK_LAUNCH();                                                                                                             \
+    hipLaunchKernelGGL(k_ctc_recursion<CPT>, dim3(N, 2), dim3(REC_THREADS), shm, st, targets, target_offsets, input_lengths,        \
+                       target_lengths, Tp, blank, Lmax, nll, ws_lp, ws_alpha, ws_beta, ws_ll);                                      \
+    DS2_CHECK_LAUNCH();                                                                                                             \
+    hipLaunchKernelGGL(k_ctc_gradient<CPT>, dim3(ds2_cdiv(Tp, GRAD_FRAMES), N), dim3(GRAD_WAVES * 64), 0, st, targets,              \
+                       target_offsets, input_lengths, target_lengths, Tp, N, C, blank, Lmax, grad_scale, dlogits, ldg, ws_lp,       \
+                       ws_alpha, ws_beta, ws_ll);                                                                                   \
+    DS2_CHECK_LAUNCH();                                                                                                             \
+  }
+  if (CP == 32) DS2_CTC_LAUNCH(32, 0)
+  else if (CP == 64) DS2_CTC_LAUNCH(64, 1)
+  else if (CP == 128) DS2_CTC_LAUNCH(128, 2)
+  else DS2_CTC_LAUNCH(256, 3)
+#undef DS2_CTC_LAUNCH
   hipLaunchKernelGGL(k_sum_small, dim3(1), dim3(64), 0, st, nll, N, loss_sum);
   DS2_CHECK_LAUNCH();
   return 0;

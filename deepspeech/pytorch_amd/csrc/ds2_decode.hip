@@ -3,7 +3,7 @@
 // collapse of repeats and the removal of blanks.  The reference moves the full (N, T', C) probability tensor to the host and
 // walks it with one .item() per frame; here only the surviving labels and their frame offsets travel.
 //
-// One wave per sample; frames in chunks of 64 (one per lane): arg-max over the C <= 64 classes of the lane's frame (first
+// One wave per sample; frames in chunks of 64 (one per lane): arg-max over the C classes of the lane's frame (first
 // maximum wins, like torch.max), keep = label != blank && (t == 0 || label != label of frame t-1) && t < size, compaction by
 // ballot + popcount prefix.  HBM-bound: reads N*T'*C floats once (the rows are 116-256 bytes, each lane streams its own row).
 #include "ds2_common.h"
@@ -61,7 +61,7 @@ extern "C" {
 int ds2_greedy_decode(const float* x, long stride_n, long stride_t, int N, int T, int C, const int* sizes, int blank,
                       int* tokens, int* offsets, int* counts, ds2_stream_t st_) {
   hipStream_t st = (hipStream_t)st_;
-  DS2_REQUIRE(N > 0 && T > 0 && C > 0 && C <= 64 && blank >= 0 && blank < C, DS2_ERR_ARG);
+  DS2_REQUIRE(N > 0 && T > 0 && C > 0 && blank >= 0 && blank < C, DS2_ERR_ARG);
   DS2_REQUIRE(x && tokens && offsets && counts, DS2_ERR_ARG);
   hipLaunchKernelGGL(k_greedy_decode, dim3(N), dim3(64), 0, st, x, stride_n, stride_t, T, C, sizes, blank, tokens, offsets, counts);
   DS2_CHECK_LAUNCH();

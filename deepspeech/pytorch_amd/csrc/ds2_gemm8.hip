@@ -1,0 +1,439 @@
+// 256x256 bf16 GEMM with a phase-split, role-alternating schedule (the large dense contractions of the step):
+//   NT:  C[M][N] = sum_k A[m][k] * B[n][k] (+ bias[n])      both operands K-contiguous   (input projections, dX;  model.py:97-99)
+//   TN:  C[M][N] = sum_k At[k][m] * Bt[k][n]                both operands K-major        (weight gradients: contraction over the
+//        T'*N rows of dGI / X / h -- no operand transposes; grouped: several products per launch)
+//
+// Geometry: 512 threads = 8 waves as 2 (M) x 4 (N); a wave owns 128 x 64 of the tile = 4 x 2 accumulators of
+// v_mfma_f32_32x32x16_bf16 (128 registers).  K-tile 64.  LDS: two K-tile buffers of 64 KiB (A 32 KiB | B 32 KiB), filled by
+// global_load_lds_dwordx4 (lane-linear destination; the bank-conflict XOR lives in the per-lane SOURCE address and in the
+// fragment read address -- both or neither).
+//
+// Schedule (one K-tile = four phases, one quadrant 64 x 32 of the wave's tile each = 8 MFMAs = 256 matrix-pipe cycles):
+//   phase 0   read A(m-half 0) [8 x ds_read_b128] + B(n-half 0) [4]     | MFMA (0,0)
+//   phase 1   read B(n-half 1) [4]                                      | MFMA (0,1)      B is dead in LDS after this phase
+//   phase 2   read A(m-half 1) [8];  DMA B of K-tile t+2 [4 x 1 KiB]    | MFMA (1,1)      A is dead in LDS after this phase
+//   phase 3   DMA A of K-tile t+2 [4];  s_waitcnt vmcnt(8)              | MFMA (1,0)      (B(n-half 0) kept in registers)
+// Every phase is  { loads ; s_barrier ; MFMAs ; s_barrier }.  The waves of M-half 1 (waves 4-7: the SIMD partners of waves 0-3)
+// run ONE barrier behind, so between two consecutive barriers one wave of every SIMD is in its MFMA section while its partner
+// issues LDS reads / DMA: the matrix pipe of a SIMD is fed by one wave at a time, back to back.
+// Hazards, by counters and barriers only (never by timing):
+//   RAW  a wave waits for ITS OWN DMA pieces (vmcnt(8) in phase 3 leaves exactly the 8 pieces of K-tile t+2 in flight, so K-tile
+//        t+1 has landed); both barriers of phase 3 lie between every wave's wait and the first read of K-tile t+1.
+//   WAR  the reads of phases 1 / 2 are retired (lgkmcnt(0)) BEFORE the phase's first barrier; the DMA that overwrites B / A is
+//        issued one phase later, i.e. behind a barrier that every wave -- of either half -- reaches only after that wait.
+// Requirements: K % 64 == 0, 16-byte aligned rows, operands < 2^31 elements; edge tiles clamp their source rows.
+#include "ds2_common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+constexpr int G8_MAX_GROUPS = 6;
+
+struct G8Problem {
+  const bf16_t* A;    // NT: [M][lda]   TN: [K][lda] (m contiguous)
+  const bf16_t* A2;   // TN only: rows (of C) >= m_split read their A columns from A2 (column index m - m_split, row stride lda2); null = none
+  const bf16_t* B;    // NT: [N][ldb]   TN: [K][ldb]
+  void* C;
+  const float* bias;
+  int M, N, m_split;
+  long lda, lda2, ldb, ldc;   // lda2: leading dimension of A2
+  int tiles_n, tile_end;   // tiles of this problem are [previous tile_end, tile_end)
+  int out_is_f32;
+};
+struct G8Args {
+  G8Problem p[G8_MAX_GROUPS];
+  int n_problems, K;
+};
+
+#define G8_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define G8_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define G8_BARRIER()                        \
+  do {                                      \
+    __builtin_amdgcn_sched_barrier(0);      \
+    __builtin_amdgcn_s_barrier();           \
+    __builtin_amdgcn_sched_barrier(0);      \
+  } while (0)
+
+template <bool TN>
+__global__ void __launch_bounds__(512, 2) k_gemm8(G8Args g) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[131072];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  // ---- which problem, which tile (XCD-aware: consecutive ids of one XCD work on neighbouring tiles)
+  int id = blockIdx.x;
+  {
+    const int nblk = gridDim.x, q = nblk / 8, r = nblk % 8, xcd = id % 8, k = id / 8;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  int pi = 0, first = 0;
+#pragma unroll
+  for (int i = 0; i < G8_MAX_GROUPS - 1; ++i)
+    if (i + 1 < g.n_problems && id >= g.p[i].tile_end) {
+      pi = i + 1;
+      first = g.p[i].tile_end;
+    }
+  const G8Problem& P = g.p[pi];
+  const int t_id = id - first;
+  const int m0 = (t_id / P.tiles_n) * 256, n0 = (t_id % P.tiles_n) * 256;
+  const int nkt = (g.K + 63) / 64;                      // NT: K % 64 == 0 (host check); TN: a ragged last K-tile is zero-filled in LDS
+  const int krem = g.K - (nkt - 1) * 64;                // valid k-rows of the last K-tile (1..64)
+  const bool tail = TN && krem < 64;
+
+  ds2_f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- DMA identity.  One instruction of the whole workgroup moves 8 KiB; wave w owns the 1 KiB piece w of it.
+  //  NT: piece = 8 tile rows x 128 B (64 k): lane -> row (lane >> 3), 16-byte slot (lane & 7); the slot holds source chunk
+  //      slot ^ ((row >> 1) & 7).                                     4 instructions = the 256 rows of an operand tile.
+  //  TN: LDS rows are k (64 per tile), 512 B = 256 m each: piece = 2 k-rows: lane -> k-row (lane >> 5), slot (lane & 31); the
+  //      slot holds source chunk slot ^ ((k & 3) << 2) (a 64-byte rotation: the four k-rows of a transposing read then sit in
+  //      four different bank quarters).                               4 instructions = the 64 k-rows of an operand tile.
+  uint32_t a_off[4], b_off[4];                 // BYTE offsets from the (wave-uniform) operand base: saddr + 32-bit voffset addressing
+  const bf16_t* a_base = P.A;
+  const bf16_t* b_base = P.B;
+  if constexpr (!TN) {
+    const int rloc = wave * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((rloc >> 1) & 7);
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      a_off[rb] = (uint32_t)(((long)min(m0 + rb * 64 + rloc, P.M - 1) * P.lda + chunk * 8) * 2);
+      b_off[rb] = (uint32_t)(((long)min(n0 + rb * 64 + rloc, P.N - 1) * P.ldb + chunk * 8) * 2);
+    }
+  } else {
+    // every lane's m / n range (8 elements) must be inside the operand row: M, N multiples of 8 (checked on the host); ranges
+    // past the edge re-read the last 8 columns (their products are never stored)
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      const int kr = rb * 16 + wave * 2 + (lane >> 5);
+      const int chunk = (lane & 31) ^ ((kr & 3) << 2);
+      int mcol = m0 + chunk * 8, ncol = min(n0 + chunk * 8, P.N - 8);
+      const int mlim = (P.A2 && m0 >= P.m_split) ? P.M - P.m_split : (P.A2 ? P.m_split : P.M);
+      if (P.A2 && m0 >= P.m_split) mcol -= P.m_split;
+      mcol = min(mcol, mlim - 8);
+      a_off[rb] = (uint32_t)(((long)kr * ((P.A2 && m0 >= P.m_split) ? P.lda2 : P.lda) + mcol) * 2);
+      b_off[rb] = (uint32_t)(((long)kr * P.ldb + ncol) * 2);
+    }
+    if (P.A2 && m0 >= P.m_split) a_base = P.A2;
+  }
+  const long lda_eff = (TN && P.A2 && m0 >= P.m_split) ? P.lda2 : P.lda;
+  // TN, ragged last K-tile: k-rows past K re-read row K - 1 (never out of bounds; they are zeroed in LDS before use)
+  const int t_kr0 = wave * 2 + (lane >> 5);
+  const uint32_t t_acol = TN ? a_off[0] - (uint32_t)((long)t_kr0 * ((P.A2 && m0 >= P.m_split) ? P.lda2 : P.lda) * 2) : 0;
+  const uint32_t t_bcol = TN ? b_off[0] - (uint32_t)((long)t_kr0 * P.ldb * 2) : 0;
+  // LDS map: A of buffer b at b * 32 KiB, B of buffer b at 64 KiB + b * 32 KiB (every fragment read = one per-lane base register +
+  // a 16-bit immediate)
+  const long a_kstep = TN ? 128 * lda_eff : 128, b_kstep = TN ? 128 * P.ldb : 128;      // bytes per K-tile
+  auto stage_a = [&](int b, int kt) {
+    const unsigned char* src = (const unsigned char*)a_base + (long)kt * a_kstep;
+    unsigned char* d = lds + b * 32768 + wave * 1024;
+    if (tail && kt == nkt - 1) {
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        const uint32_t off = (uint32_t)((long)min(t_kr0 + rb * 16, krem - 1) * lda_eff * 2) + t_acol;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + (size_t)off), (lds_ptr_t)(d + rb * 8192), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + (size_t)a_off[rb]), (lds_ptr_t)(d + rb * 8192), 16, 0, 0);
+    }
+  };
+  auto stage_b = [&](int b, int kt) {
+    const unsigned char* src = (const unsigned char*)b_base + (long)kt * b_kstep;
+    unsigned char* d = lds + 65536 + b * 32768 + wave * 1024;
+    if (tail && kt == nkt - 1) {
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        const uint32_t off = (uint32_t)((long)min(t_kr0 + rb * 16, krem - 1) * P.ldb * 2) + t_bcol;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + (size_t)off), (lds_ptr_t)(d + rb * 8192), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + (size_t)b_off[rb]), (lds_ptr_t)(d + rb * 8192), 16, 0, 0);
+    }
+  };
+  // zero the k-rows [krem, 64) of both operand tiles of buffer b (waves 0-3; the DMA of that K-tile has landed for every wave)
+  auto zero_tail = [&](int b) {
+    if (wm == 0) {
+      const int nbytes = (64 - krem) * 512;
+      for (int o = tid * 16; o < nbytes; o += 256 * 16) {
+        *reinterpret_cast<uint4*>(lds + b * 32768 + krem * 512 + o) = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(lds + 65536 + b * 32768 + krem * 512 + o) = make_uint4(0, 0, 0, 0);
+      }
+      G8_WAIT_LGKM0();
+    }
+    G8_BARRIER();
+  };
+
+  // ---- fragment reads: inline asm (the compiler then neither counts them nor guards them against the DMA in flight: every wait
+  //      below is explicit)
+  const int li = lane & 31, lq = lane >> 5;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  struct Frag {
+    uint4 v;        // NT: one ds_read_b128
+    uint2 lo, hi;   // TN: two ds_read_b64_tr_b16 (k = 0..3 | 4..7 of the lane's eight)
+  };
+  Frag fa[2][4], fbx[4], fby[4];
+  // NT: operand row (wave base + li), 16-byte chunk (2c + lq) ^ key of its 128-byte LDS row:  ra[c] / rb_[c] per k-step c
+  // TN: 16-lane group gq = lane >> 4 covers m = 16 (gq & 1) .. +15, k = 8 (gq >> 1) + {0..3 | 4..7}; lane i of a group passes the
+  //     address of (k-row i / 4, m-block 4 (i % 4)) and receives k = 0..3 of m = its own index.  Byte address of element (k, m)
+  //     of a tile: k * 512 + (((m >> 5) ^ (k & 3)) << 6) + (m & 31) * 2:  ra[j] = the wave's j-th 32-column quarter of A
+  //     (j = 2 mh + i), rb_[nh] the same for B.
+  uint32_t ra[4], rb_[4];
+  if constexpr (!TN) {
+    const int key = (li >> 1) & 7;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      ra[c] = lds0 + (wm * 128 + li) * 128 + (((2 * c + lq) ^ key) << 4);
+      rb_[c] = lds0 + 65536 + (wn * 64 + li) * 128 + (((2 * c + lq) ^ key) << 4);
+    }
+  } else {
+    const int l16 = lane & 15, gq = lane >> 4;
+    const int krow = 8 * (gq >> 1) + (l16 >> 2);          // (krow & 3) == l16 >> 2, also after + 4 / + 16 c
+    const int mloc = 16 * (gq & 1) + 4 * (l16 & 3);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ra[j] = lds0 + krow * 512 + mloc * 2 + ((((wm * 4 + j) ^ (l16 >> 2))) << 6);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) rb_[j] = lds0 + 65536 + krow * 512 + mloc * 2 + ((((wn * 2 + j) ^ (l16 >> 2))) << 6);
+    rb_[2] = rb_[3] = 0;
+  }
+#define G8_RD128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+#define G8_RDTR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+  // A fragments of m-half MH (2 MFMA tiles x 4 k-steps) / B fragments of n-half NH (4 k-steps) out of buffer BUF
+#define G8_READ_A(BUF, MH)                                                                      \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int c = 0; c < 4; ++c) { \
+    if constexpr (!TN) {                                                                        \
+      G8_RD128(fa[i][c].v, ra[c], (BUF) * 32768 + ((MH) * 64 + i * 32) * 128);                  \
+    } else {                                                                                    \
+      G8_RDTR(fa[i][c].lo, ra[(MH) * 2 + i], (BUF) * 32768 + c * 8192);                         \
+      G8_RDTR(fa[i][c].hi, ra[(MH) * 2 + i], (BUF) * 32768 + c * 8192 + 2048);                  \
+    }                                                                                           \
+  }
+#define G8_READ_B(BUF, NH, FB)                                           \
+  _Pragma("unroll") for (int c = 0; c < 4; ++c) {                        \
+    if constexpr (!TN) {                                                 \
+      G8_RD128(FB[c].v, rb_[c], (BUF) * 32768 + (NH) * 32 * 128);        \
+    } else {                                                             \
+      G8_RDTR(FB[c].lo, rb_[NH], (BUF) * 32768 + c * 8192);              \
+      G8_RDTR(FB[c].hi, rb_[NH], (BUF) * 32768 + c * 8192 + 2048);       \
+    }                                                                    \
+  }
+  auto frag = [&](const Frag& f) {
+    if constexpr (!TN)
+      return f.v;
+    else
+      return make_uint4(f.lo.x, f.lo.y, f.hi.x, f.hi.y);
+  };
+  auto mma = [&](int mh, int nh, const Frag (&fb)[4]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        // operands swapped on purpose: D rows = n, D columns = m -> a lane holds 4 consecutive n of one output row m
+        Mma<bf16_t>::mma32(acc[mh * 2 + i][nh], frag(fb[c]), frag(fa[i][c]));
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // one K-tile: buffer BUF holds K-tile KT (landed and visible), the DMA of K-tile KT + 1 into the other buffer is in flight
+#define G8_KTILE(BUF, KT)                 \
+  {                                       \
+    const bool more = (KT) + 2 < nkt;     \
+    if (tail && (KT) == nkt - 1) zero_tail(BUF); \
+    /* phase 0 */                         \
+    G8_READ_A(BUF, 0)                     \
+    G8_READ_B(BUF, 0, fbx)                \
+    G8_BARRIER();                         \
+    G8_WAIT_LGKM0();                      \
+    __builtin_amdgcn_sched_barrier(0);    \
+    mma(0, 0, fbx);                       \
+    G8_BARRIER();                         \
+    /* phase 1 */                         \
+    G8_READ_B(BUF, 1, fby)                \
+    G8_WAIT_LGKM0();                      \
+    G8_BARRIER();                         \
+    mma(0, 1, fby);                       \
+    G8_BARRIER();                         \
+    /* phase 2 */                         \
+    G8_READ_A(BUF, 1)                     \
+    if (more) stage_b(BUF, (KT) + 2);     \
+    G8_WAIT_LGKM0();                      \
+    G8_BARRIER();                         \
+    mma(1, 1, fby);                       \
+    G8_BARRIER();                         \
+    /* phase 3 */                         \
+    if (more) {                           \
+      stage_a(BUF, (KT) + 2);             \
+      G8_WAIT_VM(8);                      \
+    } else {                              \
+      G8_WAIT_VM(0);                      \
+    }                                     \
+    G8_BARRIER();                         \
+    mma(1, 0, fbx);                       \
+    G8_BARRIER();                         \
+  }
+
+  // prologue: K-tiles 0 and 1
+  stage_a(0, 0);
+  stage_b(0, 0);
+  if (nkt > 1) {
+    stage_a(1, 1);
+    stage_b(1, 1);
+    G8_WAIT_VM(8);
+  } else {
+    G8_WAIT_VM(0);
+  }
+  G8_BARRIER();
+  if (wm == 1) G8_BARRIER();        // M-half 1 runs one barrier behind
+  for (int kt = 0; kt < nkt; kt += 2) {
+    G8_KTILE(0, kt)
+    if (kt + 1 < nkt) G8_KTILE(1, kt + 1)
+  }
+  if (wm == 0) G8_BARRIER();        // balance the barrier count
+
+  // ---- epilogue
+  int eli = li, elq = lq;
+  asm volatile("" : "+v"(eli), "+v"(elq));
+  const float* bias = P.bias;
+  const int M_ = P.M, N_ = P.N;
+  const long ldc = P.ldc;
+  if (!P.out_is_f32 && (ldc % 8 == 0) && ((((uintptr_t)P.C) & 15) == 0)) {
+    // bf16 output: through LDS (free now: every wave is past the last barrier, nothing reads the operand tiles any more), so that
+    // a store instruction writes whole 128-byte row segments (8 rows x 128 B per instruction) instead of 16-byte pieces of 32
+    // rows.  A wave stages its 128 x 64 tile in two halves of 64 rows in its own 9 KiB (row stride 144 B: 16-byte aligned
+    // reads, two-way write conflicts at most); wave-private, so no barrier.
+    unsigned char* ep = lds + wave * 9216;
+    bf16_t* Cb = (bf16_t*)P.C;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int col = j * 32 + 8 * q + 4 * elq;
+            const int gcol = n0 + wn * 64 + col;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (bias) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) bv[e] = gcol + e < N_ ? bias[gcol + e] : 0.f;
+            }
+            uint2 pk;
+            pk.x = cvt_pk_bf16(acc[half * 2 + i2][j][4 * q + 0] + bv[0], acc[half * 2 + i2][j][4 * q + 1] + bv[1]);
+            pk.y = cvt_pk_bf16(acc[half * 2 + i2][j][4 * q + 2] + bv[2], acc[half * 2 + i2][j][4 * q + 3] + bv[3]);
+            *reinterpret_cast<uint2*>(ep + (i2 * 32 + eli) * 144 + col * 2) = pk;
+          }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int row_l = r * 8 + (lane >> 3), seg = lane & 7;
+        const uint4 d = *reinterpret_cast<const uint4*>(ep + row_l * 144 + seg * 16);
+        const int grow = m0 + wm * 128 + half * 64 + row_l, gcol = n0 + wn * 64 + seg * 8;
+        if (grow < M_) {
+          bf16_t* cp = Cb + (long)grow * ldc + gcol;
+          if (gcol + 7 < N_) {
+            *reinterpret_cast<uint4*>(cp) = d;
+          } else {
+            const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (gcol + e < N_) cp[e].v = (uint16_t)(w[e >> 1] >> ((e & 1) * 16));
+          }
+        }
+      }
+    }
+    return;
+  }
+  const bool n_vec_ok = (ldc % 4 == 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = m0 + wm * 128 + i * 32 + eli;
+    if (row >= M_) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = n0 + wn * 64 + j * 32 + 8 * q + 4 * elq;
+        if (col >= N_) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] + ((bias && col + e < N_) ? bias[col + e] : 0.f);
+        const long off = (long)row * ldc + col;
+        if (P.out_is_f32) {
+          float* cp = (float*)P.C + off;
+          if (col + 3 < N_ && n_vec_ok) {
+            *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (col + e < N_) cp[e] = v[e];
+          }
+        } else {
+          bf16_t* cp = (bf16_t*)P.C + off;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (col + e < N_) stf(cp + e, v[e]);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// C (f32 if out_f32 else bf16) [M][ldc] = A[M][lda] * B[N][ldb]^T (+ bias[N]) on the 256x256 phase-split kernel.
+// K % 64 == 0, lda/ldb % 8 == 0, 16-byte aligned operands of < 2^31 elements.
+int ds2_gemm8_nt(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long lda, long ldb, long ldc, int out_f32,
+                 ds2_stream_t st) {
+  DS2_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0, DS2_ERR_ARG);
+  DS2_REQUIRE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)B) & 15) == 0, DS2_ERR_ALIGN);
+  DS2_REQUIRE((long)M * lda < (1L << 31) && (long)N * ldb < (1L << 31), DS2_ERR_ARG);
+  G8Args g{};
+  g.n_problems = 1;
+  g.K = K;
+  const int tm = ds2_cdiv(M, 256), tn = ds2_cdiv(N, 256);
+  g.p[0] = G8Problem{(const bf16_t*)A, nullptr, (const bf16_t*)B, C, bias, M, N, 0, lda, 0, ldb, ldc, tn, tm * tn, out_f32};
+  hipLaunchKernelGGL(k_gemm8<false>, dim3(tm * tn), dim3(512), 0, (hipStream_t)st, g);
+  DS2_CHECK_LAUNCH();
+  return 0;
+}
+
+// Grouped TN products, one launch:  for every problem i   C_i[M_i][N_i] f32 = sum_k At_i[k][m] * Bt_i[k][n],  k < K
+// (At_i [K][lda_i], Bt_i [K][ldb_i]: the contraction index is the ROW of both operands).  A problem's A operand may be two
+// column blocks: output rows >= m_split_i take their columns from A2_i (leading dimension lda2_i), m_split_i a multiple of 256.
+// Any K (a ragged last K-tile is zero-filled on chip; no row past K - 1 is read), M_i, N_i % 8 == 0, 16-byte aligned rows.
+int ds2_gemm8_tn_grouped(int n_problems, const void* const* At, const void* const* At2, const int* m_split, const void* const* Bt, void* const* C,
+                         const int* M, const int* N, const long* lda, const long* lda2, const long* ldb, const long* ldc, int K, ds2_stream_t st) {
+  DS2_REQUIRE(n_problems >= 1 && n_problems <= G8_MAX_GROUPS && K > 0, DS2_ERR_ARG);
+  G8Args g{};
+  g.n_problems = n_problems;
+  g.K = K;
+  int total = 0;
+  for (int i = 0; i < n_problems; ++i) {
+    DS2_REQUIRE(M[i] > 0 && N[i] > 0 && M[i] % 8 == 0 && N[i] % 8 == 0 && lda[i] % 8 == 0 && ldb[i] % 8 == 0, DS2_ERR_ARG);
+    DS2_REQUIRE((((uintptr_t)At[i]) & 15) == 0 && (((uintptr_t)Bt[i]) & 15) == 0, DS2_ERR_ALIGN);
+    DS2_REQUIRE((long)K * lda[i] < (1L << 31) && (long)K * ldb[i] < (1L << 31), DS2_ERR_ARG);
+    const void* a2 = At2 ? At2[i] : nullptr;
+    const int ms = a2 ? m_split[i] : 0;
+    DS2_REQUIRE(a2 == nullptr || (ms > 0 && ms < M[i] && ms % 256 == 0 && (((uintptr_t)a2) & 15) == 0 && lda2 && lda2[i] % 8 == 0 &&
+                                  (long)K * lda2[i] < (1L << 31)), DS2_ERR_ARG);
+    const int tm = ds2_cdiv(M[i], 256), tn = ds2_cdiv(N[i], 256);
+    total += tm * tn;
+    g.p[i] = G8Problem{(const bf16_t*)At[i], (const bf16_t*)a2, (const bf16_t*)Bt[i], C[i], nullptr, M[i], N[i], ms, lda[i], a2 ? lda2[i] : 0, ldb[i], ldc[i], tn, total, 1};
+  }
+  hipLaunchKernelGGL(k_gemm8<true>, dim3(total), dim3(512), 0, (hipStream_t)st, g);
+  DS2_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

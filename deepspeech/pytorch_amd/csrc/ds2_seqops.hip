@@ -119,20 +119,24 @@ __global__ void __launch_bounds__(256) k_lookahead_bwd_w(const T* __restrict__ d
   if (h >= H) return;
   const long rows = (long)Tp * N;
   const long r0 = (long)blockIdx.y * LA_ROWS, r1 = min(rows, r0 + LA_ROWS);
-  float acc[32];
+  float* dst = partial + (long)blockIdx.y * H * ctx + (long)h * ctx;
+  for (int k0 = 0; k0 < ctx; k0 += 32) {               // 32 taps in registers per pass (the default context is 20: one pass)
+    float acc[32];
 #pragma unroll
-  for (int k = 0; k < 32; ++k) acc[k] = 0.f;
-  for (long r = r0; r < r1; ++r) {
-    const float p = ldf(pre + r * H + h);
-    if (!(p > 0.f && p < 20.f)) continue;
-    const float g = ldf(dy + r * H + h);
-    const int t = (int)(r / N);
+    for (int k = 0; k < 32; ++k) acc[k] = 0.f;
+    for (long r = r0; r < r1; ++r) {
+      const float p = ldf(pre + r * H + h);
+      if (!(p > 0.f && p < 20.f)) continue;
+      const float g = ldf(dy + r * H + h);
+      const int t = (int)(r / N);
+#pragma unroll
+      for (int k = 0; k < 32; ++k)
+        if (k0 + k < ctx && t + k0 + k < Tp) acc[k] = fmaf(g, ldf(x + (r + (long)(k0 + k) * N) * H + h), acc[k]);
+    }
 #pragma unroll
     for (int k = 0; k < 32; ++k)
-      if (k < ctx && t + k < Tp) acc[k] = fmaf(g, ldf(x + (r + (long)k * N) * H + h), acc[k]);
+      if (k0 + k < ctx) dst[k0 + k] = acc[k];
   }
-  float* dst = partial + (long)blockIdx.y * H * ctx + (long)h * ctx;
-  for (int k = 0; k < ctx; ++k) dst[k] = acc[k];
 }
 
 __global__ void __launch_bounds__(256) k_softmax_rows(const float* __restrict__ in, float* __restrict__ out, long rows, int C,
@@ -367,7 +371,7 @@ int ds2_lookahead_bwd(int dtype, const void* x, const float* w, const void* pre,
   hipStream_t st = (hipStream_t)st_;
   DS2_REQUIRE(dtype == DS2_F32 || dtype == DS2_BF16, DS2_ERR_DTYPE);
   const int V = dtype == DS2_F32 ? 4 : 8;
-  DS2_REQUIRE(H % V == 0 && ctx > 0 && ctx <= 32 && (H * ctx) % 4 == 0, DS2_ERR_ARG);
+  DS2_REQUIRE(H % V == 0 && ctx > 0 && (H * ctx) % 4 == 0, DS2_ERR_ARG);
   const long total = (long)Tp * N * (H / V);
   const int P = la_row_blocks(Tp, N);
   dim3 gw(ds2_cdiv(H, 256), P);

@@ -156,6 +156,30 @@ def _wgrad_splitk(M, N, K):
     return max(1, min(8, 768 // max(tiles, 1), K // (64 * 32)))
 
 
+def _pad_gate_rows(w, G, H, Hp):
+    """[G*H, ...] -> [G*Hp, ...]: every gate block padded with zero rows (hidden units H..Hp-1 of the internal, tile-aligned
+    width: zero weights and biases keep them at exactly 0 in every cell type, so they never touch a real unit)."""
+    if Hp == H:
+        return w
+    out = w.new_zeros((G, Hp) + tuple(w.shape[1:]))
+    out[:, :H] = w.reshape((G, H) + tuple(w.shape[1:]))
+    return out.reshape((G * Hp,) + tuple(w.shape[1:]))
+
+
+def _pad_cols(w, Cp):
+    if w.shape[-1] == Cp:
+        return w
+    out = w.new_zeros(tuple(w.shape[:-1]) + (Cp,))
+    out[..., :w.shape[-1]] = w
+    return out
+
+
+def _unpad_gate_rows(g, G, H, Hp):
+    if Hp == H:
+        return g
+    return g.reshape((G, Hp) + tuple(g.shape[1:]))[:, :H].reshape((G * H,) + tuple(g.shape[1:])).contiguous()
+
+
 def _perm_cols_to_internal(w):
     """rnns.0 weight_ih columns: reference feature c*41+f -> internal f*32+c, zero-padded to RNN_INPUT_LD columns."""
     g = w.shape[0]
@@ -245,9 +269,11 @@ class _RnnStackFn(torch.autograd.Function):
         saved, meta, outs_h, outs_c, pos = [], [], [], [], 0
         for li in range(L):
             layer = mod.rnns[li]
-            kind, H, D = layer.kind, layer.hidden_size, layer.num_directions
+            kind, Ht, D = layer.kind, layer.hidden_size, layer.num_directions
+            H = mod._Hp                                         # internal width: hidden_size rounded up to the 16-unit MFMA tile
+            G = ops.GATES[kind]
             first = li == 0
-            I = RNN_INPUT_LD if first else layer.input_size    # layer 0 sees the zero-padded conv-stack output
+            I = RNN_INPUT_LD if first else H                    # layer 0 sees the zero-padded conv-stack output
             has_bn = layer.batch_norm is not None
             bn_w, bn_b = (params[pos], params[pos + 1]) if has_bn else (None, None)
             pos += 2 if has_bn else 0
@@ -258,29 +284,46 @@ class _RnnStackFn(torch.autograd.Function):
             bih = [wts[4 * d + 2] for d in range(D)]
             bhh = [wts[4 * d + 3] for d in range(D)]
 
-            def build_ih(wih=wih, first=first):
-                w = torch.cat([p.detach() for p in wih], 0)
-                if first:
-                    w = _perm_cols_to_internal(w)
-                return w.to(dtype).contiguous()
+            def build_ih(wih=wih, first=first, G=G, Ht=Ht, H=H):
+                w = torch.cat([_pad_gate_rows(p.detach(), G, Ht, H) for p in wih], 0)
+                w = _perm_cols_to_internal(w) if first else _pad_cols(w, H)
+                out = ops.empty_padded(w.shape[0], w.shape[1], dtype, w.device)
+                out.copy_(w)
+                return out
             Wih = c.get(("wih", li, dtype), wih, build_ih)
-            Whh = c.get(("whh", li, dtype), whh, lambda whh=whh: torch.stack([p.detach() for p in whh], 0).to(dtype).contiguous())
-            Bih, Bhh = mod._bias_views(li)
+            Whh = c.get(("whh", li, dtype), whh, lambda whh=whh, G=G, Ht=Ht, H=H: torch.stack(
+                [_pad_gate_rows(_pad_cols(p.detach(), H), G, Ht, H) for p in whh], 0).to(dtype).contiguous())
+            if H == Ht:
+                Bih, Bhh = mod._bias_views(li)
+            else:
+                Bih = c.get(("bih", li), bih, lambda bih=bih, G=G, Ht=Ht, H=H: torch.cat([_pad_gate_rows(p.detach(), G, Ht, H) for p in bih], 0))
+                Bhh = c.get(("bhh", li), bhh, lambda bhh=bhh, G=G, Ht=Ht, H=H: torch.stack([_pad_gate_rows(p.detach(), G, Ht, H) for p in bhh], 0))
             sv, Xh = None, X
             if has_bn:
                 bn = layer.batch_norm.module
-                Xh = torch.empty_like(X)
+                if H == Ht:
+                    Xh = ops.empty_padded(R, I, X.dtype, X.device)   # row stride off the power of two (GEMM operand)
+                else:
+                    Xh = torch.zeros((R, I), dtype=X.dtype, device=X.device)       # the pad columns must be clean zeros
                 sv = ops.bn_fwd(X, 0, training, bn_w.detach(), bn_b.detach(), bn.running_mean, bn.running_var,
-                                bn.num_batches_tracked, R, I, I, Xh, I, eps=bn.eps, momentum=bn.momentum)
+                                bn.num_batches_tracked, R, layer.input_size, X.stride(0), Xh, Xh.stride(0), eps=bn.eps,
+                                momentum=bn.momentum)
             GI = ops.gemm_nt(Xh, Wih, bias=Bih)                                  # [R][D*G*H]
-            hext, Sv, hn, cn = ops.rnn_fwd(kind, GI, Whh, Bhh, lens_dev, D, N, H, Tp, h0=hs0[li], c0=cs0[li])
+            h0, c0 = hs0[li], cs0[li]
+            if H != Ht:
+                h0 = _pad_cols(h0, H) if h0 is not None else None
+                c0 = _pad_cols(c0, H) if c0 is not None else None
+            hext, Sv, hn, cn = ops.rnn_fwd(kind, GI, Whh, Bhh, lens_dev, D, N, H, Tp, h0=h0, c0=c0)
+            if H != Ht:
+                hn = hn[..., :Ht].contiguous()
+                cn = cn[..., :Ht].contiguous() if cn is not None else None
             del GI
             if D == 2:
                 out = ops.add2(hext[0, 1:Tp + 1].reshape(R, H), hext[1, 1:Tp + 1].reshape(R, H))
             else:
                 out = hext[0, 1:Tp + 1].reshape(R, H).clone()
             saved += [X, Xh if has_bn else None, hext, Sv]
-            meta.append((kind, H, D, ops.GATES[kind], I, has_bn, sv))
+            meta.append((kind, H, D, G, I, has_bn, sv, Ht, layer.input_size))
             outs_h.append(hn)
             if cn is not None:
                 outs_c.append(cn)
@@ -313,7 +356,7 @@ class _RnnStackFn(torch.autograd.Function):
         grads = [None] * len(params)
         dout = dout.contiguous().to(dtype)
         for li in reversed(range(L)):
-            kind, H, D, G, I, has_bn, sv = ctx.meta[li]
+            kind, H, D, G, I, has_bn, sv, Ht, It = ctx.meta[li]
             X, Xh, hext, Sv = saved[4 * li:4 * li + 4]
             if Xh is None:
                 Xh = X
@@ -323,13 +366,12 @@ class _RnnStackFn(torch.autograd.Function):
             wts = params[po:po + 4 * D]
             wih = [wts[4 * d + 0] for d in range(D)]
             whh = [wts[4 * d + 1] for d in range(D)]
-            WhhT = c.get(("whhT", li, dtype), list(whh),
-                         lambda whh=whh: torch.stack([p.detach().t() for p in whh], 0).to(dtype).contiguous())   # [D][H][G*H]
+            WhhT = c.get(("whhT", li, dtype), list(whh), lambda whh=whh, G=G, Ht=Ht, H=H: torch.stack(
+                [_pad_gate_rows(_pad_cols(p.detach(), H), G, Ht, H).t() for p in whh], 0).to(dtype).contiguous())   # [D][H][G*H]
 
-            def build_ihT(wih=wih, first=first):
-                w = torch.cat([p.detach() for p in wih], 0)
-                if first:
-                    w = _perm_cols_to_internal(w)
+            def build_ihT(wih=wih, first=first, G=G, Ht=Ht, H=H):
+                w = torch.cat([_pad_gate_rows(p.detach(), G, Ht, H) for p in wih], 0)
+                w = _perm_cols_to_internal(w) if first else _pad_cols(w, H)
                 return w.t().to(dtype).contiguous()                                                             # [I][D*G*H]
             WihT = c.get(("wihT", li, dtype), list(wih), build_ihT)
             # ---- dependent chain (caller's stream): BPTT sweep -> dX -> BatchNorm backward
@@ -337,10 +379,62 @@ class _RnnStackFn(torch.autograd.Function):
             dGI = rg.dGI
             dXh = ops.gemm_nt(dGI, WihT)                                # [R][I]
             if has_bn:
-                dX = torch.empty_like(dXh)
-                grads[offs[li]], grads[offs[li] + 1] = ops.bn_bwd(dXh, X, dX, 0, sv, R, I, I, I, I)
+                dX = torch.empty_like(dXh) if H == Ht else torch.zeros_like(dXh)
+                grads[offs[li]], grads[offs[li] + 1] = ops.bn_bwd(dXh, X, dX, 0, sv, R, It, I, X.stride(0), I)
             else:
                 dX = dXh
+            if ops.wgrad_tn_ok(dtype, R, D * GH, Xh.shape[1]) and ops.wgrad_tn_ok(dtype, R, GH, H):
+                # ---- weight gradients as ONE grouped launch of TN products (contraction over the T'*N rows, both operands as the
+                # activations are stored: no transposes), on this stream, between the layers' sweeps.  Co-resident GEMMs under
+                # the sweep are gone: what they cost was the chip's CLOCK (1.7 instead of 2.15 GHz while they ran,
+                # profiles/r03a_coresidency3.txt) -- a latency-bound sweep pays that one to one.
+                Iw = Xh.shape[1]
+                dWih = torch.empty((D * GH, Iw), dtype=torch.float32, device=dGI.device)
+                dWhh = torch.empty((D, GH, H), dtype=torch.float32, device=dGI.device)
+                probs = [dict(At=dGI, Bt=Xh, M=D * GH, N=Iw, lda=D * GH, ldb=Xh.stride(0), out=dWih)]
+                for d in range(D):
+                    # h_{t-1} of the forward direction is slot t of the guarded buffer, h_{t+1} of the reverse direction slot t+2
+                    hprev = (hext[d, 0:Tp] if d == 0 else hext[d, 2:Tp + 2]).reshape(R, H)
+                    if kind == "gru" and rg.dQ is not None:
+                        # hidden-side gate gradient = [dr, dz (columns of dGI) | dQ]
+                        if (2 * H) % 256 == 0:
+                            probs.append(dict(At=dGI[:, d * GH:], At2=rg.dQ[d], lda2=H, m_split=2 * H, Bt=hprev, M=GH, N=H, lda=D * GH, ldb=H,
+                                              out=dWhh[d]))
+                        else:
+                            probs.append(dict(At=dGI[:, d * GH:], Bt=hprev, M=2 * H, N=H, lda=D * GH, ldb=H, out=dWhh[d, :2 * H]))
+                            probs.append(dict(At=rg.dQ[d], Bt=hprev, M=H, N=H, lda=H, ldb=H, out=dWhh[d, 2 * H:]))
+                    elif kind == "gru":
+                        probs.append(dict(At=rg.dGH[d], Bt=hprev, M=GH, N=H, lda=GH, ldb=H, out=dWhh[d]))
+                    else:
+                        probs.append(dict(At=dGI[:, d * GH:], Bt=hprev, M=GH, N=H, lda=D * GH, ldb=H, out=dWhh[d]))
+                ops.gemm8_tn_grouped(probs, R)
+                if first:
+                    dWih = torch.cat([_perm_cols_to_reference(dWih[d * GH:(d + 1) * GH]) for d in range(D)], 0)
+                bsum = None
+                if rg.bacc is not None:
+                    bsum = [ops.colsum(rg.bacc[d]) for d in range(D)]                   # [NB*H] per direction
+                    dBih = torch.cat([b[:GH] for b in bsum], 0)
+                else:
+                    dBih = ops.colsum(dGI)
+                for d in range(D):
+                    if kind == "gru" and rg.dQ is not None:
+                        dBhh = torch.cat([bsum[d][:2 * H], bsum[d][3 * H:4 * H]], 0) if bsum is not None else \
+                            torch.cat([dBih[d * GH:d * GH + 2 * H], ops.colsum(rg.dQ[d].reshape(R, H))], 0)
+                    elif kind == "gru":
+                        dBhh = ops.colsum(rg.dGH[d].reshape(R, GH))
+                    else:
+                        dBhh = dBih[d * GH:(d + 1) * GH]
+                    grads[po + 4 * d:po + 4 * d + 4] = [dWih[d * GH:(d + 1) * GH], dWhh[d], dBih[d * GH:(d + 1) * GH].contiguous(),
+                                                        dBhh.contiguous()]
+                sync = getattr(mod, "_grad_sync", None)
+                if sync is not None and H == Ht:
+                    own = [dWih, dWhh, dBih]
+                    if kind == "gru":
+                        own += [grads[po + 4 * d + 3] for d in range(D)]
+                    sync.layer_ready(own, params[po:po + 4 * D])
+                _unpad_layer_grads(grads, po, D, G, Ht, H, It, first)
+                dout = dX
+                continue
             # the second stream starts this layer's weight gradients only once dX / BatchNorm backward are through, i.e. together
             # with the next layer's sweep: the dependent chain never competes with them for the CUs
             ready = torch.cuda.Event()
@@ -393,7 +487,7 @@ class _RnnStackFn(torch.autograd.Function):
                                                         dBih[d * GH:(d + 1) * GH].contiguous(), dBhh.contiguous()]
                 del dGI_T
                 sync = getattr(mod, "_grad_sync", None)
-                if sync is not None:
+                if sync is not None and H == Ht:
                     # data parallel with the opt-in early hand-off (dist.OverlappedGradSync): this layer's gradients start
                     # their all-reduce now, ordered after the GEMMs above, under the sweeps of the layers below.  The
                     # returned gradients are views of dWih / dBih (and of dBih for the biases of LSTM / RNN cells).
@@ -401,12 +495,26 @@ class _RnnStackFn(torch.autograd.Function):
                     if kind == "gru":
                         own += [grads[po + 4 * d + 3] for d in range(D)]
                     sync.layer_ready(own, params[po:po + 4 * D])
+                _unpad_layer_grads(grads, po, D, G, Ht, H, It, first)
             dout = dX
         if getattr(ctx, "defer_join", False):
             ctx.pending = (main, side, grads, mod)     # the composite node joins after the conv backward
         else:
             _join_side(main, side, grads, mod)
         return (dout, None, None, None, None, None, None, None, *([None] * (2 * L)), *grads)
+
+
+def _unpad_layer_grads(grads, po, D, G, Ht, H, It, first):
+    """Models whose hidden size is not a multiple of the tile: cut the padded units out of the layer's parameter gradients."""
+    if H == Ht:
+        return
+    for d in range(D):
+        dWih, dWhh, dBih, dBhh = grads[po + 4 * d:po + 4 * d + 4]
+        dWih = _unpad_gate_rows(dWih, G, Ht, H)
+        grads[po + 4 * d] = dWih if first else dWih[:, :It].contiguous()
+        grads[po + 4 * d + 1] = _unpad_gate_rows(dWhh, G, Ht, H)[:, :Ht].contiguous()
+        grads[po + 4 * d + 2] = _unpad_gate_rows(dBih, G, Ht, H)
+        grads[po + 4 * d + 3] = _unpad_gate_rows(dBhh, G, Ht, H)
 
 
 def _join_side(main, side, grads, mod=None):
@@ -470,19 +578,23 @@ class _LookaheadFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, X, w, N, Tp):
-        H, ctxlen = w.shape[0], w.shape[2]
-        wf = w.detach().reshape(H, ctxlen).contiguous()
+        Ht, ctxlen = w.shape[0], w.shape[2]
+        H = X.shape[1]                                        # internal width (hidden_size rounded up to the tile)
+        wf = w.detach().reshape(Ht, ctxlen)
+        if H != Ht:
+            wf = torch.cat([wf, wf.new_zeros((H - Ht, ctxlen))], 0)
+        wf = wf.contiguous()
         y, pre = ops.lookahead_fwd(X, wf, Tp, N, H)
-        ctx.dims = (N, Tp, H, ctxlen)
+        ctx.dims = (N, Tp, H, ctxlen, Ht)
         ctx.save_for_backward(X, wf, pre)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         X, wf, pre = ctx.saved_tensors
-        N, Tp, H, ctxlen = ctx.dims
+        N, Tp, H, ctxlen, Ht = ctx.dims
         dx, dw = ops.lookahead_bwd(X, wf, pre, dy.contiguous().to(X.dtype), Tp, N, H)
-        return dx, dw.reshape(H, 1, ctxlen), None, None
+        return dx, dw[:Ht].reshape(Ht, 1, ctxlen).contiguous(), None, None
 
 
 class _HeadFn(torch.autograd.Function):
@@ -492,34 +604,35 @@ class _HeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, bn_w, bn_b, wfc, mod, N, Tp, dtype, training):
         bn = mod.fc[0].module[0]
-        H, Cc = wfc.shape[1], wfc.shape[0]
+        Ht, Cc = wfc.shape[1], wfc.shape[0]
+        H, Cp = mod._Hp, mod._Cp                     # internal (tile-aligned) width and class count
         R = Tp * N
         c = mod._cache
-        Xh = torch.empty_like(X)
+        Xh = torch.empty_like(X) if H == Ht else torch.zeros_like(X)
         sv = ops.bn_fwd(X, 0, training, bn_w.detach(), bn_b.detach(), bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                        R, H, H, Xh, H, eps=bn.eps, momentum=bn.momentum)
-        Wp = c.get(("wfc", dtype), [wfc], lambda: torch.cat(
-            [wfc.detach(), torch.zeros(32 - Cc, H, device=wfc.device)], 0).to(dtype).contiguous())          # [32][H]
-        logits = ops.gemm_nt(Xh, Wp, out_dtype=torch.float32)                                                # [R][32]
-        ctx.mod, ctx.dims, ctx.sv = mod, (N, Tp, dtype, H, Cc), sv
+                        R, Ht, H, Xh, H, eps=bn.eps, momentum=bn.momentum)
+        Wp = c.get(("wfc", dtype), [wfc], lambda: _pad_cols(torch.cat(
+            [wfc.detach(), torch.zeros(Cp - Cc, Ht, device=wfc.device)], 0), H).to(dtype).contiguous())      # [Cp][H]
+        logits = ops.gemm_nt(Xh, Wp, out_dtype=torch.float32)                                                # [R][Cp]
+        ctx.mod, ctx.dims, ctx.sv = mod, (N, Tp, dtype, H, Cc, Ht, Cp), sv
         ctx.save_for_backward(X, Xh, wfc)
         return logits
 
     @staticmethod
     def backward(ctx, dlogits):
         X, Xh, wfc = ctx.saved_tensors
-        N, Tp, dtype, H, Cc = ctx.dims
+        N, Tp, dtype, H, Cc, Ht, Cp = ctx.dims
         R = Tp * N
         c = ctx.mod._cache
-        dl = dlogits.contiguous().to(dtype)                                                                  # [R][32]
-        WpT = c.get(("wfcT", dtype), [wfc], lambda: torch.cat(
-            [wfc.detach(), torch.zeros(32 - Cc, H, device=wfc.device)], 0).t().to(dtype).contiguous())       # [H][32]
+        dl = dlogits.contiguous().to(dtype)                                                                  # [R][Cp]
+        WpT = c.get(("wfcT", dtype), [wfc], lambda: _pad_cols(torch.cat(
+            [wfc.detach(), torch.zeros(Cp - Cc, Ht, device=wfc.device)], 0), H).t().to(dtype).contiguous())  # [H][Cp]
         dXh = ops.gemm_nt(dl, WpT)                                                                           # [R][H]
         dl_T, Xh_T = ops.transpose(dl), ops.transpose(Xh)
-        dW = ops.gemm_nt(dl_T, Xh_T, out_dtype=torch.float32, splitk=max(1, min(32, R // 2048)))             # [32][H]
-        dX = torch.empty_like(dXh)
-        dg, db = ops.bn_bwd(dXh, X, dX, 0, ctx.sv, R, H, H, H, H)
-        return dX, dg, db, dW[:Cc].contiguous(), None, None, None, None, None
+        dW = ops.gemm_nt(dl_T, Xh_T, out_dtype=torch.float32, splitk=max(1, min(32, R // 2048)))             # [Cp][H]
+        dX = torch.empty_like(dXh) if H == Ht else torch.zeros_like(dXh)
+        dg, db = ops.bn_bwd(dXh, X, dX, 0, ctx.sv, R, Ht, H, H, H)
+        return dX, dg, db, dW[:Cc, :Ht].contiguous(), None, None, None, None, None
 
 
 class _CtcFn(torch.autograd.Function):
@@ -572,7 +685,7 @@ class CTCLossHip(nn.Module):
         Tp, N, Cc = log_probs.shape
         if not log_probs.is_cuda:
             raise Ds2HipError("CTCLossHip needs a HIP tensor; there is no CPU fallback")
-        x = torch.zeros((Tp * N, 32), dtype=torch.float32, device=log_probs.device)
+        x = torch.zeros((Tp * N, (Cc + 31) // 32 * 32), dtype=torch.float32, device=log_probs.device)
         x[:, :Cc] = log_probs.reshape(Tp * N, Cc).float()
         loss = _CtcFn.apply(x, targets, input_lengths.to(log_probs.device, torch.int32), target_lengths, N, Tp, Cc, self.blank)
         return loss
@@ -604,10 +717,13 @@ class DeepSpeech(_Base):
         num_classes = len(self.labels)
         kind = rnn_kind(model_cfg.rnn_type)
         H, L = int(model_cfg.hidden_size), int(model_cfg.hidden_layers)
-        if H % 16 != 0:
-            raise ValueError("the gfx950 recurrent kernels tile the hidden units by 16: hidden_size %d %% 16 != 0" % H)
-        if num_classes > 32:
-            raise ValueError("the fused CTC kernel supports at most 32 output classes, got %d" % num_classes)
+        if num_classes > 256:
+            raise ValueError("the CTC kernels hold the log-probabilities of a frame in a 256-class row, got %d classes" % num_classes)
+        # Internal, tile-aligned sizes (never visible in the state_dict): the recurrent kernels tile the hidden units by 16 and
+        # the head / CTC kernels the classes by 32.  Extra hidden units carry zero weights and biases (they stay exactly 0 in
+        # GRU, LSTM and tanh cells), extra classes zero weight rows that nothing reads.
+        self._Hp = (H + 15) // 16 * 16
+        self._Cp = (num_classes + 31) // 32 * 32
 
         self.conv = MaskConv(nn.Sequential(
             nn.Conv2d(1, 32, kernel_size=(41, 11), stride=(2, 2), padding=(20, 5)),
@@ -652,6 +768,8 @@ class DeepSpeech(_Base):
         for the dX / BPTT kernels -- in one place, so that forward can run it on the second stream under the conv stack
         (after an optimizer step every copy is stale: ~130 MB of fp32 reads per step)."""
         c = self._cache
+        if self._Hp != self.rnns[0].hidden_size:
+            return          # padded hidden size (rare): the stages build their zero-padded operands themselves, through the cache
         for li, layer in enumerate(self.rnns):
             p, D, first = layer.rnn, layer.num_directions, li == 0
             sufs = [""] + (["_reverse"] if D == 2 else [])
@@ -671,13 +789,13 @@ class DeepSpeech(_Base):
                     Io = RNN_INPUT_LD if first else I
                     perm = (32, N_FREQ_CONV2) if first else None
                     dev = wih[0].device
-                    Wih = torch.empty((D * GH, Io), dtype=dtype, device=dev)
+                    Wih = ops.empty_padded(D * GH, Io, dtype, dev)
                     Whh = torch.empty((D, GH, H), dtype=dtype, device=dev)
                     WihT = torch.empty((Io, D * GH), dtype=dtype, device=dev) if need_backward else None
                     WhhT = torch.empty((D, H, GH), dtype=dtype, device=dev) if need_backward else None
                     with torch.no_grad():
                         for d in range(D):
-                            ops.cast_transpose_bf16(wih[d].detach(), Wih[d * GH:], Io,
+                            ops.cast_transpose_bf16(wih[d].detach(), Wih[d * GH:], Wih.stride(0),
                                                     WihT[:, d * GH:] if need_backward else None, D * GH, perm=perm, cout=Io)
                             ops.cast_transpose_bf16(whh[d].detach(), Whh[d], H, WhhT[d] if need_backward else None, GH)
                     c.put(("wih", li, dtype), wih, Wih)
@@ -689,7 +807,12 @@ class DeepSpeech(_Base):
             def cat_ih(wih=wih, first=first):
                 w = torch.cat([q.detach() for q in wih], 0)
                 return _perm_cols_to_internal(w) if first else w
-            c.get(("wih", li, dtype), wih, lambda: cat_ih().to(dtype).contiguous())
+            def padded_ih():
+                w = cat_ih()
+                out = ops.empty_padded(w.shape[0], w.shape[1], dtype, w.device)
+                out.copy_(w)
+                return out
+            c.get(("wih", li, dtype), wih, padded_ih)
             c.get(("whh", li, dtype), whh, lambda whh=whh: torch.stack([q.detach() for q in whh], 0).to(dtype).contiguous())
             self._bias_views(li)
             if need_backward:
@@ -726,12 +849,15 @@ class DeepSpeech(_Base):
         sm, fcw = self.conv.seq_module, self.fc[0].module[1].weight
         w1, w2 = sm[0].weight, sm[3].weight
         keys = (("w1k", [w1]), (("w2t", dtype), [w2]), (("w2d", dtype), [w2]), (("wfc", dtype), [fcw]), (("wfcT", dtype), [fcw]))
-        if all(c.valid(k, ps) for k, ps in keys):
+        if all(c.valid(k, ps) for k, ps in keys[:3]) and (c.valid(*keys[3]) or fcw.shape[0] > 32 or self._Hp != fcw.shape[1]):
             return
+        plain_head = fcw.shape[0] <= 32 and self._Hp == fcw.shape[1]
         with torch.no_grad():
-            vals = ops.small_weight_layouts(w1.detach().contiguous(), w2.detach().contiguous(), fcw.detach().contiguous(), dtype)
+            vals = ops.small_weight_layouts(w1.detach().contiguous(), w2.detach().contiguous(),
+                                            fcw.detach().contiguous() if plain_head else fcw.detach()[:min(32, fcw.shape[0])].contiguous(), dtype)
         for (k, ps), v in zip(keys, vals):
-            c.put(k, ps, v)
+            if plain_head or k[0] not in ("wfc", "wfcT"):       # > 32 classes / padded hidden size: _HeadFn builds the head's operands
+                c.put(k, ps, v)
 
     def _wgrad_stream(self, device):
         """Second HIP stream of this module on `device` (weight-gradient work of the RNN stack's backward)."""
@@ -821,7 +947,7 @@ class DeepSpeech(_Base):
         logits, output_lengths, new_hs, _, N, Tp = self._logits(x, lengths, hs)
         Cc = len(self.labels)
         if self.training:
-            out = logits.view(Tp, N, 32)[:, :, :Cc].transpose(0, 1)        # (N, T', C) view, model.py:236
+            out = logits.view(Tp, N, self._Cp)[:, :, :Cc].transpose(0, 1)  # (N, T', C) view, model.py:236
         else:
             out = ops.softmax_rows(logits, Cc).view(Tp, N, Cc).transpose(0, 1)   # model.py:238, 72-77
         return out, output_lengths, new_hs

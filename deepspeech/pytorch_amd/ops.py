@@ -76,6 +76,35 @@ class _sweep_timer:
 
 
 # ---------------------------------------------------------------------------------------------------------------
+def pad_ld(n, dtype=torch.bfloat16):
+    """Leading dimension for a matrix with n columns that the large GEMMs stream by rows: a row stride that is a multiple of
+    1 KiB maps every row of a tile onto the same few memory channels (measured: the K = 1024 input projection runs 714 TFLOP/s
+    with ld 1024 and 800-846 with ld 1088 / 1152, profiles/r03b_gemm8_ld.txt) -- such widths get 64 extra columns."""
+    esz = 2 if dtype == torch.bfloat16 else 4
+    return n + 64 if (n * esz) % 1024 == 0 else n
+
+
+def empty_padded(rows, cols, dtype, device):
+    """[rows][cols] view (row stride pad_ld(cols)) of a fresh allocation."""
+    ld = pad_ld(cols, dtype)
+    return torch.empty((rows, ld), dtype=dtype, device=device)[:, :cols] if ld != cols else torch.empty((rows, cols), dtype=dtype, device=device)
+
+
+GEMM8_ENABLED = True     # tests flip this to run the 128x128-tile kernels on shapes the 256x256 kernel covers
+
+
+def gemm8_nt_ok(A, B, M, N, K, lda, ldb):
+    """Shapes the 256x256 phase-split kernel takes (and wins on): bf16, whole K-tiles, enough tiles to fill the chip."""
+    return (GEMM8_ENABLED and A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and K % 64 == 0 and lda % 8 == 0 and ldb % 8 == 0 and
+            M >= 1024 and N >= 256 and rup(M, 256) // 256 * (rup(N, 256) // 256) >= 160 and M * lda < (1 << 31) and N * ldb < (1 << 31) and
+            A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0)
+
+
+def wgrad_tn_ok(dtype, R, M, N):
+    """Weight gradients as grouped TN products (no operand transposes): bf16 activations, a long contraction, 8-aligned widths."""
+    return GEMM8_ENABLED and dtype == torch.bfloat16 and R >= 512 and M % 8 == 0 and N % 8 == 0 and M >= 256 and N >= 256
+
+
 def gemm_nt(A, B, bias=None, out_dtype=None, M=None, N=None, K=None, lda=None, ldb=None, out=None, ldc=None, splitk=1,
             batch=1, sA=0, sB=0, sC=0, sBias=0, coresident=False):
     """C[M][N] = A[M][K] * B[N][K]^T (+bias).  A, B: 2-D row-major tensors (or explicit M/N/K/ld for views)."""
@@ -85,6 +114,8 @@ def gemm_nt(A, B, bias=None, out_dtype=None, M=None, N=None, K=None, lda=None, l
     lda = A.stride(-2) if lda is None else lda
     ldb = B.stride(-2) if ldb is None else ldb
     out_dtype = out_dtype or A.dtype
+    if out is None and splitk == 1 and batch == 1 and not coresident and gemm8_nt_ok(A, B, M, N, K, lda, ldb):
+        return gemm8_nt(A, B, bias=bias, out_dtype=out_dtype, M=M, N=N, K=K, lda=lda, ldb=ldb)
     if out is None:
         shape = (batch, M, N) if batch > 1 else (M, N)
         out = torch.empty(shape, dtype=out_dtype, device=A.device)       # split-K: the entry zeroes C itself
@@ -101,6 +132,45 @@ def gemm_nt_rows2(A, A2, m_split, B, M, N, K, lda, ldb, splitk=1, coresident=Fal
     out = torch.empty((M, N), dtype=torch.float32, device=A.device)
     call("ds2_gemm_nt_rows2", dt(A), P(A), P(A2), m_split, P(B), P(out), M, N, K, lda, ldb, N, 1, splitk, 1 if coresident else 0, S())
     return out
+
+
+def gemm8_nt(A, B, bias=None, out_dtype=None, M=None, N=None, K=None, lda=None, ldb=None):
+    """C[M][N] = A[M][K] * B[N][K]^T (+bias) on the 256x256 phase-split kernel (bf16 operands, K % 64 == 0)."""
+    M = A.shape[-2] if M is None else M
+    N = B.shape[-2] if N is None else N
+    K = A.shape[-1] if K is None else K
+    lda = A.stride(-2) if lda is None else lda
+    ldb = B.stride(-2) if ldb is None else ldb
+    out = torch.empty((M, N), dtype=out_dtype or A.dtype, device=A.device)
+    call("ds2_gemm8_nt", P(A), P(B), P(out), PF(bias), M, N, K, lda, ldb, N, 1 if out.dtype == torch.float32 else 0, S())
+    return out
+
+
+def gemm8_tn_grouped(problems, K):
+    """problems: list of dicts(At, Bt, M, N, lda, ldb[, At2, lda2, m_split][, out]); every product C[M][N] f32 = sum_{k<K} At[k][m] Bt[k][n]
+    in one launch.  Returns the list of outputs."""
+    n = len(problems)
+    outs = []
+    for pr in problems:
+        o = pr.get("out")
+        if o is None:
+            o = torch.empty((pr["M"], pr["N"]), dtype=torch.float32, device=pr["At"].device)
+        outs.append(o)
+    vp = C.c_void_p * n
+    ia, la = C.c_int * n, C.c_long * n
+    At = vp(*[pr["At"].data_ptr() for pr in problems])
+    At2 = vp(*[(pr["At2"].data_ptr() if pr.get("At2") is not None else 0) for pr in problems])
+    ms = ia(*[int(pr.get("m_split", 0)) for pr in problems])
+    Bt = vp(*[pr["Bt"].data_ptr() for pr in problems])
+    Cs = vp(*[o.data_ptr() for o in outs])
+    Ms, Ns = ia(*[pr["M"] for pr in problems]), ia(*[pr["N"] for pr in problems])
+    lda, ldb = la(*[pr["lda"] for pr in problems]), la(*[pr["ldb"] for pr in problems])
+    lda2 = la(*[int(pr.get("lda2", 0)) for pr in problems])
+    ldc = la(*[o.stride(0) for o in outs])
+    for pr in problems:
+        P(pr["At"]), P(pr["Bt"])            # refuses CPU tensors
+    call("ds2_gemm8_tn_grouped", n, At, At2, ms, Bt, Cs, Ms, Ns, lda, lda2, ldb, ldc, K, S())
+    return outs
 
 
 def colsum(X, R=None, Cc=None, ld=None, scale=1.0):
@@ -407,9 +477,10 @@ def greedy_decode(scores, sizes, blank):
 
 
 def ctc_loss_grad(logits, targets_i32, target_offsets, input_lengths, target_lengths, Tp, N, Cc, blank, max_target_len,
-                  ldg=32):
+                  ldg=None):
     """logits [Tp*N][ld] f32.  Returns (loss_sum [1], nll [N], dlogits [Tp*N][ldg] f32 with unit upstream gradient)."""
     dev = logits.device
+    ldg = logits.shape[1] if ldg is None else ldg
     nll = torch.empty(N, dtype=torch.float32, device=dev)
     loss = torch.empty(1, dtype=torch.float32, device=dev)
     dlogits = torch.empty((Tp * N, ldg), dtype=torch.float32, device=dev)

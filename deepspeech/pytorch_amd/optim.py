@@ -69,7 +69,7 @@ class _FusedStep:
             buf = self._layouts = {}
         if key not in buf:
             bt = torch.bfloat16
-            buf[key] = dict(Wih=torch.empty((D * GH, Io), dtype=bt, device=dev), Whh=torch.empty((D, GH, H), dtype=bt, device=dev),
+            buf[key] = dict(Wih=ops.empty_padded(D * GH, Io, bt, dev), Whh=torch.empty((D, GH, H), dtype=bt, device=dev),
                             WihT=torch.empty((Io, D * GH), dtype=bt, device=dev), WhhT=torch.empty((D, H, GH), dtype=bt, device=dev))
         return buf[key]
 
@@ -103,7 +103,7 @@ class _FusedStep:
         clip = self._clip(grads, dev)
         plan = self._plan()
         m = self._model
-        emit = m is not None and m.training and m.compute_dtype() == torch.bfloat16
+        emit = m is not None and m.training and m.compute_dtype() == torch.bfloat16 and m._Hp == m.rnns[0].hidden_size
         small = {}
         touched = {}
         for (gi, p, _, s1, s2), g in zip(entries, grads):
@@ -120,7 +120,7 @@ class _FusedStep:
                 io_layer = plan[id(layer.rnn.weight_ih_l0)][5]          # padded input width of this layer's W_ih layouts
                 L = self._layout_buffers(li, D, GH, layer.hidden_size, io_layer, dev)
                 if kind == "ih":
-                    dst, ldd, dstT, lddT = L["Wih"][d * GH:], L["Wih"].shape[1], L["WihT"][:, d * GH:], D * GH
+                    dst, ldd, dstT, lddT = L["Wih"][d * GH:], L["Wih"].stride(0), L["WihT"][:, d * GH:], D * GH
                 else:
                     dst, ldd, dstT, lddT = L["Whh"][d], Cc, L["WhhT"][d], GH
                 touched[li] = (L, D)

@@ -61,6 +61,19 @@ int ds2_gemm_nt_coresident(int dtype, const void* A, const void* B, void* C, con
                            long ldb, long ldc, int out_f32, int batch, long strideA, long strideB, long strideC, long strideBias,
                            int splitk, ds2_stream_t stream);
 
+/* 256x256-tile bf16 kernel with a phase-split schedule (csrc/ds2_gemm8.hip) for the large contractions of the step.
+ * ds2_gemm8_nt: same product as ds2_gemm_nt (bf16 operands; C bf16 or f32); K % 64 == 0, lda/ldb % 8 == 0.  The input
+ * projections of torch's GRU/LSTM and the dX products of their backward (model.py:97-99).
+ * ds2_gemm8_tn_grouped: n_problems (<= 6) products C_i[M_i][ldc_i] f32 = sum_{k<K} At_i[k][m] * Bt_i[k][n] in ONE launch -- both
+ * operands K-major, i.e. stored as the activations are ([T'*N rows][features]): the weight gradients dW_ih = dGI^T X and
+ * dW_hh = dGH^T h_prev of the recurrent layers' backward without operand transposes.  At2_i (may be NULL): output rows >=
+ * m_split_i (a multiple of 256) take their operand columns from At2_i (column m - m_split_i, leading dimension lda2_i) -- the GRU's hidden-side
+ * gate gradient [dr, dz | dQ] lives in two buffers.  Any K (no row past K - 1 is read); M_i, N_i, lda, ldb % 8 == 0. */
+int ds2_gemm8_nt(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long lda, long ldb, long ldc, int out_f32,
+                 ds2_stream_t stream);
+int ds2_gemm8_tn_grouped(int n_problems, const void* const* At, const void* const* At2, const int* m_split, const void* const* Bt, void* const* C,
+                         const int* M, const int* N, const long* lda, const long* lda2, const long* ldb, const long* ldc, int K, ds2_stream_t stream);
+
 /* ---- BatchNorm (model.py:159,162 BatchNorm2d in NFTC; model.py:28-33,86,196 SequenceWise BatchNorm1d) ---------------
  * mode 0: sequence matrix X[R][ldx], C features.   mode 1: conv activation NFTC (R = N*F*Tp rows, C = 32): output also
  * gets Hardtanh(0,20) (model.py:160,163) and the MaskConv time mask (model.py:61-68; t >= lens[n] -> 0).

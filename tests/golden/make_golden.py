@@ -76,13 +76,30 @@ CASES = [
     dict(name="gru_bi_1024_l5_n32", rnn_type="gru", hidden_size=1024, hidden_layers=5, bidirectional=True,
          lengths=[301, 300, 298, 297, 295, 293, 291, 290, 288, 286, 284, 282, 281, 279, 277, 275, 273, 272, 270, 268, 266, 264,
                   262, 260, 258, 256, 254, 252, 249, 247, 244, 241], data_seed=25, param_seed=115, stride=4001),
+    # ---- round 3 --------------------------------------------------------------------------------------------------------
+    # the reference's OWN test model (tests/smoke_test.py:216-219: BiDirectionalConfig(hidden_size=10, hidden_layers=1), default
+    # cell = LSTM, batch_size=10): a hidden size that is not a multiple of the 16-unit MFMA tile
+    dict(name="lstm_bi_h10_n10", rnn_type="lstm", hidden_size=10, hidden_layers=1, bidirectional=True,
+         lengths=[151, 143, 131, 120, 111, 97, 84, 70, 61, 45], data_seed=31, param_seed=131),
+    # what else the reference accepts and the kernels used to refuse: 45 output classes (> 32), lookahead context 40 (> 32;
+    # train_config.py:55 is a free int), hidden size 50
+    dict(name="gru_uni_h50_la40_c45", rnn_type="gru", hidden_size=50, hidden_layers=2, bidirectional=False,
+         lookahead_context=40, n_labels=45, lengths=[141, 120, 93, 66], data_seed=32, param_seed=132),
+    dict(name="rnn_bi_h24_c40", rnn_type="rnn", hidden_size=24, hidden_layers=2, bidirectional=True, n_labels=40,
+         lengths=[99, 80, 55], data_seed=33, param_seed=133),
+    # configs[4] at its own DEPTH (7 layers) and width (LSTM-1280), bi-directional and uni-directional + Lookahead, 18 clips (two
+    # 16-sample m-tiles per group in the general persistent kernels), clips shortened so that the float64 CPU run stays in minutes
+    dict(name="lstm_bi_1280_l7_n18", rnn_type="lstm", hidden_size=1280, hidden_layers=7, bidirectional=True,
+         lengths=[81, 80, 78, 77, 75, 73, 71, 70, 68, 66, 64, 62, 61, 59, 57, 55, 53, 51], data_seed=34, param_seed=134, stride=8009),
+    dict(name="lstm_uni_1280_la_l7_n18", rnn_type="lstm", hidden_size=1280, hidden_layers=7, bidirectional=False, lookahead_context=20,
+         lengths=[83, 81, 80, 78, 75, 74, 71, 69, 68, 65, 64, 61, 60, 58, 56, 54, 52, 50], data_seed=35, param_seed=135, stride=8009),
 ]
 
 
 def make_batch(case):
     lengths = np.asarray(case["lengths"], dtype=np.int64)
     inputs, targets, pct, tsz = synth.synth_batch(lengths, case["data_seed"],
-                                                  chars_per_second=case.get("chars_per_second", 12.0))
+                                                  chars_per_second=case.get("chars_per_second", 12.0), n_labels=case.get("n_labels", 29))
     if "long_target_sample" in case:   # make one sample infeasible: more labels than output frames
         i = case["long_target_sample"]
         rs = np.random.RandomState(case["data_seed"] + 999)
@@ -108,9 +125,13 @@ def make_params(case, shapes):
     return P
 
 
+def case_labels(ns, case):
+    return ref_harness.extended_labels(case["n_labels"]) if "n_labels" in case else ns.labels
+
+
 def fresh_model(ns, case, P, double=False):
     model = ref_harness.build_reference_model(ns, case["rnn_type"], case["hidden_size"], case["hidden_layers"],
-                                              case["bidirectional"], case.get("lookahead_context", 20))
+                                              case["bidirectional"], case.get("lookahead_context", 20), labels=case_labels(ns, case))
     model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in P.items()}, strict=True)
     return model.double() if double else model
 
@@ -138,7 +159,7 @@ def main():
             continue
         stride = case.get("stride", STRIDE)
         probe = ref_harness.build_reference_model(ns, case["rnn_type"], case["hidden_size"], case["hidden_layers"],
-                                                  case["bidirectional"], case.get("lookahead_context", 20))
+                                                  case["bidirectional"], case.get("lookahead_context", 20), labels=case_labels(ns, case))
         shapes = {k: tuple(v.shape) for k, v in probe.state_dict().items()}
         P = make_params(case, shapes)
         inputs, targets, pct, tsz = make_batch(case)
@@ -208,7 +229,7 @@ def main():
         with torch.no_grad():
             probs, sizes, hs = mev(x, input_sizes)
         out["eval_probs"] = probs.numpy()
-        dec = ns.GreedyDecoder(ns.labels)
+        dec = ns.GreedyDecoder(case_labels(ns, case))
         strings, _ = dec.decode(probs, sizes)
         transcripts = [s[0] for s in strings]
         # ---- hidden-state carry (inference.py:86-96): batch 1, feed hs back in
@@ -225,6 +246,7 @@ def main():
             out["carry_h_last"] = hs2[-1].numpy()
         meta = dict(case)
         meta["transcripts"] = transcripts
+        meta["labels"] = case_labels(ns, case)
         meta["shapes"] = {k: list(v) for k, v in shapes.items()}
         meta["torch_version"] = torch.__version__
         meta["big"] = BIG

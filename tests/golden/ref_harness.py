@@ -113,8 +113,17 @@ def load_reference():
     return ns
 
 
+def extended_labels(n):
+    """A label set of n symbols in the reference's labels.json convention (blank '_' first): its 29 symbols, then digits and
+    punctuation -- for models with more output classes than the English set (the reference takes any labels file, model.py:154)."""
+    base = ["_", "'"] + [chr(ord("A") + i) for i in range(26)] + [" "]
+    extra = list("0123456789.,?!-:;()[]{}<>/\\@#$%^&*+=~|abcdefghijklmnopqrstuvwxyz")
+    assert n <= len(base) + len(extra)
+    return (base + extra)[:n] if n > len(base) else base[:n]
+
+
 def build_reference_model(ns, rnn_type="gru", hidden_size=32, hidden_layers=2, bidirectional=True,
-                          lookahead_context=20, seed=0):
+                          lookahead_context=20, seed=0, labels=None):
     torch.manual_seed(seed)
     rt = getattr(ns.RNNType, rnn_type)
     if bidirectional:
@@ -122,6 +131,6 @@ def build_reference_model(ns, rnn_type="gru", hidden_size=32, hidden_layers=2, b
     else:
         mcfg = ns.UniDirectionalConfig(rnn_type=rt, hidden_size=hidden_size, hidden_layers=hidden_layers,
                                        lookahead_context=lookahead_context)
-    model = ns.DeepSpeech(labels=ns.labels, model_cfg=mcfg, precision=32, optim_cfg=ns.AdamConfig(),
+    model = ns.DeepSpeech(labels=labels if labels is not None else ns.labels, model_cfg=mcfg, precision=32, optim_cfg=ns.AdamConfig(),
                           spect_cfg=ns.SpectConfig())
     return model

@@ -1,0 +1,87 @@
+"""The 256x256 phase-split bf16 GEMM kernels (csrc/ds2_gemm8.hip) against fp32 products of the same bf16 operands computed by torch
+on the device: NT (input projections / dX, reference model.py:97-99) and grouped TN (weight gradients: both operands K-major).
+Shapes cover edge tiles in M and N, 1 / 2 / odd / even numbers of K-tiles (prologue and drain paths of the DMA pipeline), bias,
+both output types, several problems per launch and the two-buffer A operand of the GRU's hidden-side gradient."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rand(shape, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.rand(shape, generator=g) * 2 - 1).to(DEV).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("M,N,K,f32,bias", [
+    (256, 256, 64, True, False),          # one tile, one K-tile
+    (300, 520, 128, False, True),         # edge tiles in M and N, two K-tiles
+    (1000, 264, 192, True, True),         # three K-tiles
+    (2048, 1344, 320, False, False),      # five K-tiles, N = the padded conv feature count
+    (24032, 1024, 1024, False, True),     # cfg3's dX / input-projection row count
+])
+def test_gemm8_nt_matches_fp32_product(M, N, K, f32, bias):
+    from deepspeech.pytorch_amd import ops
+    A, B = _rand((M, K), 1), _rand((N, K), 2)
+    bv = torch.linspace(-1, 1, N, device=DEV) if bias else None
+    ref = A.float() @ B.float().t()
+    if bias:
+        ref = ref + bv
+    for rep in range(2):                                                    # a second launch: no state carried between launches
+        C = ops.gemm8_nt(A, B, bias=bv, out_dtype=torch.float32 if f32 else None)
+        assert C.dtype == (torch.float32 if f32 else torch.bfloat16) and tuple(C.shape) == (M, N)
+        err = (C.float() - ref).abs().max().item() / ref.abs().max().item()
+        assert err < (2e-5 if f32 else 6e-3), (M, N, K, err)
+
+
+def test_gemm8_nt_strided_operand_views():
+    """A and B as column windows of wider matrices (the layer-0 input projection reads a [T'N][1344] window)."""
+    from deepspeech.pytorch_amd import ops
+    Aw, Bw = _rand((700, 512), 3), _rand((300, 384), 4)
+    A, B = Aw[:, 128:384], Bw[:, 64:320]                                    # K = 256, lda = 512, ldb = 384
+    C = ops.gemm8_nt(A, B, out_dtype=torch.float32, M=700, N=300, K=256, lda=512, ldb=384)
+    ref = A.float() @ B.float().t()
+    assert (C - ref).abs().max().item() / ref.abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("K", [64, 128, 192, 448, 40, 100, 333])
+def test_gemm8_tn_grouped_matches_fp32_products(K):
+    from deepspeech.pytorch_amd import ops
+    # three products of different shapes in one launch; the second has its A operand in two buffers (rows >= 512 from At2)
+    # (ragged K: the rows past K - 1 of the last K-tile are neither read nor used -- the operands end exactly at row K - 1, and
+    # the neighbouring allocation is poisoned with NaN)
+    At0, Bt0 = _rand((K, 520), 5), _rand((K, 264), 6)
+    poison = torch.full((1 << 20,), float("nan"), device=DEV)
+    At1, At1b, Bt1 = _rand((K, 768), 7), _rand((K, 256), 8), _rand((K, 256), 9)
+    At2w, Bt2w = _rand((K, 1024), 10), _rand((K, 640), 11)
+    probs = [dict(At=At0, Bt=Bt0, M=520, N=264, lda=520, ldb=264),
+             dict(At=At1, At2=At1b, lda2=256, m_split=512, Bt=Bt1, M=768, N=256, lda=768, ldb=256),
+             dict(At=At2w[:, 256:], Bt=Bt2w[:, 128:], M=768, N=512, lda=1024, ldb=640)]
+    outs = ops.gemm8_tn_grouped(probs, K)
+    refs = [At0.float().t() @ Bt0.float(),
+            torch.cat([At1[:, :512], At1b], 1).float().t() @ Bt1.float(),
+            At2w[:, 256:].float().t() @ Bt2w[:, 128:].float()]
+    for o, r in zip(outs, refs):
+        assert tuple(o.shape) == tuple(r.shape)
+        err = (o - r).abs().max().item() / r.abs().max().item()
+        assert err < 2e-5, (K, tuple(o.shape), err)
+
+
+def test_gemm8_tn_weight_gradient_shape():
+    """cfg3's per-layer weight gradients as ONE grouped launch: dW_ih [6144][1024] and the two dW_hh [3072][1024] with the GRU's
+    [dr, dz | dQ] operand split, contraction over a zero-padded T'N = 2 x 1504 rows (a short sequence keeps the check cheap)."""
+    from deepspeech.pytorch_amd import ops
+    R, H = 3008, 1024
+    dGI, X = _rand((R, 6 * H), 12), _rand((R, H), 13)
+    dQ, Hp = _rand((2, R, H), 14), _rand((2, R, H), 15)
+    probs = [dict(At=dGI, Bt=X, M=6 * H, N=H, lda=6 * H, ldb=H)]
+    for d in range(2):
+        # rows [0, 2H) of direction d's gate gradient come from dGI, rows [2H, 3H) from dQ
+        probs.append(dict(At=dGI[:, d * 3 * H:], At2=dQ[d], lda2=H, m_split=2 * H, Bt=Hp[d], M=3 * H, N=H, lda=6 * H, ldb=H))
+    outs = ops.gemm8_tn_grouped(probs, R)
+    refs = [dGI.float().t() @ X.float()]
+    for d in range(2):
+        refs.append(torch.cat([dGI[:, d * 3 * H:d * 3 * H + 2 * H], dQ[d]], 1).float().t() @ Hp[d].float())
+    for o, r in zip(outs, refs):
+        assert (o - r).abs().max().item() / r.abs().max().item() < 2e-5

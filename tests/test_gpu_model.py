@@ -22,7 +22,7 @@ def build(fx, precision=32):
     else:
         mc = configs.UniDirectionalConfig(rnn_type=rt, hidden_size=c["hidden_size"], hidden_layers=c["hidden_layers"],
                                           lookahead_context=c["lookahead_context"])
-    m = DeepSpeech(labels=configs.LABELS, model_cfg=mc, precision=precision, optim_cfg=configs.AdamConfig(),
+    m = DeepSpeech(labels=fx.labels, model_cfg=mc, precision=precision, optim_cfg=configs.AdamConfig(),
                    spect_cfg=configs.SpectConfig())
     sd = {k: torch.from_numpy(v.copy()) for k, v in fx.params().items()}
     m.load_state_dict(sd, strict=True)     # reference state_dict keys/shapes load unchanged
@@ -95,7 +95,7 @@ def test_fp32_logits_eval_transcripts_and_carry(name):
     p = probs.cpu().numpy()
     assert np.abs(p - fx.z["eval_probs"]).max() <= 1e-4
     from deepspeech.pytorch_amd import configs
-    assert O.greedy_decode(p, sizes2.numpy(), configs.LABELS) == fx.meta["transcripts"]   # identical transcripts
+    assert O.greedy_decode(p, sizes2.numpy(), fx.labels) == fx.meta["transcripts"]        # identical transcripts
     # hidden-state carry, reference inference.py:86-96
     t0 = int(fx.lengths[0])
     x1, l1 = x[:1, :, :, :t0].contiguous(), torch.tensor([t0], dtype=torch.int)

@@ -50,7 +50,7 @@ def build_model(fx):
     else:
         mc = configs.UniDirectionalConfig(rnn_type=rt, hidden_size=c["hidden_size"], hidden_layers=c["hidden_layers"],
                                           lookahead_context=c["lookahead_context"])
-    return DeepSpeech(labels=configs.LABELS, model_cfg=mc, precision=32, optim_cfg=configs.AdamConfig(),
+    return DeepSpeech(labels=fx.labels, model_cfg=mc, precision=32, optim_cfg=configs.AdamConfig(),
                       spect_cfg=configs.SpectConfig())
 
 

@@ -61,8 +61,7 @@ def test_eval_forward_and_transcripts(name):
     assert np.array_equal(sizes, fx.z["input_sizes"])
     out, out_lens, hs, _ = O.model_forward(P, fx.cfg, inputs.astype(np.float64), sizes, train=False, keep_cache=False)
     assert np.abs(out - fx.z["eval_probs"]).max() < 2e-5
-    labels = ["_", "'"] + [chr(ord("A") + i) for i in range(26)] + [" "]
-    assert O.greedy_decode(out, out_lens, labels) == fx.meta["transcripts"]
+    assert O.greedy_decode(out, out_lens, fx.labels) == fx.meta["transcripts"]
     # hidden-state carry (reference inference.py:86-96)
     t0 = int(fx.lengths[0])
     x1 = inputs[:1, :, :, :t0].astype(np.float64)

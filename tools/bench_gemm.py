@@ -36,3 +36,66 @@ for name, M, N, K, f32, sk in shapes:
     ref = (A[rows].float() @ B.float().t())
     err = (C[rows].float() - ref).abs().max().item() / ref.abs().max().item()
     assert err < (1e-5 if f32 else 6e-3), (name, err)
+    if K % 64 == 0 and N >= 256:
+        ts = []
+        for it in range(12):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            C8 = ops.gemm8_nt(A, B, out_dtype=torch.float32 if f32 else None)
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        t = sorted(ts[2:])[len(ts[2:]) // 2]
+        err = (C8[rows].float() - ref).abs().max().item() / ref.abs().max().item()
+        print("   gemm8 256x256 phase-split:            %.3f ms  %.0f TFLOP/s  (err %.1e)" % (t, 2.0 * M * N * K / t / 1e9, err))
+# grouped TN: one layer's weight gradients of cfg3 (dW_ih + 2 x dW_hh with the [dr, dz | dQ] split) in one launch
+R, H = 24064, 1024
+dGI = torch.randn(R, 6 * H, device=dev).to(torch.bfloat16)
+X = torch.randn(R, H, device=dev).to(torch.bfloat16)
+dQ = torch.randn(2, R, H, device=dev).to(torch.bfloat16)
+Hp = torch.randn(2, R, H, device=dev).to(torch.bfloat16)
+probs = [dict(At=dGI, Bt=X, M=6 * H, N=H, lda=6 * H, ldb=H)]
+for d in range(2):
+    probs.append(dict(At=dGI[:, d * 3 * H:], At2=dQ[d], lda2=H, m_split=2 * H, Bt=Hp[d], M=3 * H, N=H, lda=6 * H, ldb=H))
+ts = []
+for it in range(12):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    outs = ops.gemm8_tn_grouped(probs, R)
+    e1.record()
+    torch.cuda.synchronize()
+    ts.append(e0.elapsed_time(e1))
+t = sorted(ts[2:])[len(ts[2:]) // 2]
+fl = 2.0 * R * (6 * H * H + 2 * 3 * H * H)
+ref = dGI[:, :256].float().t() @ X.float()
+print("grouped TN weight gradients of one cfg3 layer (192 tiles, K = %d): %.3f ms  %.0f TFLOP/s  (err %.1e)" % (
+    R, t, fl / t / 1e9, (outs[0][:256] - ref).abs().max().item() / ref.abs().max().item()))
+# leading-dimension sensitivity of the K = 1024 input projection (row stride 2048 B = a power of two: channel camping?)
+for ld in (1024, 1032, 1088, 1152):
+    M, N, K = 24032, 6144, 1024
+    Aw = torch.randn(M, ld, device=dev).to(torch.bfloat16)
+    Bw = torch.randn(N, ld, device=dev).to(torch.bfloat16)
+    ts = []
+    for it in range(12):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        C8 = ops.gemm8_nt(Aw, Bw, M=M, N=N, K=K, lda=ld, ldb=ld)
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    t = sorted(ts[2:])[len(ts[2:]) // 2]
+    print("i2h K=1024 with lda = ldb = %d: %.3f ms  %.0f TFLOP/s" % (ld, t, 2.0 * M * N * K / t / 1e9))
+for Kx in (1024, 2048, 4096):
+    M, N = 24032, 6144
+    Aw = torch.randn(M, Kx + 64, device=dev).to(torch.bfloat16)
+    Bw = torch.randn(N, Kx + 64, device=dev).to(torch.bfloat16)
+    ts = []
+    for it in range(8):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        C8 = ops.gemm8_nt(Aw, Bw, M=M, N=N, K=Kx, lda=Kx + 64, ldb=Kx + 64)
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    t = sorted(ts[2:])[len(ts[2:]) // 2]
+    print("M=24032 N=6144 K=%d (ld K+64): %.3f ms  %.0f TFLOP/s" % (Kx, t, 2.0 * M * N * Kx / t / 1e9))

@@ -72,6 +72,74 @@ extern "C" __global__ void __launch_bounds__(256, 1) k_lds(int iters, uint32_t* 
   }
   if (sink) sink[blockIdx.x * 256 + threadIdx.x] = s;
 }
+// (d) global loads into registers (L2-resident source, through the CU's texture-address / L1 path), 8 x 16 B in flight per lane
+extern "C" __global__ void __launch_bounds__(256, 1) k_gload(const uint4* __restrict__ src, long n_chunks, int iters, uint32_t* sink) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  long pos = ((long)blockIdx.x * 4 + wave) * 64 * 8;
+  uint32_t s = 0;
+  for (int it = 0; it < iters; ++it) {
+    uint4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = src[(pos + (long)j * 64 + lane) % n_chunks];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[j].x ^ v[j].w;
+    pos += 64 * 8 * 4 * (long)gridDim.x;
+  }
+  if (sink) sink[blockIdx.x * 256 + threadIdx.x] = s;
+}
+// (e) VALU only: four independent fma chains per lane
+extern "C" __global__ void __launch_bounds__(256, 1) k_valu(int iters, float* sink) {
+  float a = threadIdx.x, b = 1.f, c = 2.f, d = 3.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { a = fmaf(a, 1.0001f, 0.5f); b = fmaf(b, 0.9999f, 0.25f); c = fmaf(c, 1.0002f, 0.125f); d = fmaf(d, 0.9998f, 0.0625f); }
+  }
+  if (sink) sink[blockIdx.x * 256 + threadIdx.x] = a + b + c + d;
+}
+// (f) matrix pipe with the short instruction (16x16x32: 16 cycles of pipe per instruction instead of 32)
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+extern "C" __global__ void __launch_bounds__(256, 1) k_mfma16(int iters, float* sink) {
+  f32x4 acc[8];
+  for (int i = 0; i < 8; ++i)
+    for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+  bf16x8 a, b;
+  for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(float)(threadIdx.x + i); b[i] = (__bf16)(float)(i + 1); }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+  }
+  if (sink) sink[blockIdx.x * 256 + threadIdx.x] = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] + acc[4][0] + acc[5][1] + acc[6][2] + acc[7][3];
+}
+// (g) matrix pipe at ~1/3 duty: 4 x 32x32x16 (128 cycles of pipe), then ~256 cycles asleep
+extern "C" __global__ void __launch_bounds__(256, 1) k_mfma_duty(int iters, float* sink) {
+  f32x16 acc[4];
+  for (int i = 0; i < 4; ++i)
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  bf16x8 a, b;
+  for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(float)(threadIdx.x + i); b[i] = (__bf16)(float)(i + 1); }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+    __builtin_amdgcn_s_sleep(4);
+  }
+  if (sink) sink[blockIdx.x * 256 + threadIdx.x] = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3];
+}
+extern "C" int run_gload(const void* src, long n_chunks, int iters, void* sink, int grid, void* st) {
+  hipLaunchKernelGGL(k_gload, dim3(grid), dim3(256), 0, (hipStream_t)st, (const uint4*)src, n_chunks, iters, (uint32_t*)sink);
+  return (int)hipGetLastError();
+}
+extern "C" int run_valu(int iters, void* sink, int grid, void* st) {
+  hipLaunchKernelGGL(k_valu, dim3(grid), dim3(256), 0, (hipStream_t)st, iters, (float*)sink);
+  return (int)hipGetLastError();
+}
+extern "C" int run_mfma16(int iters, void* sink, int grid, void* st) {
+  hipLaunchKernelGGL(k_mfma16, dim3(grid), dim3(256), 0, (hipStream_t)st, iters, (float*)sink);
+  return (int)hipGetLastError();
+}
+extern "C" int run_mfma_duty(int iters, void* sink, int grid, void* st) {
+  hipLaunchKernelGGL(k_mfma_duty, dim3(grid), dim3(256), 0, (hipStream_t)st, iters, (float*)sink);
+  return (int)hipGetLastError();
+}
 extern "C" int run_dma(const void* src, long n_chunks, int iters, void* sink, int grid, void* st) {
   hipLaunchKernelGGL(k_dma, dim3(grid), dim3(256), 0, (hipStream_t)st, (const uint4*)src, n_chunks, iters, (uint32_t*)sink);
   return (int)hipGetLastError();
@@ -123,6 +191,10 @@ def main():
         "dma (global -> LDS, 8 x 1 KB per wave and iteration)": lambda it, st: L.run_dma(P(big), ctypes.c_long(big.numel() // 16), it, P(sink), 256, S(st)),
         "mfma (4 x 32x32x16 per wave and iteration)": lambda it, st: L.run_mfma(it, P(sink), 256, S(st)),
         "lds (8 x ds_read_b128 per lane and iteration)": lambda it, st: L.run_lds(it, P(sink), 256, S(st)),
+        "gload (8 x 16-B global loads to registers per lane)": lambda it, st: L.run_gload(P(big), ctypes.c_long(big.numel() // 16), it, P(sink), 256, S(st)),
+        "valu (64 dependent-chain fmas per lane and iteration)": lambda it, st: L.run_valu(it, P(sink), 256, S(st)),
+        "mfma16 (8 x 16x16x32 per wave and iteration)": lambda it, st: L.run_mfma16(it, P(sink), 256, S(st)),
+        "mfma at ~1/3 duty (4 x 32x32x16, s_sleep 4)": lambda it, st: L.run_mfma_duty(it, P(sink), 256, S(st)),
     }
 
     def sweep_ms(before=None):
@@ -154,6 +226,38 @@ def main():
         t = sweep_ms(lambda: run(it, side))
         print("next to {:<52s} (rc {}, {} iterations, {:.2f} ms alone per 1000): {:.3f} ms = {:.2f} us per time step (+{:.2f})".format(
             name, rc, it, alone, t, t * 1e3 / Tp, (t - base) * 1e3 / Tp))
+    # the real thing: the low-register weight-gradient GEMM (dW_ih shape of cfg3: [6144][1024] = dGI^T [6144][K] x Xh^T [1024][K], K = T'N)
+    Kp = (Tp * N + 63) // 64 * 64
+    At = torch.randn(D * G * H, Kp, device=dev).to(torch.bfloat16)
+    Bt = torch.randn(H, Kp, device=dev).to(torch.bfloat16)
+    for cores, label in ((True, "co-resident 128x128 low-register GEMM (x4 launches)"), (False, "full-size-tile GEMM (x4 launches; cannot share the CUs)")):
+        def run_gemm(cores=cores):
+            with torch.cuda.stream(side):
+                for _ in range(4):
+                    ops.gemm_nt(At, Bt, out_dtype=torch.float32, coresident=cores)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(side)
+        run_gemm()
+        e1.record(side)
+        torch.cuda.synchronize()
+        alone = e0.elapsed_time(e1)
+        ts = []
+        for _ in range(4):
+            torch.cuda.synchronize()
+            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g0.record(side)
+            run_gemm()
+            g1.record(side)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ops.rnn_bwd(kind, dout, WhhT, hext, Sv, lens, D, N, H, Tp)
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append((e0.elapsed_time(e1), g0.elapsed_time(g1)))
+        t, tg = min(ts[1:])
+        print("next to {:<58s}: sweep {:.3f} ms = {:.2f} us per time step (+{:.2f}); the GEMMs {:.3f} ms alone, {:.3f} ms beside the sweep".format(
+            label, t, t * 1e3 / Tp, (t - base) * 1e3 / Tp, alone, tg))
     ops.check_persistent_kernels()
 
 
