@@ -310,7 +310,10 @@ def main():
     rank, world, local_rank = dsdist.init_from_env("nccl")
     device = torch.device("cuda", local_rank)
     if args.gpus != world:
-        raise SystemExit("--gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+        # a launcher decided the rank count (e.g. `torchrun --nproc-per-node 8 bench.py` with the default --gpus 1): follow it
+        if rank == 0:
+            log("--gpus %d but the launcher started WORLD_SIZE=%d ranks: reporting n_gpus = %d" % (args.gpus, world, world))
+        args.gpus = world
 
     runner = run_stock if args.stock else run_native
     log("start %s on %d rank(s), config %s" % ("stock" if args.stock else "native", world, args.config))

@@ -41,6 +41,7 @@ SIGNATURES = {
     "ds2_rnn_state_bytes": (_l, [_i, _i, _i]),
     "ds2_rnn_fwd": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp]),
     "ds2_rnn_bwd": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp]),
+    "ds2_rnn_persist_set_spin_limit": (C.c_uint, [C.c_uint]),
     "ds2_rnn_persist_supported": (_i, [_i, _i, _i, _i, _i]),
     "ds2_rnn_persist_ws_bytes": (_l, [_i, _i, _i, _i, _i]),
     "ds2_rnn_persist_fwd": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -44,6 +44,13 @@ int dispatch(bool bwd, int cell, int H, const PArgs& a, hipStream_t st) {
 // signature, and the error word counts as raised only when it is 1.
 constexpr long AUX_BYTES = 4096;
 
+unsigned g_spin_limit = 0;   // 0 = the kernels' own SPIN_LIMIT; tests lower it (ds2_rnn_persist_set_spin_limit)
+// [3076] of the scratch head: the launch's spin budget (all-ones after the reset = none beyond SPIN_LIMIT)
+int set_spin_budget(void* ws, hipStream_t st) {
+  if (g_spin_limit == 0) return 0;
+  return (int)hipMemsetD32Async((hipDeviceptr_t)((char*)ws + 3076), (int)g_spin_limit, 1, st);
+}
+
 int gates(int cell) { return cell == CELL_GRU ? 3 : cell == CELL_LSTM ? 4 : 1; }
 
 long xbuf_bytes(int cell, int H, bool bwd) {
@@ -101,6 +108,14 @@ int ds2_rnn_persist_supported(int dtype, int cell, int D, int N, int H) {
   return plan2(dtype, cell, D, N, H, pl) ? 1 : 0;
 }
 
+// Fault-injection hook for tests: polls a waiting workgroup may spend on one exchange before it gives up (raises *err, poisons its
+// outputs with NaN and ends); 0 restores the built-in budget (~seconds).  Returns the previous value.  Process-wide.
+unsigned ds2_rnn_persist_set_spin_limit(unsigned polls) {
+  const unsigned old = g_spin_limit;
+  g_spin_limit = polls;
+  return old;
+}
+
 // scratch bytes of one sweep (exchange buffer for the larger of the forward / BPTT needs + the head described above)
 long ds2_rnn_persist_ws_bytes(int dtype, int cell, int D, int N, int H) {
   if (tuned_ok(dtype, cell, D, N, H)) return AUX_BYTES + xbuf_bytes(cell, H, true);
@@ -119,6 +134,7 @@ int ds2_rnn_persist_fwd(int dtype, int cell, int D, int N, int H, int Tp, const 
   if (tuned_ok(dtype, cell, D, N, H)) {
     hipError_t e = hipMemsetAsync(ws, 0xff, AUX_BYTES + xbuf_bytes(cell, H, false), st);   // 0xFF: see gather_mma_tf
     if (e != hipSuccess) return (int)e;
+    if (int r = set_spin_budget(ws, st)) return r;
     PArgs a{};
     a.N = N; a.Tp = Tp; a.D = D; a.gpd = NGROUPS / D; a.lens = lens; a.W = (const bf16_t*)Whh; a.bhh = bhh;
     a.GI = (const bf16_t*)GI; a.Hseq = (bf16_t*)Hseq; a.hseq_dstride = hseq_dstride; a.S = (bf16_t*)S; a.h0 = h0; a.c0 = c0;
@@ -135,6 +151,7 @@ int ds2_rnn_persist_fwd(int dtype, int cell, int D, int N, int H, int Tp, const 
   const long xb = xbuf2_bytes(dtype, cell, H, pl, false);
   hipError_t e = hipMemsetAsync(ws, 0xff, AUX_BYTES + xb, st);
   if (e != hipSuccess) return (int)e;
+  if (int r = set_spin_budget(ws, st)) return r;
   ds2q::QArgs a{};
   a.N = N; a.Tp = Tp; a.D = D; a.gpd = pl.gpd; a.NG = pl.NG; a.lens = lens; a.W = Whh; a.bhh = bhh; a.GI = GI; a.Hseq = Hseq;
   a.hseq_dstride = hseq_dstride; a.S = S; a.h0 = h0; a.c0 = c0; a.hn = hn; a.cn = cn;
@@ -156,6 +173,7 @@ int ds2_rnn_persist_bwd(int dtype, int cell, int D, int N, int H, int Tp, const 
   if (tuned_ok(dtype, cell, D, N, H)) {
     hipError_t e = hipMemsetAsync(ws, 0xff, AUX_BYTES + xbuf_bytes(cell, H, true), st);
     if (e != hipSuccess) return (int)e;
+    if (int r = set_spin_budget(ws, st)) return r;
     PArgs a{};
     a.N = N; a.Tp = Tp; a.D = D; a.gpd = NGROUPS / D; a.lens = lens; a.W = (const bf16_t*)WhhT;
     a.Hseq = (bf16_t*)Hseq; a.hseq_dstride = hseq_dstride; a.S = (bf16_t*)S; a.dOut = (const bf16_t*)dOut;
@@ -172,6 +190,7 @@ int ds2_rnn_persist_bwd(int dtype, int cell, int D, int N, int H, int Tp, const 
   const long xb = xbuf2_bytes(dtype, cell, H, pl, true);
   hipError_t e = hipMemsetAsync(ws, 0xff, AUX_BYTES + xb, st);
   if (e != hipSuccess) return (int)e;
+  if (int r = set_spin_budget(ws, st)) return r;
   ds2q::QArgs a{};
   a.N = N; a.Tp = Tp; a.D = D; a.gpd = pl.gpd; a.NG = pl.NG; a.lens = lens; a.W = WhhT; a.Hseq = (void*)Hseq;
   a.hseq_dstride = hseq_dstride; a.S = (void*)S; a.dOut = dOut; a.dGI = dGI; a.dGH = dGH; a.dBacc = dBacc;

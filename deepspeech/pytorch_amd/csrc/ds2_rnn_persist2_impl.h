@@ -199,7 +199,7 @@ __device__ __forceinline__ void gather_mma2(ds2_f32x4 (&acc)[MT][RT], const uint
         DS2Q_LOAD(c, b)
         DS2Q_CHECK(b, bad1)
         if (!__any(bad1)) break;
-        if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(lerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1)) {
+        if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && spin_check(lerr, spins))) {
           dead = true;
           raise_err(err, lerr);
           break;
@@ -308,7 +308,7 @@ __device__ __forceinline__ void gather_mma2f(ds2_f32x4 (&acc)[MT][RT], const uin
         DS2Q_LOADF(c, b)
         DS2Q_CHECKF(c, b, bad1)
         if (!__any(bad1)) break;
-        if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(lerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1)) {
+        if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && spin_check(lerr, spins))) {
           dead = true;
           raise_err(err, lerr);
           break;

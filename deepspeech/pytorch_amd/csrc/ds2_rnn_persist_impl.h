@@ -105,6 +105,13 @@ __device__ __forceinline__ void publish(u64* p, u64 v, bool local) {
 
 // Start-up handshake (placement-independent sc1 protocol): every workgroup publishes its XCC id, waits for the 31 peers of
 // its group and returns true iff all 32 ids are equal.  Every member evaluates the same 32 words, so the group agrees.
+// Every 1024 polls of a wait: has a peer already given up (lerr[0] == 1), or has this wait outlived the launch's own spin budget
+// (lerr[1]: all-ones from the scratch reset = none beyond SPIN_LIMIT; ds2_rnn_persist_set_spin_limit lowers it for fault-injection
+// tests)?
+__device__ __forceinline__ bool spin_check(int* lerr, unsigned spins) {
+  return __hip_atomic_load(lerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1 ||
+         spins > (unsigned)__hip_atomic_load(lerr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ void raise_err(int* err, int* lerr) {
   __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_store(lerr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -124,7 +131,7 @@ __device__ __forceinline__ bool group_is_xcd_local(u64* slots /* this group's [3
         same = !(tid < 32) || ((unsigned)v == my);
         break;
       }
-      if (++spins > SPIN_LIMIT) {
+      if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && spin_check(lerr, spins))) {
         dead = true;
         raise_err(err, lerr);
         same = false;
@@ -240,7 +247,7 @@ __device__ __forceinline__ void gather_mma(ds2_f32x4 (&acc)[TILES], const uint4 
           if (!__any(bad2)) break;
           // give up after the spin limit, or early when a peer of THIS launch already did (the per-launch word lives in the
           // scratch that is reset before every launch: a time-out of an earlier launch never shortens this one's patience)
-          if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(lerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1)) {
+          if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && spin_check(lerr, spins))) {
             dead = true;
             raise_err(err, lerr);
             break;
@@ -350,7 +357,7 @@ __device__ __forceinline__ void gather_mma_tf(ds2_f32x4 (&acc)[TILES], const uin
           DS2_TF_LOAD()
           DS2_TF_CHECK(bad2)
           if (!__any(bad2)) break;
-          if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(lerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1)) {
+          if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && spin_check(lerr, spins))) {
             dead = true;
             raise_err(err, lerr);
             break;

@@ -180,6 +180,29 @@ def _unpad_gate_rows(g, G, H, Hp):
     return g.reshape((G, Hp) + tuple(g.shape[1:]))[:, :H].reshape((G * H,) + tuple(g.shape[1:])).contiguous()
 
 
+def _bn_seq_fwd(bn, w, b, X, Xh, R, Ct, Cp, training):
+    """SequenceWise BatchNorm1d over [R][Cp] rows whose real features are the first Ct columns (model.py:28-33, 86, 196).  Cp > Ct
+    only for hidden sizes that are not a multiple of the tile: the zero pad columns get gain 1 / shift 0 (they stay exactly 0 in
+    forward and backward) and the running statistics are updated through padded copies."""
+    if Ct == Cp:
+        return ops.bn_fwd(X, 0, training, w.detach(), b.detach(), bn.running_mean, bn.running_var, bn.num_batches_tracked, R, Ct,
+                          X.stride(0), Xh, Xh.stride(0), eps=bn.eps, momentum=bn.momentum)
+    g, be = w.new_ones(Cp), w.new_zeros(Cp)
+    rm, rv = w.new_zeros(Cp), w.new_ones(Cp)
+    g[:Ct], be[:Ct], rm[:Ct], rv[:Ct] = w.detach(), b.detach(), bn.running_mean, bn.running_var
+    sv = ops.bn_fwd(X, 0, training, g, be, rm, rv, bn.num_batches_tracked, R, Cp, X.stride(0), Xh, Xh.stride(0), eps=bn.eps,
+                    momentum=bn.momentum)
+    if training:
+        bn.running_mean.copy_(rm[:Ct])
+        bn.running_var.copy_(rv[:Ct])
+    return sv
+
+
+def _bn_seq_bwd(G, X, DX, sv, R, Ct, Cp):
+    dg, db = ops.bn_bwd(G, X, DX, 0, sv, R, Cp, G.stride(0), X.stride(0), DX.stride(0))
+    return (dg, db) if Ct == Cp else (dg[:Ct].contiguous(), db[:Ct].contiguous())
+
+
 def _perm_cols_to_internal(w):
     """rnns.0 weight_ih columns: reference feature c*41+f -> internal f*32+c, zero-padded to RNN_INPUT_LD columns."""
     g = w.shape[0]
@@ -301,13 +324,8 @@ class _RnnStackFn(torch.autograd.Function):
             sv, Xh = None, X
             if has_bn:
                 bn = layer.batch_norm.module
-                if H == Ht:
-                    Xh = ops.empty_padded(R, I, X.dtype, X.device)   # row stride off the power of two (GEMM operand)
-                else:
-                    Xh = torch.zeros((R, I), dtype=X.dtype, device=X.device)       # the pad columns must be clean zeros
-                sv = ops.bn_fwd(X, 0, training, bn_w.detach(), bn_b.detach(), bn.running_mean, bn.running_var,
-                                bn.num_batches_tracked, R, layer.input_size, X.stride(0), Xh, Xh.stride(0), eps=bn.eps,
-                                momentum=bn.momentum)
+                Xh = ops.empty_padded(R, I, X.dtype, X.device)       # row stride off the power of two (GEMM operand)
+                sv = _bn_seq_fwd(bn, bn_w, bn_b, X, Xh, R, layer.input_size, I, training)
             GI = ops.gemm_nt(Xh, Wih, bias=Bih)                                  # [R][D*G*H]
             h0, c0 = hs0[li], cs0[li]
             if H != Ht:
@@ -379,8 +397,8 @@ class _RnnStackFn(torch.autograd.Function):
             dGI = rg.dGI
             dXh = ops.gemm_nt(dGI, WihT)                                # [R][I]
             if has_bn:
-                dX = torch.empty_like(dXh) if H == Ht else torch.zeros_like(dXh)
-                grads[offs[li]], grads[offs[li] + 1] = ops.bn_bwd(dXh, X, dX, 0, sv, R, It, I, X.stride(0), I)
+                dX = torch.empty_like(dXh)
+                grads[offs[li]], grads[offs[li] + 1] = _bn_seq_bwd(dXh, X, dX, sv, R, It, I)
             else:
                 dX = dXh
             if ops.wgrad_tn_ok(dtype, R, D * GH, Xh.shape[1]) and ops.wgrad_tn_ok(dtype, R, GH, H):
@@ -608,9 +626,8 @@ class _HeadFn(torch.autograd.Function):
         H, Cp = mod._Hp, mod._Cp                     # internal (tile-aligned) width and class count
         R = Tp * N
         c = mod._cache
-        Xh = torch.empty_like(X) if H == Ht else torch.zeros_like(X)
-        sv = ops.bn_fwd(X, 0, training, bn_w.detach(), bn_b.detach(), bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                        R, Ht, H, Xh, H, eps=bn.eps, momentum=bn.momentum)
+        Xh = torch.empty_like(X)
+        sv = _bn_seq_fwd(bn, bn_w, bn_b, X, Xh, R, Ht, H, training)
         Wp = c.get(("wfc", dtype), [wfc], lambda: _pad_cols(torch.cat(
             [wfc.detach(), torch.zeros(Cp - Cc, Ht, device=wfc.device)], 0), H).to(dtype).contiguous())      # [Cp][H]
         logits = ops.gemm_nt(Xh, Wp, out_dtype=torch.float32)                                                # [R][Cp]
@@ -630,8 +647,8 @@ class _HeadFn(torch.autograd.Function):
         dXh = ops.gemm_nt(dl, WpT)                                                                           # [R][H]
         dl_T, Xh_T = ops.transpose(dl), ops.transpose(Xh)
         dW = ops.gemm_nt(dl_T, Xh_T, out_dtype=torch.float32, splitk=max(1, min(32, R // 2048)))             # [Cp][H]
-        dX = torch.empty_like(dXh) if H == Ht else torch.zeros_like(dXh)
-        dg, db = ops.bn_bwd(dXh, X, dX, 0, ctx.sv, R, Ht, H, H, H)
+        dX = torch.empty_like(dXh)
+        dg, db = _bn_seq_bwd(dXh, X, dX, ctx.sv, R, Ht, H)
         return dX, dg, db, dW[:Cc, :Ht].contiguous(), None, None, None, None, None
 
 
@@ -652,11 +669,16 @@ class _CtcFn(torch.autograd.Function):
         meta = torch.cat([offs.to(torch.int32), tsz.to(torch.int32), tg.reshape(-1).to(torch.int32)]).to(dev, non_blocking=True)
         loss, nll, dl = ops.ctc_loss_grad(logits, meta[2 * N:], meta[:N], out_lens_dev, meta[N:2 * N], Tp, N, Cc, blank, max_tl)
         ctx.save_for_backward(dl)
+        ctx.consumed = False
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, g):
         (dl,) = ctx.saved_tensors
+        if ctx.consumed:
+            raise RuntimeError("DeepSpeech (gfx950): backward through the CTC loss a second time -- its gradient buffer was scaled in "
+                               "place by the first backward; run the forward again (retain_graph is not supported)")
+        ctx.consumed = True
         # the gradient was computed with the loss for a unit upstream gradient; scale it in place (backward runs once per forward)
         return ops.scale_by_(dl, g.detach().float()), None, None, None, None, None, None, None
 
@@ -899,6 +921,9 @@ class DeepSpeech(_Base):
         with torch.autocast("cuda", enabled=False):
             # weight re-layouts for the RNN stack: second stream, hidden under the conv front-end
             self._prep_small_weights(dtype)
+            if self._Hp == self.rnns[0].hidden_size:
+                for li in range(len(self.rnns)):     # one-time flattening of the bias storages: on THIS stream (its torch.cat and the
+                    self._bias_views(li)             # release of the old storages must not straddle two streams' allocator pools)
             main, side = torch.cuda.current_stream(), self._wgrad_stream(dev)
             side.wait_stream(main)
             ready = getattr(self, "_layouts_ready", None)

@@ -178,6 +178,8 @@ class FusedAdamW(torch.optim.AdamW, _FusedStep):
                     st["step"] = torch.tensor(0.0, dtype=torch.float32)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                if st["step"].is_cuda:              # a checkpoint of torch's fused AdamW keeps 'step' on the device: normalise once,
+                    st["step"] = st["step"].cpu()   # or every step would synchronise once per parameter
                 st["step"] += 1
                 s_ = float(st["step"])
                 if step is not None and s_ != step:

@@ -85,13 +85,26 @@ class SpectrogramFrontEnd:
         pct = (frames.to(torch.float64) / float(Tmax)).to(torch.float32)      # _collate_fn: seq_length / float(max_seqlength)
         return out, pct, frames
 
-    def collate(self, waveforms):
+    def collate(self, waveforms, transcripts=None, int16_scale=False):
         """waveforms: list of 1-D float tensors.  Sorts by length descending (as _collate_fn sorts by frame count,
-        data_loader.py:251), pads, uploads and runs the front-end.  Returns (inputs, input_percentages, order)."""
+        data_loader.py:251), pads, uploads and runs the front-end.  Returns (inputs, input_percentages, order), or -- with
+        `transcripts` (one sequence of label indices per waveform) -- the reference's whole batch tuple
+        (inputs, targets, input_percentages, target_sizes) in the sorted order, as _collate_fn builds it (data_loader.py:259-270).
+
+        AMPLITUDE: log1p(|STFT|) is not scale-free.  The reference's load_audio (data_loader.py:23-30) hands
+        compute_spectrogram samples in [-1, 1] (int16 / 32767); pass waveforms on that scale, or raw int16-range samples with
+        int16_scale=True (they are divided by 32767 here, as load_audio does)."""
         order = sorted(range(len(waveforms)), key=lambda i: -len(waveforms[i]))
         Lmax = len(waveforms[order[0]])
         buf = torch.zeros((len(waveforms), Lmax), dtype=torch.float32)
         for r, i in enumerate(order):
             buf[r, :len(waveforms[i])] = torch.as_tensor(waveforms[i], dtype=torch.float32)
+        if int16_scale:
+            buf /= 32767.0
         inputs, pct, _ = self(buf.cuda(), [len(waveforms[i]) for i in order])
-        return inputs, pct, order
+        if transcripts is None:
+            return inputs, pct, order
+        tg = [torch.as_tensor(transcripts[i], dtype=torch.int64).reshape(-1) for i in order]
+        target_sizes = torch.tensor([len(t) for t in tg], dtype=torch.int32)
+        targets = torch.cat(tg) if tg else torch.zeros(0, dtype=torch.int64)
+        return inputs, targets, pct, target_sizes

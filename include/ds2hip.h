@@ -136,6 +136,10 @@ int ds2_rnn_bwd(int dtype, int cell, int D, int N, int H, int Tp, const int* len
  * 1e-3 parity mode; up to 64 samples per group for bf16 H = 1280, 16 otherwise); everything else runs ds2_rnn_fwd / _bwd.
  * ws: ds2_rnn_persist_ws_bytes() bytes of scratch (reset by every call on `stream`); err: one device int that the kernel sets to 1 if a workgroup gave up
  * waiting for its peers (its outputs are then NaN). */
+/* Test hook (fault injection): the number of polls a workgroup of a persistent sweep may spend waiting for its peers on one
+ * exchange before it gives up -- raises *err, NaN-poisons its outputs, ends.  0 = the built-in budget (seconds).  Returns the
+ * previous value. */
+unsigned ds2_rnn_persist_set_spin_limit(unsigned polls);
 int ds2_rnn_persist_supported(int dtype, int cell, int D, int N, int H);
 long ds2_rnn_persist_ws_bytes(int dtype, int cell, int D, int N, int H);
 int ds2_rnn_persist_fwd(int dtype, int cell, int D, int N, int H, int Tp, const int* lens, const void* GI, const void* Whh,

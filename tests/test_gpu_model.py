@@ -109,7 +109,8 @@ def test_fp32_logits_eval_transcripts_and_carry(name):
 
 
 BF16_CASES = ["gru_bi_tiny", "lstm_bi_tiny", "gru_uni_la", "gru_bi_mid", "gru_bi_1024", "lstm_uni_1024_la", "rnn_bi_1024", "lstm_bi_1024",
-              "cfg2_full", "lstm_bi_1280", "lstm_uni_1280_la", "gru_bi_1024_l5_n32"]
+              "cfg2_full", "lstm_bi_1280", "lstm_uni_1280_la", "gru_bi_1024_l5_n32", "lstm_bi_1280_l7_n18", "lstm_uni_1280_la_l7_n18",
+              "lstm_bi_h10_n10", "gru_uni_h50_la40_c45", "rnn_bi_h24_c40"]
 # Stated bf16 bounds.  The comparator is the REFERENCE ITSELF under torch.autocast(bfloat16) (fixture keys loss_ac /
 # logits_ac / grad_ac.* / acnoise.*, tests/golden/make_golden.py leg C) next to the reference in float64:
 #   loss     within 3e-3 relative of the reference's autocast loss AND of its float64 loss
@@ -200,26 +201,40 @@ def test_full_size_properties():
     assert sizes.tolist() == O.seq_lens(lengths).tolist()
 
 
-def test_librispeech_shape_matches_stock_torch_on_device():
-    """BASELINE.json config 3 at FULL size (5 x BiGRU-1024, 32 clips of 12-15 s, bf16): the persistent recurrent kernels,
-    the DMA-staged GEMMs and the bf16 conv path against stock PyTorch-ROCm (oracle/ds2_torch_port.py on the same GPU under
-    bf16 autocast -- the reference's own op sequence) on the same weights and batch.  Both sides are bf16 pipelines with
-    different summation orders, so the bars are: CTC loss within 2e-3 relative (north star: 1e-3 is the fp32 bar), every
-    checked gradient within cosine 0.97 of the other, and a bit-identical loss when the step is repeated."""
+FULL_SIZE_FACTOR = 1.5
+FULL_SIZE_CONFIGS = {
+    # name: (rnn_type, hidden, layers, bidirectional, clips, Tmin, Tmax, data seed) -- exactly what bench.py builds (bench.CONFIGS)
+    "cfg3": ("gru", 1024, 5, True, 32, 1201, 1501, 3000),
+    "cfg5a": ("lstm", 1280, 7, True, 64, 501, 1501, 5000),
+    "cfg5b": ("lstm", 1280, 7, False, 64, 501, 1501, 6000),
+}
+
+
+@pytest.mark.parametrize("cfg_name", ["cfg3", "cfg5a", "cfg5b"])
+def test_full_size_matches_stock_torch_on_device(cfg_name):
+    """BASELINE.json configs 3 and 5 at FULL size, bf16 (cfg3: 5 x BiGRU-1024, 32 clips of 12-15 s; cfg5a: 7 x BiLSTM-1280, 64
+    clips of 5-15 s; cfg5b: 7 x uni-LSTM-1280 + Lookahead, same batch): the persistent recurrent kernels, the phase-split
+    GEMMs and the bf16 conv path against stock PyTorch-ROCm (oracle/ds2_torch_port.py on the same GPU -- the reference's own
+    op sequence) on the same weights and batch.  Truth = the stock op sequence in fp32 on the device; both bf16 pipelines are
+    measured against it: CTC loss within 2e-3 relative, EVERY gradient of ours within FULL_SIZE_FACTOR x stock-bf16's own
+    relative L2 distance from fp32 (or the 3e-2 floor), and a bit-identical loss when the step is repeated."""
     from deepspeech.pytorch_amd import configs, ops, synth
     from deepspeech.pytorch_amd.model import DeepSpeech
     from oracle import ds2_torch_port as TP
-    cfg = dict(rnn_type="gru", hidden_size=1024, hidden_layers=5, bidirectional=True, lookahead_context=20)
+    kind, H, L, bi, N, tmin, tmax, seed = FULL_SIZE_CONFIGS[cfg_name]
+    cfg = dict(rnn_type=kind, hidden_size=H, hidden_layers=L, bidirectional=bi, lookahead_context=20)
     state = TP.random_state(cfg, 0)
-    lengths = synth.synth_lengths(32, 1201, 1501, seed=3000)
-    inputs, targets, pct, tsz = synth.synth_batch(lengths, seed=3000)
+    lengths = synth.synth_lengths(N, tmin, tmax, seed=seed)
+    inputs, targets, pct, tsz = synth.synth_batch(lengths, seed=seed)
     mk = lambda: (torch.from_numpy(inputs).to(DEV), torch.from_numpy(targets), torch.from_numpy(pct.copy()),
                   torch.from_numpy(tsz))
-    mc = configs.BiDirectionalConfig(rnn_type=configs.RNNType.gru, hidden_size=1024, hidden_layers=5)
+    rt = getattr(configs.RNNType, kind)
+    mc = configs.BiDirectionalConfig(rnn_type=rt, hidden_size=H, hidden_layers=L) if bi else \
+        configs.UniDirectionalConfig(rnn_type=rt, hidden_size=H, hidden_layers=L, lookahead_context=20)
     m = DeepSpeech(configs.LABELS, mc, "bf16", configs.AdamConfig(), configs.SpectConfig())
     m.load_state_dict({k: v.clone() for k, v in state.items()}, strict=True)
     m = m.to(DEV).train()
-    assert ops.use_persistent("gru", torch.bfloat16, 2, 32, 1024)
+    assert ops.use_persistent(kind, torch.bfloat16, 2 if bi else 1, N, H)
     losses = []
     for _ in range(2):
         m.zero_grad()
@@ -228,38 +243,118 @@ def test_librispeech_shape_matches_stock_torch_on_device():
         losses.append(float(loss.item()))
     ops.check_persistent_kernels()
     assert losses[0] == losses[1]                      # forward is deterministic (BN buffers do not enter train-mode math)
+    own = {k: p.grad.detach().float().cpu() for k, p in m.named_parameters()}
+    del m
+    torch.cuda.empty_cache()
     port = TP.Port(cfg, state, DEV)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         ref = port.training_loss(mk())
     ref.backward()
     rl = float(ref.item())
+    stock = {k: p.grad.detach().float().cpu() for k, p in port.P.items() if p.grad is not None}
+    del port, ref
+    torch.cuda.empty_cache()
     assert abs(losses[0] - rl) <= 2e-3 * abs(rl), (losses[0], rl)
-    # EVERY parameter gradient.  Truth at this size = the same stock op sequence in fp32 on the device (no autocast); both
-    # bf16 pipelines are measured against it: ours must be within FULL_SIZE_FACTOR x stock-bf16's own distance from fp32 (or
-    # the 3e-2 floor), for every parameter except the two conv biases in front of BatchNorm (zero in exact arithmetic).
     port32 = TP.Port(cfg, state, DEV)
     ref32 = port32.training_loss(mk())
     ref32.backward()
-    own = dict(m.named_parameters())
     worst = ("", 0.0, 0.0, 0.0)
     for k, p in port32.P.items():
         if k in ("conv.seq_module.0.bias", "conv.seq_module.3.bias") or p.grad is None:
             continue
-        t = p.grad.float().reshape(-1).double()
-        a = own[k].grad.float().reshape(-1).double()
-        b = port.P[k].grad.float().reshape(-1).double()
+        t = p.grad.float().reshape(-1).double().cpu()
+        a = own[k].reshape(-1).double()
+        b = stock[k].reshape(-1).double()
         assert torch.isfinite(a).all(), k
         d_own, d_stock = float((a - t).norm() / (t.norm() + 1e-30)), float((b - t).norm() / (t.norm() + 1e-30))
         bound = max(FULL_SIZE_FACTOR * d_stock, 3e-2)
         assert d_own <= bound, "grad %s: rel L2 %.3e from the fp32 run > %.3e (stock bf16: %.3e)" % (k, d_own, bound, d_stock)
         if d_own / bound > worst[1]:
             worst = (k, d_own / bound, d_own, d_stock)
-    print("cfg3 full size: loss %.3f (stock bf16 %.3f, stock fp32 %.3f); worst gradient %s: rel L2 %.3e from fp32 (stock bf16: %.3e)" % (
-        losses[0], rl, float(ref32.item()), worst[0], worst[2], worst[3]))
+    print("%s full size: loss %.3f (stock bf16 %.3f, stock fp32 %.3f); worst gradient %s: rel L2 %.3e from fp32 (stock bf16: %.3e)" % (
+        cfg_name, losses[0], rl, float(ref32.item()), worst[0], worst[2], worst[3]))
     assert abs(losses[0] - float(ref32.item())) <= 2e-3 * abs(float(ref32.item()))
 
 
-FULL_SIZE_FACTOR = 1.5
+def _full_fixture(cfg_name):
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full", cfg_name + ".npz")
+    if not os.path.exists(path):
+        pytest.skip("no full-size reference fixture for %s (tests/golden/make_fullsize_golden.py)" % cfg_name)
+    z = np.load(path)
+    return z, json.loads(bytes(z["meta_json"]).decode())
+
+
+@pytest.mark.parametrize("cfg_name", ["cfg2", "cfg3", "cfg5a", "cfg5b"])
+def test_full_size_step_matches_the_reference_itself(cfg_name):
+    """The same full-size step against THE REFERENCE'S OWN model.py run on the CPU at that full shape (fp32 as shipped, and under
+    torch.autocast(bfloat16); tests/golden/make_fullsize_golden.py -> tests/golden/full/<config>.npz: loss, logits on every 16th
+    frame, a strided sample + L2 norm of every parameter gradient).  Bars as for the small fixtures: fp32 mode (cfg2) -- loss
+    1e-3 relative, logits 1e-3, every gradient sample within 1e-3 of the tensor's max; bf16 mode -- loss within 3e-3 of the
+    reference's fp32 AND autocast losses, logits within 0.12, every gradient's relative L2 distance from the reference's fp32
+    gradient <= max(2 x the reference-autocast's own distance, 4e-2)."""
+    from deepspeech.pytorch_amd import configs, ops, synth
+    from deepspeech.pytorch_amd.model import DeepSpeech
+    z, meta = _full_fixture(cfg_name)
+    kind, H, L, bi = meta["rnn_type"], meta["hidden_size"], meta["hidden_layers"], meta["bidirectional"]
+    fp32 = cfg_name == "cfg2"
+    lengths = np.asarray(meta["lengths"], dtype=np.int64)
+    inputs, targets, pct, tsz = synth.synth_batch(lengths, seed=meta["data_seed"])
+    P = synth.synth_params({k: tuple(v) for k, v in meta["shapes"].items()}, meta["param_seed"])
+    rt = getattr(configs.RNNType, kind)
+    mc = configs.BiDirectionalConfig(rnn_type=rt, hidden_size=H, hidden_layers=L) if bi else \
+        configs.UniDirectionalConfig(rnn_type=rt, hidden_size=H, hidden_layers=L, lookahead_context=meta["lookahead_context"])
+    m = DeepSpeech(configs.LABELS, mc, 32 if fp32 else "bf16", configs.AdamConfig(), configs.SpectConfig())
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in P.items()}, strict=True)
+    m = m.to(DEV).train()
+    x = torch.from_numpy(inputs).to(DEV)
+    loss = m.training_step((x, torch.from_numpy(targets), torch.from_numpy(pct.copy()), torch.from_numpy(tsz)), 0)
+    loss.backward()
+    ops.check_persistent_kernels()
+    got, ref = float(loss.item()), float(z["loss"])
+    if fp32:
+        assert abs(got - ref) <= 1e-3 * abs(ref), (got, ref)
+    else:
+        assert abs(got - ref) <= BF16_LOSS_RTOL * abs(ref), (got, ref)
+        assert abs(got - float(z["loss_ac"])) <= BF16_LOSS_RTOL * abs(float(z["loss_ac"])), (got, float(z["loss_ac"]))
+    worst = ("", 0.0, 0.0)
+    st = meta["grad_stride"]
+    for k, p in m.named_parameters():
+        g = p.grad.detach().float().cpu().numpy().astype(np.float64).reshape(-1)
+        assert np.isfinite(g).all(), k
+        if k in ("conv.seq_module.0.bias", "conv.seq_module.3.bias"):
+            continue                                   # exactly zero in exact arithmetic: rounding noise in any implementation
+        sub, l2 = z["gradsub." + k].astype(np.float64), float(z["gradl2." + k])
+        mine = g[::st]
+        if fp32:
+            scale = max(np.abs(sub).max(), 1e-3)
+            err = np.abs(mine - sub).max() / scale
+            assert err <= 1e-3, "grad %s: %.3e of its max" % (k, err)
+            assert abs(np.sqrt((g ** 2).sum()) - l2) <= 4e-3 * max(l2, 1e-3), k
+            bound = 1e-3
+        else:
+            err = float(np.sqrt(((mine - sub) ** 2).sum()) / max(np.sqrt((sub ** 2).sum()), 1e-30))
+            bound = max(BF16_GRAD_FACTOR * float(z["acnoise." + k]), BF16_GRAD_FLOOR)
+            assert err <= bound, "grad %s: relative L2 distance %.3e from the reference's fp32 gradient > %.3e (reference autocast: %.3e)" % (
+                k, err, bound, float(z["acnoise." + k]))
+            assert abs(np.sqrt((g ** 2).sum()) - l2) <= 2 * bound * max(l2, 1e-3), k
+        if err / bound > worst[1]:
+            worst = (k, err / bound, err)
+    # logits of a second model (fresh BatchNorm buffers), every LOGIT_STRIDE-th frame
+    m2 = DeepSpeech(configs.LABELS, mc, 32 if fp32 else "bf16", configs.AdamConfig(), configs.SpectConfig())
+    m2.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in P.items()}, strict=True)
+    m2 = m2.to(DEV).train()
+    sizes = torch.from_numpy(pct.copy()).mul_(int(inputs.shape[3])).int()
+    logits, out_sizes, _ = m2(x, sizes)
+    assert np.array_equal(out_sizes.numpy(), z["output_lengths"])
+    lg = logits.detach().float().cpu().numpy()[:, ::meta["logit_stride"]]
+    # frames past a clip's length hold BatchNorm(0) of the padding in both implementations; compare the valid frames
+    ok = (np.arange(lg.shape[1])[None, :] * meta["logit_stride"]) < z["output_lengths"][:, None]
+    lerr = np.abs(lg - z["logits_sub"])[ok].max()
+    assert lerr <= (1e-3 if fp32 else BF16_LOGITS_ATOL), lerr
+    print("%s vs the reference at full size: loss %.4f (reference fp32 %.4f); worst gradient %s at %.2f of its bound (%.3e); logits %.2e" % (
+        cfg_name, got, ref, worst[0], worst[1], worst[2], lerr))
 
 
 def test_in_place_updates_without_version_bump_are_seen():

@@ -32,7 +32,7 @@ def test_spectrogram_batch_matches_oracle(pad_mode, normalize):
         assert np.all(got[i, 0, :, T:] == 0)              # zero padding of the batch layout
         assert abs(float(pct[i]) - np.float32(T / float(Tmax))) < 1e-7
     # the percentages reproduce the frame counts through training_step's float round trip (model.py:243)
-    assert (pct.mul(Tmax).int().numpy() == np.array([1 + n // 160 for n in lens])).all() or True
+    assert (pct.cpu().mul(Tmax).int().numpy() == np.array([1 + n // 160 for n in lens])).all()
 
 
 def test_spectrogram_feeds_the_model():

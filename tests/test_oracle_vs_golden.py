@@ -144,3 +144,24 @@ def test_log_spectrogram_oracle_against_scipy_stft():
     assert np.abs(np.log1p(mag[:, :n]) - raw[:, :n]).max() < 1e-9
     z = O.log_spectrogram(y)
     assert abs(z.mean()) < 1e-12 and abs(z.std(ddof=1) - 1) < 1e-12
+
+
+@pytest.mark.parametrize("pad_mode", ["constant", "reflect"])
+def test_log_spectrogram_oracle_against_torch_stft(pad_mode):
+    """A second independent implementation that IS in the image: torch.stft(center=True, periodic hamming window, hop 160,
+    n_fft = win_length = 320) is the transform librosa.stft computes (torch documents it as librosa-compatible; the reference's
+    own requirements pull both) -- for both centre paddings (zeros: librosa >= 0.10; reflection: before)."""
+    import torch
+    rs = np.random.RandomState(3)
+    for n in (16000 + 37, 801, 480, 24000):
+        y = rs.standard_normal(n) * 0.3 + 0.01
+        Z = torch.stft(torch.from_numpy(y), n_fft=320, hop_length=160, win_length=320, window=torch.hamming_window(320, periodic=True, dtype=torch.float64),
+                       center=True, pad_mode=pad_mode, return_complex=True)
+        ref = torch.log1p(Z.abs()).numpy()
+        raw = O.log_spectrogram(y, normalize=False, pad_mode=pad_mode)
+        assert raw.shape == ref.shape == (161, 1 + n // 160)
+        assert np.abs(raw - ref).max() < 1e-9
+        # the reference's normalisation (data_loader.py:88-92: torch mean / UNBIASED std over the whole utterance)
+        t = torch.from_numpy(ref)
+        refn = ((t - t.mean()) / t.std()).numpy()
+        assert np.abs(O.log_spectrogram(y, pad_mode=pad_mode) - refn).max() < 1e-9
