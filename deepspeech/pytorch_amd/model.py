@@ -53,6 +53,12 @@ except Exception:  # pragma: no cover
 
 from .configs import AdamConfig, BiDirectionalConfig, SGDConfig, SpectConfig, UniDirectionalConfig, rnn_kind  # noqa: E402
 
+import os  # noqa: E402
+
+# DS2_WGRAD_BESIDE_DX=1: the grouped weight-gradient launch of a layer runs beside its dX GEMM on the second stream (measured and
+# rejected as the default: 28.0 vs 27.4 ms per cfg3 step, 143.9 vs 142.4 on cfg5a -- two tile streams through one dispatcher)
+WGRAD_BESIDE_DX = os.environ.get("DS2_WGRAD_BESIDE_DX", "0") not in ("", "0")
+
 N_FREQ_CONV2 = 41
 RNN_INPUT = 32 * N_FREQ_CONV2  # 1312, model.py:166-169
 RNN_INPUT_LD = 1344            # leading dimension of the conv-stack output: 1312 rounded up to the GEMM K-tile (64); pad = 0
@@ -373,6 +379,7 @@ class _RnnStackFn(torch.autograd.Function):
             pos += (2 if has_bn else 0) + 4 * D
         grads = [None] * len(params)
         dout = dout.contiguous().to(dtype)
+        wgrad_done = None
         for li in reversed(range(L)):
             kind, H, D, G, I, has_bn, sv, Ht, It = ctx.meta[li]
             X, Xh, hext, Sv = saved[4 * li:4 * li + 4]
@@ -392,65 +399,84 @@ class _RnnStackFn(torch.autograd.Function):
                 w = _perm_cols_to_internal(w) if first else _pad_cols(w, H)
                 return w.t().to(dtype).contiguous()                                                             # [I][D*G*H]
             WihT = c.get(("wihT", li, dtype), list(wih), build_ihT)
-            # ---- dependent chain (caller's stream): BPTT sweep -> dX -> BatchNorm backward
+            # ---- BPTT sweep (caller's stream).  A persistent sweep wants every CU: it starts after the weight-gradient launch of the
+            # layer above has drained (otherwise its first workgroups would spin on peers that are still waiting for a CU)
+            if wgrad_done is not None:
+                main.wait_event(wgrad_done)
+                wgrad_done = None
             rg = ops.rnn_bwd(kind, dout, WhhT, hext, Sv, lens_dev, D, N, H, Tp)
             dGI = rg.dGI
+            fast = ops.wgrad_tn_ok(dtype, R, D * GH, Xh.shape[1]) and ops.wgrad_tn_ok(dtype, R, GH, H)
+            if fast:
+                # ---- weight gradients as ONE grouped launch of TN products (contraction over the T'*N rows, both operands as the
+                # activations are stored: no transposes).  Never under a sweep: what co-resident GEMMs cost the sweeps was the
+                # chip's CLOCK (1.7 instead of 2.15 GHz while they ran, profiles/r03a_coresidency3.txt) -- a latency-bound kernel
+                # pays that one to one.  On the caller's stream, right behind the sweep (optionally beside the dX GEMM on the second
+                # stream, WGRAD_BESIDE_DX: no gain measured).
+                swept = torch.cuda.Event()
+                swept.record(main)
+                wstream = side if WGRAD_BESIDE_DX else main
+                with torch.cuda.stream(wstream):
+                    if wstream is not main:
+                        wstream.wait_event(swept)
+                        for t_ in rg.tensors() + [Xh, hext]:
+                            t_.record_stream(wstream)
+                    Iw = Xh.shape[1]
+                    dWih = torch.empty((D * GH, Iw), dtype=torch.float32, device=dGI.device)
+                    dWhh = torch.empty((D, GH, H), dtype=torch.float32, device=dGI.device)
+                    probs = [dict(At=dGI, Bt=Xh, M=D * GH, N=Iw, lda=D * GH, ldb=Xh.stride(0), out=dWih)]
+                    for d in range(D):
+                        # h_{t-1} of the forward direction is slot t of the guarded buffer, h_{t+1} of the reverse direction slot t+2
+                        hprev = (hext[d, 0:Tp] if d == 0 else hext[d, 2:Tp + 2]).reshape(R, H)
+                        if kind == "gru" and rg.dQ is not None:
+                            # hidden-side gate gradient = [dr, dz (columns of dGI) | dQ]
+                            if (2 * H) % 256 == 0:
+                                probs.append(dict(At=dGI[:, d * GH:], At2=rg.dQ[d], lda2=H, m_split=2 * H, Bt=hprev, M=GH, N=H, lda=D * GH, ldb=H,
+                                                  out=dWhh[d]))
+                            else:
+                                probs.append(dict(At=dGI[:, d * GH:], Bt=hprev, M=2 * H, N=H, lda=D * GH, ldb=H, out=dWhh[d, :2 * H]))
+                                probs.append(dict(At=rg.dQ[d], Bt=hprev, M=H, N=H, lda=H, ldb=H, out=dWhh[d, 2 * H:]))
+                        elif kind == "gru":
+                            probs.append(dict(At=rg.dGH[d], Bt=hprev, M=GH, N=H, lda=GH, ldb=H, out=dWhh[d]))
+                        else:
+                            probs.append(dict(At=dGI[:, d * GH:], Bt=hprev, M=GH, N=H, lda=D * GH, ldb=H, out=dWhh[d]))
+                    ops.gemm8_tn_grouped(probs, R)
+                    if first:
+                        dWih = torch.cat([_perm_cols_to_reference(dWih[d * GH:(d + 1) * GH]) for d in range(D)], 0)
+                    bsum = None
+                    if rg.bacc is not None:
+                        bsum = [ops.colsum(rg.bacc[d]) for d in range(D)]                   # [NB*H] per direction
+                        dBih = torch.cat([b[:GH] for b in bsum], 0)
+                    else:
+                        dBih = ops.colsum(dGI)
+                    for d in range(D):
+                        if kind == "gru" and rg.dQ is not None:
+                            dBhh = torch.cat([bsum[d][:2 * H], bsum[d][3 * H:4 * H]], 0) if bsum is not None else \
+                                torch.cat([dBih[d * GH:d * GH + 2 * H], ops.colsum(rg.dQ[d].reshape(R, H))], 0)
+                        elif kind == "gru":
+                            dBhh = ops.colsum(rg.dGH[d].reshape(R, GH))
+                        else:
+                            dBhh = dBih[d * GH:(d + 1) * GH]
+                        grads[po + 4 * d:po + 4 * d + 4] = [dWih[d * GH:(d + 1) * GH], dWhh[d], dBih[d * GH:(d + 1) * GH].contiguous(),
+                                                            dBhh.contiguous()]
+                    sync = getattr(mod, "_grad_sync", None)
+                    if sync is not None and H == Ht:
+                        own = [dWih, dWhh, dBih]
+                        if kind == "gru":
+                            own += [grads[po + 4 * d + 3] for d in range(D)]
+                        sync.layer_ready(own, params[po:po + 4 * D])
+                    _unpad_layer_grads(grads, po, D, G, Ht, H, It, first)
+                    if wstream is not main:
+                        wgrad_done = torch.cuda.Event()
+                        wgrad_done.record(wstream)
+            # ---- dependent chain (caller's stream): dX -> BatchNorm backward
             dXh = ops.gemm_nt(dGI, WihT)                                # [R][I]
             if has_bn:
                 dX = torch.empty_like(dXh)
                 grads[offs[li]], grads[offs[li] + 1] = _bn_seq_bwd(dXh, X, dX, sv, R, It, I)
             else:
                 dX = dXh
-            if ops.wgrad_tn_ok(dtype, R, D * GH, Xh.shape[1]) and ops.wgrad_tn_ok(dtype, R, GH, H):
-                # ---- weight gradients as ONE grouped launch of TN products (contraction over the T'*N rows, both operands as the
-                # activations are stored: no transposes), on this stream, between the layers' sweeps.  Co-resident GEMMs under
-                # the sweep are gone: what they cost was the chip's CLOCK (1.7 instead of 2.15 GHz while they ran,
-                # profiles/r03a_coresidency3.txt) -- a latency-bound sweep pays that one to one.
-                Iw = Xh.shape[1]
-                dWih = torch.empty((D * GH, Iw), dtype=torch.float32, device=dGI.device)
-                dWhh = torch.empty((D, GH, H), dtype=torch.float32, device=dGI.device)
-                probs = [dict(At=dGI, Bt=Xh, M=D * GH, N=Iw, lda=D * GH, ldb=Xh.stride(0), out=dWih)]
-                for d in range(D):
-                    # h_{t-1} of the forward direction is slot t of the guarded buffer, h_{t+1} of the reverse direction slot t+2
-                    hprev = (hext[d, 0:Tp] if d == 0 else hext[d, 2:Tp + 2]).reshape(R, H)
-                    if kind == "gru" and rg.dQ is not None:
-                        # hidden-side gate gradient = [dr, dz (columns of dGI) | dQ]
-                        if (2 * H) % 256 == 0:
-                            probs.append(dict(At=dGI[:, d * GH:], At2=rg.dQ[d], lda2=H, m_split=2 * H, Bt=hprev, M=GH, N=H, lda=D * GH, ldb=H,
-                                              out=dWhh[d]))
-                        else:
-                            probs.append(dict(At=dGI[:, d * GH:], Bt=hprev, M=2 * H, N=H, lda=D * GH, ldb=H, out=dWhh[d, :2 * H]))
-                            probs.append(dict(At=rg.dQ[d], Bt=hprev, M=H, N=H, lda=H, ldb=H, out=dWhh[d, 2 * H:]))
-                    elif kind == "gru":
-                        probs.append(dict(At=rg.dGH[d], Bt=hprev, M=GH, N=H, lda=GH, ldb=H, out=dWhh[d]))
-                    else:
-                        probs.append(dict(At=dGI[:, d * GH:], Bt=hprev, M=GH, N=H, lda=D * GH, ldb=H, out=dWhh[d]))
-                ops.gemm8_tn_grouped(probs, R)
-                if first:
-                    dWih = torch.cat([_perm_cols_to_reference(dWih[d * GH:(d + 1) * GH]) for d in range(D)], 0)
-                bsum = None
-                if rg.bacc is not None:
-                    bsum = [ops.colsum(rg.bacc[d]) for d in range(D)]                   # [NB*H] per direction
-                    dBih = torch.cat([b[:GH] for b in bsum], 0)
-                else:
-                    dBih = ops.colsum(dGI)
-                for d in range(D):
-                    if kind == "gru" and rg.dQ is not None:
-                        dBhh = torch.cat([bsum[d][:2 * H], bsum[d][3 * H:4 * H]], 0) if bsum is not None else \
-                            torch.cat([dBih[d * GH:d * GH + 2 * H], ops.colsum(rg.dQ[d].reshape(R, H))], 0)
-                    elif kind == "gru":
-                        dBhh = ops.colsum(rg.dGH[d].reshape(R, GH))
-                    else:
-                        dBhh = dBih[d * GH:(d + 1) * GH]
-                    grads[po + 4 * d:po + 4 * d + 4] = [dWih[d * GH:(d + 1) * GH], dWhh[d], dBih[d * GH:(d + 1) * GH].contiguous(),
-                                                        dBhh.contiguous()]
-                sync = getattr(mod, "_grad_sync", None)
-                if sync is not None and H == Ht:
-                    own = [dWih, dWhh, dBih]
-                    if kind == "gru":
-                        own += [grads[po + 4 * d + 3] for d in range(D)]
-                    sync.layer_ready(own, params[po:po + 4 * D])
-                _unpad_layer_grads(grads, po, D, G, Ht, H, It, first)
+            if fast:
                 dout = dX
                 continue
             # the second stream starts this layer's weight gradients only once dX / BatchNorm backward are through, i.e. together
