@@ -23,6 +23,7 @@ SIGNATURES = {
     "ds2_gemm_nt_rows2": (_i, [_i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _l, _l, _l, _i, _i, _i, _vp]),
     "ds2_gemm8_nt": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _l, _l, _l, _i, _vp]),
     "ds2_gemm8_tn_grouped": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "ds2_gemm8_wgrad_dx": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _l, _l, _l, _vp]),
     "ds2_norm_partials": (_i, [_l]),
     "ds2_bn_fwd": (_i, [_i, _i, _i, _vp, _vp, _l, _i, _l, _l, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp,
                         _vp, _vp, _vp, _vp]),
@@ -54,6 +55,7 @@ SIGNATURES = {
     "ds2_lookahead_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ds2_lookahead_ws_floats": (_l, [_i, _i, _i, _i]),
     "ds2_lookahead_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "ds2_rnn_bias_grads": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ds2_softmax_rows": (_i, [_vp, _vp, _l, _i, _l, _l, _vp]),
     "ds2_opt_max_tensors": (_i, []),
     "ds2_clip_ws_floats": (_l, [_i, _vp]),

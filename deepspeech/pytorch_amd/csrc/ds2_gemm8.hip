@@ -41,10 +41,11 @@ struct G8Problem {
   long lda, lda2, ldb, ldc;   // lda2: leading dimension of A2
   int tiles_n, tile_end;   // tiles of this problem are [previous tile_end, tile_end)
   int out_is_f32;
+  int K, tn;               // contraction length; tn != 0: both operands K-major
 };
 struct G8Args {
   G8Problem p[G8_MAX_GROUPS];
-  int n_problems, K;
+  int n_problems;
 };
 
 #define G8_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -56,31 +57,17 @@ struct G8Args {
     __builtin_amdgcn_sched_barrier(0);      \
   } while (0)
 
+// One output tile.  TN is a template parameter of the body; a launch that mixes NT and TN problems (k_gemm8<2>) selects the body
+// per workgroup with a wave-uniform branch.
 template <bool TN>
-__global__ void __launch_bounds__(512, 2) k_gemm8(G8Args g) {
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[131072];
+__device__ __forceinline__ void g8_tile(const G8Problem& P, int t_id, unsigned char* lds) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-
-  // ---- which problem, which tile (XCD-aware: consecutive ids of one XCD work on neighbouring tiles)
-  int id = blockIdx.x;
-  {
-    const int nblk = gridDim.x, q = nblk / 8, r = nblk % 8, xcd = id % 8, k = id / 8;
-    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-  }
-  int pi = 0, first = 0;
-#pragma unroll
-  for (int i = 0; i < G8_MAX_GROUPS - 1; ++i)
-    if (i + 1 < g.n_problems && id >= g.p[i].tile_end) {
-      pi = i + 1;
-      first = g.p[i].tile_end;
-    }
-  const G8Problem& P = g.p[pi];
-  const int t_id = id - first;
   const int m0 = (t_id / P.tiles_n) * 256, n0 = (t_id % P.tiles_n) * 256;
-  const int nkt = (g.K + 63) / 64;                      // NT: K % 64 == 0 (host check); TN: a ragged last K-tile is zero-filled in LDS
-  const int krem = g.K - (nkt - 1) * 64;                // valid k-rows of the last K-tile (1..64)
+  const int K_ = P.K;
+  const int nkt = (K_ + 63) / 64;                       // NT: K % 64 == 0 (host check); TN: a ragged last K-tile is zero-filled in LDS
+  const int krem = K_ - (nkt - 1) * 64;                 // valid k-rows of the last K-tile (1..64)
   const bool tail = TN && krem < 64;
 
   ds2_f32x16 acc[4][2];
@@ -387,6 +374,41 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(G8Args g) {
   }
 }
 
+
+// MODE 0: every problem NT, 1: every problem TN, 2: mixed.  Workgroup -> (problem, tile): problems own consecutive id ranges (the
+// host orders them by decreasing K, so the long tiles are dispatched first); inside a problem's range the ids that the dispatcher
+// places on one XCD (id % 8) get a contiguous run of its tiles (neighbouring tiles share operand panels in that XCD's L2).
+template <int MODE>
+__global__ void __launch_bounds__(512, 2) k_gemm8(G8Args g) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[131072];
+  const int id = blockIdx.x;
+  int pi = 0, first = 0;
+#pragma unroll
+  for (int i = 0; i < G8_MAX_GROUPS - 1; ++i)
+    if (i + 1 < g.n_problems && id >= g.p[i].tile_end) {
+      pi = i + 1;
+      first = g.p[i].tile_end;
+    }
+  const G8Problem& P = g.p[pi];
+  const int count = P.tile_end - first, local = id - first, xcd = id & 7;
+  int base = 0;
+#pragma unroll
+  for (int y = 0; y < 8; ++y) {
+    const int l0 = (y - first) & 7;                     // first local id of this problem that lands on XCD y
+    const int n_y = l0 < count ? (count - l0 - 1) / 8 + 1 : 0;
+    if (y < xcd) base += n_y;
+  }
+  const int t_id = base + (local - ((xcd - first) & 7)) / 8;
+  if (MODE == 0)
+    g8_tile<false>(P, t_id, lds);
+  else if (MODE == 1)
+    g8_tile<true>(P, t_id, lds);
+  else if (P.tn)
+    g8_tile<true>(P, t_id, lds);
+  else
+    g8_tile<false>(P, t_id, lds);
+}
+
 }  // namespace
 
 extern "C" {
@@ -400,10 +422,9 @@ int ds2_gemm8_nt(const void* A, const void* B, void* C, const float* bias, int M
   DS2_REQUIRE((long)M * lda < (1L << 31) && (long)N * ldb < (1L << 31), DS2_ERR_ARG);
   G8Args g{};
   g.n_problems = 1;
-  g.K = K;
   const int tm = ds2_cdiv(M, 256), tn = ds2_cdiv(N, 256);
-  g.p[0] = G8Problem{(const bf16_t*)A, nullptr, (const bf16_t*)B, C, bias, M, N, 0, lda, 0, ldb, ldc, tn, tm * tn, out_f32};
-  hipLaunchKernelGGL(k_gemm8<false>, dim3(tm * tn), dim3(512), 0, (hipStream_t)st, g);
+  g.p[0] = G8Problem{(const bf16_t*)A, nullptr, (const bf16_t*)B, C, bias, M, N, 0, lda, 0, ldb, ldc, tn, tm * tn, out_f32, K, 0};
+  hipLaunchKernelGGL(k_gemm8<0>, dim3(tm * tn), dim3(512), 0, (hipStream_t)st, g);
   DS2_CHECK_LAUNCH();
   return 0;
 }
@@ -417,7 +438,6 @@ int ds2_gemm8_tn_grouped(int n_problems, const void* const* At, const void* cons
   DS2_REQUIRE(n_problems >= 1 && n_problems <= G8_MAX_GROUPS && K > 0, DS2_ERR_ARG);
   G8Args g{};
   g.n_problems = n_problems;
-  g.K = K;
   int total = 0;
   for (int i = 0; i < n_problems; ++i) {
     DS2_REQUIRE(M[i] > 0 && N[i] > 0 && M[i] % 8 == 0 && N[i] % 8 == 0 && lda[i] % 8 == 0 && ldb[i] % 8 == 0, DS2_ERR_ARG);
@@ -429,9 +449,44 @@ int ds2_gemm8_tn_grouped(int n_problems, const void* const* At, const void* cons
                                   (long)K * lda2[i] < (1L << 31)), DS2_ERR_ARG);
     const int tm = ds2_cdiv(M[i], 256), tn = ds2_cdiv(N[i], 256);
     total += tm * tn;
-    g.p[i] = G8Problem{(const bf16_t*)At[i], (const bf16_t*)a2, (const bf16_t*)Bt[i], C[i], nullptr, M[i], N[i], ms, lda[i], a2 ? lda2[i] : 0, ldb[i], ldc[i], tn, total, 1};
+    g.p[i] = G8Problem{(const bf16_t*)At[i], (const bf16_t*)a2, (const bf16_t*)Bt[i], C[i], nullptr, M[i], N[i], ms, lda[i], a2 ? lda2[i] : 0, ldb[i], ldc[i], tn, total, 1, K, 1};
   }
-  hipLaunchKernelGGL(k_gemm8<true>, dim3(total), dim3(512), 0, (hipStream_t)st, g);
+  hipLaunchKernelGGL(k_gemm8<1>, dim3(total), dim3(512), 0, (hipStream_t)st, g);
+  DS2_CHECK_LAUNCH();
+  return 0;
+}
+
+// The weight gradients of a recurrent layer AND its dX product in one launch: the TN problems of ds2_gemm8_tn_grouped (contraction
+// over K_tn rows) followed by ONE NT problem (dX [M_nt][ldc_nt] bf16 = A_nt[M_nt][K_nt] * B_nt[N_nt][K_nt]^T).  Alone, the weight
+// gradients leave a quarter of the CUs idle (192 tiles of 376 K-tiles on cfg3) and the dX product half of its second round (376
+// tiles of 96 K-tiles); in one grid the long tiles start first and the short ones fill in behind them.
+int ds2_gemm8_wgrad_dx(int n_tn, const void* const* At, const void* const* At2, const int* m_split, const void* const* Bt, void* const* C,
+                       const int* M, const int* N, const long* lda, const long* lda2, const long* ldb, const long* ldc, int K_tn,
+                       const void* A_nt, const void* B_nt, void* C_nt, int M_nt, int N_nt, int K_nt, long lda_nt, long ldb_nt, long ldc_nt,
+                       ds2_stream_t st) {
+  DS2_REQUIRE(n_tn >= 1 && n_tn < G8_MAX_GROUPS && K_tn > 0, DS2_ERR_ARG);
+  DS2_REQUIRE(M_nt > 0 && N_nt > 0 && K_nt > 0 && K_nt % 64 == 0 && lda_nt % 8 == 0 && ldb_nt % 8 == 0, DS2_ERR_ARG);
+  DS2_REQUIRE((((uintptr_t)A_nt) & 15) == 0 && (((uintptr_t)B_nt) & 15) == 0, DS2_ERR_ALIGN);
+  DS2_REQUIRE((long)M_nt * lda_nt < (1L << 31) && (long)N_nt * ldb_nt < (1L << 31), DS2_ERR_ARG);
+  G8Args g{};
+  g.n_problems = n_tn + 1;
+  int total = 0;
+  for (int i = 0; i < n_tn; ++i) {
+    DS2_REQUIRE(M[i] > 0 && N[i] > 0 && M[i] % 8 == 0 && N[i] % 8 == 0 && lda[i] % 8 == 0 && ldb[i] % 8 == 0, DS2_ERR_ARG);
+    DS2_REQUIRE((((uintptr_t)At[i]) & 15) == 0 && (((uintptr_t)Bt[i]) & 15) == 0, DS2_ERR_ALIGN);
+    DS2_REQUIRE((long)K_tn * lda[i] < (1L << 31) && (long)K_tn * ldb[i] < (1L << 31), DS2_ERR_ARG);
+    const void* a2 = At2 ? At2[i] : nullptr;
+    const int ms = a2 ? m_split[i] : 0;
+    DS2_REQUIRE(a2 == nullptr || (ms > 0 && ms < M[i] && ms % 256 == 0 && (((uintptr_t)a2) & 15) == 0 && lda2 && lda2[i] % 8 == 0 &&
+                                  (long)K_tn * lda2[i] < (1L << 31)), DS2_ERR_ARG);
+    const int tm = ds2_cdiv(M[i], 256), tn = ds2_cdiv(N[i], 256);
+    total += tm * tn;
+    g.p[i] = G8Problem{(const bf16_t*)At[i], (const bf16_t*)a2, (const bf16_t*)Bt[i], C[i], nullptr, M[i], N[i], ms, lda[i], a2 ? lda2[i] : 0, ldb[i], ldc[i], tn, total, 1, K_tn, 1};
+  }
+  const int tm = ds2_cdiv(M_nt, 256), tn = ds2_cdiv(N_nt, 256);
+  total += tm * tn;
+  g.p[n_tn] = G8Problem{(const bf16_t*)A_nt, nullptr, (const bf16_t*)B_nt, C_nt, nullptr, M_nt, N_nt, 0, lda_nt, 0, ldb_nt, ldc_nt, tn, total, 0, K_nt, 0};
+  hipLaunchKernelGGL(k_gemm8<2>, dim3(total), dim3(512), 0, (hipStream_t)st, g);
   DS2_CHECK_LAUNCH();
   return 0;
 }

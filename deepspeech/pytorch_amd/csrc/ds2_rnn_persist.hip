@@ -61,7 +61,7 @@ long xbuf_bytes(int cell, int H, bool bwd) {
 bool tuned_ok(int dtype, int cell, int D, int N, int H) {
   if (dtype != DS2_BF16 || H != 1024 || (D != 1 && D != 2)) return false;
   const int gpd = NGROUPS / D;
-  return N >= 1 && (N + gpd - 1) / gpd <= MAXS && cu_count() == 256;
+  return N >= 1 && (N + gpd - 1) / gpd <= MAXS && cu_count() >= NGROUPS * 32;   // one workgroup per CU, all 256 co-resident
 }
 
 // Geometry of the general kernels: P = H/16 workgroups per group, as many groups per direction as the chip holds.

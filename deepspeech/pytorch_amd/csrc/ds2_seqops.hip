@@ -265,6 +265,28 @@ inline int ew_grid(long n) {
   return (int)g;
 }
 
+
+// Bias gradients of a recurrent layer from the BPTT sweep's per-sample sums (ds2_rnn_persist_bwd: dBacc [D][N][NB*H], NB = 4 for
+// GRU -- dr, dz, dn, dq -- else G): bias_ih.grad [D][G*H] = sum over samples of planes 0..G-1, bias_hh.grad [D][G*H] = the same,
+// except GRU: planes 0, 1, 3 (the n slot of the hidden side is dq = dn * r).  One thread per (direction, plane, unit); fixed
+// summation order.
+__global__ void __launch_bounds__(256) k_rnn_bias_grads(const float* __restrict__ bacc, int D, int N, int H, int G, int NB,
+                                                        float* __restrict__ dbih, float* __restrict__ dbhh) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long per_d = (long)NB * H;
+  if (i >= D * per_d) return;
+  const int d = (int)(i / per_d), c = (int)(i % per_d), plane = c / H, u = c % H;
+  const float* p = bacc + (long)d * N * per_d + c;
+  float s = 0.f;
+  for (int n = 0; n < N; ++n) s += p[(long)n * per_d];
+  const long gh = (long)G * H;
+  if (plane < G) dbih[d * gh + (long)plane * H + u] = s;
+  if (NB == G)
+    dbhh[d * gh + (long)plane * H + u] = s;
+  else if (plane != 2)
+    dbhh[d * gh + (long)(plane == 3 ? 2 : plane) * H + u] = s;
+}
+
 }  // namespace
 
 extern "C" {
@@ -385,6 +407,15 @@ int ds2_lookahead_bwd(int dtype, const void* x, const float* w, const void* pre,
   DS2_CHECK_LAUNCH();
   const int C = H * ctx;
   return ds2_colsum(DS2_F32, ws, P, C, C, dw, 1.0f, ws + (long)P * C, st_);
+}
+
+int ds2_rnn_bias_grads(int cell, int D, int N, int H, const float* dBacc, float* dbih, float* dbhh, ds2_stream_t st_) {
+  hipStream_t st = (hipStream_t)st_;
+  DS2_REQUIRE(dBacc && dbih && dbhh && D >= 1 && D <= 2 && N > 0 && H > 0 && cell >= 0 && cell <= 2, DS2_ERR_ARG);
+  const int G = cell == 0 ? 3 : cell == 1 ? 4 : 1, NB = cell == 0 ? 4 : G;
+  hipLaunchKernelGGL(k_rnn_bias_grads, dim3(ds2_cdiv((long)D * NB * H, 256)), dim3(256), 0, st, dBacc, D, N, H, G, NB, dbih, dbhh);
+  DS2_CHECK_LAUNCH();
+  return 0;
 }
 
 int ds2_softmax_rows(const float* logits, float* probs, long rows, int C, long ld_in, long ld_out, ds2_stream_t st_) {

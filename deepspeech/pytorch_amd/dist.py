@@ -82,12 +82,18 @@ class OverlappedGradSync:
         t.mul_(1.0 / self.world)                       # gloo has no AVG
         return dist.all_reduce(t, group=self.group, async_op=True)
 
-    def layer_ready(self, tensors, params):
-        """tensors: gradient storages that are final (distinct storages; the gradients returned to autograd may be views
-        of them); params: the parameters they belong to.  Call inside backward, on the stream that produces them."""
+    def arm(self, *_):
+        """Queues `finish` behind the running backward pass (the autograd engine's end-of-backward callback, what DDP's reducer
+        uses for its own finalize).  Only valid while a backward pass is running: OverlappedDataParallel calls it from a hook
+        on the step's loss, i.e. when backward starts -- models that never hand a layer over early are reduced too."""
         if not self._queued:
             torch.autograd.Variable._execution_engine.queue_callback(self.finish)
             self._queued = True
+
+    def layer_ready(self, tensors, params):
+        """tensors: gradient storages that are final (distinct storages; the gradients returned to autograd may be views
+        of them); params: the parameters they belong to.  Call inside backward, on the stream that produces them."""
+        self.arm()
         for t in tensors:
             self._handles.append(self._start(t))
         self._early.update(p.data_ptr() for p in params)
@@ -131,7 +137,10 @@ class OverlappedDataParallel(torch.nn.Module):
 
     def forward(self, *args):
         self.sync.begin_step()
-        return self.module(*args)
+        out = self.module(*args)
+        if torch.is_tensor(out) and out.requires_grad:
+            out.register_hook(self.sync.arm)       # fires when backward reaches the loss: end-of-backward reduction is queued
+        return out
 
     def finish_backward(self):
         """Explicit end of backward for loops that want it (idempotent: the engine callback normally ran already)."""
@@ -139,13 +148,19 @@ class OverlappedDataParallel(torch.nn.Module):
 
 
 def overlap_allreduce():
-    return os.environ.get("DS2_OVERLAP_ALLREDUCE", "0") not in ("", "0")
+    """Default for world > 1: OverlappedDataParallel (every recurrent layer's gradients start their all-reduce the moment they
+    exist, under the sweeps of the layers below -- the north star's "all-reduce overlapped with backward").  DS2_USE_DDP=1 (or
+    DS2_OVERLAP_ALLREDUCE=0) selects torch DDP instead, whose reducer sees the composite node's gradients only at the end of
+    backward."""
+    if os.environ.get("DS2_USE_DDP", "0") not in ("", "0"):
+        return False
+    return os.environ.get("DS2_OVERLAP_ALLREDUCE", "1") not in ("", "0")
 
 
 def wrap_data_parallel(step_module, device, world, bucket_cap_mb=64, overlap=None):
-    """DDP over the step module (identity for world == 1).  broadcast_buffers=False: BatchNorm running statistics are
-    per-rank like the reference's sync_batchnorm=False; gradient_as_bucket_view avoids one copy per parameter.
-    overlap=True (or DS2_OVERLAP_ALLREDUCE=1): OverlappedDataParallel instead of DDP."""
+    """Data-parallel wrapper of the step module (identity for world == 1): OverlappedDataParallel by default, torch DDP with
+    overlap=False / DS2_USE_DDP=1 (broadcast_buffers=False: BatchNorm running statistics are per-rank like the reference's
+    sync_batchnorm=False; gradient_as_bucket_view avoids one copy per parameter)."""
     if world == 1 and not (force_ddp() and dist.is_initialized()):
         return step_module
     if overlap_allreduce() if overlap is None else overlap:

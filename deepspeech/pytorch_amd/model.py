@@ -58,6 +58,9 @@ import os  # noqa: E402
 # DS2_WGRAD_BESIDE_DX=1: the grouped weight-gradient launch of a layer runs beside its dX GEMM on the second stream (measured and
 # rejected as the default: 28.0 vs 27.4 ms per cfg3 step, 143.9 vs 142.4 on cfg5a -- two tile streams through one dispatcher)
 WGRAD_BESIDE_DX = os.environ.get("DS2_WGRAD_BESIDE_DX", "0") not in ("", "0")
+# the layer's dX product rides in the same launch as its weight gradients (long tiles first, the short dX tiles fill the CUs the
+# weight gradients leave idle); DS2_WGRAD_WITH_DX=0 launches them one after the other
+WGRAD_WITH_DX = os.environ.get("DS2_WGRAD_WITH_DX", "1") not in ("", "0")
 
 N_FREQ_CONV2 = 41
 RNN_INPUT = 32 * N_FREQ_CONV2  # 1312, model.py:166-169
@@ -407,6 +410,7 @@ class _RnnStackFn(torch.autograd.Function):
             rg = ops.rnn_bwd(kind, dout, WhhT, hext, Sv, lens_dev, D, N, H, Tp)
             dGI = rg.dGI
             fast = ops.wgrad_tn_ok(dtype, R, D * GH, Xh.shape[1]) and ops.wgrad_tn_ok(dtype, R, GH, H)
+            dXh_fused = None
             if fast:
                 # ---- weight gradients as ONE grouped launch of TN products (contraction over the T'*N rows, both operands as the
                 # activations are stored: no transposes).  Never under a sweep: what co-resident GEMMs cost the sweeps was the
@@ -440,37 +444,36 @@ class _RnnStackFn(torch.autograd.Function):
                             probs.append(dict(At=rg.dGH[d], Bt=hprev, M=GH, N=H, lda=GH, ldb=H, out=dWhh[d]))
                         else:
                             probs.append(dict(At=dGI[:, d * GH:], Bt=hprev, M=GH, N=H, lda=D * GH, ldb=H, out=dWhh[d]))
-                    ops.gemm8_tn_grouped(probs, R)
+                    if WGRAD_WITH_DX and wstream is main and len(probs) < 6 and ops.gemm8_nt_ok(dGI, WihT, R, WihT.shape[0], D * GH, D * GH,
+                                                                                                WihT.stride(0)):
+                        _, dXh_fused = ops.gemm8_tn_grouped(probs, R, dx=(dGI, WihT))   # + the layer's dX in the same launch
+                    else:
+                        ops.gemm8_tn_grouped(probs, R)
                     if first:
                         dWih = torch.cat([_perm_cols_to_reference(dWih[d * GH:(d + 1) * GH]) for d in range(D)], 0)
-                    bsum = None
                     if rg.bacc is not None:
-                        bsum = [ops.colsum(rg.bacc[d]) for d in range(D)]                   # [NB*H] per direction
-                        dBih = torch.cat([b[:GH] for b in bsum], 0)
+                        dBih, dBhh_all = ops.rnn_bias_grads(kind, rg.bacc, D, N, H)          # one launch: [D*G*H], [D][G*H]
+                        dBhh_l = [dBhh_all[d] for d in range(D)]
                     else:
                         dBih = ops.colsum(dGI)
-                    for d in range(D):
-                        if kind == "gru" and rg.dQ is not None:
-                            dBhh = torch.cat([bsum[d][:2 * H], bsum[d][3 * H:4 * H]], 0) if bsum is not None else \
-                                torch.cat([dBih[d * GH:d * GH + 2 * H], ops.colsum(rg.dQ[d].reshape(R, H))], 0)
-                        elif kind == "gru":
-                            dBhh = ops.colsum(rg.dGH[d].reshape(R, GH))
+                        dBhh_all = None
+                        if kind == "gru":
+                            dBhh_l = [ops.colsum(rg.dGH[d].reshape(R, GH)) for d in range(D)]
                         else:
-                            dBhh = dBih[d * GH:(d + 1) * GH]
-                        grads[po + 4 * d:po + 4 * d + 4] = [dWih[d * GH:(d + 1) * GH], dWhh[d], dBih[d * GH:(d + 1) * GH].contiguous(),
-                                                            dBhh.contiguous()]
+                            dBhh_l = [dBih[d * GH:(d + 1) * GH] for d in range(D)]
+                    for d in range(D):
+                        grads[po + 4 * d:po + 4 * d + 4] = [dWih[d * GH:(d + 1) * GH], dWhh[d], dBih[d * GH:(d + 1) * GH], dBhh_l[d]]
                     sync = getattr(mod, "_grad_sync", None)
                     if sync is not None and H == Ht:
-                        own = [dWih, dWhh, dBih]
-                        if kind == "gru":
-                            own += [grads[po + 4 * d + 3] for d in range(D)]
+                        own = [dWih, dWhh, dBih] + ([dBhh_all] if dBhh_all is not None else
+                                                    [dBhh_l[d] for d in range(D)] if kind == "gru" else [])
                         sync.layer_ready(own, params[po:po + 4 * D])
                     _unpad_layer_grads(grads, po, D, G, Ht, H, It, first)
                     if wstream is not main:
                         wgrad_done = torch.cuda.Event()
                         wgrad_done.record(wstream)
             # ---- dependent chain (caller's stream): dX -> BatchNorm backward
-            dXh = ops.gemm_nt(dGI, WihT)                                # [R][I]
+            dXh = dXh_fused if dXh_fused is not None else ops.gemm_nt(dGI, WihT)                                # [R][I]
             if has_bn:
                 dX = torch.empty_like(dXh)
                 grads[offs[li]], grads[offs[li] + 1] = _bn_seq_bwd(dXh, X, dX, sv, R, It, I)
@@ -599,6 +602,7 @@ class _FrontFn(torch.autograd.Function):
         outs = _RnnStackFn.forward(c2, X0, mod, lens_dev, N, Tp, dtype, training, n_layers, *rnn_rest)
         ctx.c1, ctx.c2, ctx.L = c1, c2, n_layers
         ctx.mark_non_differentiable(*outs[1:])
+        ctx.set_materialize_grads(False)           # no zero tensors for the (non-differentiable) state outputs in backward
         return outs
 
     @staticmethod

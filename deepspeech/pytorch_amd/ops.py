@@ -146,9 +146,10 @@ def gemm8_nt(A, B, bias=None, out_dtype=None, M=None, N=None, K=None, lda=None, 
     return out
 
 
-def gemm8_tn_grouped(problems, K):
+def gemm8_tn_grouped(problems, K, dx=None):
     """problems: list of dicts(At, Bt, M, N, lda, ldb[, At2, lda2, m_split][, out]); every product C[M][N] f32 = sum_{k<K} At[k][m] Bt[k][n]
-    in one launch.  Returns the list of outputs."""
+    in one launch.  Returns the list of outputs.  dx = (A, B): additionally the NT product A[M][Kx] * B[N][Kx]^T (bf16) in the SAME
+    launch (the layer's dX beside its weight gradients); returns (outputs, dX) then."""
     n = len(problems)
     outs = []
     for pr in problems:
@@ -169,6 +170,13 @@ def gemm8_tn_grouped(problems, K):
     ldc = la(*[o.stride(0) for o in outs])
     for pr in problems:
         P(pr["At"]), P(pr["Bt"])            # refuses CPU tensors
+    if dx is not None:
+        A, B = dx
+        Mx, Nx, Kx = A.shape[0], B.shape[0], A.shape[1]
+        out_x = torch.empty((Mx, Nx), dtype=A.dtype, device=A.device)
+        call("ds2_gemm8_wgrad_dx", n, At, At2, ms, Bt, Cs, Ms, Ns, lda, lda2, ldb, ldc, K, P(A), P(B), P(out_x), Mx, Nx, Kx, A.stride(0),
+             B.stride(0), Nx, S())
+        return outs, out_x
     call("ds2_gemm8_tn_grouped", n, At, At2, ms, Bt, Cs, Ms, Ns, lda, lda2, ldb, ldc, K, S())
     return outs
 
@@ -355,15 +363,22 @@ def use_persistent(kind, dtype, D, N, H):
         return False
     ok = bool(query("ds2_rnn_persist_supported", dt(dtype), CELLS[kind], D, N, H))
     if not ok:
-        # never silent: a device that does not expose all 256 CUs (partition / CU-mask modes) cannot host the persistent sweeps
-        # (one workgroup per CU, all co-resident) and runs the launch-per-time-step kernels instead (several times slower)
+        # never silent: a device that does not expose 256 CUs (partition / CU-mask modes) cannot host the persistent sweeps (one
+        # workgroup per CU, all co-resident).  That is an ERROR unless the caller opted into the launch-per-time-step kernels
+        # (several times slower): a CU-masked rank of a data-parallel job must not quietly become the straggler.
         dev = torch.cuda.current_device()
         cus = torch.cuda.get_device_properties(dev).multi_processor_count
-        if cus < 256 and dev not in _WARNED_CUS:
-            _WARNED_CUS.add(dev)
-            import warnings
-            warnings.warn("ds2hip: device %d exposes %d compute units (< 256): the persistent recurrent kernels are disabled, the "
-                          "recurrent sweeps use one launch per time step" % (dev, cus))
+        if cus < 256:
+            import os
+            if os.environ.get("DS2_ALLOW_LAUNCH_PER_STEP", "0") in ("", "0"):
+                raise _lib.Ds2HipError("ds2hip: device %d exposes %d compute units (< 256): the persistent recurrent kernels need one "
+                                       "workgroup per CU, all co-resident.  Set DS2_ALLOW_LAUNCH_PER_STEP=1 to run the launch-per-time-step "
+                                       "kernels instead (several times slower)." % (dev, cus))
+            if dev not in _WARNED_CUS:
+                _WARNED_CUS.add(dev)
+                import warnings
+                warnings.warn("ds2hip: device %d exposes %d compute units (< 256): the persistent recurrent kernels are disabled, the "
+                              "recurrent sweeps use one launch per time step" % (dev, cus))
     return ok
 
 
@@ -431,6 +446,15 @@ def rnn_bwd(kind, dOut, WhhT, hext, Sv, lens, D, N, H, Tp):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+def rnn_bias_grads(kind, bacc, D, N, H):
+    """(bias_ih.grad [D*G*H], bias_hh.grad [D][G*H]) from the BPTT sweep's per-sample sums bacc [D][N][NB*H] -- one launch."""
+    G = GATES[kind]
+    dbih = torch.empty(D * G * H, dtype=torch.float32, device=bacc.device)
+    dbhh = torch.empty((D, G * H), dtype=torch.float32, device=bacc.device)
+    call("ds2_rnn_bias_grads", CELLS[kind], D, N, H, PF(bacc), P(dbih), P(dbhh), S())
+    return dbih, dbhh
+
+
 def lookahead_fwd(x, w, Tp, N, H, save=True):
     y = torch.empty_like(x)
     pre = torch.empty_like(x) if save else None

@@ -74,6 +74,13 @@ int ds2_gemm8_nt(const void* A, const void* B, void* C, const float* bias, int M
 int ds2_gemm8_tn_grouped(int n_problems, const void* const* At, const void* const* At2, const int* m_split, const void* const* Bt, void* const* C,
                          const int* M, const int* N, const long* lda, const long* lda2, const long* ldb, const long* ldc, int K, ds2_stream_t stream);
 
+/* ds2_gemm8_wgrad_dx: the TN problems of ds2_gemm8_tn_grouped (n_tn <= 5) AND one NT product (bf16 out, no bias; the dX of the
+ * layer: same contract as ds2_gemm8_nt) in ONE launch, long tiles first -- the backward of one recurrent layer behind its sweep. */
+int ds2_gemm8_wgrad_dx(int n_tn, const void* const* At, const void* const* At2, const int* m_split, const void* const* Bt, void* const* C,
+                       const int* M, const int* N, const long* lda, const long* lda2, const long* ldb, const long* ldc, int K_tn,
+                       const void* A_nt, const void* B_nt, void* C_nt, int M_nt, int N_nt, int K_nt, long lda_nt, long ldb_nt, long ldc_nt,
+                       ds2_stream_t stream);
+
 /* ---- BatchNorm (model.py:159,162 BatchNorm2d in NFTC; model.py:28-33,86,196 SequenceWise BatchNorm1d) ---------------
  * mode 0: sequence matrix X[R][ldx], C features.   mode 1: conv activation NFTC (R = N*F*Tp rows, C = 32): output also
  * gets Hardtanh(0,20) (model.py:160,163) and the MaskConv time mask (model.py:61-68; t >= lens[n] -> 0).
@@ -178,6 +185,10 @@ int ds2_lookahead_fwd(int dtype, const void* x, const float* w, void* y, void* p
 long ds2_lookahead_ws_floats(int Tp, int N, int H, int ctx);
 int ds2_lookahead_bwd(int dtype, const void* x, const float* w, const void* pre, const void* dy, void* dx, float* dw, int Tp,
                       int N, int H, int ctx, float* ws, ds2_stream_t stream);
+/* bias_ih.grad [D][G*H] and bias_hh.grad [D][G*H] of a recurrent layer (torch GRU/LSTM/RNN backward, model.py:97-99) from the
+ * per-sample sums dBacc [D][N][NB*H] that ds2_rnn_persist_bwd accumulates (cell: 0 GRU, 1 LSTM, 2 tanh RNN). */
+int ds2_rnn_bias_grads(int cell, int D, int N, int H, const float* dBacc, float* dbih, float* dbhh, ds2_stream_t stream);
+
 /* probs = softmax(logits) row-wise (InferenceBatchSoftmax, model.py:72-77), f32 [rows][C] */
 int ds2_softmax_rows(const float* logits, float* probs, long rows, int C, long ld_in, long ld_out, ds2_stream_t stream);
 

@@ -36,14 +36,17 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out):
-    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+def _worker(rank, world, port, out, use_ddp=False):
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      DS2_USE_DDP="1" if use_ddp else "0")
     from deepspeech.pytorch_amd import dist as dsdist
     r, w, lr = dsdist.init_from_env("gloo")
     assert (r, w, lr) == (rank, world, rank)
     dev = torch.device("cpu")
     model = _StandIn()
     step_mod = dsdist.wrap_data_parallel(dsdist.StepModule(model), dev, world)
+    # default = the overlapped wrapper (a model without early hand-offs is reduced by its end-of-backward bucket); DS2_USE_DDP=1 = torch DDP
+    assert isinstance(step_mod, torch.nn.parallel.DistributedDataParallel if use_ddp else dsdist.OverlappedDataParallel)
     g = torch.Generator().manual_seed(100 + rank)          # every rank has its own minibatch
     x = torch.randn(6, 8, generator=g)
     pct = torch.ones(6)
@@ -73,11 +76,12 @@ def _worker(rank, world, port, out):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_gloo_data_parallel_step():
+@pytest.mark.parametrize("use_ddp", [False, True])
+def test_two_rank_gloo_data_parallel_step(use_ddp):
     world = 2
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out, use_ddp), nprocs=world, join=True)
     assert sorted(out.keys()) == [0, 1]
     for r in range(world):
         o = out[r]

@@ -85,3 +85,29 @@ def test_gemm8_tn_weight_gradient_shape():
         refs.append(torch.cat([dGI[:, d * 3 * H:d * 3 * H + 2 * H], dQ[d]], 1).float().t() @ Hp[d].float())
     for o, r in zip(outs, refs):
         assert (o - r).abs().max().item() / r.abs().max().item() < 2e-5
+
+
+def test_gemm8_weight_gradients_and_dx_in_one_launch():
+    """The mixed launch (TN weight-gradient problems + the NT dX product, ds2_gemm8_wgrad_dx) gives exactly what the two separate
+    launches give -- the same tiles, the same order of summation."""
+    from deepspeech.pytorch_amd import ops
+    R, H = 3008 + 40, 1024                                   # ragged K for the TN problems
+    dGI, X = _rand((R, 6 * H), 21), _rand((R, H + 64), 22)[:, :H]
+    dQ, Hp = _rand((2, R, H), 23), _rand((2, R, H), 24)
+    WihT = _rand((H, 6 * H), 25)
+
+    def problems():
+        probs = [dict(At=dGI, Bt=X, M=6 * H, N=H, lda=6 * H, ldb=X.stride(0))]
+        for d in range(2):
+            probs.append(dict(At=dGI[:, d * 3 * H:], At2=dQ[d], lda2=H, m_split=2 * H, Bt=Hp[d], M=3 * H, N=H, lda=6 * H, ldb=H))
+        return probs
+    outs_a = ops.gemm8_tn_grouped(problems(), R)
+    dx_a = ops.gemm8_nt(dGI, WihT)
+    outs_b, dx_b = ops.gemm8_tn_grouped(problems(), R, dx=(dGI, WihT))
+    for a, b in zip(outs_a, outs_b):
+        assert torch.equal(a, b)
+    assert torch.equal(dx_a, dx_b)
+    ref = dGI.float() @ WihT.float().t()
+    assert (dx_b.float() - ref).abs().max().item() / ref.abs().max().item() < 6e-3
+    ref_w = dGI.float().t() @ X.float()
+    assert (outs_b[0] - ref_w).abs().max().item() / ref_w.abs().max().item() < 2e-5
