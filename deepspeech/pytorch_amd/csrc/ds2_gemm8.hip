@@ -59,7 +59,7 @@ struct G8Args {
 
 // One output tile.  TN is a template parameter of the body; a launch that mixes NT and TN problems (k_gemm8<2>) selects the body
 // per workgroup with a wave-uniform branch.
-template <bool TN>
+template <bool TN, bool SPREAD>
 __device__ __forceinline__ void g8_tile(const G8Problem& P, int t_id, unsigned char* lds) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -119,32 +119,36 @@ __device__ __forceinline__ void g8_tile(const G8Problem& P, int t_id, unsigned c
   // LDS map: A of buffer b at b * 32 KiB, B of buffer b at 64 KiB + b * 32 KiB (every fragment read = one per-lane base register +
   // a 16-bit immediate)
   const long a_kstep = TN ? 128 * lda_eff : 128, b_kstep = TN ? 128 * P.ldb : 128;      // bytes per K-tile
-  auto stage_a = [&](int b, int kt) {
+  auto stage_a = [&](int b, int kt, int r0 = 0, int r1 = 4) {
     const unsigned char* src = (const unsigned char*)a_base + (long)kt * a_kstep;
     unsigned char* d = lds + b * 32768 + wave * 1024;
     if (tail && kt == nkt - 1) {
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) {
-        const uint32_t off = (uint32_t)((long)min(t_kr0 + rb * 16, krem - 1) * lda_eff * 2) + t_acol;
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + (size_t)off), (lds_ptr_t)(d + rb * 8192), 16, 0, 0);
-      }
+      for (int rb = 0; rb < 4; ++rb)
+        if (rb >= r0 && rb < r1) {
+          const uint32_t off = (uint32_t)((long)min(t_kr0 + rb * 16, krem - 1) * lda_eff * 2) + t_acol;
+          __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + (size_t)off), (lds_ptr_t)(d + rb * 8192), 16, 0, 0);
+        }
     } else {
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + (size_t)a_off[rb]), (lds_ptr_t)(d + rb * 8192), 16, 0, 0);
+      for (int rb = 0; rb < 4; ++rb)
+        if (rb >= r0 && rb < r1) __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + (size_t)a_off[rb]), (lds_ptr_t)(d + rb * 8192), 16, 0, 0);
     }
   };
-  auto stage_b = [&](int b, int kt) {
+  auto stage_b = [&](int b, int kt, int r0 = 0, int r1 = 4) {
     const unsigned char* src = (const unsigned char*)b_base + (long)kt * b_kstep;
     unsigned char* d = lds + 65536 + b * 32768 + wave * 1024;
     if (tail && kt == nkt - 1) {
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) {
-        const uint32_t off = (uint32_t)((long)min(t_kr0 + rb * 16, krem - 1) * P.ldb * 2) + t_bcol;
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + (size_t)off), (lds_ptr_t)(d + rb * 8192), 16, 0, 0);
-      }
+      for (int rb = 0; rb < 4; ++rb)
+        if (rb >= r0 && rb < r1) {
+          const uint32_t off = (uint32_t)((long)min(t_kr0 + rb * 16, krem - 1) * P.ldb * 2) + t_bcol;
+          __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + (size_t)off), (lds_ptr_t)(d + rb * 8192), 16, 0, 0);
+        }
     } else {
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + (size_t)b_off[rb]), (lds_ptr_t)(d + rb * 8192), 16, 0, 0);
+      for (int rb = 0; rb < 4; ++rb)
+        if (rb >= r0 && rb < r1) __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + (size_t)b_off[rb]), (lds_ptr_t)(d + rb * 8192), 16, 0, 0);
     }
   };
   // zero the k-rows [krem, 64) of both operand tiles of buffer b (waves 0-3; the DMA of that K-tile has landed for every wave)
@@ -230,42 +234,56 @@ __device__ __forceinline__ void g8_tile(const G8Problem& P, int t_id, unsigned c
     __builtin_amdgcn_s_setprio(0);
   };
 
-  // one K-tile: buffer BUF holds K-tile KT (landed and visible), the DMA of K-tile KT + 1 into the other buffer is in flight
-#define G8_KTILE(BUF, KT)                 \
-  {                                       \
-    const bool more = (KT) + 2 < nkt;     \
-    if (tail && (KT) == nkt - 1) zero_tail(BUF); \
-    /* phase 0 */                         \
-    G8_READ_A(BUF, 0)                     \
-    G8_READ_B(BUF, 0, fbx)                \
-    G8_BARRIER();                         \
-    G8_WAIT_LGKM0();                      \
-    __builtin_amdgcn_sched_barrier(0);    \
-    mma(0, 0, fbx);                       \
-    G8_BARRIER();                         \
-    /* phase 1 */                         \
-    G8_READ_B(BUF, 1, fby)                \
-    G8_WAIT_LGKM0();                      \
-    G8_BARRIER();                         \
-    mma(0, 1, fby);                       \
-    G8_BARRIER();                         \
-    /* phase 2 */                         \
-    G8_READ_A(BUF, 1)                     \
-    if (more) stage_b(BUF, (KT) + 2);     \
-    G8_WAIT_LGKM0();                      \
-    G8_BARRIER();                         \
-    mma(1, 1, fby);                       \
-    G8_BARRIER();                         \
-    /* phase 3 */                         \
-    if (more) {                           \
-      stage_a(BUF, (KT) + 2);             \
-      G8_WAIT_VM(8);                      \
-    } else {                              \
-      G8_WAIT_VM(0);                      \
-    }                                     \
-    G8_BARRIER();                         \
-    mma(1, 0, fbx);                       \
-    G8_BARRIER();                         \
+  // one K-tile: buffer BUF holds K-tile KT (landed and visible).
+  //  !SPREAD: the DMA of K-tile KT + 1 into the other buffer is in flight; K-tile KT + 2 is staged into BUF in phases 2 (B) and 3 (A).
+  //   SPREAD (experiment, not the default): two DMA pieces per phase -- B of K-tile KT + 2 goes into BUF in phases 2 and 3, A of
+  //           K-tile KT + 1 into the other buffer in phases 0 and 1 (its A rows were last read in phase 2 of the K-tile before).  In
+  //           flight at the phase-3 wait: the four B pieces just issued -> s_waitcnt vmcnt(4) retires everything K-tile KT + 1 needs.
+#define G8_KTILE(BUF, KT)                                      \
+  {                                                            \
+    const bool more = (KT) + 2 < nkt;                          \
+    const bool more_a = SPREAD && (KT) >= 1 && (KT) + 1 < nkt; \
+    if (tail && (KT) == nkt - 1) zero_tail(BUF);               \
+    /* phase 0 */                                              \
+    G8_READ_A(BUF, 0)                                          \
+    G8_READ_B(BUF, 0, fbx)                                     \
+    if (more_a) stage_a((BUF) ^ 1, (KT) + 1, 0, 2);            \
+    G8_BARRIER();                                              \
+    G8_WAIT_LGKM0();                                           \
+    __builtin_amdgcn_sched_barrier(0);                         \
+    mma(0, 0, fbx);                                            \
+    G8_BARRIER();                                              \
+    /* phase 1 */                                              \
+    G8_READ_B(BUF, 1, fby)                                     \
+    if (more_a) stage_a((BUF) ^ 1, (KT) + 1, 2, 4);            \
+    G8_WAIT_LGKM0();                                           \
+    G8_BARRIER();                                              \
+    mma(0, 1, fby);                                            \
+    G8_BARRIER();                                              \
+    /* phase 2 */                                              \
+    G8_READ_A(BUF, 1)                                          \
+    if (more) stage_b(BUF, (KT) + 2, 0, SPREAD ? 2 : 4);       \
+    G8_WAIT_LGKM0();                                           \
+    G8_BARRIER();                                              \
+    mma(1, 1, fby);                                            \
+    G8_BARRIER();                                              \
+    /* phase 3 */                                              \
+    if (SPREAD) {                                              \
+      if (more) {                                              \
+        stage_b(BUF, (KT) + 2, 2, 4);                          \
+        G8_WAIT_VM(4);                                         \
+      } else {                                                 \
+        G8_WAIT_VM(0);                                         \
+      }                                                        \
+    } else if (more) {                                         \
+      stage_a(BUF, (KT) + 2);                                  \
+      G8_WAIT_VM(8);                                           \
+    } else {                                                   \
+      G8_WAIT_VM(0);                                           \
+    }                                                          \
+    G8_BARRIER();                                              \
+    mma(1, 0, fbx);                                            \
+    G8_BARRIER();                                              \
   }
 
   // prologue: K-tiles 0 and 1
@@ -378,7 +396,7 @@ __device__ __forceinline__ void g8_tile(const G8Problem& P, int t_id, unsigned c
 // MODE 0: every problem NT, 1: every problem TN, 2: mixed.  Workgroup -> (problem, tile): problems own consecutive id ranges (the
 // host orders them by decreasing K, so the long tiles are dispatched first); inside a problem's range the ids that the dispatcher
 // places on one XCD (id % 8) get a contiguous run of its tiles (neighbouring tiles share operand panels in that XCD's L2).
-template <int MODE>
+template <int MODE, bool SPREAD>
 __global__ void __launch_bounds__(512, 2) k_gemm8(G8Args g) {
   __shared__ __attribute__((aligned(1024))) unsigned char lds[131072];
   const int id = blockIdx.x;
@@ -400,18 +418,36 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(G8Args g) {
   }
   const int t_id = base + (local - ((xcd - first) & 7)) / 8;
   if (MODE == 0)
-    g8_tile<false>(P, t_id, lds);
+    g8_tile<false, SPREAD>(P, t_id, lds);
   else if (MODE == 1)
-    g8_tile<true>(P, t_id, lds);
+    g8_tile<true, SPREAD>(P, t_id, lds);
   else if (P.tn)
-    g8_tile<true>(P, t_id, lds);
+    g8_tile<true, SPREAD>(P, t_id, lds);
   else
-    g8_tile<false>(P, t_id, lds);
+    g8_tile<false, SPREAD>(P, t_id, lds);
+}
+
+int g_variant = 0;   // 0: four DMA pieces in phases 2 and 3 (default); 1: two per phase (SPREAD) -- measured: no gain on the NT
+                     // shapes of the step (0.289 vs 0.290 ms), slower on the grouped TN launch (0.555 vs 0.589 ms), profiles/r03d_gemm8_ab.txt
+template <int MODE>
+void g8_launch(int total, const G8Args& g, hipStream_t st) {
+  if (g_variant)
+    hipLaunchKernelGGL((k_gemm8<MODE, true>), dim3(total), dim3(512), 0, st, g);
+  else
+    hipLaunchKernelGGL((k_gemm8<MODE, false>), dim3(total), dim3(512), 0, st, g);
 }
 
 }  // namespace
 
 extern "C" {
+
+// Staging schedule of the 256x256 kernels (for A/B measurements): 0 = four DMA pieces in the last two phases of a K-tile (default),
+// 1 = two per phase.  Returns the previous value.  Results are identical either way.
+int ds2_gemm8_set_variant(int v) {
+  const int old = g_variant;
+  g_variant = v != 0;
+  return old;
+}
 
 // C (f32 if out_f32 else bf16) [M][ldc] = A[M][lda] * B[N][ldb]^T (+ bias[N]) on the 256x256 phase-split kernel.
 // K % 64 == 0, lda/ldb % 8 == 0, 16-byte aligned operands of < 2^31 elements.
@@ -424,7 +460,7 @@ int ds2_gemm8_nt(const void* A, const void* B, void* C, const float* bias, int M
   g.n_problems = 1;
   const int tm = ds2_cdiv(M, 256), tn = ds2_cdiv(N, 256);
   g.p[0] = G8Problem{(const bf16_t*)A, nullptr, (const bf16_t*)B, C, bias, M, N, 0, lda, 0, ldb, ldc, tn, tm * tn, out_f32, K, 0};
-  hipLaunchKernelGGL(k_gemm8<0>, dim3(tm * tn), dim3(512), 0, (hipStream_t)st, g);
+  g8_launch<0>(tm * tn, g, (hipStream_t)st);
   DS2_CHECK_LAUNCH();
   return 0;
 }
@@ -451,7 +487,7 @@ int ds2_gemm8_tn_grouped(int n_problems, const void* const* At, const void* cons
     total += tm * tn;
     g.p[i] = G8Problem{(const bf16_t*)At[i], (const bf16_t*)a2, (const bf16_t*)Bt[i], C[i], nullptr, M[i], N[i], ms, lda[i], a2 ? lda2[i] : 0, ldb[i], ldc[i], tn, total, 1, K, 1};
   }
-  hipLaunchKernelGGL(k_gemm8<1>, dim3(total), dim3(512), 0, (hipStream_t)st, g);
+  g8_launch<1>(total, g, (hipStream_t)st);
   DS2_CHECK_LAUNCH();
   return 0;
 }
@@ -486,7 +522,7 @@ int ds2_gemm8_wgrad_dx(int n_tn, const void* const* At, const void* const* At2, 
   const int tm = ds2_cdiv(M_nt, 256), tn = ds2_cdiv(N_nt, 256);
   total += tm * tn;
   g.p[n_tn] = G8Problem{(const bf16_t*)A_nt, nullptr, (const bf16_t*)B_nt, C_nt, nullptr, M_nt, N_nt, 0, lda_nt, 0, ldb_nt, ldc_nt, tn, total, 0, K_nt, 0};
-  hipLaunchKernelGGL(k_gemm8<2>, dim3(total), dim3(512), 0, (hipStream_t)st, g);
+  g8_launch<2>(total, g, (hipStream_t)st);
   DS2_CHECK_LAUNCH();
   return 0;
 }

@@ -71,6 +71,8 @@ int ds2_gemm_nt_coresident(int dtype, const void* A, const void* B, void* C, con
  * gate gradient [dr, dz | dQ] lives in two buffers.  Any K (no row past K - 1 is read); M_i, N_i, lda, ldb % 8 == 0. */
 int ds2_gemm8_nt(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long lda, long ldb, long ldc, int out_f32,
                  ds2_stream_t stream);
+/* staging schedule of the 256x256 kernels, for A/B measurements (0 = default); returns the previous value */
+int ds2_gemm8_set_variant(int v);
 int ds2_gemm8_tn_grouped(int n_problems, const void* const* At, const void* const* At2, const int* m_split, const void* const* Bt, void* const* C,
                          const int* M, const int* N, const long* lda, const long* lda2, const long* ldb, const long* ldc, int K, ds2_stream_t stream);
 
