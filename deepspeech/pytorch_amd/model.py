@@ -286,11 +286,12 @@ class _RnnStackFn(torch.autograd.Function):
     """The whole stack of BatchRNN layers (model.py:228-230 over BatchRNN.forward, model.py:94-102):
     per layer [SequenceWise BatchNorm1d] -> input projection GEMM -> packed bi/uni GRU/LSTM/RNN sweep -> direction sum.
 
-    One autograd node for all layers so that backward controls the schedule: the BPTT sweeps, the dX GEMM and the
-    BatchNorm backward form the dependent chain on the caller's stream, while every layer's weight-gradient work
-    (operand transposes, dW_ih / dW_hh GEMMs, bias column sums) runs on a second HIP stream UNDER the next layer's sweep --
-    the persistent recurrent kernel is latency-bound and leaves most of each CU's registers, LDS and MFMA issue slots free.
-    The streams join before backward returns, so the gradients handed to autograd / DDP are complete."""
+    One autograd node for all layers so that backward controls the schedule.  bf16 (the performance mode): per layer the BPTT
+    sweep, then ONE launch with the layer's weight gradients (grouped TN products over the activations as stored) and its dX,
+    then the BatchNorm backward -- all on the caller's stream; nothing runs beside a sweep (a co-runner costs the latency-bound
+    sweep the chip's clock).  fp32 / small / odd shapes: the round-2 path (operand transposes + 128x128
+    GEMMs on a second HIP stream).  The streams join before backward returns, so the gradients handed to autograd / DDP are
+    complete."""
 
     @staticmethod
     def forward(ctx, X, mod, lens_dev, N, Tp, dtype, training, n_layers, *rest):
