@@ -111,3 +111,38 @@ def test_gemm8_weight_gradients_and_dx_in_one_launch():
     assert (dx_b.float() - ref).abs().max().item() / ref.abs().max().item() < 6e-3
     ref_w = dGI.float().t() @ X.float()
     assert (outs_b[0] - ref_w).abs().max().item() / ref_w.abs().max().item() < 2e-5
+
+
+def test_gemm8_race_screen_bit_identical_under_uneven_load():
+    """The kernels order their LDS hand-offs by counters and barriers, never by timing; the summation order is fixed.  So repeated
+    launches must be BIT-identical whatever else the chip does: 25 rounds of an NT, a grouped TN and a mixed launch while a second
+    stream streams HBM (uneven load moves the DMA landing times around), every output compared with the first round's bit for bit."""
+    from deepspeech.pytorch_amd import ops
+    A, B = _rand((2048 + 77, 576), 31), _rand((1024 + 40, 576), 32)
+    R, H = 1000, 512
+    dG, X, Hp = _rand((R, 3 * H), 33), _rand((R, H), 34), _rand((R, H), 35)
+    W = _rand((H, 3 * H), 36)
+
+    def problems():
+        return [dict(At=dG, Bt=X, M=3 * H, N=H, lda=3 * H, ldb=H), dict(At=dG[:, H:], Bt=Hp, M=2 * H, N=H, lda=3 * H, ldb=H)]
+    hog_src = torch.empty(256 << 20, dtype=torch.uint8, device=DEV)
+    hog_dst = torch.empty_like(hog_src)
+    side = torch.cuda.Stream()
+    first = None
+    for rnd in range(25):
+        if rnd % 2 == 1:
+            with torch.cuda.stream(side):
+                for _ in range(1 + rnd % 3):
+                    hog_dst.copy_(hog_src, non_blocking=True)
+        c_nt = ops.gemm8_nt(A, B, out_dtype=torch.float32)
+        c_tn = ops.gemm8_tn_grouped(problems(), R)
+        c_mx, dx = ops.gemm8_tn_grouped(problems(), R, dx=(dG, W))
+        torch.cuda.synchronize()
+        cur = [c_nt] + c_tn + c_mx + [dx]
+        if first is None:
+            first = [t.clone() for t in cur]
+            ref = A.float() @ B.float().t()
+            assert (c_nt - ref).abs().max().item() / ref.abs().max().item() < 2e-5
+        else:
+            for a, b in zip(first, cur):
+                assert torch.equal(a, b), rnd
