@@ -57,6 +57,7 @@ SIGNATURES = {
     "ds2_lookahead_ws_floats": (_l, [_i, _i, _i, _i]),
     "ds2_lookahead_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "ds2_rnn_bias_grads": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "ds2_ctc_set_variant": (_i, [_i]),
     "ds2_softmax_rows": (_i, [_vp, _vp, _l, _i, _l, _l, _vp]),
     "ds2_opt_max_tensors": (_i, []),
     "ds2_clip_ws_floats": (_l, [_i, _vp]),

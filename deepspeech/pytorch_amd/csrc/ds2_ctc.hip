@@ -233,6 +233,152 @@ __global__ void __launch_bounds__(REC_THREADS) k_ctc_recursion(const int* __rest
   }
 }
 
+// The same recursion with ONE WAVE per (sample, direction) -- the fast path for 32 classes and SHORT targets (see ds2_ctc_set_variant).
+// The states of the extended label sequence live in registers, NS per lane, blocked (lane l owns states l*NS .. l*NS + NS - 1); the
+// neighbours s-1 / s-2 (alpha) or s+1 / s+2 (beta) of a lane's first / last states come from the adjacent lane by a wave
+// shift.  No LDS round trip of the rows and no workgroup barrier per step (the 4-wave kernel above spends most of its 0.48 us per
+// step there); the log-prob rows are staged in LDS by the wave itself, LP_CHUNK steps ahead.  Same formulas, same values.
+// lane i <- lane i - 1 / lane i + 1 of the whole wave in ONE VALU instruction (GFX9 DPP wave shifts; the lane without a source gets
+// 0, which only ever meets a -inf transition mask)
+__device__ __forceinline__ float wave_from_below(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_from_above(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, true));
+}
+
+template <int NS>
+__global__ void __launch_bounds__(64) k_ctc_recursion_wave(const int* __restrict__ targets, const int* __restrict__ toff,
+                                                           const int* __restrict__ in_len, const int* __restrict__ tg_len,
+                                                           int Tp, int blank, int Lmax, float* __restrict__ nll_out,
+                                                           const float* __restrict__ ws_lp, float* __restrict__ ws_alpha,
+                                                           float* __restrict__ ws_beta, float* __restrict__ ws_ll) {
+  constexpr int CP = 32;
+  constexpr int PE = LP_CHUNK * CP / 64;             // staged elements per lane and chunk
+  __shared__ float lpl[2][LP_CHUNK * CP];
+  __shared__ float fin[64 * NS];
+  const int lane = threadIdx.x;
+  const int n = blockIdx.x;
+  const bool is_beta = blockIdx.y != 0;
+  int Ti = in_len[n];
+  if (Ti > Tp) Ti = Tp;
+  const int S = tg_len[n];
+  const int L = 2 * S + 1;
+  if (Ti <= 0) {
+    if (!is_beta && lane == 0) {
+      nll_out[n] = 0.f;
+      ws_ll[n] = INFINITY;
+    }
+    return;
+  }
+  const int* tg = targets + toff[n];
+  const float* lp = ws_lp + (long)n * Tp * CP;
+  float* dst = (is_beta ? ws_beta : ws_alpha) + (long)n * Tp * Lmax;
+  auto ext = [&](int s) { return (s & 1) ? tg[s >> 1] : blank; };
+  int e_[NS];
+  bool valid[NS];
+  float m0[NS], m1[NS], m2[NS], prev[NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    const int s = lane * NS + j;
+    valid[j] = s < L;
+    const int sc = valid[j] ? s : L - 1;
+    const int e = ext(sc);
+    e_[j] = e;
+    bool ok1, ok2, entry;
+    if (!is_beta) {
+      ok1 = sc >= 1;
+      ok2 = sc >= 2 && e != blank && e != ext(sc >= 2 ? sc - 2 : 0);
+      entry = sc <= 1;
+    } else {
+      ok1 = sc + 1 < L;
+      ok2 = sc + 2 < L && ext(sc + 2 < L ? sc + 2 : L - 1) != blank && ext(sc + 2 < L ? sc + 2 : L - 1) != e;
+      entry = sc >= L - 2;
+    }
+    m0[j] = entry ? 0.f : -INFINITY;
+    m1[j] = ok1 ? 0.f : -INFINITY;
+    m2[j] = ok2 ? 0.f : -INFINITY;
+    prev[j] = -INFINITY;
+  }
+  // stage the first chunk of log-prob rows
+#pragma unroll
+  for (int q = 0; q < PE; ++q) {
+    const int el = lane + q * 64, prow = el / CP, pcol = el % CP;
+    const int i = prow < Ti ? prow : Ti - 1;
+    lpl[0][el] = lp[(long)(is_beta ? Ti - 1 - i : i) * CP + pcol];
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int i0 = 0; i0 < Ti; i0 += LP_CHUNK) {
+    const float* lpc = lpl[(i0 / LP_CHUNK) & 1];
+    float nxt[PE];
+#pragma unroll
+    for (int q = 0; q < PE; ++q) {
+      const int el = lane + q * 64;
+      int pi = i0 + LP_CHUNK + el / CP;
+      if (pi > Ti - 1) pi = Ti - 1;
+      nxt[q] = lp[(long)(is_beta ? Ti - 1 - pi : pi) * CP + el % CP];
+    }
+    const int kend = Ti - i0 < LP_CHUNK ? Ti - i0 : LP_CHUNK;
+    float pe_n[NS];                                    // emission terms one step ahead (their LDS latency under the step before)
+#pragma unroll
+    for (int j = 0; j < NS; ++j) pe_n[j] = lpc[e_[j]];
+    for (int k = 0; k < kend; ++k) {
+      const int i = i0 + k;
+      const int t = is_beta ? Ti - 1 - i : i;
+      float pe[NS], cur[NS];
+#pragma unroll
+      for (int j = 0; j < NS; ++j) {
+        pe[j] = pe_n[j];
+        pe_n[j] = lpc[(k + 1 < LP_CHUNK ? k + 1 : k) * CP + e_[j]];
+      }
+      // the two states beyond this lane's block: alpha looks down (s-1, s-2 of the lane's first states), beta up
+      float n1, n2;
+      if (!is_beta) {
+        n1 = wave_from_below(prev[NS - 1]);
+        n2 = NS >= 2 ? wave_from_below(prev[NS >= 2 ? NS - 2 : 0]) : wave_from_below(n1);
+      } else {
+        n1 = wave_from_above(prev[0]);
+        n2 = NS >= 2 ? wave_from_above(prev[NS >= 2 ? 1 : 0]) : wave_from_above(n1);
+      }
+#pragma unroll
+      for (int j = 0; j < NS; ++j) {
+        float a1, a2;
+        if (!is_beta) {
+          a1 = j >= 1 ? prev[j >= 1 ? j - 1 : 0] : n1;
+          a2 = j >= 2 ? prev[j >= 2 ? j - 2 : 0] : (j == 1 ? n1 : n2);
+        } else {
+          a1 = j + 1 < NS ? prev[j + 1 < NS ? j + 1 : 0] : n1;
+          a2 = j + 2 < NS ? prev[j + 2 < NS ? j + 2 : 0] : (j + 2 == NS ? n1 : n2);
+        }
+        const float rec = lse3(prev[j], a1 + m1[j], a2 + m2[j]);
+        float v = (i == 0 ? m0[j] : rec) + pe[j];
+        if (!valid[j]) v = -INFINITY;                  // states past L never feed a real one anything but -inf
+        cur[j] = v;
+        if (valid[j]) dst[(long)t * Lmax + lane * NS + j] = v;
+      }
+#pragma unroll
+      for (int j = 0; j < NS; ++j) prev[j] = cur[j];
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < PE; ++q) lpl[((i0 / LP_CHUNK) + 1) & 1][lane + q * 64] = nxt[q];
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (!is_beta) {
+#pragma unroll
+    for (int j = 0; j < NS; ++j) fin[lane * NS + j] = prev[j];
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      const float l1 = fin[L - 1];
+      const float l2 = L > 1 ? fin[L - 2] : -INFINITY;
+      const float ll = lse3(l1, l2, -INFINITY);
+      const bool feasible = L <= 2 * Ti + 1 && ll != -INFINITY;      // zero_infinity: only an infinite loss is zeroed (see above)
+      nll_out[n] = feasible ? -ll : 0.f;
+      ws_ll[n] = feasible ? ll : INFINITY;
+    }
+  }
+}
+
 // grid (ceil(Tp / GRAD_FRAMES), N); one wave per frame.  Writes EVERY row of dlogits of its frames (zeros past the
 // sample's length and for infeasible samples).
 template <int CP>
@@ -316,6 +462,17 @@ __global__ void k_sum_small(const float* __restrict__ v, int n, float* __restric
 
 extern "C" {
 
+// 1 (default): the one-wave-per-recursion kernel where it wins -- <= 32 classes and targets of <= 63 labels (2 states per lane:
+//    253 vs 330 us on 32 clips of 751 frames; with 6 states per lane -- cfg3's 180 labels -- the single SIMD's VALU throughput loses
+//    to the four-wave kernel, 555 vs 414 us; profiles/r03g_ctc_ab.txt);  0: always the four-wave kernel;  2: the one-wave kernel up
+//    to 255 labels (tests).  Results are identical in every setting.
+static int g_ctc_wave = 1;
+int ds2_ctc_set_variant(int mode) {
+  const int old = g_ctc_wave;
+  g_ctc_wave = mode < 0 ? 0 : mode > 2 ? 2 : mode;
+  return old;
+}
+
 static int ctc_class_stride(int C) { return C <= 32 ? 32 : C <= 64 ? 64 : C <= 128 ? 128 : 256; }
 
 long ds2_ctc_ws_floats(int Tp, int N, int C, int max_target_len) {
@@ -350,8 +507,24 @@ int ds2_ctc_loss_grad(const float* logits, long ldl, const int* targets, const i
     hipLaunchKernelGGL(k_ctc_logsoftmax<CPT>, dim3(ds2_cdiv((long)Tp * N, 256)), dim3(256), 0, st, logits, ldl, input_lengths, Tp, \
                        N, C, ws_lp);                                                                                                \
     DS2_CHECK_LAUNCH();                                                                                                             \
-    hipLaunchKernelGGL(k_ctc_recursion<CPT>, dim3(N, 2), dim3(REC_THREADS), shm, st, targets, target_offsets, input_lengths,        \
-                       target_lengths, Tp, blank, Lmax, nll, ws_lp, ws_alpha, ws_beta, ws_ll);                                      \
+    if (CPT == 32 && ((g_ctc_wave == 1 && Lmax <= 128) || (g_ctc_wave == 2 && Lmax <= 512))) {                                                                                   \
+      /* one wave per (sample, direction), 2 / 4 / 6 / 8 states per lane */                                                        \
+      if (Lmax <= 128)                                                                                                              \
+        hipLaunchKernelGGL(k_ctc_recursion_wave<2>, dim3(N, 2), dim3(64), 0, st, targets, target_offsets, input_lengths,            \
+                           target_lengths, Tp, blank, Lmax, nll, ws_lp, ws_alpha, ws_beta, ws_ll);                                  \
+      else if (Lmax <= 256)                                                                                                         \
+        hipLaunchKernelGGL(k_ctc_recursion_wave<4>, dim3(N, 2), dim3(64), 0, st, targets, target_offsets, input_lengths,            \
+                           target_lengths, Tp, blank, Lmax, nll, ws_lp, ws_alpha, ws_beta, ws_ll);                                  \
+      else if (Lmax <= 384)                                                                                                         \
+        hipLaunchKernelGGL(k_ctc_recursion_wave<6>, dim3(N, 2), dim3(64), 0, st, targets, target_offsets, input_lengths,            \
+                           target_lengths, Tp, blank, Lmax, nll, ws_lp, ws_alpha, ws_beta, ws_ll);                                  \
+      else                                                                                                                          \
+        hipLaunchKernelGGL(k_ctc_recursion_wave<8>, dim3(N, 2), dim3(64), 0, st, targets, target_offsets, input_lengths,            \
+                           target_lengths, Tp, blank, Lmax, nll, ws_lp, ws_alpha, ws_beta, ws_ll);                                  \
+    } else {                                                                                                                        \
+      hipLaunchKernelGGL(k_ctc_recursion<CPT>, dim3(N, 2), dim3(REC_THREADS), shm, st, targets, target_offsets, input_lengths,      \
+                         target_lengths, Tp, blank, Lmax, nll, ws_lp, ws_alpha, ws_beta, ws_ll);                                    \
+    }                                                                                                                               \
     DS2_CHECK_LAUNCH();                                                                                                             \
     hipLaunchKernelGGL(k_ctc_gradient<CPT>, dim3(ds2_cdiv(Tp, GRAD_FRAMES), N), dim3(GRAD_WAVES * 64), 0, st, targets,              \
                        target_offsets, input_lengths, target_lengths, Tp, N, C, blank, Lmax, grad_scale, dlogits, ldg, ws_lp,       \

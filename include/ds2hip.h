@@ -194,6 +194,10 @@ int ds2_rnn_bias_grads(int cell, int D, int N, int H, const float* dBacc, float*
 /* probs = softmax(logits) row-wise (InferenceBatchSoftmax, model.py:72-77), f32 [rows][C] */
 int ds2_softmax_rows(const float* logits, float* probs, long rows, int C, long ld_in, long ld_out, ds2_stream_t stream);
 
+/* recursion kernel of ds2_ctc_loss_grad: 1 (default) = one wave per (sample, direction) for <= 32 classes and targets of <= 63
+ * labels, the four-wave kernel otherwise; 0 = always the four-wave kernel; 2 = the one-wave kernel up to 255 labels.  A/B and test
+ * hook; identical results.  Returns the previous value. */
+int ds2_ctc_set_variant(int mode);
 /* ---- log_softmax + CTC loss + gradient (model.py:246,203,248) -----------------------------------------------------------
  * logits [Tp*N][ldl] f32 (row = t*N+n, C classes), targets int32 concatenated with target_offsets[N] (start of each
  * sample's labels), input_lengths/target_lengths int32 [N].  blank index `blank`; reduction 'sum'; zero_infinity: an
