@@ -206,6 +206,163 @@ __global__ void __launch_bounds__(256) k_lookahead_bwd_w(const T* __restrict__ d
   }
 }
 
+// ---- sliding-window versions for the reference's default context (CTX compiled in) ----------------------------------------
+// The kernels above read every operand row once per TAP (20 x the tensor through L1/L2: 1.9 ms for the weight gradient, 0.9 for
+// the data gradient, 0.5 forward at config 5b).  Here a thread walks a time segment of one (sample, four channels) column with the
+// last CTX operand values in registers: one load per operand and frame.  The frame loop is unrolled CTX times so that every
+// window slot is a compile-time register index; a segment re-reads CTX-1 halo frames (19 % at 100-frame segments).  The
+// summation order over the taps is the one of the kernels above.
+constexpr int LA_SEG_STEPS = 5;          // a segment = LA_SEG_STEPS * CTX frames
+__device__ __forceinline__ void la_store4(bf16_t* p, const float (&v)[4]) {
+  uint2 o;
+  o.x = cvt_pk_bf16(v[0], v[1]);
+  o.y = cvt_pk_bf16(v[2], v[3]);
+  *reinterpret_cast<uint2*>(p) = o;
+}
+__device__ __forceinline__ void la_store4(float* p, const float (&v)[4]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+struct LaCol { int h0, n, t0, t1; bool ok; };
+template <int CTX>
+__device__ __forceinline__ LaCol la_column(int Tp, int N, int H) {
+  const int hv = H / 4;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  LaCol c;
+  c.h0 = (int)(e % hv) * 4;
+  const long rest = e / hv;
+  c.n = (int)(rest % N);
+  c.t0 = (int)(rest / N) * (LA_SEG_STEPS * CTX);
+  c.t1 = min(Tp, c.t0 + LA_SEG_STEPS * CTX);
+  c.ok = c.t0 < Tp;
+  return c;
+}
+
+template <typename T, int CTX>
+__global__ void __launch_bounds__(256) k_lookahead_fwd_slide(const T* __restrict__ x, const float* __restrict__ w,
+                                                              T* __restrict__ y, T* __restrict__ pre, int Tp, int N, int H) {
+  const LaCol c = la_column<CTX>(Tp, N, H);
+  if (!c.ok) return;
+  float wk[CTX][4], xw[CTX][4];
+#pragma unroll
+  for (int k = 0; k < CTX; ++k)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wk[k][i] = w[(long)(c.h0 + i) * CTX + k];
+  const long col = (long)c.n * H + c.h0, ts = (long)N * H;
+#pragma unroll
+  for (int s = 0; s < CTX - 1; ++s) {                       // x[t0 .. t0+CTX-2] -> slots 0 .. CTX-2
+    la_load4(x + (long)min(c.t0 + s, Tp - 1) * ts + col, xw[s]);
+    if (c.t0 + s >= Tp)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xw[s][i] = 0.f;
+  }
+  for (int tb = c.t0; tb < c.t1; tb += CTX) {
+#pragma unroll
+    for (int j = 0; j < CTX; ++j) {
+      const int t = tb + j;
+      if (t < c.t1) {
+        const int tn = t + CTX - 1, slot = (j + CTX - 1) % CTX;
+        la_load4(x + (long)min(tn, Tp - 1) * ts + col, xw[slot]);
+        if (tn >= Tp)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) xw[slot][i] = 0.f;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < CTX; ++k)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i] = fmaf(wk[k][i], xw[(j + k) % CTX][i], acc[i]);
+        const long o = (long)t * ts + col;
+        if (pre) la_store4(pre + o, acc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = fminf(fmaxf(acc[i], 0.f), 20.f);
+        la_store4(y + o, acc);
+      }
+    }
+  }
+}
+
+// g[t] = dy[t] * [0 < pre[t] < 20] of this thread's column; zero outside [0, Tp)
+template <typename T>
+__device__ __forceinline__ void la_load_g(const T* __restrict__ dy, const T* __restrict__ pre, int t, int Tp, long ts, long col,
+                                          float (&g)[4]) {
+  const long o = (long)min(max(t, 0), Tp - 1) * ts + col;
+  float p[4];
+  la_load4(dy + o, g);
+  la_load4(pre + o, p);
+  const bool in = t >= 0 && t < Tp;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) g[i] = (in && p[i] > 0.f && p[i] < 20.f) ? g[i] : 0.f;
+}
+
+template <typename T, int CTX>
+__global__ void __launch_bounds__(256) k_lookahead_bwd_x_slide(const T* __restrict__ dy, const T* __restrict__ pre,
+                                                                const float* __restrict__ w, T* __restrict__ dx, int Tp, int N,
+                                                                int H) {
+  const LaCol c = la_column<CTX>(Tp, N, H);
+  if (!c.ok) return;
+  float wk[CTX][4], gw[CTX][4];
+#pragma unroll
+  for (int k = 0; k < CTX; ++k)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wk[k][i] = w[(long)(c.h0 + i) * CTX + k];
+  const long col = (long)c.n * H + c.h0, ts = (long)N * H;
+#pragma unroll
+  for (int s = 1; s < CTX; ++s) la_load_g(dy, pre, c.t0 - CTX + s, Tp, ts, col, gw[s]);   // g[t0-CTX+1 .. t0-1] -> slots 1 .. CTX-1
+  for (int tb = c.t0; tb < c.t1; tb += CTX) {
+#pragma unroll
+    for (int j = 0; j < CTX; ++j) {
+      const int t = tb + j;
+      if (t < c.t1) {
+        la_load_g(dy, pre, t, Tp, ts, col, gw[j]);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < CTX; ++k)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i] = fmaf(wk[k][i], gw[(j - k + CTX) % CTX][i], acc[i]);
+        la_store4(dx + (long)t * ts + col, acc);
+      }
+    }
+  }
+}
+
+// partial[(segment * N + n)][h * CTX + k] = sum over the segment's frames t' of g[t'-k] * x[t']
+template <typename T, int CTX>
+__global__ void __launch_bounds__(256) k_lookahead_bwd_w_slide(const T* __restrict__ dy, const T* __restrict__ pre,
+                                                                const T* __restrict__ x, float* __restrict__ partial, int Tp,
+                                                                int N, int H) {
+  const LaCol c = la_column<CTX>(Tp, N, H);
+  if (!c.ok) return;
+  float acc[CTX][4], gw[CTX][4];
+#pragma unroll
+  for (int k = 0; k < CTX; ++k)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[k][i] = 0.f;
+  const long col = (long)c.n * H + c.h0, ts = (long)N * H;
+#pragma unroll
+  for (int s = 1; s < CTX; ++s) la_load_g(dy, pre, c.t0 - CTX + s, Tp, ts, col, gw[s]);
+  for (int tb = c.t0; tb < c.t1; tb += CTX) {
+#pragma unroll
+    for (int j = 0; j < CTX; ++j) {
+      const int t = tb + j;
+      if (t < c.t1) {
+        float xv[4];
+        la_load_g(dy, pre, t, Tp, ts, col, gw[j]);
+        la_load4(x + (long)t * ts + col, xv);
+#pragma unroll
+        for (int k = 0; k < CTX; ++k)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[k][i] = fmaf(gw[(j - k + CTX) % CTX][i], xv[i], acc[k][i]);
+      }
+    }
+  }
+  float* dst = partial + ((long)(c.t0 / (LA_SEG_STEPS * CTX)) * N + c.n) * H * CTX + (long)c.h0 * CTX;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int k = 0; k < CTX; k += 4)
+      *reinterpret_cast<float4*>(dst + (long)i * CTX + k) = make_float4(acc[k][i], acc[k + 1][i], acc[k + 2][i], acc[k + 3][i]);
+}
+constexpr int LA_CTX = 20;               // the compiled-in context (reference default, model.py:117); others take the kernels above
+
 __global__ void __launch_bounds__(256) k_softmax_rows(const float* __restrict__ in, float* __restrict__ out, long rows, int C,
                                                        long ldi, long ldo) {
   for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (long)gridDim.x * blockDim.x) {
@@ -434,6 +591,7 @@ int ds2_scale_by(float* x, const float* s, long n, ds2_stream_t st_) {
   return 0;
 }
 
+static int la_segments(int Tp) { return ds2_cdiv(Tp, LA_SEG_STEPS * LA_CTX); }
 // y = hardtanh(lookahead(x)); `pre` (same shape, may be null in eval) keeps the pre-activation for backward
 int ds2_lookahead_fwd(int dtype, const void* x, const float* w, void* y, void* pre, int Tp, int N, int H, int ctx,
                       ds2_stream_t st_) {
@@ -442,6 +600,15 @@ int ds2_lookahead_fwd(int dtype, const void* x, const float* w, void* y, void* p
   const int V = dtype == DS2_F32 ? 4 : 8;
   DS2_REQUIRE(H % V == 0 && ctx > 0, DS2_ERR_ARG);
   const long total = (long)ds2_cdiv(Tp, LA_TB) * N * (H / V);
+  if (ctx == LA_CTX) {
+    const int grid = ds2_cdiv((long)la_segments(Tp) * N * (H / 4), 256);
+    if (dtype == DS2_F32)
+      hipLaunchKernelGGL((k_lookahead_fwd_slide<float, LA_CTX>), dim3(grid), dim3(256), 0, st, (const float*)x, w, (float*)y, (float*)pre, Tp, N, H);
+    else
+      hipLaunchKernelGGL((k_lookahead_fwd_slide<bf16_t, LA_CTX>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, w, (bf16_t*)y, (bf16_t*)pre, Tp, N, H);
+    DS2_CHECK_LAUNCH();
+    return 0;
+  }
   if (dtype == DS2_F32)
     hipLaunchKernelGGL(k_lookahead_fwd<float>, dim3(ew_grid(total)), dim3(256), 0, st, (const float*)x, w, (float*)y, (float*)pre, Tp, N, H, ctx);
   else
@@ -452,7 +619,7 @@ int ds2_lookahead_fwd(int dtype, const void* x, const float* w, void* y, void* p
 
 static int la_row_blocks(int Tp, int N) { return ds2_cdiv((long)Tp * N, LA_ROWS); }
 long ds2_lookahead_ws_floats(int Tp, int N, int H, int ctx) {
-  const long P = la_row_blocks(Tp, N);
+  const long P = ctx == LA_CTX ? (long)la_segments(Tp) * N : la_row_blocks(Tp, N);
   return P * H * ctx + (long)ds2_norm_partials(P) * H * ctx;
 }
 int ds2_lookahead_bwd(int dtype, const void* x, const float* w, const void* pre, const void* dy, void* dx, float* dw, int Tp,
@@ -462,6 +629,19 @@ int ds2_lookahead_bwd(int dtype, const void* x, const float* w, const void* pre,
   const int V = dtype == DS2_F32 ? 4 : 8;
   DS2_REQUIRE(H % V == 0 && ctx > 0 && (H * ctx) % 4 == 0, DS2_ERR_ARG);
   const long total = (long)ds2_cdiv(Tp, LA_TB) * N * (H / V);
+  const int C = H * ctx;
+  if (ctx == LA_CTX) {
+    const int Ps = la_segments(Tp) * N, grid = ds2_cdiv((long)Ps * (H / 4), 256);
+    if (dtype == DS2_F32) {
+      hipLaunchKernelGGL((k_lookahead_bwd_x_slide<float, LA_CTX>), dim3(grid), dim3(256), 0, st, (const float*)dy, (const float*)pre, w, (float*)dx, Tp, N, H);
+      hipLaunchKernelGGL((k_lookahead_bwd_w_slide<float, LA_CTX>), dim3(grid), dim3(256), 0, st, (const float*)dy, (const float*)pre, (const float*)x, ws, Tp, N, H);
+    } else {
+      hipLaunchKernelGGL((k_lookahead_bwd_x_slide<bf16_t, LA_CTX>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)pre, w, (bf16_t*)dx, Tp, N, H);
+      hipLaunchKernelGGL((k_lookahead_bwd_w_slide<bf16_t, LA_CTX>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)pre, (const bf16_t*)x, ws, Tp, N, H);
+    }
+    DS2_CHECK_LAUNCH();
+    return ds2_colsum(DS2_F32, ws, Ps, C, C, dw, 1.0f, ws + (long)Ps * C, st_);
+  }
   const int P = la_row_blocks(Tp, N);
   dim3 gw(ds2_cdiv(H, 1024), P);                           // a thread of k_lookahead_bwd_w owns four channels
   if (dtype == DS2_F32) {
@@ -472,7 +652,6 @@ int ds2_lookahead_bwd(int dtype, const void* x, const float* w, const void* pre,
     hipLaunchKernelGGL(k_lookahead_bwd_w<bf16_t>, gw, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)pre, (const bf16_t*)x, ws, Tp, N, H, ctx);
   }
   DS2_CHECK_LAUNCH();
-  const int C = H * ctx;
   return ds2_colsum(DS2_F32, ws, P, C, C, dw, 1.0f, ws + (long)P * C, st_);
 }
 

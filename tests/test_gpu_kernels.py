@@ -476,9 +476,12 @@ def test_rnn_initial_state(dtype):
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("ctx", [20, 7])
-def test_lookahead(dtype, ctx):
+@pytest.mark.parametrize("shape", [(33, 3, 48), (257, 2, 24), (100, 1, 8), (101, 2, 8), (7, 2, 16)])
+def test_lookahead(dtype, ctx, shape):
+    """ctx = 20 (the reference default) takes the sliding-window kernels: shapes cover one segment, several segments with a ragged
+    tail, exactly one full segment, one frame into the next, and a sequence shorter than the context."""
     rs = np.random.RandomState(12)
-    Tp, N, H = 33, 3, 48
+    Tp, N, H = shape
     x = rs.standard_normal((Tp, N, H)) * 3
     w = rs.uniform(-0.6, 0.9, (H, 1, ctx))
     xr = rnd(x, dtype)
