@@ -4,7 +4,9 @@
 
 hipcc cross-compiles without a GPU; the .so travels to the GPU box with the repo snapshot (it is git-ignored).
 """
+import glob
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -19,6 +21,31 @@ SOURCES = ["ds2_norm.hip", "ds2_gemm.hip", "ds2_gemm8.hip", "ds2_rnn.hip", "ds2_
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-pass-failed"] + \
     os.environ.get("DS2_EXTRA_HIPCC_FLAGS", "").split()
+
+
+# ds2_rnn_persist_impl.h lands its fire-and-forget scalar loads (l2_touch) in one fixed SGPR; nothing else may name that register,
+# because the write arrives asynchronously.  The device assembly of these sources (kept by -save-temps) is checked after every compile.
+L2_SINK_SOURCES = ("ds2_rnn_persist_gru.hip", "ds2_rnn_persist_lstm.hip", "ds2_rnn_persist_rnn.hip")
+L2_SINK = 101
+
+
+def _l2_sink_misuse(obj):
+    stem = os.path.splitext(obj)[0]
+    asm = [f for f in glob.glob(stem + "*gfx950*.s")]
+    if not asm:
+        return ["no device assembly found next to %s (-save-temps=obj)" % obj]
+    bad = []
+    single = re.compile(r"\bs%d\b" % L2_SINK)
+    rng = re.compile(r"\bs\[(\d+):(\d+)\]")
+    for f in asm:
+        for ln, line in enumerate(open(f), 1):
+            code = line.split(";")[0]
+            if not code.strip() or code.lstrip().startswith("."):
+                continue
+            hit = bool(single.search(code)) or any(int(a) <= L2_SINK <= int(b) for a, b in rng.findall(code))
+            if hit and not re.match(r"\s*s_load_dword s%d, s\[\d+:\d+\], 0x0\s*$" % L2_SINK, code):
+                bad.append("%s:%d: %s" % (os.path.basename(f), ln, code.strip()))
+    return bad
 
 
 def _stale(target, deps):
@@ -51,8 +78,18 @@ def _build(OBJ, LIB, FLAGS, force, verbose):
 
     def cc(job):
         s, o = job
-        r = subprocess.run([HIPCC] + FLAGS + ["-c", s, "-o", o], capture_output=True, text=True)
-        return s, r.returncode, r.stdout + r.stderr
+        extra = ["-save-temps=obj"] if os.path.basename(s) in L2_SINK_SOURCES else []
+        r = subprocess.run([HIPCC] + FLAGS + extra + ["-c", s, "-o", o], capture_output=True, text=True)
+        out = r.stdout + r.stderr
+        if extra:
+            bad = _l2_sink_misuse(o) if r.returncode == 0 else []
+            stem = os.path.splitext(o)[0]
+            for f in glob.glob(stem + "-hip-*") + glob.glob(stem + "-host-*") + glob.glob(stem + ".hip-hip-*"):   # -save-temps by-products
+                os.remove(f)
+            if bad:
+                os.remove(o)
+                return s, 1, "%s: the L2-touch sink register is used outside the touches:\n%s" % (s, "\n".join(bad[:10]))
+        return s, r.returncode, out
 
     with ThreadPoolExecutor(max_workers=8) as ex:
         for s, rc, out in ex.map(cc, jobs):

@@ -26,6 +26,7 @@
 // Roofline: MFMA-shaped work (2*samples*G*H*H flops per step and direction) but latency-bound by construction; the
 // measured quantity is us per time step (bench.py roofline object).
 #pragma once
+#include <type_traits>
 #include <stdlib.h>
 
 #include "ds2_common.h"
@@ -80,7 +81,7 @@ struct PArgs {
   u64* xcc;                 // [NGROUPS][32] start-up exchange of the workgroups' XCC ids, reset (0xFF bytes) before the launch
 #ifdef DS2_PROBE            // tools/probe_rnn_persist.py builds its own library with -DDS2_PROBE; the shipping kernels carry none of it
   unsigned long long* dbg;  // [NGROUPS][8] cycle counters of workgroup 0 of each group
-  int dbgmask;              // 1 skip GI/dOut/S prefetch loads, 2 skip output stores, 8 skip the gather (no exchange)
+  int dbgmask;              // 1 skip GI/dOut/S prefetch loads, 2 skip output stores, 8 skip the gather (no exchange), 16 no L2 warm-up
 #endif
 };
 #ifdef DS2_PROBE
@@ -157,6 +158,33 @@ __device__ __forceinline__ float ftanh(float x) { return 1.0f - 2.0f * __builtin
 __device__ __forceinline__ uint32_t ror8(uint32_t v) {   // lane i <- lane i^8 within each row of 16 lanes
   return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xf, 0xf, true);
 }
+
+// ---- L2 warm-up through the scalar cache --------------------------------------------------------------------------------------
+// The gate phase's operands (hoisted input projection; dOut / saved planes / h_prev in BPTT) are 2-byte reads that walk through
+// tensors of hundreds of MB: every one is an HBM miss, and a vector load that is still out holds up everything behind it in the
+// wave (vmcnt retires in order: the gather's waits, and every re-poll).  A scalar load has its own counter and its own path to
+// the same L2, so a wave touches the 64-byte runs its workgroup will read a few steps AHEAD with `s_load_dword` and never looks
+// at the result: by the time the vector loads are issued the lines are L2 hits.
+constexpr int L2_AHEAD = 3;   // steps
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) {   // uniform values may still live in vector registers (64-bit multiplies do)
+  return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) |
+         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);          // the builtin returns int: no sign extension
+}
+__device__ __forceinline__ uint64_t uniform64(const void* p) { return uniform64(reinterpret_cast<uint64_t>(p)); }
+// Every touch lands in ONE fixed scalar register, L2_SINK, that nothing else in these kernels uses: the write arrives
+// asynchronously (tens to hundreds of cycles after the instruction), so the destination must not be a register the allocator may
+// hand to something else in the meantime -- an ordinary asm output can be copied and released right after the statement.  The
+// clobber keeps values from living in it ACROSS a touch; build.py additionally checks the generated assembly of these files: the
+// only instructions that may name the register are the touches themselves.  `addr` must be wave-uniform (uniform64) and 4-byte
+// aligned.  l2_touch_retire() (end of the step: the loads have long returned, no stall) bounds the number in flight.
+#define DS2_L2_SINK "s101"
+__device__ __forceinline__ void l2_touch(uint64_t addr) {
+  asm volatile("s_load_dword " DS2_L2_SINK ", %0, 0x0" : : "s"(addr) : "memory", DS2_L2_SINK);
+}
+__device__ __forceinline__ void l2_touch_retire() { asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory", DS2_L2_SINK); }
+struct NoTouch {
+  __device__ __forceinline__ void operator()() const {}
+};
 
 constexpr int chunk_ksteps(int KS, int SPLIT) {
 #ifdef DS2_CHUNK
@@ -306,10 +334,10 @@ __device__ __forceinline__ void publish32(void* p, uint32_t v, bool local) {
     __hip_atomic_store((uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int TILES, int KS>
+template <int TILES, int KS, typename F = NoTouch>
 __device__ __forceinline__ void gather_mma_tf(ds2_f32x4 (&acc)[TILES], const uint4 (&w)[TILES][KS], __amdgpu_buffer_rsrc_t rsrc,
                                               int slot_off, int kstep0, int lq, int srow, int half, bool need, int* err, int* lerr,
-                                              bool& dead, unsigned& rounds) {
+                                              bool& dead, unsigned& rounds, F after_issue = F()) {
   constexpr int CH = chunk_ksteps_tf(KS);
   constexpr int PER = CH / 2;       // k-steps a lane loads per chunk (the other half arrives by the DPP row rotate)
   static_assert(KS % CH == 0 && CH % 2 == 0, "k-steps per wave must tile into poll chunks");
@@ -319,17 +347,20 @@ __device__ __forceinline__ void gather_mma_tf(ds2_f32x4 (&acc)[TILES], const uin
     u32x4 v[PER];
     ds2_f32x4 part_[KS == CH ? 1 : TILES];
     ds2_f32x4 (&part)[TILES] = *reinterpret_cast<ds2_f32x4 (*)[TILES]>(KS == CH ? &acc[0] : &part_[0]);
-#define DS2_TF_LOAD()                                                                                                  \
-    if (need) {                                                                                                        \
-      _Pragma("unroll") for (int i = 0; i < PER; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(                    \
-          rsrc, slot_off + xtf_unit_bytes(kstep0 + c * CH + half * PER + i, lq, srow), 0, 16 /* sc1 */);               \
+    // rows without a sample load from beyond the resource's range: the buffer check returns zeros, and there is no branch (a
+    // conditional block would end in the copies of its first result, i.e. in a wait, ahead of after_issue)
+#define DS2_TF_LOAD(FIRST)                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < PER; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(                      \
+        rsrc, need ? slot_off + xtf_unit_bytes(kstep0 + c * CH + half * PER + i, lq, srow) : 0x7ffffff0, 0, 16 /* sc1 */); \
+    if (FIRST && c == 0 && !std::is_same<F, NoTouch>::value) {                                                         \
+      after_issue();                     /* scalar work that hides under the first round trip (l2_touch) */            \
+      __builtin_amdgcn_sched_barrier(0); /* nothing that waits for the loads may be scheduled above it   */            \
     }
 #define DS2_TF_MMA()                                                                                                   \
     _Pragma("unroll") for (int t = 0; t < TILES; ++t) part[t] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};                        \
     _Pragma("unroll") for (int k = 0; k < CH; ++k) {                                                                   \
       const int i = k % PER;                                                                                           \
-      uint4 a = make_uint4(0, 0, 0, 0);                                                                                \
-      if (need) a = make_uint4(v[i][0], v[i][1], v[i][2], v[i][3]);                                                    \
+      uint4 a = make_uint4(v[i][0], v[i][1], v[i][2], v[i][3]);                                                        \
       if (k >= PER) a = make_uint4(ror8(a.x), ror8(a.y), ror8(a.z), ror8(a.w));                                        \
       _Pragma("unroll") for (int t = 0; t < TILES; ++t) Mma<bf16_t>::mma16(part[t], a, w[t][c * CH + k]);              \
     }
@@ -340,13 +371,13 @@ __device__ __forceinline__ void gather_mma_tf(ds2_f32x4 (&acc)[TILES], const uin
       _Pragma("unroll") for (int i = 0; i < PER; ++i) m = max(max(m, max(v[i][0], v[i][1])), max(v[i][2], v[i][3]));   \
       bad = m == XSENT;                                                                                                \
     }
-    DS2_TF_LOAD()
+    DS2_TF_LOAD(true)
     DS2_TF_MMA()              // speculative: runs k-step by k-step as the loads land
     DS2_TF_CHECK(bad0)
     if (__any(bad0) && !dead) {
       __builtin_amdgcn_s_sleep(1);
       ++rounds;
-      DS2_TF_LOAD()
+      DS2_TF_LOAD(false)
       DS2_TF_MMA()
       DS2_TF_CHECK(bad1)
       if (__any(bad1)) {
@@ -354,7 +385,7 @@ __device__ __forceinline__ void gather_mma_tf(ds2_f32x4 (&acc)[TILES], const uin
         for (;;) {
           __builtin_amdgcn_s_sleep(1);
           ++rounds;
-          DS2_TF_LOAD()
+          DS2_TF_LOAD(false)
           DS2_TF_CHECK(bad2)
           if (!__any(bad2)) break;
           if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && spin_check(lerr, spins))) {
@@ -731,10 +762,32 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd4(PArgs a) {
   // runs at 1.66 instead of 1.97 us per step without them -- but moving them behind the gather (one or two steps ahead, three
   // rotating register sets) was slower in the training step, 2.05 vs 1.90: the gather then returns before every peer has
   // published (0.65 instead of 0.02 re-polls per step, each a full L2 round trip), i.e. the slow loads also pace the group.
+  // Round 3: the lines are made L2 hits instead (l2_touch, L2_AHEAD steps ahead, issued while the gather's first round trip is
+  // out): wave w touches samples 2w and 2w + 1; running scalar pointers, one add per step.
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  uint64_t pf_p[2];
+  const int pf_s0 = min(L2_AHEAD, Tp - 1);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const long nr = min(slice + a.gpd * max(0, min(2 * wv + i, Ns - 1)), N - 1);
+    pf_p[i] = uniform64(a.GI + ((long)(d == 0 ? pf_s0 : Tp - 1 - pf_s0) * N + nr) * ldgi + (long)d * GH + p * U);
+  }
+  const uint64_t pf_step = uniform64((uint64_t)(dstep * N * ldgi * 2));
   for (int s = 0; s < Tp; ++s) {
     DS2_PROBE_ONLY(const unsigned long long t0 = __builtin_readcyclecounter();)
     const int t = d == 0 ? s : Tp - 1 - s;
     const int par = s & 1;
+    auto touch = [&]() {
+      if (DS2_DBG(a, 16)) return;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < G; ++g) l2_touch(pf_p[i] + (uint64_t)(g * H * 2));
+      if (s + L2_AHEAD < Tp - 1) {
+        pf_p[0] += pf_step;
+        pf_p[1] += pf_step;
+      }
+    };
     float gi[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) gi[g] = 0.f;
@@ -746,7 +799,9 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd4(PArgs a) {
 #pragma unroll
     for (int tt = 0; tt < TILES; ++tt) acc[tt] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
     if (s > 0 || a.h0)
-      gather_mma_tf<TILES, KS>(acc, w, rsrc, ((s + 3) & 3) * SLOT_BYTES, wave * KS, lq, srow, half, need, a.err, a.lerr, dead, rounds);
+      gather_mma_tf<TILES, KS>(acc, w, rsrc, ((s + 3) & 3) * SLOT_BYTES, wave * KS, lq, srow, half, need, a.err, a.lerr, dead, rounds, touch);
+    else
+      touch();
     DS2_PROBE_ONLY(const unsigned long long t1 = __builtin_readcyclecounter();)
     store_partials<TILES>(part[par], acc, wave, lane);
     __syncthreads();
@@ -806,6 +861,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd4(PArgs a) {
     gi_ptr += gi_stride;
     if (NS) sv_ptr += sv_stride;
     hs_ptr += hs_stride;
+    l2_touch_retire();
     DS2_PROBE_ONLY(const unsigned long long t3 = __builtin_readcyclecounter(); c_gather += t1 - t0; c_bar += t2 - t1; c_gate += t3 - t2;)
   }
 #ifdef DS2_PROBE
@@ -1160,14 +1216,51 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd4(PArgs a) {
   prefetch(pra, 0, 0);
   prefetch(prb, Tp > 1 ? 1 : 0, Tp > 1 ? 1 : 0);
   prefetch(prc, 0, 0);            // defined contents for the set that is filled from step 2 on
+  // L2 warm-up (l2_touch) of what `prefetch` will load L2_AHEAD steps from now: wave w touches the 64-byte runs of samples 2w, 2w+1
+  // in dOut, the NS saved planes and the state sequence (h_prev of a step: guard frames exist at t = -1 and t = T')
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  uint64_t pf_do[2], pf_sv[2], pf_hs[2];
+  {
+    const int sa = min(L2_AHEAD, Tp - 1);
+    const long ta = d == 0 ? Tp - 1 - sa : sa;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const long nr = min(slice + a.gpd * max(0, min(2 * wv + i, Ns - 1)), N - 1);
+      pf_do[i] = uniform64(a.dOut + (ta * N + nr) * H + p * U);
+      pf_sv[i] = NS ? uniform64(a.S + (((long)d * Tp + ta) * N + nr) * NSH_ + p * U) : 0;
+      pf_hs[i] = uniform64(a.Hseq + (long)d * a.hseq_dstride + ((ta + prev_off) * N + nr) * H + p * U);
+    }
+  }
+  const uint64_t pf_step_h = uniform64((uint64_t)(dstep * N * H * 2)), pf_step_s = uniform64((uint64_t)(dstep * N * NSH_ * 2));
   auto body = [&](int s, Pre& pu, Pre& pn) {
     DS2_PROBE_ONLY(const unsigned long long t0 = __builtin_readcyclecounter();)
     const int t = d == 0 ? Tp - 1 - s : s;
     const int par = s & 1;
+    auto touch = [&]() {
+      if (DS2_DBG(a, 16)) return;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        l2_touch(pf_do[i]);
+        l2_touch(pf_hs[i]);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) l2_touch(pf_sv[i] + (uint64_t)(q * H * 2));
+      }
+      if (s + L2_AHEAD < Tp - 1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          pf_do[i] += pf_step_h;
+          pf_hs[i] += pf_step_h;
+          pf_sv[i] += pf_step_s;
+        }
+      }
+    };
     ds2_f32x4 acc[TILES];
 #pragma unroll
     for (int tt = 0; tt < TILES; ++tt) acc[tt] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
-    if (s > 0) gather_mma_tf<TILES, KS>(acc, w, rsrc, ((s + 3) & 3) * SLOT_BYTES, wave * KS, lq, srow, half, need, a.err, a.lerr, dead, rounds);
+    if (s > 0)
+      gather_mma_tf<TILES, KS>(acc, w, rsrc, ((s + 3) & 3) * SLOT_BYTES, wave * KS, lq, srow, half, need, a.err, a.lerr, dead, rounds, touch);
+    else
+      touch();
     // this step's values first (loaded two steps ago; the gather has just drained vmcnt), THEN the new loads: converted after
     // them, the compiler's wait-count bookkeeping across the rotated loop would wait for the new loads as well
     const float dout = __uint_as_float(pu.dout << 16), hp = __uint_as_float(pu.hp << 16), cp = __uint_as_float(pu.cp << 16);
@@ -1269,6 +1362,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd4(PArgs a) {
     hs_ptr += dstep * N * H;
     dgi_ptr += dstep * N * ldgi;
     if (CELL == CELL_GRU) dgh_ptr += dstep * N * H;
+    l2_touch_retire();
     DS2_PROBE_ONLY(const unsigned long long t3 = __builtin_readcyclecounter(); c_gather += t1 - t0; c_bar += t2 - t1; c_gate += t3 - t2;)
   };
   for (int s = 0; s < Tp; s += 3) {
