@@ -317,6 +317,7 @@ constexpr int chunk_ksteps_tf(int KS) {
   // measured on cfg3 inside the training step (tools/bench_with_lib.py, us per time step forward / BPTT): chunks of 2: 2.55 / 5.38,
   // 4: 2.18 / 4.04, 6: - / 3.66, 8: 1.90 / 3.51, 12: - / 3.41, 24: - / 2.85 -- but the 24-k-step form holds 409 registers and
   // locks the weight-gradient GEMMs out of the CU (116 registers: they then run after the sweep, +2 ms per step), 12 holds 340
+  // round 3 (nothing co-resident any more, L2-warm operands): 24 in one chunk again -- 2.19 us per BPTT step against 1.81-1.95 with 12
   return KS <= 8 ? KS : (KS % 12 == 0 ? 12 : 8);
 #endif
 }
