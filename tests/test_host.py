@@ -208,3 +208,20 @@ def test_bench_frame_arithmetic_equals_get_seq_lens():
         pct = torch.from_numpy((lengths / float(tmax)).astype(np.float32))
         sizes = pct.mul_(tmax).int()
         assert m.get_seq_lens(sizes).tolist() == bench.out_frames(lengths).tolist()
+
+
+def test_build_rejects_any_other_use_of_the_l2_touch_sink_register(tmp_path):
+    """ds2_rnn_persist_impl.h lands its fire-and-forget scalar loads in one fixed SGPR whose write arrives asynchronously;
+    build.py checks the device assembly of those sources: only the touches themselves may name the register."""
+    from deepspeech.pytorch_amd import build
+    obj = tmp_path / "k.o"
+    asm = tmp_path / "k-hip-amdgcn-amd-amdhsa-gfx950.s"
+    good = "\ts_load_dword s%d, s[42:43], 0x0\n\ts_add_u32 s8, s64, 0x800\n\tv_mov_b32_e32 v101, v3\n; NumSgprs: 108 s101\n" % build.L2_SINK
+    asm.write_text(good)
+    assert build._l2_sink_misuse(str(obj)) == []
+    for bad in ("\ts_mov_b32 s%d, s3\n" % build.L2_SINK, "\ts_load_dwordx4 s[%d:%d], s[0:1], 0x0\n" % (build.L2_SINK - 1, build.L2_SINK + 2),
+                "\ts_load_dword s%d, s[42:43], 0x10\n" % build.L2_SINK, "\ts_add_u32 s3, s%d, s4\n" % build.L2_SINK):
+        asm.write_text(good + bad)
+        assert len(build._l2_sink_misuse(str(obj))) == 1, bad
+    asm.unlink()
+    assert build._l2_sink_misuse(str(obj))          # no assembly to check = not verified = rejected
