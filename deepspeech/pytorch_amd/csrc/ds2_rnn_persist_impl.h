@@ -415,6 +415,17 @@ __device__ __forceinline__ void store_partials(float* part, const ds2_f32x4 (&ac
 #pragma unroll
     for (int r = 0; r < 4; ++r) part[((wave * TILES + t) * 16 + mma16_row(r, lane)) * 16 + (lane & 15)] = acc[t][r];
 }
+// The 8-sample kernels' form: a tile is stored [col][row] with a column stride of PT_COL floats, so that the four rows a lane holds
+// of an accumulator are ONE 16-byte store (6 instead of 24 LDS instructions per forward step); 20 = 16 + 4: the 16 lanes of a row
+// group then cover the 64 banks exactly once (16-float columns would put lanes li, li+4, li+8, li+12 on the same banks).
+constexpr int PT_COL = 20, PT_TILE = 16 * PT_COL;
+template <int TILES>
+__device__ __forceinline__ void store_partials_t(float* part, const ds2_f32x4 (&acc)[TILES], int wave, int lane) {
+#pragma unroll
+  for (int t = 0; t < TILES; ++t)
+    *reinterpret_cast<ds2_f32x4*>(part + (wave * TILES + t) * PT_TILE + (lane & 15) * PT_COL + 4 * (lane >> 4)) = acc[t];
+}
+__device__ __forceinline__ int partial_t_index(int tile, int row, int col) { return tile * PT_TILE + col * PT_COL + row; }
 // sum over the 4 waves of the two adjacent columns (col, col+1) of row `row` of tile `t`
 template <int TILES>
 __device__ __forceinline__ float2 load_partials(const float* part, int t, int row, int col) {
@@ -674,7 +685,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd4(PArgs a) {
   constexpr int KS = H / 128;
   constexpr int X2 = H / 2;
   static_assert(U == 32 && H % 128 == 0, "the one-unit-per-thread gate map assumes 32 hidden units per workgroup");
-  __shared__ __attribute__((aligned(16))) float part[2][4 * TILES * 256];
+  __shared__ __attribute__((aligned(16))) float part[2][4 * TILES * PT_TILE];
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = blockIdx.x % NGROUPS, p = blockIdx.x / NGROUPS;
@@ -754,7 +765,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd4(PArgs a) {
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     const int r = g * U + 2 * up + e;
-    pidx[g] = ((r / 16) * 16 + gi_i) * 16 + (r % 16);
+    pidx[g] = partial_t_index(r / 16, gi_i, r % 16);
   }
 
   DS2_PROBE_ONLY(unsigned long long c_gather = 0, c_bar = 0, c_gate = 0;)
@@ -804,7 +815,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd4(PArgs a) {
     else
       touch();
     DS2_PROBE_ONLY(const unsigned long long t1 = __builtin_readcyclecounter();)
-    store_partials<TILES>(part[par], acc, wave, lane);
+    store_partials_t<TILES>(part[par], acc, wave, lane);
     __syncthreads();
     DS2_PROBE_ONLY(const unsigned long long t2 = __builtin_readcyclecounter();)
     float hn = 0.f;                 // emitted h_t (0 when inactive)
@@ -817,7 +828,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd4(PArgs a) {
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const float* pp = part[par] + pidx[g];
-        gh[g] = (pp[0] + pp[TILES * 256]) + (pp[2 * TILES * 256] + pp[3 * TILES * 256]);
+        gh[g] = (pp[0] + pp[TILES * PT_TILE]) + (pp[2 * TILES * PT_TILE] + pp[3 * TILES * PT_TILE]);
       }
       if (act) {
         if (CELL == CELL_GRU) {
@@ -1125,7 +1136,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd4(PArgs a) {
   constexpr int KS = G * H / 128;
   constexpr int X2 = G * H / 2;
   static_assert(U == 32 && (G * H) % 128 == 0, "the one-unit-per-thread gate map assumes 32 hidden units per workgroup");
-  __shared__ __attribute__((aligned(16))) float part[2][4 * TILES * 256];
+  __shared__ __attribute__((aligned(16))) float part[2][4 * TILES * PT_TILE];
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = blockIdx.x % NGROUPS, p = blockIdx.x / NGROUPS;
@@ -1180,7 +1191,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd4(PArgs a) {
   bool dead = false;
   const bool local = group_is_xcd_local(a.xcc + grp * 32, p, tid, a.err, a.lerr, dead);
   unsigned rounds = 0;
-  const int pidx = (((2 * up + e) / 16) * 16 + gi_i) * 16 + ((2 * up + e) % 16);
+  const int pidx = partial_t_index((2 * up + e) / 16, gi_i, (2 * up + e) % 16);
   const int xoff = xtf_pair_bytes(j, gi_i);     // this pair's dword of gate 0 inside a slot
 
   DS2_PROBE_ONLY(unsigned long long c_gather = 0, c_bar = 0, c_gate = 0;)
@@ -1272,7 +1283,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd4(PArgs a) {
     if (s + 2 < Tp) prefetch(pn, s + 2, 2);
     __builtin_amdgcn_sched_barrier(0);
     DS2_PROBE_ONLY(const unsigned long long t1 = __builtin_readcyclecounter();)
-    store_partials<TILES>(part[par], acc, wave, lane);
+    store_partials_t<TILES>(part[par], acc, wave, lane);
     __syncthreads();
     DS2_PROBE_ONLY(const unsigned long long t2 = __builtin_readcyclecounter();)
     // gate gradients of this thread's unit (zeros when inactive); gq[] = what is exchanged, gs[] = what is stored in dGI
@@ -1282,7 +1293,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd4(PArgs a) {
     if (gate_thread) {
       const bool act = t < len;
       const float* pp = part[par] + pidx;
-      const float din = car + ((pp[0] + pp[TILES * 256]) + (pp[2 * TILES * 256] + pp[3 * TILES * 256]));
+      const float din = car + ((pp[0] + pp[TILES * PT_TILE]) + (pp[2 * TILES * PT_TILE] + pp[3 * TILES * PT_TILE]));
       car = din;
       if (CELL == CELL_GRU) {
         if (act) {
