@@ -1275,10 +1275,16 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd4(PArgs a) {
       touch();
     // this step's values first (loaded two steps ago; the gather has just drained vmcnt), THEN the new loads: converted after
     // them, the compiler's wait-count bookkeeping across the rotated loop would wait for the new loads as well
-    const float dout = __uint_as_float(pu.dout << 16), hp = __uint_as_float(pu.hp << 16), cp = __uint_as_float(pu.cp << 16);
+    const float dout_ = __uint_as_float(pu.dout << 16), hp_ = __uint_as_float(pu.hp << 16), cp_ = __uint_as_float(pu.cp << 16);
     float sp[M];
 #pragma unroll
     for (int q = 0; q < M; ++q) sp[q] = __uint_as_float(pu.sp[q] << 16);
+    // ... and pinned HERE: left alone, the conversions sink into the gate phase's `act` block, i.e. behind the new loads, and the
+    // first use of a raw value then waits vmcnt(0) -- for the loads just issued (a full L2 round trip after every barrier)
+    float dout = dout_, hp = hp_, cp = cp_;
+    asm volatile("" : "+v"(dout), "+v"(hp), "+v"(cp));
+#pragma unroll
+    for (int q = 0; q < M; ++q) asm volatile("" : "+v"(sp[q]));
     __builtin_amdgcn_sched_barrier(0);
     if (s + 2 < Tp) prefetch(pn, s + 2, 2);
     __builtin_amdgcn_sched_barrier(0);
