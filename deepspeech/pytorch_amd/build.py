@@ -65,6 +65,13 @@ def build(force=False, verbose=True, probe=False):
     return _build(obj_dir, lib_path, flags, force, verbose)
 
 
+def build_variant(name, extra_flags, force=False, verbose=False):
+    """A/B builds (tools/ab_variants.py): the same sources with extra compiler flags (-DDS2_L2_AHEAD=4, -DDS2_CHUNK=8, ...) as
+    libds2hip_<name>.so next to the shipping library -- never loaded by the product."""
+    assert name.isidentifier() and name not in ("probe",), name
+    return _build(OBJ + "_" + name, LIB.replace("libds2hip.so", "libds2hip_%s.so" % name), FLAGS + list(extra_flags), force, verbose)
+
+
 def _build(OBJ, LIB, FLAGS, force, verbose):
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, "ds2_common.h"), os.path.join(CSRC, "ds2_rnn_persist_impl.h"), os.path.join(CSRC, "ds2_rnn_persist2_impl.h"),

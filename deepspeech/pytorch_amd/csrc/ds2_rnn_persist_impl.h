@@ -165,7 +165,10 @@ __device__ __forceinline__ uint32_t ror8(uint32_t v) {   // lane i <- lane i^8 w
 // wave (vmcnt retires in order: the gather's waits, and every re-poll).  A scalar load has its own counter and its own path to
 // the same L2, so a wave touches the 64-byte runs its workgroup will read a few steps AHEAD with `s_load_dword` and never looks
 // at the result: by the time the vector loads are issued the lines are L2 hits.
-constexpr int L2_AHEAD = 3;   // steps
+#ifndef DS2_L2_AHEAD
+#define DS2_L2_AHEAD 3        // steps; a build flag for A/B runs (tools/ab_variants.py)
+#endif
+constexpr int L2_AHEAD = DS2_L2_AHEAD;
 __device__ __forceinline__ uint64_t uniform64(uint64_t v) {   // uniform values may still live in vector registers (64-bit multiplies do)
   return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) |
          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);          // the builtin returns int: no sign extension
