@@ -164,7 +164,8 @@ int ds2_rnn_persist_bwd(int dtype, int cell, int D, int N, int H, int Tp, const 
 /* ---- small sequence ops ---------------------------------------------------------------------------------------------------
  * add2: out = a + b (direction sum, model.py:101).  transpose: dst[C][ldd] = src[R][lds]^T, zero-filling r in [R, ldd).
  * lookahead (model.py:105-135, uni-directional models): y[t] = hardtanh(sum_k w[h][k] * x[t+k]), x/y [Tp*N][H] (T),
- * w [H][ctx] f32, ctx <= 32; `pre` keeps the pre-Hardtanh value for backward (may be null in eval).
+ * w [H][ctx] f32, any ctx >= 1 (ctx = 20, the reference default, takes the sliding-window kernels: one load per operand and frame);
+ * `pre` keeps the pre-Hardtanh value for backward (may be null in eval).
  * bwd: dx and dw (dw via ws of ds2_lookahead_ws_floats). */
 int ds2_add2(int dtype, const void* a, const void* b, void* out, long n, ds2_stream_t stream);
 int ds2_transpose(int dtype, const void* src, void* dst, long R, int C, long lds, long ldd, ds2_stream_t stream);
