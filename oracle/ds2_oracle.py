@@ -67,40 +67,70 @@ def _out_size(n, k, s, p):
     return (n + 2 * p - (k - 1) - 1) // s + 1
 
 
-def conv2d_fwd(x, w, b, stride, pad):
-    """torch.nn.Conv2d cross-correlation (model.py:158,161). x (N,C,F,T), w (O,C,KF,KT), b (O)."""
+def _padded(x, pad):
     n, c, f, t = x.shape
-    o, _, kf, kt = w.shape
-    fo, to = _out_size(f, kf, stride[0], pad[0]), _out_size(t, kt, stride[1], pad[1])
     xp = np.zeros((n, c, f + 2 * pad[0], t + 2 * pad[1]), dtype=x.dtype)
     xp[:, :, pad[0]:pad[0] + f, pad[1]:pad[1] + t] = x
+    return xp
+
+
+# numpy has no convolution, and a product per tap over gathered operands spends its time in the gathers (minutes on the full-size
+# fixtures).  Evaluation order used here, per sample: unfold the KERNEL ROWS only -- row (c, a) of U holds xpad[c, sf*f + a, :] over
+# the whole padded time axis -- so that all KT time taps are ONE matrix product  Z[(bb, o)][(f, t')] = W[(bb, o)][(c, a)] U[(c, a)][(f, t')],
+# and y[o, f, t] = sum_bb Z[bb, o, f, st*t + bb]: the time offset of a tap is applied to its product, not to its operand.
+def _unfold_rows(xpi, kf, sf, fo):
+    """[C][F_padded][T_padded] -> [(C*KF)][FO*T_padded]."""
+    c, _, tp = xpi.shape
+    win = np.lib.stride_tricks.sliding_window_view(xpi, kf, axis=1)[:, ::sf][:, :fo]      # [C][FO][T_padded][KF]
+    return np.ascontiguousarray(win.transpose(0, 3, 1, 2)).reshape(c * kf, fo * tp)
+
+
+def _taps_as_rows(w):
+    """w (O,C,KF,KT) -> [(KT*O)][(C*KF)]: block bb = time tap bb of every output channel."""
+    o, c, kf, kt = w.shape
+    return np.ascontiguousarray(w.transpose(3, 0, 1, 2)).reshape(kt * o, c * kf)
+
+
+def conv2d_fwd(x, w, b, stride, pad):
+    """torch.nn.Conv2d cross-correlation (model.py:158,161). x (N,C,F,T), w (O,C,KF,KT), b (O):
+    y[n,o,f,t] = b[o] + sum_{c,a,bb} w[o,c,a,bb] * xpad[n,c,sf*f+a,st*t+bb]."""
+    n, c, f, t = x.shape
+    o, _, kf, kt = w.shape
+    (sf, st), tp = stride, t + 2 * pad[1]
+    fo, to = _out_size(f, kf, sf, pad[0]), _out_size(t, kt, st, pad[1])
+    xp = _padded(x, pad)
+    wr = _taps_as_rows(w)
     y = np.zeros((n, o, fo, to), dtype=x.dtype)
-    for a in range(kf):
+    for i in range(n):
+        z = (wr @ _unfold_rows(xp[i], kf, sf, fo)).reshape(kt, o, fo, tp)
         for bb in range(kt):
-            xs = xp[:, :, a:a + stride[0] * fo:stride[0], bb:bb + stride[1] * to:stride[1]]
-            y += np.einsum("oc,ncft->noft", w[:, :, a, bb], xs, optimize=True)
-    y += b[None, :, None, None]
-    return y
+            y[i] += z[bb, :, :, bb:bb + st * to:st]
+    return y + b[None, :, None, None]
 
 
 def conv2d_bwd(x, w, dy, stride, pad, need_dx=True):
     n, c, f, t = x.shape
     o, _, kf, kt = w.shape
+    (sf, st), tp = stride, t + 2 * pad[1]
     fo, to = dy.shape[2], dy.shape[3]
-    xp = np.zeros((n, c, f + 2 * pad[0], t + 2 * pad[1]), dtype=x.dtype)
-    xp[:, :, pad[0]:pad[0] + f, pad[1]:pad[1] + t] = x
-    dw = np.zeros_like(w)
+    xp = _padded(x, pad)
+    wr = _taps_as_rows(w)
+    dwr = np.zeros_like(wr)
     dxp = np.zeros_like(xp) if need_dx else None
-    for a in range(kf):
+    for i in range(n):
+        dsh = np.zeros((kt, o, fo, tp), dtype=dy.dtype)                # dy[i] placed where time tap bb reads: position st*t + bb
         for bb in range(kt):
-            sl = (slice(None), slice(None), slice(a, a + stride[0] * fo, stride[0]),
-                  slice(bb, bb + stride[1] * to, stride[1]))
-            dw[:, :, a, bb] = np.einsum("noft,ncft->oc", dy, xp[sl], optimize=True)
-            if need_dx:
-                dxp[sl] += np.einsum("oc,noft->ncft", w[:, :, a, bb], dy, optimize=True)
+            dsh[bb, :, :, bb:bb + st * to:st] = dy[i]
+        dsh = dsh.reshape(kt * o, fo * tp)
+        dwr += dsh @ _unfold_rows(xp[i], kf, sf, fo).T
+        if need_dx:
+            du = (wr.T @ dsh).reshape(c, kf, fo, tp)                   # gradient of the unfolded rows, folded back row by row
+            for a in range(kf):
+                dxp[i, :, a:a + sf * fo:sf, :] += du[:, a]
+    dw = dwr.reshape(kt, o, c, kf).transpose(1, 2, 3, 0)
     db = dy.sum(axis=(0, 2, 3))
     dx = dxp[:, :, pad[0]:pad[0] + f, pad[1]:pad[1] + t] if need_dx else None
-    return dx, dw, db
+    return dx, np.ascontiguousarray(dw), db
 
 
 def time_mask(shape, lens):
