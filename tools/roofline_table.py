@@ -72,6 +72,24 @@ def main():
         avg = tot / calls
         print("| `%s` | %s | %s | %.1f | %.1f | %.1f %s | %.1f |" % (key, what, bound, calls / steps, avg, work / (avg * 1e-6) / 1e12, unit,
                                                                      100 * work / (avg * 1e-6) / pk))
+    # the general persistent kernels gather the whole exchanged vector of their group's samples every step: bytes per workgroup and
+    # step over the step's duration = what one CU's vector-memory path delivers (the large-batch regime is
+    # bound by this volume)
+    for key, K_ in (("k_rnn_persist2_fwd", H), ("k_rnn_persist2_bwd", G * H)):
+        hit = [(k, v) for k, v in got.items() if key in k]
+        if not hit:
+            continue
+        P = H // 16
+        groups_per_dir = max(1, (256 // P) // D)
+        ns = -(-N // groups_per_dir)
+        m = re.search(r"<\d+, (\w+), \d+, (\d+), (\d+)>", hit[0][0])
+        mt = int(m.group(2)) if m else 1
+        tagged = not (dtype == "bf16" and mt >= 2)
+        byts = ns * K_ * esz * (2 if tagged else 1)
+        calls, tot = sum(v[0] for _, v in hit), sum(v[1] for _, v in hit)
+        us_step = tot / calls / TP
+        print("| `%s` exchange | every workgroup gathers %d samples x %d values%s = %.0f KB per time step | vector-memory path of one CU | - | %.2f per step | %.1f GB/s per CU | - |" % (
+            key, ns, K_, " (tagged granules: x2)" if tagged else "", byts / 1e3, us_step, byts / (us_step * 1e-6) / 1e9))
     total = sum(v[1] for v in got.values())
     print("\nShapes: %s (N = %d, T' = %d, H = %d, %d x %s%s, %s); %d valid frames; %d train steps in the trace; kernel time per step %.2f ms; "
           "whole step %.1f %% of the MFMA roofline (%.2f TFLOP algorithmic per step)." % (
