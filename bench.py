@@ -81,6 +81,25 @@ def train_flops(cfg_name, lengths):
     return 3 * 2.0 * macs * frames
 
 
+PARAM_SEED = {"cfg2": 2202, "cfg3": 3303, "cfg5a": 5505, "cfg5b": 6606}     # tests/golden/make_fullsize_golden.py
+
+
+def load_reference_loss(cfg_name, model):
+    """Random-init weights of the architecture, drawn the way the full-size reference fixture draws them (synth.synth_params, the
+    fixture's seed), so that the FIRST step of the bench on rank 0's batch is exactly the step the reference's own model.py was run
+    on when tests/golden/full/<config>.npz was generated (make_fullsize_golden.py: same batch seed, same parameters): its CTC loss
+    is the `ctc_loss_ref` of the JSON line.  Returns {"fp32": loss of the reference as shipped, "autocast": under bf16 autocast}."""
+    from deepspeech.pytorch_amd import synth
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    P = synth.synth_params(shapes, PARAM_SEED[cfg_name])
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in P.items()}, strict=True)
+    path = os.path.join(ROOT, "tests", "golden", "full", cfg_name + ".npz")
+    if not os.path.exists(path):
+        return None
+    z = np.load(path)
+    return {"fp32": float(z["loss"]), "autocast": float(z["loss_ac"]) if "loss_ac" in z.files else None}
+
+
 def run_native(args, rank, world, device):
     from deepspeech.pytorch_amd import configs, ops
     from deepspeech.pytorch_amd import dist as dsdist
@@ -90,7 +109,9 @@ def run_native(args, rank, world, device):
     rt = getattr(configs.RNNType, kind)
     mc = configs.BiDirectionalConfig(rnn_type=rt, hidden_size=H, hidden_layers=L) if bi else \
         configs.UniDirectionalConfig(rnn_type=rt, hidden_size=H, hidden_layers=L, lookahead_context=20)
-    model = DeepSpeech(configs.LABELS, mc, "bf16" if dtype == "bf16" else 32, configs.AdamConfig(), configs.SpectConfig()).to(device)
+    model = DeepSpeech(configs.LABELS, mc, "bf16" if dtype == "bf16" else 32, configs.AdamConfig(), configs.SpectConfig())
+    ref = load_reference_loss(args.config, model)          # parameters of the full-size reference fixture (same on every rank)
+    model = model.to(device)
     model.train()
     lengths, batch = build_batch(args.config, rank, device)
     opt = model.configure_optimizers()[0][0]       # FusedAdamW: clip + AdamW + next step's bf16 weight layouts on HIP kernels
@@ -103,7 +124,13 @@ def run_native(args, rank, world, device):
     step_mod = dsdist.wrap_data_parallel(dsdist.StepModule(model), device, world)
     params = [p for p in model.parameters()]
 
+    marks = []                                     # one event per timed step start (+ one at the end): per-step durations, no host sync
+
     def step():
+        if marks is not None and ops.SWEEP_EVENTS is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append(ev)
         opt.zero_grad(set_to_none=True)
         loss = step_mod(batch[0], batch[1], batch[2].clone(), batch[3])
         loss.backward()
@@ -128,6 +155,14 @@ def run_native(args, rank, world, device):
     ops.SWEEP_EVENTS = []
     dt, last = dsdist.timed_steps(step, args.steps, device, world)
     events, ops.SWEEP_EVENTS = ops.SWEEP_EVENTS, None
+    end = torch.cuda.Event(enable_timing=True)
+    end.record()
+    end.synchronize()
+    marks.append(end)
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(len(marks) - 1))
+    step_stats = {"median_ms": round(per_step[len(per_step) // 2], 3), "min_ms": round(per_step[0], 3), "max_ms": round(per_step[-1], 3),
+                  "p90_ms": round(per_step[min(len(per_step) - 1, int(0.9 * len(per_step)))], 3),
+                  "how": "HIP events at every step start on the step's stream (device time between consecutive steps)"} if per_step else None
     log("timed region done: %.1f ms/step" % (dt / args.steps * 1e3))
     last_loss = float(last.detach().item())
 
@@ -177,6 +212,8 @@ def run_native(args, rank, world, device):
                         "h2h products over valid frames",
                 "recurrent_kernels": {names.get(k, k): v for k, v in kernels.items()},
                 "whole_step_frac_of_mfma_roofline": None}
+    roofline["_step_stats"] = step_stats
+    roofline["_loss_ref"] = ref
     return lengths, dt, first_loss, last_loss, roofline
 
 
@@ -185,7 +222,10 @@ def run_stock(args, rank, world, device):
     from oracle import ds2_torch_port as TP
     kind, H, L, bi, N, tmin, tmax, dtype = CONFIGS[args.config]
     cfg = dict(rnn_type=kind, hidden_size=H, hidden_layers=L, bidirectional=bi, lookahead_context=20)
-    port = TP.Port(cfg, TP.random_state(cfg, 0), device)
+    from deepspeech.pytorch_amd import synth
+    st0 = TP.random_state(cfg, 0)
+    st0 = synth.synth_params({k: tuple(np.asarray(v).shape) for k, v in st0.items()}, PARAM_SEED[args.config])   # the native leg's parameters
+    port = TP.Port(cfg, st0, device)
     lengths, batch = build_batch(args.config, rank, device)
     opt = port.make_optimizer()
     ac = torch.bfloat16 if dtype == "bf16" else None
@@ -237,6 +277,30 @@ def cpu_baseline_subprocess(args):
     except subprocess.TimeoutExpired:
         return {"value": None, "unit": "audio-seconds/sec", "cores": usable_cores(), "kind": "port",
                 "sample": "cpu leg exceeded its %d s limit" % args.cpu_timeout}
+
+
+def stock_baseline_subprocess(args):
+    """`bench.py --stock` (stock PyTorch-ROCm on this GPU, same configuration) in a child process under a time limit: the
+    denominator of the north star's ">= 3x over stock PyTorch-ROCm", measured in the same driver run as the native number."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--stock", "--config", args.config, "--steps", str(args.stock_steps),
+           "--warmup", str(args.stock_warmup), "--no-cpu-baseline"]
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    base = {"impl": "stock-pytorch-rocm", "unit": "audio-seconds/sec", "steps": args.stock_steps, "warmup": args.stock_warmup}
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.stock_timeout, env=env)
+        for line in r.stdout.splitlines()[::-1]:
+            if line.startswith("{"):
+                j = json.loads(line)
+                base.update(value=j["value"], ms_per_step=j["ms_per_step"], dtype=j["dtype"], ctc_loss_first_step=j.get("ctc_loss_first_step"),
+                            torch=torch.__version__)
+                return base
+        base.update(value=None, note="stock leg failed: " + (r.stderr.strip().splitlines() or ["?"])[-1][:200])
+    except subprocess.TimeoutExpired:
+        base.update(value=None, note="stock leg exceeded its %d s limit" % args.stock_timeout)
+    return base
 
 
 def cpu_baseline(args):
@@ -292,6 +356,10 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=301)
     ap.add_argument("--cpu-timeout", type=int, default=170)
     ap.add_argument("--cpu-baseline-only", action="store_true")
+    ap.add_argument("--no-stock-baseline", action="store_true", help="skip the stock PyTorch-ROCm leg of the N=1 run")
+    ap.add_argument("--stock-steps", type=int, default=3)
+    ap.add_argument("--stock-warmup", type=int, default=2)
+    ap.add_argument("--stock-timeout", type=int, default=150)
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args)))
@@ -334,6 +402,8 @@ def main():
         # whole-step view: algorithmic train FLOPs over valid frames / step time / MFMA peak
         roofline["whole_step_frac_of_mfma_roofline"] = round(train_flops(args.config, lengths) / (ms_per_step / 1e3) / 1e12 /
                                                              PEAK_TFLOPS[dtype], 6)
+    step_stats = roofline.pop("_step_stats", None) if roofline is not None else None
+    loss_ref = roofline.pop("_loss_ref", None) if roofline is not None else None
     out = {
         "metric": "audio-seconds/sec (train step)", "value": round(value, 2), "unit": "audio-seconds/sec", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
@@ -345,8 +415,30 @@ def main():
             "audio_seconds_per_step": round(secs_total, 2)},
         "ctc_loss_first_step": first_loss, "ctc_loss_last_step": last_loss,
     }
+    if step_stats is not None:
+        out["ms_per_step_median"] = step_stats["median_ms"]
+        out["step_time_distribution"] = step_stats
+    if loss_ref is not None and first_loss == first_loss:
+        # BASELINE.json's metric is "audio-s/s + CTC loss vs ref": the first step runs on the full-size fixture's parameters and
+        # (on rank 0) its batch, so its loss is directly comparable with the reference's own model.py on the CPU
+        ref_mode = loss_ref["autocast"] if (dtype == "bf16" and loss_ref.get("autocast") is not None) else loss_ref["fp32"]
+        out["ctc_loss_ref"] = loss_ref["fp32"]
+        out["ctc_loss_ref_autocast_bf16"] = loss_ref.get("autocast")
+        out["ctc_loss_rel_diff"] = round(abs(first_loss - loss_ref["fp32"]) / abs(loss_ref["fp32"]), 8)
+        out["ctc_loss_rel_diff_vs_same_precision_ref"] = round(abs(first_loss - ref_mode) / abs(ref_mode), 8)
+        out["ctc_loss_ref_source"] = ("tests/golden/full/%s.npz: the reference's model.py (imported unmodified) on the CPU, same parameters "
+                                      "(synth.synth_params seed %d), rank 0's batch" % (args.config, PARAM_SEED[args.config]))
     if roofline is not None:
         out["roofline"] = roofline
+    if rank == 0 and world == 1 and not args.stock and not args.no_stock_baseline:
+        log("stock PyTorch-ROCm leg (subprocess, <= %d s)" % args.stock_timeout)
+        sb = stock_baseline_subprocess(args)
+        out["stock_baseline"] = sb
+        if sb.get("value"):
+            out["vs_baseline"] = round(value / sb["value"], 3)
+            out["vs_baseline_kind"] = ("this run's audio-s/s over stock PyTorch-ROCm's (MIOpen conv / BatchNorm / RNN + ATen CTC, same "
+                                       "model, batch and precision) measured on the same GPU right after the timed region; BASELINE.md "
+                                       "holds no published number for this metric")
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.stock:
         log("cpu baseline leg (subprocess, <= %d s)" % args.cpu_timeout)
         out["cpu_baseline"] = cpu_baseline_subprocess(args)
