@@ -189,13 +189,12 @@ def run_native(args, rank, world, device):
                         "us_per_time_step": round(ms * 1e3 / n / tp, 3), "achieved_tflops": round(fl / avg_s / 1e12, 2),
                         "ms_per_train_step": round(ms / max(1, args.steps), 3)}
     dom = max(kernels, key=lambda k: kernels[k]["ms_per_train_step"]) if kernels else None
-    # the kernel symbols behind the tags (what rocprofv3 lists): tuned H = 1024 / bf16 kernels with <= 8 (suffix 4) or <= 16 samples
-    # per group, else the general kernels of ds2_rnn_persist2_impl.h
-    per_group = -(-N // (8 // D))
-    sfx = ("4" if per_group <= 8 else "") if (H == 1024 and dtype == "bf16" and per_group <= 16) else None
-    names = {"rnn_fwd_persistent": "k_rnn_persist_fwd" + sfx if sfx is not None else "k_rnn_persist2_fwd",
-             "rnn_bwd_persistent": "k_rnn_persist_bwd" + sfx if sfx is not None else "k_rnn_persist2_bwd",
-             "rnn_fwd": "k_rnn_step_fwd", "rnn_bwd": "k_rnn_step_bwd"}
+    # the kernel symbols behind the tags (what rocprofv3 lists), from the library's own dispatch decision
+    from deepspeech.pytorch_amd._lib import query
+    fam = query("ds2_rnn_persist_kind", ops.dt(torch.bfloat16 if dtype == "bf16" else torch.float32), ops.CELLS[kind], D, N, H)
+    stem = {1: ("k_rnn_persist_fwd4", "k_rnn_persist_bwd4"), 2: ("k_rnn_persist_fwd", "k_rnn_persist_bwd"),
+            3: ("k_rnn_persist3_fwd", "k_rnn_persist3_bwd"), 4: ("k_rnn_persist2_fwd", "k_rnn_persist2_bwd")}.get(fam, ("?", "?"))
+    names = {"rnn_fwd_persistent": stem[0], "rnn_bwd_persistent": stem[1], "rnn_fwd": "k_rnn_step_fwd", "rnn_bwd": "k_rnn_step_bwd"}
     traffic, traffic_src = None, None
     try:   # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/pmc_traffic.json)
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))

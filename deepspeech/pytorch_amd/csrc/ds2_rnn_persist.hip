@@ -1,9 +1,12 @@
 // Host side of the persistent recurrent sweeps: support query, scratch sizing, launch.
 //   tuned kernels  (ds2_rnn_persist_impl.h,  instantiated per cell in ds2_rnn_persist_{gru,lstm,rnn}.hip): bf16, H = 1024,
 //                   8 XCD-local groups of 32 workgroups, <= 16 samples per group -- BASELINE.json config 3;
-//   general kernels (ds2_rnn_persist2_impl.h, instantiated in ds2_rnn_persist2_*.hip): H in {800, 1024, 1280}, bf16 and fp32
-//                   storage, GRU / LSTM, up to 64 samples per group -- configs 2 and 5 and the fp32 parity mode.
-#include "ds2_rnn_persist2_impl.h"
+//   general kernels, round 4 (ds2_rnn_persist3_impl.h, instantiated in ds2_rnn_persist3_*.hip): bf16, GRU / LSTM, H in {512, 768,
+//                   800, 1024, 1280, 1536}: 32 units per workgroup, XCD-local groups for H <= 1024, up to 32 samples per group in
+//                   two interleaved sets -- config 5 and every bf16 width / batch the tuned kernels do not take;
+//   general kernels, round 2 (ds2_rnn_persist2_impl.h, instantiated in ds2_rnn_persist2_*.hip): H in {800, 1024, 1280}, bf16 and fp32
+//                   storage, GRU / LSTM, up to 64 samples per group -- config 2 (the fp32 parity mode) and bf16 groups of > 32 samples.
+#include "ds2_rnn_persist3_impl.h"
 
 namespace ds2p {
 int launch_gru(bool bwd, int H, const PArgs& a, hipStream_t st);
@@ -17,6 +20,15 @@ int launch_bf16_1280(bool probe, bool bwd, int cell, int MT, const QArgs& a, hip
 int launch_f32_800(bool probe, bool bwd, int cell, int MT, const QArgs& a, hipStream_t st);
 int launch_f32_1024(bool probe, bool bwd, int cell, int MT, const QArgs& a, hipStream_t st);
 }  // namespace ds2q
+
+namespace ds2r {
+int launch3_512(bool probe, bool bwd, int cell, const RArgs& a, hipStream_t st);
+int launch3_768(bool probe, bool bwd, int cell, const RArgs& a, hipStream_t st);
+int launch3_800(bool probe, bool bwd, int cell, const RArgs& a, hipStream_t st);
+int launch3_1024(bool probe, bool bwd, int cell, const RArgs& a, hipStream_t st);
+int launch3_1280(bool probe, bool bwd, int cell, const RArgs& a, hipStream_t st);
+int launch3_1536(bool probe, bool bwd, int cell, const RArgs& a, hipStream_t st);
+}  // namespace ds2r
 
 namespace {
 using namespace ds2p;
@@ -89,6 +101,53 @@ bool plan2(int dtype, int cell, int D, int N, int H, Plan2& pl) {
   ds2q::QArgs dummy{};
   return launch2_any(true, false, dtype, cell, H, pl.MT, dummy, nullptr) == 0;
 }
+// ---- round-4 general kernels (bf16, 32 units per workgroup) -----------------------------------------------------------------
+unsigned g_variant = 0;      // ds2_rnn_persist_set_variant: bit 0 = do not use the round-4 general kernels (A/B runs on one box)
+struct Plan3H {
+  int gpd, NG, P, xmap, gx, nset;
+};
+int launch3_any(bool probe, bool bwd, int cell, int H, const ds2r::RArgs& a, hipStream_t st) {
+  switch (H) {
+    case 512: return ds2r::launch3_512(probe, bwd, cell, a, st);
+    case 768: return ds2r::launch3_768(probe, bwd, cell, a, st);
+    case 800: return ds2r::launch3_800(probe, bwd, cell, a, st);
+    case 1024: return ds2r::launch3_1024(probe, bwd, cell, a, st);
+    case 1280: return ds2r::launch3_1280(probe, bwd, cell, a, st);
+    case 1536: return ds2r::launch3_1536(probe, bwd, cell, a, st);
+  }
+  return DS2_ERR_ARG;
+}
+// cus = compute units to plan for (the device's, or 256 for the "would a full device take this shape" question)
+bool plan3h(int dtype, int cell, int D, int N, int H, int cus, Plan3H& pl) {
+  if ((g_variant & 1u) || dtype != DS2_BF16 || (D != 1 && D != 2) || N < 1 || H % 32 != 0) return false;
+  if (cell != CELL_GRU && cell != CELL_LSTM) return false;
+  if (cus < 256) return false;
+  pl.P = H / 32;
+  int slots;
+  if (pl.P <= 32) {            // a group fits one XCD: 8 x floor(32 / P) group slots, block b on XCD b % 8
+    pl.xmap = 1;
+    pl.gx = 32 / pl.P;
+    slots = 8 * pl.gx;
+  } else {
+    pl.xmap = 0;
+    pl.gx = 0;
+    slots = 256 / pl.P;
+  }
+  pl.gpd = slots / D;
+  if (pl.gpd < 1) return false;
+  if (pl.gpd > N) pl.gpd = N;
+  pl.NG = pl.gpd * D;
+  const int ns = (N + pl.gpd - 1) / pl.gpd;
+  pl.nset = ns <= 16 ? 1 : ns <= 32 ? 2 : 0;
+  if (pl.nset == 0) return false;
+  ds2r::RArgs dummy{};
+  return launch3_any(true, false, cell, H, dummy, nullptr) == 0;
+}
+long xbuf3_bytes(int cell, int H, const Plan3H& pl, bool bwd) {
+  const long kt = (bwd ? (long)gates(cell) * H : (long)H) / 32;
+  return (long)pl.NG * pl.nset * 4 * kt * 1024;       // per group: nset sets x four payload slots of [k-step][lq][16 rows] x 16 B
+}
+
 long xbuf2_bytes(int dtype, int cell, int H, const Plan2& pl, bool bwd) {
   const int ksz = dtype == DS2_BF16 ? 32 : 16;
   const long kt = (bwd ? (long)gates(cell) * H : (long)H) / ksz;
@@ -104,8 +163,49 @@ extern "C" {
 int ds2_rnn_persist_supported(int dtype, int cell, int D, int N, int H) {
   if (cell != CELL_GRU && cell != CELL_LSTM && cell != CELL_RNN) return 0;
   if (tuned_ok(dtype, cell, D, N, H)) return 1;
+  Plan3H p3;
+  if (plan3h(dtype, cell, D, N, H, cu_count(), p3)) return 1;
   Plan2 pl;
   return plan2(dtype, cell, D, N, H, pl) ? 1 : 0;
+}
+
+// Which kernel family ds2_rnn_persist_fwd / _bwd run for the problem on the current device: 0 none, 1 tuned (H = 1024, <= 8 samples
+// per group: k_rnn_persist_fwd4 / bwd4), 2 tuned (9-16 samples: k_rnn_persist_fwd / bwd), 3 round-4 general (k_rnn_persist3_*),
+// 4 round-2 general (k_rnn_persist2_*).  For measurement tools (bench.py names the rocprofv3 kernel from it).
+int ds2_rnn_persist_kind(int dtype, int cell, int D, int N, int H) {
+  if (cell != CELL_GRU && cell != CELL_LSTM && cell != CELL_RNN) return 0;
+  if (tuned_ok(dtype, cell, D, N, H)) return (N + NGROUPS / D - 1) / (NGROUPS / D) <= 8 ? 1 : 2;
+  Plan3H p3;
+  if (plan3h(dtype, cell, D, N, H, cu_count(), p3)) return 3;
+  Plan2 pl;
+  return plan2(dtype, cell, D, N, H, pl) ? 4 : 0;
+}
+
+// 1 if a persistent kernel is INSTANTIATED for this problem, whatever the current device's CU count (what a full 256-CU device
+// would run): lets the caller tell "this device is too small" (an error) from "no persistent kernel for this shape" (a warning).
+int ds2_rnn_persist_shape_covered(int dtype, int cell, int D, int N, int H) {
+  if (cell != CELL_GRU && cell != CELL_LSTM && cell != CELL_RNN) return 0;
+  if (dtype == DS2_BF16 && H == 1024 && (D == 1 || D == 2) && N >= 1 && (N + NGROUPS / D - 1) / (NGROUPS / D) <= MAXS) return 1;
+  Plan3H p3;
+  if (plan3h(dtype, cell, D, N, H, 256, p3)) return 1;
+  if ((dtype != DS2_BF16 && dtype != DS2_F32) || (D != 1 && D != 2) || N < 1 || H % 16 != 0) return 0;
+  const int P = H / 16;
+  if (P * D > 256) return 0;
+  int gpd = 256 / P / D;
+  if (gpd > N) gpd = N;
+  const int ns = (N + gpd - 1) / gpd;
+  const int MT = ns <= 16 ? 1 : ns <= 32 ? 2 : ns <= 64 ? 4 : 0;
+  if (MT == 0) return 0;
+  ds2q::QArgs dummy{};
+  return launch2_any(true, false, dtype, cell, H, MT, dummy, nullptr) == 0 ? 1 : 0;
+}
+
+// A/B hook: bit 0 = route the shapes of the round-4 general kernels to the round-2 general kernels (or launch-per-step) instead.
+// Returns the previous value.  Process-wide.
+unsigned ds2_rnn_persist_set_variant(unsigned bits) {
+  const unsigned old = g_variant;
+  g_variant = bits;
+  return old;
 }
 
 // Fault-injection hook for tests: polls a waiting workgroup may spend on one exchange before it gives up (raises *err, poisons its
@@ -119,6 +219,8 @@ unsigned ds2_rnn_persist_set_spin_limit(unsigned polls) {
 // scratch bytes of one sweep (exchange buffer for the larger of the forward / BPTT needs + the head described above)
 long ds2_rnn_persist_ws_bytes(int dtype, int cell, int D, int N, int H) {
   if (tuned_ok(dtype, cell, D, N, H)) return AUX_BYTES + xbuf_bytes(cell, H, true);
+  Plan3H p3;
+  if (plan3h(dtype, cell, D, N, H, cu_count(), p3)) return AUX_BYTES + xbuf3_bytes(cell, H, p3, true);
   Plan2 pl;
   if (!plan2(dtype, cell, D, N, H, pl)) return 0;
   return AUX_BYTES + xbuf2_bytes(dtype, cell, H, pl, true);
@@ -145,6 +247,20 @@ int ds2_rnn_persist_fwd(int dtype, int cell, int D, int N, int H, int Tp, const 
     { const char* e_ = getenv("DS2_PERSIST_DBG"); a.dbgmask = e_ ? atoi(e_) : 0; }
 #endif
     return dispatch(false, cell, H, a, st);
+  }
+  Plan3H p3;
+  if (plan3h(dtype, cell, D, N, H, cu_count(), p3)) {
+    const long xb = xbuf3_bytes(cell, H, p3, false);
+    hipError_t e = hipMemsetAsync(ws, 0xff, AUX_BYTES + xb, st);
+    if (e != hipSuccess) return (int)e;
+    if (int r = set_spin_budget(ws, st)) return r;
+    ds2r::RArgs ra{};
+    ds2q::QArgs& a = ra.q;
+    a.N = N; a.Tp = Tp; a.D = D; a.gpd = p3.gpd; a.NG = p3.NG; a.lens = lens; a.W = Whh; a.bhh = bhh; a.GI = GI; a.Hseq = Hseq;
+    a.hseq_dstride = hseq_dstride; a.S = S; a.h0 = h0; a.c0 = c0; a.hn = hn; a.cn = cn;
+    a.xbuf = (char*)ws + AUX_BYTES; a.xgroup_bytes = xb / p3.NG; a.err = err; a.lerr = (int*)((char*)ws + 3072);
+    ra.xcc = (u64*)((char*)ws + 1024); ra.P = p3.P; ra.xmap = p3.xmap; ra.gx = p3.gx; ra.nset = p3.nset;
+    return launch3_any(false, false, cell, H, ra, st);
   }
   Plan2 pl;
   DS2_REQUIRE(plan2(dtype, cell, D, N, H, pl), DS2_ERR_ARG);
@@ -184,6 +300,20 @@ int ds2_rnn_persist_bwd(int dtype, int cell, int D, int N, int H, int Tp, const 
     { const char* e_ = getenv("DS2_PERSIST_DBG"); a.dbgmask = e_ ? atoi(e_) : 0; }
 #endif
     return dispatch(true, cell, H, a, st);
+  }
+  Plan3H p3;
+  if (plan3h(dtype, cell, D, N, H, cu_count(), p3)) {
+    const long xb = xbuf3_bytes(cell, H, p3, true);
+    hipError_t e = hipMemsetAsync(ws, 0xff, AUX_BYTES + xb, st);
+    if (e != hipSuccess) return (int)e;
+    if (int r = set_spin_budget(ws, st)) return r;
+    ds2r::RArgs ra{};
+    ds2q::QArgs& a = ra.q;
+    a.N = N; a.Tp = Tp; a.D = D; a.gpd = p3.gpd; a.NG = p3.NG; a.lens = lens; a.W = WhhT; a.Hseq = (void*)Hseq;
+    a.hseq_dstride = hseq_dstride; a.S = (void*)S; a.dOut = dOut; a.dGI = dGI; a.dGH = dGH; a.dBacc = dBacc;
+    a.xbuf = (char*)ws + AUX_BYTES; a.xgroup_bytes = xb / p3.NG; a.err = err; a.lerr = (int*)((char*)ws + 3072);
+    ra.xcc = (u64*)((char*)ws + 1024); ra.P = p3.P; ra.xmap = p3.xmap; ra.gx = p3.gx; ra.nset = p3.nset;
+    return launch3_any(false, true, cell, H, ra, st);
   }
   Plan2 pl;
   DS2_REQUIRE(plan2(dtype, cell, D, N, H, pl), DS2_ERR_ARG);

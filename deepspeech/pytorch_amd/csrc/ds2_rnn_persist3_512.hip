@@ -1,0 +1,11 @@
+// Instantiations of the round-4 general persistent recurrent kernels (ds2_rnn_persist3_impl.h: bf16 storage, 32 hidden units per
+// workgroup): hidden size 512, GRU and LSTM.  One translation unit per width keeps hipcc's time per file bounded.
+#include "ds2_rnn_persist3_impl.h"
+
+namespace ds2r {
+int launch3_512(bool probe, bool bwd, int cell, const RArgs& a, hipStream_t st) {
+  if (cell == CELL_GRU) return launch3<CELL_GRU, 512>(probe, bwd, a, st);
+  if (cell == CELL_LSTM) return launch3<CELL_LSTM, 512>(probe, bwd, a, st);
+  return DS2_ERR_ARG;
+}
+}  // namespace ds2r

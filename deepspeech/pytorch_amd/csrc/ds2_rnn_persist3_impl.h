@@ -1,0 +1,718 @@
+// General persistent recurrent sweeps, round 4 (bf16 storage): 32 hidden units per workgroup for ANY hidden size that is a
+// multiple of 32 -- BASELINE.json config 5 (7 x LSTM-1280, 64 clips) and every width the tuned H = 1024 kernels do not cover.
+//
+// What round 3's general kernels (ds2_rnn_persist2_impl.h: 16 units per workgroup) paid for, and what changes here:
+//   * a workgroup gathers the WHOLE exchanged vector of its group's samples every step through one CU's vector-memory path
+//     (~64 GB/s when the group spans XCDs): config 5a had 2 groups of 64 samples on 160 of the 256 CUs, 655 KB per workgroup and
+//     BPTT step.  With 32 units per workgroup a group is P = H/32 workgroups: H = 1280 -> 6 groups of 40 (240 CUs), 22 samples per
+//     group (a third of the bytes); H <= 1024 -> P <= 32 and the groups are laid out INSIDE one XCD (8 x floor(32/P) groups,
+//     block b -> XCD b % 8): publishes are plain stores that stay in that XCD's L2 (905 instead of 2 236 cycles per bare exchange
+//     step, profiles/r03k_exchange.txt) -- checked at start-up by the XCC-id handshake, correct under any placement;
+//   * the W_hh slice of 32 units x G gates (LSTM-1280: 327 KB) no longer fits the register file beside the accumulators: the last
+//     KL k-steps of every wave's K-quarter live in LDS as ready-made MFMA B fragments (one conflict-free ds_read_b128 per
+//     fragment), the first KR in registers (plan3: <= 224 weight registers per lane, LDS <= 156 KB incl. the partial sums);
+//   * a group's samples are cut into NSET interleaved SETS of <= 16 (one MFMA m-tile each).  Samples are independent recurrences,
+//     so a time step is NSET half-steps, each with its own four exchange slots: while set A's hand-off is in flight the
+//     workgroup multiplies set B -- the exchange latency (the floor of a persistent sweep) hides behind the other set's work,
+//     and only ONE m-tile of accumulators, gather buffers and gate state is live at a time;
+//   * all 256 threads run the gate phase (one sample row x one pair of hidden units each), thread bits in the order of the
+//     exchange layout so that a wave publishes one contiguous 1 KiB run.
+// Exchange: payload-only bf16 in MFMA A-fragment order, four slots per set, the all-ones dword = "not published yet", publishers
+// re-arm slot (s + 2) & 3 at step s -- the protocol of gather_mma_tf (ds2_rnn_persist_impl.h), model-checked in
+// tests/test_exchange_protocol.py.  Safety as everywhere: grid <= CU count (one workgroup per CU by LDS / register use), bounded
+// spins, *err / per-launch word, NaN poisoning.  Reference: BatchRNN.forward, model.py:94-102 (nn.GRU / nn.LSTM and their autograd).
+#pragma once
+#include "ds2_rnn_persist2_impl.h"
+
+namespace ds2r {
+using namespace ds2q;
+
+struct RArgs {
+  QArgs q;
+  u64* xcc;      // [NG][32] start-up exchange of the workgroups' XCC ids (xmap only)
+  int P;         // workgroups per group = H / 32
+  int xmap;      // 1: group g's workgroups are the blocks with blockIdx % 8 == g % 8 (one XCD, if the dispatcher keeps its habit)
+  int gx;        // xmap: group slots per XCD (floor(32 / P)); the grid is 8 * gx * P blocks, groups >= NG stay empty
+  int nset;      // interleaved sample sets per group (the kernel's NSET)
+};
+
+struct Plan3 {
+  int KR, PB;
+  bool ok;
+};
+// KR = k-steps of a wave's K-quarter whose B fragments stay in registers (the other KSW - KR live in LDS), PB = partial-sum
+// buffers (2: one barrier per half-step; 1: a second barrier before the stores, when LDS is short).
+constexpr Plan3 plan3(int RT, int KSW) {
+  const int krmax = 56 / RT;                         // <= 224 weight registers per lane
+  for (int pb = 2; pb >= 1; --pb) {
+    const int part_kb = pb * 4 * RT;
+    const int max_kl = (156 - part_kb) / (RT * 4);
+    const int kr = KSW < krmax ? KSW : krmax;
+    if (KSW - kr <= max_kl) return Plan3{kr, pb, true};
+  }
+  return Plan3{0, 0, false};
+}
+constexpr int lds_bytes3(int RT, int KSW) {
+  const Plan3 pl = plan3(RT, KSW);
+  return (KSW - pl.KR) * RT * 4096 + pl.PB * 4 * RT * 1024;
+}
+
+// XCC-id handshake of ds2_rnn_persist_impl.h for groups of P <= 32 workgroups
+__device__ __forceinline__ bool group_is_xcd_local3(u64* slots, int p, int P, int tid, int* err, int* lerr, bool& dead) {
+  __shared__ int s_local3;
+  if (tid < 64) {
+    const unsigned my = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf;   // HW_REG_XCC_ID[3:0]
+    if (tid == 0) g_store(slots + p, (0x5ca1ab1eull << 32) | my);
+    bool same = true;
+    unsigned spins = 0;
+    for (;;) {
+      u64 v = 0;
+      if (tid < P) v = g_load(slots + tid);
+      const bool bad = tid < P && (unsigned)(v >> 32) != 0x5ca1ab1eu;
+      if (!__any(bad)) {
+        same = !(tid < P) || ((unsigned)v == my);
+        break;
+      }
+      if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && spin_check(lerr, spins))) {
+        dead = true;
+        raise_err(err, lerr);
+        same = false;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    const bool all_same = __all(same);
+    if (tid == 0) s_local3 = all_same ? 1 : 0;
+  }
+  __syncthreads();
+  return s_local3 != 0;
+}
+
+__device__ __forceinline__ void pub32(char* p, uint32_t v, bool local) {
+  if (local)
+    __builtin_nontemporal_store(v, (uint32_t*)p);     // plain-policy store: stays in this XCD's L2
+  else
+    __hip_atomic_store((uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t pay_word(float a, float b) {
+  const uint32_t pk = cvt_pk_bf16(a, b);
+  return pk == XSENT2 ? 0x7fc07fc0u : pk;
+}
+
+constexpr int chunk3(int KSW, int SP) { return KSW <= 12 ? (KSW + SP - 1) / SP * SP : 8; }
+
+// One half-step's gather + products: acc[t] += A(16 sample rows x this wave's K-quarter) * W[t](16 rows x K-quarter)^T.
+// `base` = byte offset of (set, slot) + lq * 256 + sample row * 16 inside the group's buffer; k-step k adds k * 1024.  Lanes whose
+// row carries no sample (or whose k-step lies beyond the wave's ragged share) load from beyond the resource: zeros, no branch.
+// SP == 2 (at most 8 rows in the set): lane (part, row) = (li >> 3, li & 7) loads the k-steps part, part + 2, ... of a chunk and the
+// fragment of an odd k-step is rotated into place (DPP row rotate by 8): half the load instructions per lane.
+template <int RT, int KSW, int KR, int SP, bool RAGGED>
+__device__ __forceinline__ void gather_mma3(ds2_f32x4 (&acc)[RT], const uint4 (&w)[RT][KR > 0 ? KR : 1], const uint4* wl_lane,
+                                            __amdgpu_buffer_rsrc_t rsrc, int base, bool need, int ks0, int cnt, int part, int* err,
+                                            int* lerr, bool& dead) {
+  constexpr int CH = chunk3(KSW, SP);
+  constexpr int PER = CH / SP;
+  constexpr int NCH = (KSW + CH - 1) / CH;
+  constexpr int NB = NCH > 1 ? 2 : 1;
+  static_assert(CH % SP == 0, "chunk tiles into lane parts");
+  u32x4_t v[NB][PER];
+#define DS2R_LOAD(c, b)                                                                                                  \
+  _Pragma("unroll") for (int i = 0; i < PER; ++i) {                                                                     \
+    const int k_ = (c) * CH + part + SP * i;                                                                             \
+    const bool ok_ = need && k_ < KSW && (!RAGGED || k_ < cnt);                                                          \
+    v[b][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok_ ? base + (ks0 + k_) * 1024 : XOOB, 0, 16 /* sc1 */);       \
+  }
+#define DS2R_CHECK(b, bad)                                                                                               \
+  bool bad;                                                                                                              \
+  {                                                                                                                      \
+    uint32_t mx = 0;                                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < PER; ++i) mx = max(max(mx, max(v[b][i][0], v[b][i][1])), max(v[b][i][2], v[b][i][3])); \
+    bad = mx == XSENT2;                                                                                                  \
+  }
+  DS2R_LOAD(0, 0)
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int b = NB > 1 ? (c & 1) : 0;
+    if (c + 1 < NCH) { DS2R_LOAD(c + 1, (NB > 1 ? (b ^ 1) : 0)) }
+    DS2R_CHECK(b, bad0)
+    if (__any(bad0) && !dead) {        // a sentinel in the chunk: poll it (bounded) before its products
+      unsigned spins = 0;
+      for (;;) {
+        __builtin_amdgcn_s_sleep(1);
+        DS2R_LOAD(c, b)
+        DS2R_CHECK(b, bad1)
+        if (!__any(bad1)) break;
+        if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && spin_check(lerr, spins))) {
+          dead = true;
+          raise_err(err, lerr);
+          break;
+        }
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < CH; ++kk) {
+      const int k_ = c * CH + kk;                    // compile-time after unrolling
+      if (k_ < KSW) {
+        const int i = kk / SP;
+        uint4 a_ = make_uint4(v[b][i][0], v[b][i][1], v[b][i][2], v[b][i][3]);
+        if (SP == 2 && (kk & 1)) a_ = row_from_plus4(a_, 8);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+          if (k_ < KR) {
+            Mma<bf16_t>::mma16(acc[t], a_, w[t][k_ < KR ? k_ : 0]);
+          } else {
+            const uint4 wv = wl_lane[((k_ - KR) * RT + t) * 256];
+            Mma<bf16_t>::mma16(acc[t], a_, wv);
+          }
+        }
+      }
+    }
+  }
+#undef DS2R_LOAD
+#undef DS2R_CHECK
+}
+
+template <int RT>
+__device__ __forceinline__ void store_partials3(float* part, const ds2_f32x4 (&acc)[RT], int wave, int lane) {
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[((wave * RT + t) * 16 + mma16_row(r, lane)) * 16 + (lane & 15)] = acc[t][r];
+}
+template <int RT>
+__device__ __forceinline__ float2 load_partials3(const float* part, int t, int row, int col) {
+  float2 s = make_float2(0.f, 0.f);
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const float2 v = *reinterpret_cast<const float2*>(part + ((w * RT + t) * 16 + row) * 16 + col);
+    s.x += v.x;
+    s.y += v.y;
+  }
+  return s;
+}
+
+__device__ __forceinline__ void block_map3(const RArgs& ra, int& grp, int& p) {
+  if (ra.xmap) {
+    const int x = blockIdx.x & 7, i = blockIdx.x >> 3;
+    grp = (i / ra.P) * 8 + x;
+    p = i % ra.P;
+  } else {
+    grp = blockIdx.x % ra.q.NG;
+    p = blockIdx.x / ra.q.NG;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// forward sweep
+// ------------------------------------------------------------------------------------------------------------------
+template <int CELL, int H, int NSET, int SP>
+__global__ void __launch_bounds__(256, 1) k_rnn_persist3_fwd(RArgs ra) {
+  typedef XT<bf16_t> X;
+  const QArgs& a = ra.q;
+  constexpr int G = CellInfo<CELL>::G, NS = CellInfo<CELL>::NS, M = NS ? NS : 1;
+  constexpr int RT = 2 * G;                              // tile 2g + ut = gate g, units 16 ut .. 16 ut + 15 of this workgroup's 32
+  constexpr int KT = H / 32, KSW = (KT + 3) / 4;
+  constexpr bool RAGGED = KT % 4 != 0;
+  constexpr Plan3 PL = plan3(RT, KSW);
+  constexpr int KR = PL.KR, KL = KSW - KR, PB = PL.PB;
+  constexpr int SLOT = KT * 1024, SETB = 4 * SLOT;       // bytes of one slot / of one set's four slots
+  static_assert(H % 32 == 0 && PL.ok, "unsupported hidden size");
+  static_assert(SP == 1 || NSET == 1, "lane sharing is instantiated for single-set groups only");
+  extern __shared__ __attribute__((aligned(16))) uint4 smem3[];
+  uint4* wl = smem3;                                                   // [KL][RT][4 waves][64 lanes]
+  float* part = reinterpret_cast<float*>(smem3 + KL * RT * 256);       // [PB][4][RT][256]
+  constexpr int PART_FLOATS = 4 * RT * 256;
+  __builtin_amdgcn_s_setprio(3);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int grp, p;
+  block_map3(ra, grp, p);
+  if (grp >= a.NG) return;                                 // an empty group slot (fewer samples than groups): the whole workgroup leaves
+  const int d = grp / a.gpd, slice = grp % a.gpd;
+  const int N = a.N, Tp = a.Tp;
+  const int Ns = (N - slice + a.gpd - 1) / a.gpd;          // samples n = slice + gpd*i, i < Ns; set = i % NSET, row = i / NSET
+  const int li = lane & 15, lq = lane >> 4;
+  constexpr long GH = (long)G * H;
+  const long ldgi = (long)a.D * GH;
+  const int ks0 = wave * KSW;
+  const int cnt = RAGGED ? max(0, min(KSW, KT - ks0)) : KSW;
+
+  uint4 w[RT][KR > 0 ? KR : 1];
+  {
+    const bf16_t* Wd = (const bf16_t*)a.W + (long)d * GH * H;
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      const bf16_t* row = Wd + ((long)(t >> 1) * H + p * 32 + (t & 1) * 16 + li) * H + lq * 8;
+#pragma unroll
+      for (int k = 0; k < KSW; ++k) {
+        const uint4 f = (!RAGGED || k < cnt) ? *reinterpret_cast<const uint4*>(row + (long)(ks0 + k) * 32) : make_uint4(0, 0, 0, 0);
+        if (k < KR)
+          w[t][k < KR ? k : 0] = f;
+        else
+          wl[((k - KR) * RT + t) * 256 + tid] = f;
+      }
+    }
+  }
+  const uint4* wl_lane = wl + tid;
+  char* xg = a.xbuf + (long)grp * a.xgroup_bytes;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, NSET * SETB, 0x00020000);
+  // gather identity of this lane
+  const int srow = SP == 2 ? (li & 7) : li, gpart = SP == 2 ? (li >> 3) : 0;
+  const int gbase = lq * 256 + srow * 16;
+  bool gneed[NSET];
+#pragma unroll
+  for (int q = 0; q < NSET; ++q) gneed[q] = srow * NSET + q < Ns;
+
+  // ---- gate identity: thread bits (dw: unit pair of the 16-byte unit (2), sample row (4), lq (2)) = the exchange layout's order
+  const int lqw = tid >> 6, grow = (tid >> 2) & 15, dw = tid & 3;
+  const int jl = lqw * 8 + dw * 2, j = p * 32 + jl;                   // units (j, j + 1)
+  const int xoff = ((p * 4 + lqw) * 16 + grow) * 16 + dw * 4;         // this pair's dword inside a slot (k-step p)
+  bool on[NSET];
+  int len[NSET];
+  float hprev[NSET][2], cprev[NSET][2], bh[G][2];
+  const bf16_t* gi_ptr[NSET];      // where the NEXT prefetch of the set's input projection reads
+  bf16_t* sv_ptr[NSET];
+  bf16_t* hs_ptr[NSET];
+  const long dstep = d == 0 ? 1 : -1;
+  const int t_first = d == 0 ? 0 : Tp - 1;
+  constexpr long NSH_ = (long)M * H;
+  int nsmp[NSET];
+#pragma unroll
+  for (int q = 0; q < NSET; ++q) {
+    const int i = grow * NSET + q;
+    on[q] = i < Ns && grow < 16 / SP;
+    const int n = on[q] ? slice + a.gpd * i : 0;
+    nsmp[q] = n;
+    len[q] = on[q] ? a.lens[n] : 0;
+    hprev[q][0] = hprev[q][1] = cprev[q][0] = cprev[q][1] = 0.f;
+    if (on[q]) {
+      const long so = ((long)d * N + n) * H + j;
+      if (a.h0) {
+        hprev[q][0] = a.h0[so];
+        hprev[q][1] = a.h0[so + 1];
+      }
+      if (CELL == CELL_LSTM && a.c0) {
+        cprev[q][0] = a.c0[so];
+        cprev[q][1] = a.c0[so + 1];
+      }
+    }
+    gi_ptr[q] = (const bf16_t*)a.GI + ((long)t_first * N + n) * ldgi + (long)d * GH + j;
+    sv_ptr[q] = NS ? (bf16_t*)a.S + (((long)d * Tp + t_first) * N + n) * NSH_ + j : nullptr;
+    hs_ptr[q] = (bf16_t*)a.Hseq + (long)d * a.hseq_dstride + ((long)t_first * N + n) * H + j;
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    bh[g][0] = a.bhh[(long)d * GH + (long)g * H + j];
+    bh[g][1] = a.bhh[(long)d * GH + (long)g * H + j + 1];
+  }
+  const long gi_stride = dstep * N * ldgi, sv_stride = dstep * N * NSH_, hs_stride = dstep * N * H;
+  bool dead = false;
+  const bool local = ra.xmap ? group_is_xcd_local3(ra.xcc + grp * 32, p, ra.P, tid, a.err, a.lerr, dead) : false;
+#pragma unroll
+  for (int q = 0; q < NSET; ++q)
+    if (on[q]) {   // zero guard slots of the state sequence at t = -1 and t = T' ("previous h" reads are unconditional)
+      bf16_t* hb = (bf16_t*)a.Hseq + (long)d * a.hseq_dstride + (long)nsmp[q] * H + j;
+      X::st(hb - (long)N * H, 0.f, 0.f);
+      X::st(hb + (long)Tp * N * H, 0.f, 0.f);
+      if (a.h0) pub32(xg + q * SETB + 3 * SLOT + xoff, pay_word(hprev[q][0], hprev[q][1]), local);   // "step -1": slot 3
+    }
+  __syncthreads();      // the LDS-resident fragments are in place
+
+  // the input projection of a half-step is loaded ONE HALF-STEP AHEAD (vmcnt retires in order: a load that is still on its way
+  // from HBM when the gather's loads come back would hold the gather up)
+  uint32_t gin[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) gin[g] = on[0] ? X::ld(gi_ptr[0] + (long)g * H) : 0u;
+  gi_ptr[0] += gi_stride;
+  int hstep = 0;
+  for (int s = 0; s < Tp; ++s) {
+    const int t = d == 0 ? s : Tp - 1 - s;
+#pragma unroll
+    for (int q = 0; q < NSET; ++q, ++hstep) {
+      uint32_t gi[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) gi[g] = gin[g];
+      {
+        constexpr bool wrap = true;
+        const int qn = q + 1 < NSET ? q + 1 : 0;
+        const bool more = q + 1 < NSET || s + 1 < Tp;
+        (void)wrap;
+#pragma unroll
+        for (int g = 0; g < G; ++g) gin[g] = (more && on[qn]) ? X::ld(gi_ptr[qn] + (long)g * H) : 0u;
+        gi_ptr[qn] += gi_stride;
+      }
+      ds2_f32x4 acc[RT];
+#pragma unroll
+      for (int tt = 0; tt < RT; ++tt) acc[tt] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
+      if (s > 0 || a.h0)
+        gather_mma3<RT, KSW, KR, SP, RAGGED>(acc, w, wl_lane, rsrc, q * SETB + ((s + 3) & 3) * SLOT + gbase, gneed[q], ks0, cnt, gpart,
+                                             a.err, a.lerr, dead);
+      float* pp = part + (PB == 2 ? (hstep & 1) * PART_FLOATS : 0);
+      if (PB == 1) __syncthreads();       // every wave is through with the previous half-step's partial sums
+      store_partials3<RT>(pp, acc, wave, lane);
+      __syncthreads();
+      if (on[q]) {
+        const bool act = t < len[q];
+        float hn0 = 0.f, hn1 = 0.f;       // emitted h_t (0 when inactive)
+        float2 gh[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) gh[g] = load_partials3<RT>(pp, 2 * g + (jl >> 4), grow, jl & 15);
+        float pl[M][2];
+#pragma unroll
+        for (int m = 0; m < M; ++m) pl[m][0] = pl[m][1] = 0.f;
+        if (CELL == CELL_GRU) {
+          if (act) {
+            const float q0 = gh[2 % G].x + bh[2 % G][0], q1 = gh[2 % G].y + bh[2 % G][1];
+            const float r0 = X::sig(X::lo(gi[0]) + gh[0].x + bh[0][0]), r1 = X::sig(X::hi(gi[0]) + gh[0].y + bh[0][1]);
+            const float z0 = X::sig(X::lo(gi[1 % G]) + gh[1 % G].x + bh[1 % G][0]);
+            const float z1 = X::sig(X::hi(gi[1 % G]) + gh[1 % G].y + bh[1 % G][1]);
+            const float n0 = X::tnh(X::lo(gi[2 % G]) + r0 * q0), n1 = X::tnh(X::hi(gi[2 % G]) + r1 * q1);
+            hn0 = (1.f - z0) * n0 + z0 * hprev[q][0];
+            hn1 = (1.f - z1) * n1 + z1 * hprev[q][1];
+            hprev[q][0] = hn0;
+            hprev[q][1] = hn1;
+            pl[0][0] = r0; pl[0][1] = r1;
+            pl[1 % M][0] = z0; pl[1 % M][1] = z1;
+            pl[2 % M][0] = n0; pl[2 % M][1] = n1;
+            pl[3 % M][0] = q0; pl[3 % M][1] = q1;
+          }
+        } else if (CELL == CELL_LSTM) {
+          if (act) {
+            const float i0 = X::sig(X::lo(gi[0]) + gh[0].x + bh[0][0]), i1 = X::sig(X::hi(gi[0]) + gh[0].y + bh[0][1]);
+            const float f0 = X::sig(X::lo(gi[1 % G]) + gh[1 % G].x + bh[1 % G][0]);
+            const float f1 = X::sig(X::hi(gi[1 % G]) + gh[1 % G].y + bh[1 % G][1]);
+            const float g0 = X::tnh(X::lo(gi[2 % G]) + gh[2 % G].x + bh[2 % G][0]);
+            const float g1 = X::tnh(X::hi(gi[2 % G]) + gh[2 % G].y + bh[2 % G][1]);
+            const float o0 = X::sig(X::lo(gi[3 % G]) + gh[3 % G].x + bh[3 % G][0]);
+            const float o1 = X::sig(X::hi(gi[3 % G]) + gh[3 % G].y + bh[3 % G][1]);
+            const float c0 = f0 * cprev[q][0] + i0 * g0, c1 = f1 * cprev[q][1] + i1 * g1;
+            hn0 = o0 * X::tnh(c0);
+            hn1 = o1 * X::tnh(c1);
+            cprev[q][0] = c0;
+            cprev[q][1] = c1;
+            hprev[q][0] = hn0;
+            hprev[q][1] = hn1;
+            pl[0][0] = i0; pl[0][1] = i1;
+            pl[1 % M][0] = f0; pl[1 % M][1] = f1;
+            pl[2 % M][0] = g0; pl[2 % M][1] = g1;
+            pl[3 % M][0] = o0; pl[3 % M][1] = o1;
+            pl[4 % M][0] = c0; pl[4 % M][1] = c1;
+          }
+        } else {
+          if (act) {
+            hn0 = X::tnh(X::lo(gi[0]) + gh[0].x + bh[0][0]);
+            hn1 = X::tnh(X::hi(gi[0]) + gh[0].y + bh[0][1]);
+            hprev[q][0] = hn0;
+            hprev[q][1] = hn1;
+          }
+        }
+        if (dead) hn0 = hn1 = hprev[q][0] = hprev[q][1] = QNAN;   // fail loudly downstream
+        // publish the carried state first (inactive samples republish their unchanged state), then the bookkeeping stores
+        pub32(xg + q * SETB + (s & 3) * SLOT + xoff, pay_word(hprev[q][0], hprev[q][1]), local);
+        pub32(xg + q * SETB + ((s + 2) & 3) * SLOT + xoff, XSENT2, local);     // re-arm the slot of step s + 2
+        X::st(hs_ptr[q], hn0, hn1);
+#pragma unroll
+        for (int m = 0; m < NS; ++m) X::st(sv_ptr[q] + (long)m * H, pl[m][0], pl[m][1]);
+      }
+      if (NS) sv_ptr[q] += sv_stride;
+      hs_ptr[q] += hs_stride;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NSET; ++q) {
+    if (on[q]) {
+      const long so = ((long)d * N + nsmp[q]) * H + j;
+      if (a.hn) {
+        a.hn[so] = hprev[q][0];
+        a.hn[so + 1] = hprev[q][1];
+      }
+      if (CELL == CELL_LSTM && a.cn) {
+        a.cn[so] = cprev[q][0];
+        a.cn[so + 1] = cprev[q][1];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// BPTT sweep.  dh_t = dOut[t] + carry (elementwise part of dh from the step processed before) + dgates_{t'} * W_hh.
+// The workgroup owns the W_hh^T rows of its 32 units (two 16-row tiles), K = G*H: gate g's element j is k = g*H + j.
+// ------------------------------------------------------------------------------------------------------------------
+template <int CELL, int H, int NSET, int SP>
+__global__ void __launch_bounds__(256, 1) k_rnn_persist3_bwd(RArgs ra) {
+  typedef XT<bf16_t> X;
+  const QArgs& a = ra.q;
+  constexpr int G = CellInfo<CELL>::G, NS = CellInfo<CELL>::NS, M = NS ? NS : 1;
+  constexpr int RT = 2;
+  constexpr int KTH = H / 32, KT = G * KTH, KSW = (KT + 3) / 4;
+  constexpr bool RAGGED = KT % 4 != 0;
+  constexpr Plan3 PL = plan3(RT, KSW);
+  constexpr int KR = PL.KR, KL = KSW - KR, PB = PL.PB;
+  constexpr int SLOT = KT * 1024, SETB = 4 * SLOT, GATEB = KTH * 1024;
+  static_assert(H % 32 == 0 && PL.ok, "unsupported hidden size");
+  static_assert(SP == 1 || NSET == 1, "lane sharing is instantiated for single-set groups only");
+  extern __shared__ __attribute__((aligned(16))) uint4 smem3[];
+  uint4* wl = smem3;
+  float* part = reinterpret_cast<float*>(smem3 + KL * RT * 256);
+  constexpr int PART_FLOATS = 4 * RT * 256;
+  __builtin_amdgcn_s_setprio(3);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int grp, p;
+  block_map3(ra, grp, p);
+  if (grp >= a.NG) return;                                 // an empty group slot (fewer samples than groups): the whole workgroup leaves
+  const int d = grp / a.gpd, slice = grp % a.gpd;
+  const int N = a.N, Tp = a.Tp;
+  const int Ns = (N - slice + a.gpd - 1) / a.gpd;
+  const int li = lane & 15, lq = lane >> 4;
+  constexpr long GH = (long)G * H;
+  const long ldgi = (long)a.D * GH;
+  const int ks0 = wave * KSW;
+  const int cnt = RAGGED ? max(0, min(KSW, KT - ks0)) : KSW;
+
+  uint4 w[RT][KR > 0 ? KR : 1];
+  {
+    const bf16_t* WT = (const bf16_t*)a.W + (long)d * H * GH;
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      const bf16_t* row = WT + (long)(p * 32 + t * 16 + li) * GH + lq * 8;
+#pragma unroll
+      for (int k = 0; k < KSW; ++k) {
+        const uint4 f = (!RAGGED || k < cnt) ? *reinterpret_cast<const uint4*>(row + (long)(ks0 + k) * 32) : make_uint4(0, 0, 0, 0);
+        if (k < KR)
+          w[t][k < KR ? k : 0] = f;
+        else
+          wl[((k - KR) * RT + t) * 256 + tid] = f;
+      }
+    }
+  }
+  const uint4* wl_lane = wl + tid;
+  char* xg = a.xbuf + (long)grp * a.xgroup_bytes;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, NSET * SETB, 0x00020000);
+  const int srow = SP == 2 ? (li & 7) : li, gpart = SP == 2 ? (li >> 3) : 0;
+  const int gbase = lq * 256 + srow * 16;
+  bool gneed[NSET];
+#pragma unroll
+  for (int q = 0; q < NSET; ++q) gneed[q] = srow * NSET + q < Ns;
+
+  const int lqw = tid >> 6, grow = (tid >> 2) & 15, dw = tid & 3;
+  const int jl = lqw * 8 + dw * 2, j = p * 32 + jl;
+  const int xoff = ((p * 4 + lqw) * 16 + grow) * 16 + dw * 4;         // gate 0's dword of this pair inside a slot; gate g: + g * GATEB
+  constexpr int NB = CELL == CELL_GRU ? 4 : G;
+  bool on[NSET];
+  int len[NSET], nsmp[NSET];
+  float car[NSET][2], dc[NSET][2], bsum[NSET][NB][2];
+  const bf16_t* do_ptr[NSET];      // the three read pointers run one half-step AHEAD (next prefetch)
+  const bf16_t* sv_ptr[NSET];
+  const bf16_t* hs_ptr[NSET];
+  int tnext[NSET];                 // time index the read pointers of the set stand at
+  bf16_t* dgi_ptr[NSET];
+  bf16_t* dgh_ptr[NSET];
+  const long dstep = d == 0 ? -1 : 1;                       // BPTT walks the direction's time axis backwards
+  const int t_first = d == 0 ? Tp - 1 : 0;
+  const long prev_off = d == 0 ? -1 : 1;                    // previous step in FORWARD order of this direction
+  constexpr long NSH_ = (long)M * H;
+#pragma unroll
+  for (int q = 0; q < NSET; ++q) {
+    const int i = grow * NSET + q;
+    on[q] = i < Ns && grow < 16 / SP;
+    const int n = on[q] ? slice + a.gpd * i : 0;
+    nsmp[q] = n;
+    len[q] = on[q] ? a.lens[n] : 0;
+    car[q][0] = car[q][1] = dc[q][0] = dc[q][1] = 0.f;
+#pragma unroll
+    for (int g = 0; g < NB; ++g) bsum[q][g][0] = bsum[q][g][1] = 0.f;
+    do_ptr[q] = (const bf16_t*)a.dOut + ((long)t_first * N + n) * H + j;
+    sv_ptr[q] = NS ? (const bf16_t*)a.S + (((long)d * Tp + t_first) * N + n) * NSH_ + j : nullptr;
+    hs_ptr[q] = (const bf16_t*)a.Hseq + (long)d * a.hseq_dstride + ((long)t_first * N + n) * H + j;   // h_t
+    tnext[q] = t_first;
+    dgi_ptr[q] = (bf16_t*)a.dGI + ((long)t_first * N + n) * ldgi + (long)d * GH + j;
+    dgh_ptr[q] = a.dGH ? (bf16_t*)a.dGH + (((long)d * Tp + t_first) * N + n) * H + j : nullptr;     // dQ
+  }
+  bool dead = false;
+  const bool local = ra.xmap ? group_is_xcd_local3(ra.xcc + grp * 32, p, ra.P, tid, a.err, a.lerr, dead) : false;
+  __syncthreads();
+
+  // gate-phase operands of a half-step, loaded one half-step ahead (raw pairs)
+  struct Pre {
+    uint32_t dout, sp[M], hp, cp;
+  };
+  auto prefetch = [&](Pre& r, int q) {          // reads the set's pointers (they stand at tnext[q]) and advances them
+    r.dout = r.hp = r.cp = 0u;
+#pragma unroll
+    for (int m = 0; m < M; ++m) r.sp[m] = 0u;
+    if (on[q]) {
+      const int t = tnext[q];
+      r.dout = X::ld(do_ptr[q]);
+#pragma unroll
+      for (int m = 0; m < NS; ++m) r.sp[m] = X::ld(sv_ptr[q] + (long)m * H);
+      r.hp = X::ld(hs_ptr[q] + prev_off * N * H);     // guard slots / inactive frames hold zeros: unconditional (tprev in [-1, Tp])
+      if (CELL == CELL_LSTM) {
+        const bool has_prev = d == 0 ? (t > 0) : (t + 1 < len[q]);
+        if (has_prev) r.cp = X::ld(sv_ptr[q] + prev_off * N * NSH_ + 4 * H);
+      }
+      if (CELL == CELL_RNN) r.hp = X::ld(hs_ptr[q]);
+    }
+    do_ptr[q] += dstep * N * H;
+    if (NS) sv_ptr[q] += dstep * N * NSH_;
+    hs_ptr[q] += dstep * N * H;
+    tnext[q] += (int)dstep;
+  };
+  Pre pn;
+  prefetch(pn, 0);
+  int hstep = 0;
+  for (int s = 0; s < Tp; ++s) {
+    const int t = d == 0 ? Tp - 1 - s : s;
+#pragma unroll
+    for (int q = 0; q < NSET; ++q, ++hstep) {
+      const Pre pc = pn;
+      {
+        const int qn = q + 1 < NSET ? q + 1 : 0;
+        const bool more = q + 1 < NSET || s + 1 < Tp;
+        if (more) prefetch(pn, qn);
+      }
+      ds2_f32x4 acc[RT];
+#pragma unroll
+      for (int tt = 0; tt < RT; ++tt) acc[tt] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
+      if (s > 0)
+        gather_mma3<RT, KSW, KR, SP, RAGGED>(acc, w, wl_lane, rsrc, q * SETB + ((s + 3) & 3) * SLOT + gbase, gneed[q], ks0, cnt, gpart,
+                                             a.err, a.lerr, dead);
+      float* pp = part + (PB == 2 ? (hstep & 1) * PART_FLOATS : 0);
+      if (PB == 1) __syncthreads();
+      store_partials3<RT>(pp, acc, wave, lane);
+      __syncthreads();
+      if (on[q]) {
+        const bool act = t < len[q];
+        const float2 mp = load_partials3<RT>(pp, jl >> 4, grow, jl & 15);
+        const float din0 = car[q][0] + mp.x, din1 = car[q][1] + mp.y;
+        char* xo = xg + q * SETB + (s & 3) * SLOT + xoff;
+        char* xr = xg + q * SETB + ((s + 2) & 3) * SLOT + xoff;      // the slot re-armed for step s + 2
+        bf16_t* dgi = dgi_ptr[q];
+        float gx[G][2], gn[2] = {0.f, 0.f};       // gx: the exchanged planes (GRU: dr, dz, dq), gn: GRU's dn (stored, not exchanged)
+#pragma unroll
+        for (int g = 0; g < G; ++g) gx[g][0] = gx[g][1] = 0.f;
+        car[q][0] = din0;
+        car[q][1] = din1;
+        if (CELL == CELL_GRU) {
+          if (act) {
+            const float r0 = X::lo(pc.sp[0]), r1 = X::hi(pc.sp[0]), z0 = X::lo(pc.sp[1 % M]), z1 = X::hi(pc.sp[1 % M]);
+            const float n0 = X::lo(pc.sp[2 % M]), n1 = X::hi(pc.sp[2 % M]), q0 = X::lo(pc.sp[3 % M]), q1 = X::hi(pc.sp[3 % M]);
+            const float dh0 = X::lo(pc.dout) + din0, dh1 = X::hi(pc.dout) + din1;
+            gn[0] = dh0 * (1.f - z0) * (1.f - n0 * n0);
+            gn[1] = dh1 * (1.f - z1) * (1.f - n1 * n1);
+            gx[1 % G][0] = dh0 * (X::lo(pc.hp) - n0) * z0 * (1.f - z0);
+            gx[1 % G][1] = dh1 * (X::hi(pc.hp) - n1) * z1 * (1.f - z1);
+            gx[0][0] = gn[0] * q0 * r0 * (1.f - r0);
+            gx[0][1] = gn[1] * q1 * r1 * (1.f - r1);
+            gx[2 % G][0] = gn[0] * r0;
+            gx[2 % G][1] = gn[1] * r1;
+            car[q][0] = dh0 * z0;
+            car[q][1] = dh1 * z1;
+          }
+        } else if (CELL == CELL_LSTM) {
+          if (act) {
+            const float i0 = X::lo(pc.sp[0]), i1 = X::hi(pc.sp[0]), f0 = X::lo(pc.sp[1 % M]), f1 = X::hi(pc.sp[1 % M]);
+            const float g0 = X::lo(pc.sp[2 % M]), g1 = X::hi(pc.sp[2 % M]), o0 = X::lo(pc.sp[3 % M]), o1 = X::hi(pc.sp[3 % M]);
+            const float tc0 = X::tnh(X::lo(pc.sp[4 % M])), tc1 = X::tnh(X::hi(pc.sp[4 % M]));
+            const float dh0 = X::lo(pc.dout) + din0, dh1 = X::hi(pc.dout) + din1;
+            const float dcn0 = dc[q][0] + dh0 * o0 * (1.f - tc0 * tc0), dcn1 = dc[q][1] + dh1 * o1 * (1.f - tc1 * tc1);
+            gx[0][0] = dcn0 * g0 * i0 * (1.f - i0);
+            gx[0][1] = dcn1 * g1 * i1 * (1.f - i1);
+            gx[1 % G][0] = dcn0 * X::lo(pc.cp) * f0 * (1.f - f0);
+            gx[1 % G][1] = dcn1 * X::hi(pc.cp) * f1 * (1.f - f1);
+            gx[2 % G][0] = dcn0 * i0 * (1.f - g0 * g0);
+            gx[2 % G][1] = dcn1 * i1 * (1.f - g1 * g1);
+            gx[3 % G][0] = dh0 * tc0 * o0 * (1.f - o0);
+            gx[3 % G][1] = dh1 * tc1 * o1 * (1.f - o1);
+            car[q][0] = car[q][1] = 0.f;
+            dc[q][0] = dcn0 * f0;
+            dc[q][1] = dcn1 * f1;
+          }
+        } else {
+          if (act) {
+            const float h0v = X::lo(pc.hp), h1v = X::hi(pc.hp);
+            gx[0][0] = (X::lo(pc.dout) + din0) * (1.f - h0v * h0v);
+            gx[0][1] = (X::hi(pc.dout) + din1) * (1.f - h1v * h1v);
+            car[q][0] = car[q][1] = 0.f;
+          }
+        }
+        if (dead) gx[0][0] = gx[0][1] = QNAN;
+        uint32_t pk[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) pk[g] = cvt_pk_bf16(gx[g][0], gx[g][1]);
+        const uint32_t pkn = cvt_pk_bf16(gn[0], gn[1]);
+#pragma unroll
+        for (int g = 0; g < G; ++g) pub32(xo + g * GATEB, pk[g] == XSENT2 ? 0x7fc07fc0u : pk[g], local);
+#pragma unroll
+        for (int g = 0; g < G; ++g) pub32(xr + g * GATEB, XSENT2, local);
+        // stored planes: the values as exchanged (GRU: dGI = [dr, dz, dn], dQ apart), bias sums from the ROUNDED values
+        if (CELL == CELL_GRU) {
+          *reinterpret_cast<uint32_t*>(dgi) = pk[0];
+          *reinterpret_cast<uint32_t*>(dgi + H) = pk[1 % G];
+          *reinterpret_cast<uint32_t*>(dgi + 2 * H) = pkn;
+          *reinterpret_cast<uint32_t*>(dgh_ptr[q]) = pk[2 % G];
+          bsum[q][0][0] += bf_lo(pk[0]); bsum[q][0][1] += bf_hi(pk[0]);
+          bsum[q][1 % NB][0] += bf_lo(pk[1 % G]); bsum[q][1 % NB][1] += bf_hi(pk[1 % G]);
+          bsum[q][2 % NB][0] += bf_lo(pkn); bsum[q][2 % NB][1] += bf_hi(pkn);
+          bsum[q][3 % NB][0] += bf_lo(pk[2 % G]); bsum[q][3 % NB][1] += bf_hi(pk[2 % G]);
+        } else {
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            *reinterpret_cast<uint32_t*>(dgi + (long)g * H) = pk[g];
+            bsum[q][g % NB][0] += bf_lo(pk[g]);
+            bsum[q][g % NB][1] += bf_hi(pk[g]);
+          }
+        }
+      }
+      dgi_ptr[q] += dstep * N * ldgi;
+      if (CELL == CELL_GRU) dgh_ptr[q] += dstep * N * H;
+    }
+  }
+  if (a.dBacc) {
+#pragma unroll
+    for (int q = 0; q < NSET; ++q) {
+      if (on[q]) {
+        float* bo = a.dBacc + ((long)d * N + nsmp[q]) * NB * H + j;
+#pragma unroll
+        for (int g = 0; g < NB; ++g) *reinterpret_cast<float2*>(bo + (long)g * H) = make_float2(bsum[q][g][0], bsum[q][g][1]);
+      }
+    }
+  }
+}
+
+template <int CELL, int H>
+constexpr bool covered3() {
+  constexpr int G = CellInfo<CELL>::G;
+  return H % 32 == 0 && plan3(2 * G, (H / 32 + 3) / 4).ok && plan3(2, (G * H / 32 + 3) / 4).ok;
+}
+
+template <int CELL, int H, int NSET, int SP>
+int launch3_one(bool bwd, const RArgs& ra, hipStream_t st) {
+  constexpr int G = CellInfo<CELL>::G;
+  if constexpr (!covered3<CELL, H>()) {
+    return DS2_ERR_ARG;
+  } else {
+    const size_t shm = bwd ? (size_t)lds_bytes3(2, (G * H / 32 + 3) / 4) : (size_t)lds_bytes3(2 * G, (H / 32 + 3) / 4);
+    static bool attr[2][DS2_MAX_DEVICES];
+    const void* fn = bwd ? (const void*)k_rnn_persist3_bwd<CELL, H, NSET, SP> : (const void*)k_rnn_persist3_fwd<CELL, H, NSET, SP>;
+    if (ds2_first_use_on_device(attr[bwd ? 1 : 0])) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    const int grid = ra.xmap ? 8 * ra.gx * ra.P : ra.q.NG * ra.P;
+    if (bwd)
+      hipLaunchKernelGGL((k_rnn_persist3_bwd<CELL, H, NSET, SP>), dim3(grid), dim3(256), shm, st, ra);
+    else
+      hipLaunchKernelGGL((k_rnn_persist3_fwd<CELL, H, NSET, SP>), dim3(grid), dim3(256), shm, st, ra);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+  }
+}
+
+// nset = interleaved sets (1 or 2); single-set groups of <= 8 samples share the gather loads between lane pairs (SP = 2)
+template <int CELL, int H>
+int launch3(bool probe, bool bwd, const RArgs& ra, hipStream_t st) {
+  if (!covered3<CELL, H>()) return DS2_ERR_ARG;
+  if (probe) return 0;
+  const int ns = (ra.q.N + ra.q.gpd - 1) / ra.q.gpd;
+  if (ra.nset == 2) return launch3_one<CELL, H, 2, 1>(bwd, ra, st);
+  if (ns <= 8) return launch3_one<CELL, H, 1, 2>(bwd, ra, st);
+  return launch3_one<CELL, H, 1, 1>(bwd, ra, st);
+}
+
+}  // namespace ds2r

@@ -1,16 +1,21 @@
 """Data-parallel plumbing of the training step: one process per GPU, ``torch.distributed`` over RCCL (backend "nccl" on
-ROCm), gradients averaged by torch DDP's bucketed all-reduce.
+ROCm); the only exchange of the path is the gradient mean over the ranks.
 
-The reference has no explicit collective: Lightning's ``strategy: ddp`` (configs/an4.yaml:13, librispeech.yaml:14) wraps
-the LightningModule in ``DistributedDataParallel`` with ``sync_batchnorm=False`` (lightning_config.py:53), i.e. BatchNorm
-statistics stay rank-local and the only exchange is the gradient mean.  The drop-in class works unchanged under that
-wrapper.  The conv front-end and the RNN stack are ONE autograd node (their weight-gradient GEMMs run on a second HIP
-stream under the BPTT sweeps of the layers below and are joined at the end of that node), so DDP's reducer receives the
-recurrent layers' gradients together when the node returns and the all-reduce of those buckets is exposed after the
-backward (~260 MB fp32 on cfg3; the head's bucket overlaps).  Buckets are sized for xGMI (point-to-point links, ring
-collectives are per-link bound): 64 MB, about one GRU-1024 layer (~50 MB fp32) per bucket, few large collectives.
-DS2_FORCE_DDP=1 wraps (and initialises a 1-rank process group) even for world == 1, to exercise the wrapper + RCCL on a
-single-GPU box.
+The reference has no explicit collective: Lightning's ``strategy: ddp`` (configs/an4.yaml:13, librispeech.yaml:14) wraps the
+LightningModule in ``DistributedDataParallel`` with ``sync_batchnorm=False`` (lightning_config.py:53), i.e. BatchNorm statistics
+stay rank-local.  The drop-in class works unchanged under that wrapper, and since round 4 it OVERLAPS there: every BatchRNN layer is
+its own autograd node (model._RnnLayerFn), so a layer's weight gradients reach the reducer's hooks the moment the layer's backward
+returns (its BPTT sweep, then one launch with the weight gradients + dX, all on the caller's stream) and the bucket's all-reduce
+runs on RCCL's stream under the sweeps of the layers below -- exactly how DDP overlaps the reference's nn.GRU layers.  Buckets are
+sized for xGMI (point-to-point links: a ring collective is bound by ONE link): 64 MB, about one GRU-1024 layer (~50 MB fp32) per
+bucket -- few, large collectives.  tests/test_dist.py proves on two gloo ranks, with a stand-in of the same node structure, that
+the buckets' all-reduces are launched before backward ends.
+
+``wrap_data_parallel`` returns torch DDP by default (round 4; the advisor's round-3 finding: the custom wrapper below had never run
+on real multi-GPU hardware).  ``OverlappedDataParallel`` / ``OverlappedGradSync`` stay available behind DS2_OVERLAP_ALLREDUCE=1: one
+in-place all-reduce per layer straight on the gradient storages (no bucket copies), started inside the layer's backward.
+DS2_FORCE_DDP=1 wraps (and initialises a 1-rank process group) even for world == 1, to exercise the wrapper + RCCL on a single-GPU
+box.
 
 Everything here is device-agnostic so that the N > 1 path is covered on CPU with the gloo backend (tests/test_dist.py).
 """
@@ -66,14 +71,14 @@ class OverlappedGradSync:
     def __init__(self, world, group=None):
         self.world, self.group = world, group
         self._params = []
-        self._handles, self._early = [], set()
+        self._handles, self._early, self._deferred = [], set(), []
         self._queued = self._done = False
 
     def attach(self, params):
         self._params = list(params)
 
     def begin_step(self):
-        self._handles, self._early = [], set()
+        self._handles, self._early, self._deferred = [], set(), []
         self._queued = self._done = False
 
     def _start(self, t):
@@ -98,6 +103,18 @@ class OverlappedGradSync:
             self._handles.append(self._start(t))
         self._early.update(p.data_ptr() for p in params)
 
+    def defer_early(self, params, grads):
+        """Per-layer graph (model._RnnLayerFn): the layer's backward returns while its all-reduce is still in flight, so the
+        gradients handed over early must not travel through autograd (AccumulateGrad may clone or add to them on the caller's
+        stream).  They are withheld here -- the node returns None for them -- and become ``p.grad`` in ``finish``, after the
+        all-reduces.  Returns `grads` with those entries replaced by None."""
+        out = list(grads)
+        for i, (p, g) in enumerate(zip(params, grads)):
+            if g is not None and p.data_ptr() in self._early:
+                self._deferred.append((p, g))
+                out[i] = None
+        return out
+
     def wait_early(self):
         """Orders the caller's stream (CPU: the caller) after every all-reduce started so far; call before the early
         gradients are returned to autograd."""
@@ -109,16 +126,40 @@ class OverlappedGradSync:
         if self._done:
             return
         self.wait_early()
-        rest = [p for p in self._params if p.grad is not None and p.data_ptr() not in self._early]
-        if rest:
-            flat = torch.cat([p.grad.reshape(-1).float() for p in rest])
-            self._start(flat).wait()
-            off = 0
-            for p in rest:
-                n = p.grad.numel()
-                p.grad.copy_(flat[off:off + n].view_as(p.grad))
-                off += n
+        with torch.no_grad():
+            for p, g in self._deferred:                   # withheld from autograd by defer_early: averaged by now
+                p.grad = g if p.grad is None else p.grad.add_(g)
+            self._deferred = []
+            # everything else in ONE flat bucket; a parameter that got no gradient on THIS rank contributes zeros (every rank
+            # reduces the same set: the trainable parameters that were not handed over early)
+            rest = [p for p in self._params if p.requires_grad and p.data_ptr() not in self._early]
+            if rest:
+                flat = torch.cat([(p.grad.reshape(-1).float() if p.grad is not None else p.new_zeros(p.numel(), dtype=torch.float32))
+                                  for p in rest])
+                self._start(flat).wait()
+                off = 0
+                for p in rest:
+                    n = p.numel()
+                    if p.grad is None:
+                        p.grad = flat[off:off + n].view_as(p).to(p.dtype).clone()
+                    else:
+                        p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                    off += n
         self._done = True
+
+
+def _first_grad_tensor(out):
+    """First tensor that requires grad in a (nested) tuple / list / dict of outputs."""
+    if torch.is_tensor(out):
+        return out if out.requires_grad else None
+    if isinstance(out, dict):
+        out = list(out.values())
+    if isinstance(out, (tuple, list)):
+        for o in out:
+            t = _first_grad_tensor(o)
+            if t is not None:
+                return t
+    return None
 
 
 class OverlappedDataParallel(torch.nn.Module):
@@ -138,8 +179,12 @@ class OverlappedDataParallel(torch.nn.Module):
     def forward(self, *args):
         self.sync.begin_step()
         out = self.module(*args)
-        if torch.is_tensor(out) and out.requires_grad:
-            out.register_hook(self.sync.arm)       # fires when backward reaches the loss: end-of-backward reduction is queued
+        if torch.is_grad_enabled():
+            t = _first_grad_tensor(out)
+            if t is None:
+                raise RuntimeError("OverlappedDataParallel: the wrapped module returned nothing that requires grad -- the end-of-backward "
+                                   "gradient reduction cannot be armed (use torch DDP: DS2_OVERLAP_ALLREDUCE=0)")
+            t.register_hook(self.sync.arm)         # fires when backward reaches it: the end-of-backward reduction is queued
         return out
 
     def finish_backward(self):
@@ -148,19 +193,19 @@ class OverlappedDataParallel(torch.nn.Module):
 
 
 def overlap_allreduce():
-    """Default for world > 1: OverlappedDataParallel (every recurrent layer's gradients start their all-reduce the moment they
-    exist, under the sweeps of the layers below -- the north star's "all-reduce overlapped with backward").  DS2_USE_DDP=1 (or
-    DS2_OVERLAP_ALLREDUCE=0) selects torch DDP instead, whose reducer sees the composite node's gradients only at the end of
-    backward."""
+    """Default for world > 1: torch DDP -- with one autograd node per BatchRNN layer its reducer overlaps the bucketed all-reduce
+    with the BPTT sweeps of the layers below, as Lightning's ``strategy: ddp`` does in the reference's own loop.
+    DS2_OVERLAP_ALLREDUCE=1 selects OverlappedDataParallel instead (one in-place all-reduce per layer, started inside the layer's
+    backward; never validated on more than one GPU: opt-in).  DS2_USE_DDP=1 forces DDP whatever the other variable says."""
     if os.environ.get("DS2_USE_DDP", "0") not in ("", "0"):
         return False
-    return os.environ.get("DS2_OVERLAP_ALLREDUCE", "1") not in ("", "0")
+    return os.environ.get("DS2_OVERLAP_ALLREDUCE", "0") not in ("", "0")
 
 
 def wrap_data_parallel(step_module, device, world, bucket_cap_mb=64, overlap=None):
-    """Data-parallel wrapper of the step module (identity for world == 1): OverlappedDataParallel by default, torch DDP with
-    overlap=False / DS2_USE_DDP=1 (broadcast_buffers=False: BatchNorm running statistics are per-rank like the reference's
-    sync_batchnorm=False; gradient_as_bucket_view avoids one copy per parameter)."""
+    """Data-parallel wrapper of the step module (identity for world == 1): torch DDP by default (broadcast_buffers=False: BatchNorm
+    running statistics are per-rank like the reference's sync_batchnorm=False; gradient_as_bucket_view avoids one copy per
+    parameter; 64 MB buckets ~ one recurrent layer each), OverlappedDataParallel with overlap=True / DS2_OVERLAP_ALLREDUCE=1."""
     if world == 1 and not (force_ddp() and dist.is_initialized()):
         return step_module
     if overlap_allreduce() if overlap is None else overlap:

@@ -29,10 +29,23 @@ except Exception:  # pragma: no cover - exercised in the build image
     pl = None
 
     class _Base(nn.Module):
-        """Minimal stand-in for pl.LightningModule (save_hyperparameters / log / device) when Lightning is absent."""
+        """Minimal stand-in for pl.LightningModule when Lightning is absent: what the reference's model and its callers use of it
+        -- ``save_hyperparameters()`` (model.py:147: the constructor arguments, stored in ``hparams`` and written into a checkpoint
+        as ``hyper_parameters``), ``log`` (model.py:270-271), ``device`` (model.py:254) and ``load_from_checkpoint`` (utils.py:31,
+        search_lm_params.py:47-51) on Lightning's ``.ckpt`` layout ``{"state_dict": ..., "hyper_parameters": ...}``."""
 
         def save_hyperparameters(self, *a, **k):
-            pass
+            import inspect
+            frame = inspect.currentframe().f_back
+            try:
+                names = [n for n in inspect.signature(type(self).__init__).parameters if n != "self"]
+                self._hparams = {n: frame.f_locals[n] for n in names if n in frame.f_locals}
+            finally:
+                del frame
+
+        @property
+        def hparams(self):
+            return getattr(self, "_hparams", {})
 
         def log(self, *a, **k):
             pass
@@ -40,6 +53,15 @@ except Exception:  # pragma: no cover - exercised in the build image
         @property
         def device(self):
             return next(self.parameters()).device
+
+        @classmethod
+        def load_from_checkpoint(cls, checkpoint_path, map_location=None, strict=True, **overrides):
+            ckpt = torch.load(checkpoint_path, map_location=map_location or "cpu", weights_only=False)
+            hp = dict(ckpt.get("hyper_parameters", {}))
+            hp.update(overrides)
+            model = cls(**hp)
+            model.load_state_dict(ckpt["state_dict"], strict=strict)
+            return model
 
 try:
     from omegaconf import OmegaConf
@@ -61,6 +83,10 @@ WGRAD_BESIDE_DX = os.environ.get("DS2_WGRAD_BESIDE_DX", "0") not in ("", "0")
 # the layer's dX product rides in the same launch as its weight gradients (long tiles first, the short dX tiles fill the CUs the
 # weight gradients leave idle); DS2_WGRAD_WITH_DX=0 launches them one after the other
 WGRAD_WITH_DX = os.environ.get("DS2_WGRAD_WITH_DX", "1") not in ("", "0")
+
+# DS2_COMPOSITE_NODE=1: conv front-end + RNN stack as ONE autograd node (the round-1..3 graph, _FrontFn): the fp32 / small-shape
+# backward then keeps its weight-gradient GEMMs on the second stream until the end of the node.  Default: one node per layer.
+COMPOSITE_NODE = os.environ.get("DS2_COMPOSITE_NODE", "0") not in ("", "0")
 
 N_FREQ_CONV2 = 41
 RNN_INPUT = 32 * N_FREQ_CONV2  # 1312, model.py:166-169
@@ -282,76 +308,301 @@ class _ConvStackFn(torch.autograd.Function):
         return (None, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, None, None, None, None, None)
 
 
-class _RnnStackFn(torch.autograd.Function):
-    """The whole stack of BatchRNN layers (model.py:228-230 over BatchRNN.forward, model.py:94-102):
-    per layer [SequenceWise BatchNorm1d] -> input projection GEMM -> packed bi/uni GRU/LSTM/RNN sweep -> direction sum.
+def _layer_param_count(layer):
+    return (2 if layer.batch_norm is not None else 0) + 4 * layer.num_directions
 
-    One autograd node for all layers so that backward controls the schedule.  bf16 (the performance mode): per layer the BPTT
-    sweep, then ONE launch with the layer's weight gradients (grouped TN products over the activations as stored) and its dX,
-    then the BatchNorm backward -- all on the caller's stream; nothing runs beside a sweep (a co-runner costs the latency-bound
-    sweep the chip's clock).  fp32 / small / odd shapes: the round-2 path (operand transposes + 128x128
-    GEMMs on a second HIP stream).  The streams join before backward returns, so the gradients handed to autograd / DDP are
-    complete."""
+
+def _rnn_layer_forward(mod, li, X, lens_dev, N, Tp, dtype, training, h0, c0, lparams):
+    """One BatchRNN layer (model.py:94-102): [SequenceWise BatchNorm1d] -> input projection GEMM -> packed bi/uni GRU/LSTM/RNN
+    sweep -> direction sum.  lparams: [bn.weight, bn.bias]? + per direction (weight_ih, weight_hh, bias_ih, bias_hh).
+    Returns (out [T'N][H], hn, cn, saved = [X, Xh or None, hext, Sv], meta)."""
+    c = mod._cache
+    R = Tp * N
+    layer = mod.rnns[li]
+    kind, Ht, D = layer.kind, layer.hidden_size, layer.num_directions
+    H = mod._Hp                                         # internal width: hidden_size rounded up to the 16-unit MFMA tile
+    G = ops.GATES[kind]
+    first = li == 0
+    I = RNN_INPUT_LD if first else H                    # layer 0 sees the zero-padded conv-stack output
+    has_bn = layer.batch_norm is not None
+    bn_w, bn_b = (lparams[0], lparams[1]) if has_bn else (None, None)
+    wts = lparams[2 if has_bn else 0:]
+    wih = [wts[4 * d + 0] for d in range(D)]
+    whh = [wts[4 * d + 1] for d in range(D)]
+    bih = [wts[4 * d + 2] for d in range(D)]
+    bhh = [wts[4 * d + 3] for d in range(D)]
+
+    def build_ih():
+        w = torch.cat([_pad_gate_rows(p.detach(), G, Ht, H) for p in wih], 0)
+        w = _perm_cols_to_internal(w) if first else _pad_cols(w, H)
+        out = ops.empty_padded(w.shape[0], w.shape[1], dtype, w.device)
+        out.copy_(w)
+        return out
+    Wih = c.get(("wih", li, dtype), wih, build_ih)
+    Whh = c.get(("whh", li, dtype), whh, lambda: torch.stack(
+        [_pad_gate_rows(_pad_cols(p.detach(), H), G, Ht, H) for p in whh], 0).to(dtype).contiguous())
+    if H == Ht:
+        Bih, Bhh = mod._bias_views(li)
+    else:
+        Bih = c.get(("bih", li), bih, lambda: torch.cat([_pad_gate_rows(p.detach(), G, Ht, H) for p in bih], 0))
+        Bhh = c.get(("bhh", li), bhh, lambda: torch.stack([_pad_gate_rows(p.detach(), G, Ht, H) for p in bhh], 0))
+    sv, Xh = None, X
+    if has_bn:
+        bn = layer.batch_norm.module
+        Xh = ops.empty_padded(R, I, X.dtype, X.device)       # row stride off the power of two (GEMM operand)
+        sv = _bn_seq_fwd(bn, bn_w, bn_b, X, Xh, R, layer.input_size, I, training)
+    GI = ops.gemm_nt(Xh, Wih, bias=Bih)                                  # [R][D*G*H]
+    if H != Ht:
+        h0 = _pad_cols(h0, H) if h0 is not None else None
+        c0 = _pad_cols(c0, H) if c0 is not None else None
+    hext, Sv, hn, cn = ops.rnn_fwd(kind, GI, Whh, Bhh, lens_dev, D, N, H, Tp, h0=h0, c0=c0)
+    if H != Ht:
+        hn = hn[..., :Ht].contiguous()
+        cn = cn[..., :Ht].contiguous() if cn is not None else None
+    del GI
+    if D == 2:
+        out = ops.add2(hext[0, 1:Tp + 1].reshape(R, H), hext[1, 1:Tp + 1].reshape(R, H))
+    else:
+        out = hext[0, 1:Tp + 1].reshape(R, H).clone()
+    return out, hn, cn, [X, Xh if has_bn else None, hext, Sv], (kind, H, D, G, I, has_bn, sv, Ht, layer.input_size)
+
+
+def _rnn_layer_backward(mod, li, meta, saved, lparams, dout, lens_dev, N, Tp, dtype, main, side, wgrad_done):
+    """Backward of one BatchRNN layer.  bf16 (the performance mode): the BPTT sweep, then ONE launch with the layer's weight
+    gradients (grouped TN products over the activations as stored) and its dX, then the BatchNorm backward -- all on the caller's
+    stream; nothing runs beside a sweep (a co-runner costs the latency-bound sweep the chip's clock).  fp32 /
+    small / odd shapes: the round-2 path (operand transposes + 128x128 GEMMs on the second HIP stream `side`; the caller joins the
+    streams before the gradients reach autograd).  Returns (dX, gradients in the order of lparams, wgrad_done event or None)."""
+    c = mod._cache
+    R = Tp * N
+    kind, H, D, G, I, has_bn, sv, Ht, It = meta
+    X, Xh, hext, Sv = saved
+    if Xh is None:
+        Xh = X
+    first = li == 0
+    GH = G * H
+    grads = [None] * len(lparams)
+    po = 2 if has_bn else 0
+    wts = lparams[po:po + 4 * D]
+    wih = [wts[4 * d + 0] for d in range(D)]
+    whh = [wts[4 * d + 1] for d in range(D)]
+    WhhT = c.get(("whhT", li, dtype), list(whh), lambda: torch.stack(
+        [_pad_gate_rows(_pad_cols(p.detach(), H), G, Ht, H).t() for p in whh], 0).to(dtype).contiguous())   # [D][H][G*H]
+
+    def build_ihT():
+        w = torch.cat([_pad_gate_rows(p.detach(), G, Ht, H) for p in wih], 0)
+        w = _perm_cols_to_internal(w) if first else _pad_cols(w, H)
+        return w.t().to(dtype).contiguous()                                                             # [I][D*G*H]
+    WihT = c.get(("wihT", li, dtype), list(wih), build_ihT)
+    # ---- BPTT sweep (caller's stream).  A persistent sweep wants every CU: it starts after the weight-gradient launch of the
+    # layer above has drained (otherwise its first workgroups would spin on peers that are still waiting for a CU)
+    if wgrad_done is not None:
+        main.wait_event(wgrad_done)
+        wgrad_done = None
+    rg = ops.rnn_bwd(kind, dout, WhhT, hext, Sv, lens_dev, D, N, H, Tp)
+    dGI = rg.dGI
+    fast = ops.wgrad_tn_ok(dtype, R, D * GH, Xh.shape[1], lda=D * GH, ldb=Xh.stride(0)) and \
+        ops.wgrad_tn_ok(dtype, R, GH, H, lda=D * GH, ldb=H)
+    dXh_fused = None
+    if fast:
+        # ---- weight gradients as ONE grouped launch of TN products (contraction over the T'*N rows, both operands as the
+        # activations are stored: no transposes).  Never under a sweep: what co-resident GEMMs cost the sweeps was the
+        # chip's CLOCK (1.7 instead of 2.15 GHz while they ran, profiles/r03a_coresidency3.txt) -- a latency-bound kernel
+        # pays that one to one.  On the caller's stream, right behind the sweep (optionally beside the dX GEMM on the second
+        # stream, WGRAD_BESIDE_DX: no gain measured).
+        swept = torch.cuda.Event()
+        swept.record(main)
+        wstream = side if WGRAD_BESIDE_DX else main
+        with torch.cuda.stream(wstream):
+            if wstream is not main:
+                wstream.wait_event(swept)
+                for t_ in rg.tensors() + [Xh, hext]:
+                    t_.record_stream(wstream)
+            Iw = Xh.shape[1]
+            dWih = torch.empty((D * GH, Iw), dtype=torch.float32, device=dGI.device)
+            dWhh = torch.empty((D, GH, H), dtype=torch.float32, device=dGI.device)
+            probs = [dict(At=dGI, Bt=Xh, M=D * GH, N=Iw, lda=D * GH, ldb=Xh.stride(0), out=dWih)]
+            for d in range(D):
+                # h_{t-1} of the forward direction is slot t of the guarded buffer, h_{t+1} of the reverse direction slot t+2
+                hprev = (hext[d, 0:Tp] if d == 0 else hext[d, 2:Tp + 2]).reshape(R, H)
+                if kind == "gru" and rg.dQ is not None:
+                    # hidden-side gate gradient = [dr, dz (columns of dGI) | dQ]
+                    if (2 * H) % 256 == 0:
+                        probs.append(dict(At=dGI[:, d * GH:], At2=rg.dQ[d], lda2=H, m_split=2 * H, Bt=hprev, M=GH, N=H, lda=D * GH, ldb=H,
+                                          out=dWhh[d]))
+                    else:
+                        probs.append(dict(At=dGI[:, d * GH:], Bt=hprev, M=2 * H, N=H, lda=D * GH, ldb=H, out=dWhh[d, :2 * H]))
+                        probs.append(dict(At=rg.dQ[d], Bt=hprev, M=H, N=H, lda=H, ldb=H, out=dWhh[d, 2 * H:]))
+                elif kind == "gru":
+                    probs.append(dict(At=rg.dGH[d], Bt=hprev, M=GH, N=H, lda=GH, ldb=H, out=dWhh[d]))
+                else:
+                    probs.append(dict(At=dGI[:, d * GH:], Bt=hprev, M=GH, N=H, lda=D * GH, ldb=H, out=dWhh[d]))
+            if WGRAD_WITH_DX and wstream is main and len(probs) < 6 and ops.gemm8_nt_ok(dGI, WihT, R, WihT.shape[0], D * GH, D * GH,
+                                                                                        WihT.stride(0)):
+                _, dXh_fused = ops.gemm8_tn_grouped(probs, R, dx=(dGI, WihT))   # + the layer's dX in the same launch
+            else:
+                ops.gemm8_tn_grouped(probs, R)
+            if first:
+                dWih = torch.cat([_perm_cols_to_reference(dWih[d * GH:(d + 1) * GH]) for d in range(D)], 0)
+            if rg.bacc is not None:
+                dBih, dBhh_all = ops.rnn_bias_grads(kind, rg.bacc, D, N, H)          # one launch: [D*G*H], [D][G*H]
+                dBhh_l = [dBhh_all[d] for d in range(D)]
+            else:
+                dBih = ops.colsum(dGI)
+                dBhh_all = None
+                if kind == "gru":
+                    dBhh_l = [ops.colsum(rg.dGH[d].reshape(R, GH)) for d in range(D)]
+                else:
+                    dBhh_l = [dBih[d * GH:(d + 1) * GH] for d in range(D)]
+            for d in range(D):
+                grads[po + 4 * d:po + 4 * d + 4] = [dWih[d * GH:(d + 1) * GH], dWhh[d], dBih[d * GH:(d + 1) * GH], dBhh_l[d]]
+            sync = getattr(mod, "_grad_sync", None)
+            if sync is not None and H == Ht:
+                own = [dWih, dWhh, dBih] + ([dBhh_all] if dBhh_all is not None else
+                                            [dBhh_l[d] for d in range(D)] if kind == "gru" else [])
+                sync.layer_ready(own, lparams[po:po + 4 * D])
+            _unpad_layer_grads(grads, po, D, G, Ht, H, It, first)
+            if wstream is not main:
+                wgrad_done = torch.cuda.Event()
+                wgrad_done.record(wstream)
+    # ---- dependent chain (caller's stream): dX -> BatchNorm backward
+    dXh = dXh_fused if dXh_fused is not None else ops.gemm_nt(dGI, WihT)                                # [R][I]
+    if has_bn:
+        dX = torch.empty_like(dXh)
+        grads[0], grads[1] = _bn_seq_bwd(dXh, X, dX, sv, R, It, I)
+    else:
+        dX = dXh
+    if fast:
+        return dX, grads, wgrad_done
+    # the second stream starts this layer's weight gradients only once dX / BatchNorm backward are through, i.e. together
+    # with the next layer's sweep: the dependent chain never competes with them for the CUs
+    ready = torch.cuda.Event()
+    ready.record(main)
+    # ---- weight gradients (second stream, under the next layer's sweep): contraction over the T'*N rows.  Layer 0's run
+    # under the conv backward instead, where no persistent sweep needs most of every CU's registers: the full-size tiles
+    cores = li > 0
+    with torch.cuda.stream(side):
+        side.wait_event(ready)
+        for t in rg.tensors() + [Xh, hext]:
+            t.record_stream(side)
+        dGI_T = ops.transpose(dGI)                              # [D*G*H][ldT]
+        Xh_T = ops.transpose(Xh)                                # [I][ldT]
+        ldT = dGI_T.shape[1]
+        dWih = ops.gemm_nt(dGI_T, Xh_T, out_dtype=torch.float32, splitk=_wgrad_splitk(dGI_T.shape[0], Xh_T.shape[0], ldT),
+                           coresident=cores)
+        del Xh_T
+        if first:
+            dWih = torch.cat([_perm_cols_to_reference(dWih[d * GH:(d + 1) * GH]) for d in range(D)], 0)
+        # bias gradients: from the sweep's own per-sample sums (persistent kernels: a [N][NB*H] reduction instead of
+        # column sums over the T'*N rows of dGI / dGH), else column sums
+        bsum = None
+        if rg.bacc is not None:
+            bsum = [ops.colsum(rg.bacc[d]) for d in range(D)]                   # [NB*H] per direction
+            dBih = torch.cat([b[:GH] for b in bsum], 0)
+        else:
+            dBih = ops.colsum(dGI)
+        for d in range(D):
+            # h_{t-1} of the forward direction is slot t of the guarded buffer, h_{t+1} of the reverse direction slot t+2
+            hprev = hext[d, 0:Tp] if d == 0 else hext[d, 2:Tp + 2]
+            Hp_T = ops.transpose(hprev.reshape(R, H))           # [H][ldT]
+            if kind == "gru" and rg.dQ is not None:
+                # hidden-side gate gradient = [dr, dz (rows of dGI^T) | dQ^T]: one GEMM whose A operand is two row blocks
+                dQ_T = ops.transpose(rg.dQ[d].reshape(R, H))   # [H][ldT]
+                dWhh = ops.gemm_nt_rows2(dGI_T[d * GH:d * GH + 2 * H], dQ_T, 2 * H, Hp_T, GH, H, ldT, ldT, ldT,
+                                         splitk=_wgrad_splitk(GH, H, ldT), coresident=cores)
+                dBhh = torch.cat([bsum[d][:2 * H], bsum[d][3 * H:4 * H]], 0) if bsum is not None else \
+                    torch.cat([dBih[d * GH:d * GH + 2 * H], ops.colsum(rg.dQ[d].reshape(R, H))], 0)
+            else:
+                if kind == "gru":
+                    dGH_T = ops.transpose(rg.dGH[d].reshape(R, GH))    # [G*H][ldT]
+                    dBhh = ops.colsum(rg.dGH[d].reshape(R, GH))
+                else:
+                    dGH_T = dGI_T[d * GH:(d + 1) * GH]
+                    dBhh = dBih[d * GH:(d + 1) * GH]
+                dWhh = ops.gemm_nt(dGH_T, Hp_T, out_dtype=torch.float32, M=GH, N=H, K=ldT, lda=ldT, ldb=ldT,
+                                   splitk=_wgrad_splitk(GH, H, ldT), coresident=cores)
+            grads[po + 4 * d:po + 4 * d + 4] = [dWih[d * GH:(d + 1) * GH].contiguous(), dWhh,
+                                                dBih[d * GH:(d + 1) * GH].contiguous(), dBhh.contiguous()]
+        del dGI_T
+        sync = getattr(mod, "_grad_sync", None)
+        if sync is not None and H == Ht:
+            # data parallel with the opt-in early hand-off (dist.OverlappedGradSync): this layer's gradients start
+            # their all-reduce now, ordered after the GEMMs above, under the sweeps of the layers below.  The
+            # returned gradients are views of dWih / dBih (and of dBih for the biases of LSTM / RNN cells).
+            own = [dWih, dBih] + [grads[po + 4 * d + 1] for d in range(D)]
+            if kind == "gru":
+                own += [grads[po + 4 * d + 3] for d in range(D)]
+            sync.layer_ready(own, lparams[po:po + 4 * D])
+        _unpad_layer_grads(grads, po, D, G, Ht, H, It, first)
+    return dX, grads, None
+
+
+class _RnnLayerFn(torch.autograd.Function):
+    """ONE BatchRNN layer as an autograd node (model.py:94-102).  The default graph is conv stack -> L of these -> [lookahead] ->
+    head -> CTC: a layer's parameter gradients reach their AccumulateGrad nodes -- and with them the hooks of
+    ``DistributedDataParallel``'s reducer, i.e. the bucketed RCCL all-reduce -- the moment the layer's backward returns, while
+    the BPTT sweeps of the layers below are still to run: Lightning's ``strategy: ddp`` (configs/librispeech.yaml:14) overlaps
+    the gradient exchange with backward as it does for the reference's nn.GRU layers."""
+
+    @staticmethod
+    def forward(ctx, X, mod, lens_dev, N, Tp, dtype, training, li, h0, c0, *lparams):
+        out, hn, cn, saved, meta = _rnn_layer_forward(mod, li, X, lens_dev, N, Tp, dtype, training, h0, c0, lparams)
+        ctx.mod, ctx.dims, ctx.meta, ctx.li = mod, (N, Tp, dtype), meta, li
+        ctx.had_state = h0 is not None
+        ctx.none_mask = [t is None for t in saved]
+        ctx.save_for_backward(lens_dev, *[t for t in saved if t is not None], *lparams)
+        ctx.n_saved = sum(1 for t in saved if t is not None)
+        outs = (out, hn) + ((cn,) if cn is not None else ())
+        ctx.mark_non_differentiable(*outs[1:])
+        ctx.set_materialize_grads(False)
+        return outs
+
+    @staticmethod
+    def backward(ctx, dout, *unused):
+        if ctx.had_state:
+            raise Ds2HipError("backward through a forward that was given initial hidden states (hs) is not supported")
+        N, Tp, dtype = ctx.dims
+        mod = ctx.mod
+        st = ctx.saved_tensors
+        it = iter(st[1:1 + ctx.n_saved])
+        saved = [None if is_none else next(it) for is_none in ctx.none_mask]
+        lparams = st[1 + ctx.n_saved:]
+        main = torch.cuda.current_stream()
+        side = mod._wgrad_stream(dout.device)
+        dX, grads, wgrad_done = _rnn_layer_backward(mod, ctx.li, ctx.meta, saved, lparams, dout.contiguous().to(dtype), st[0], N, Tp,
+                                                    dtype, main, side, None)
+        # the gradients leave this node now (AccumulateGrad, DDP's reducer): whatever the second stream produced must be complete.
+        # The early all-reduces of the opt-in OverlappedGradSync are NOT waited for here -- that is their point -- but at the end
+        # of backward (its finish callback)
+        if wgrad_done is not None:
+            main.wait_event(wgrad_done)
+        main.wait_stream(side)
+        for g in grads:
+            if g is not None:
+                g.record_stream(main)
+        sync = getattr(mod, "_grad_sync", None)
+        if sync is not None:
+            grads = sync.defer_early(lparams, grads)      # in flight on RCCL's stream: they become .grad at the end of backward
+        return (dX, None, None, None, None, None, None, None, None, None, *grads)
+
+
+class _RnnStackFn(torch.autograd.Function):
+    """The whole stack of BatchRNN layers (model.py:228-230) as ONE autograd node (DS2_COMPOSITE_NODE=1; the round-1..3 graph): the
+    backward of the fp32 / small-shape path keeps every layer's weight-gradient GEMMs on the second stream under the next layer's
+    sweep and joins the streams once, at the very end -- at the price that DDP's reducer sees all recurrent gradients together when
+    the node returns.  Same per-layer functions as _RnnLayerFn."""
 
     @staticmethod
     def forward(ctx, X, mod, lens_dev, N, Tp, dtype, training, n_layers, *rest):
         L = n_layers
         hs0, cs0, params = rest[:L], rest[L:2 * L], rest[2 * L:]
-        c = mod._cache
-        R = Tp * N
         saved, meta, outs_h, outs_c, pos = [], [], [], [], 0
         for li in range(L):
-            layer = mod.rnns[li]
-            kind, Ht, D = layer.kind, layer.hidden_size, layer.num_directions
-            H = mod._Hp                                         # internal width: hidden_size rounded up to the 16-unit MFMA tile
-            G = ops.GATES[kind]
-            first = li == 0
-            I = RNN_INPUT_LD if first else H                    # layer 0 sees the zero-padded conv-stack output
-            has_bn = layer.batch_norm is not None
-            bn_w, bn_b = (params[pos], params[pos + 1]) if has_bn else (None, None)
-            pos += 2 if has_bn else 0
-            wts = params[pos:pos + 4 * D]
-            pos += 4 * D
-            wih = [wts[4 * d + 0] for d in range(D)]
-            whh = [wts[4 * d + 1] for d in range(D)]
-            bih = [wts[4 * d + 2] for d in range(D)]
-            bhh = [wts[4 * d + 3] for d in range(D)]
-
-            def build_ih(wih=wih, first=first, G=G, Ht=Ht, H=H):
-                w = torch.cat([_pad_gate_rows(p.detach(), G, Ht, H) for p in wih], 0)
-                w = _perm_cols_to_internal(w) if first else _pad_cols(w, H)
-                out = ops.empty_padded(w.shape[0], w.shape[1], dtype, w.device)
-                out.copy_(w)
-                return out
-            Wih = c.get(("wih", li, dtype), wih, build_ih)
-            Whh = c.get(("whh", li, dtype), whh, lambda whh=whh, G=G, Ht=Ht, H=H: torch.stack(
-                [_pad_gate_rows(_pad_cols(p.detach(), H), G, Ht, H) for p in whh], 0).to(dtype).contiguous())
-            if H == Ht:
-                Bih, Bhh = mod._bias_views(li)
-            else:
-                Bih = c.get(("bih", li), bih, lambda bih=bih, G=G, Ht=Ht, H=H: torch.cat([_pad_gate_rows(p.detach(), G, Ht, H) for p in bih], 0))
-                Bhh = c.get(("bhh", li), bhh, lambda bhh=bhh, G=G, Ht=Ht, H=H: torch.stack([_pad_gate_rows(p.detach(), G, Ht, H) for p in bhh], 0))
-            sv, Xh = None, X
-            if has_bn:
-                bn = layer.batch_norm.module
-                Xh = ops.empty_padded(R, I, X.dtype, X.device)       # row stride off the power of two (GEMM operand)
-                sv = _bn_seq_fwd(bn, bn_w, bn_b, X, Xh, R, layer.input_size, I, training)
-            GI = ops.gemm_nt(Xh, Wih, bias=Bih)                                  # [R][D*G*H]
-            h0, c0 = hs0[li], cs0[li]
-            if H != Ht:
-                h0 = _pad_cols(h0, H) if h0 is not None else None
-                c0 = _pad_cols(c0, H) if c0 is not None else None
-            hext, Sv, hn, cn = ops.rnn_fwd(kind, GI, Whh, Bhh, lens_dev, D, N, H, Tp, h0=h0, c0=c0)
-            if H != Ht:
-                hn = hn[..., :Ht].contiguous()
-                cn = cn[..., :Ht].contiguous() if cn is not None else None
-            del GI
-            if D == 2:
-                out = ops.add2(hext[0, 1:Tp + 1].reshape(R, H), hext[1, 1:Tp + 1].reshape(R, H))
-            else:
-                out = hext[0, 1:Tp + 1].reshape(R, H).clone()
-            saved += [X, Xh if has_bn else None, hext, Sv]
-            meta.append((kind, H, D, G, I, has_bn, sv, Ht, layer.input_size))
+            n = _layer_param_count(mod.rnns[li])
+            out, hn, cn, sv4, mt = _rnn_layer_forward(mod, li, X, lens_dev, N, Tp, dtype, training, hs0[li], cs0[li], params[pos:pos + n])
+            pos += n
+            saved += sv4
+            meta.append(mt)
             outs_h.append(hn)
             if cn is not None:
                 outs_c.append(cn)
@@ -369,182 +620,24 @@ class _RnnStackFn(torch.autograd.Function):
         if ctx.had_state:
             raise Ds2HipError("backward through a forward that was given initial hidden states (hs) is not supported")
         mod = ctx.mod
-        c = mod._cache
         st = ctx.saved_tensors
         lens_dev, saved, params = st[0], st[1:1 + 4 * L], st[1 + 4 * L:]
-        R = Tp * N
         main = torch.cuda.current_stream()
         side = mod._wgrad_stream(dout.device)
-        # parameter offsets per layer
         offs, pos = [], 0
         for li in range(L):
-            has_bn, D = ctx.meta[li][5], ctx.meta[li][2]
             offs.append(pos)
-            pos += (2 if has_bn else 0) + 4 * D
+            pos += _layer_param_count(mod.rnns[li])
         grads = [None] * len(params)
         dout = dout.contiguous().to(dtype)
         wgrad_done = None
         for li in reversed(range(L)):
-            kind, H, D, G, I, has_bn, sv, Ht, It = ctx.meta[li]
-            X, Xh, hext, Sv = saved[4 * li:4 * li + 4]
-            if Xh is None:
-                Xh = X
-            first = li == 0
-            GH = G * H
-            po = offs[li] + (2 if has_bn else 0)
-            wts = params[po:po + 4 * D]
-            wih = [wts[4 * d + 0] for d in range(D)]
-            whh = [wts[4 * d + 1] for d in range(D)]
-            WhhT = c.get(("whhT", li, dtype), list(whh), lambda whh=whh, G=G, Ht=Ht, H=H: torch.stack(
-                [_pad_gate_rows(_pad_cols(p.detach(), H), G, Ht, H).t() for p in whh], 0).to(dtype).contiguous())   # [D][H][G*H]
-
-            def build_ihT(wih=wih, first=first, G=G, Ht=Ht, H=H):
-                w = torch.cat([_pad_gate_rows(p.detach(), G, Ht, H) for p in wih], 0)
-                w = _perm_cols_to_internal(w) if first else _pad_cols(w, H)
-                return w.t().to(dtype).contiguous()                                                             # [I][D*G*H]
-            WihT = c.get(("wihT", li, dtype), list(wih), build_ihT)
-            # ---- BPTT sweep (caller's stream).  A persistent sweep wants every CU: it starts after the weight-gradient launch of the
-            # layer above has drained (otherwise its first workgroups would spin on peers that are still waiting for a CU)
-            if wgrad_done is not None:
-                main.wait_event(wgrad_done)
-                wgrad_done = None
-            rg = ops.rnn_bwd(kind, dout, WhhT, hext, Sv, lens_dev, D, N, H, Tp)
-            dGI = rg.dGI
-            fast = ops.wgrad_tn_ok(dtype, R, D * GH, Xh.shape[1]) and ops.wgrad_tn_ok(dtype, R, GH, H)
-            dXh_fused = None
-            if fast:
-                # ---- weight gradients as ONE grouped launch of TN products (contraction over the T'*N rows, both operands as the
-                # activations are stored: no transposes).  Never under a sweep: what co-resident GEMMs cost the sweeps was the
-                # chip's CLOCK (1.7 instead of 2.15 GHz while they ran, profiles/r03a_coresidency3.txt) -- a latency-bound kernel
-                # pays that one to one.  On the caller's stream, right behind the sweep (optionally beside the dX GEMM on the second
-                # stream, WGRAD_BESIDE_DX: no gain measured).
-                swept = torch.cuda.Event()
-                swept.record(main)
-                wstream = side if WGRAD_BESIDE_DX else main
-                with torch.cuda.stream(wstream):
-                    if wstream is not main:
-                        wstream.wait_event(swept)
-                        for t_ in rg.tensors() + [Xh, hext]:
-                            t_.record_stream(wstream)
-                    Iw = Xh.shape[1]
-                    dWih = torch.empty((D * GH, Iw), dtype=torch.float32, device=dGI.device)
-                    dWhh = torch.empty((D, GH, H), dtype=torch.float32, device=dGI.device)
-                    probs = [dict(At=dGI, Bt=Xh, M=D * GH, N=Iw, lda=D * GH, ldb=Xh.stride(0), out=dWih)]
-                    for d in range(D):
-                        # h_{t-1} of the forward direction is slot t of the guarded buffer, h_{t+1} of the reverse direction slot t+2
-                        hprev = (hext[d, 0:Tp] if d == 0 else hext[d, 2:Tp + 2]).reshape(R, H)
-                        if kind == "gru" and rg.dQ is not None:
-                            # hidden-side gate gradient = [dr, dz (columns of dGI) | dQ]
-                            if (2 * H) % 256 == 0:
-                                probs.append(dict(At=dGI[:, d * GH:], At2=rg.dQ[d], lda2=H, m_split=2 * H, Bt=hprev, M=GH, N=H, lda=D * GH, ldb=H,
-                                                  out=dWhh[d]))
-                            else:
-                                probs.append(dict(At=dGI[:, d * GH:], Bt=hprev, M=2 * H, N=H, lda=D * GH, ldb=H, out=dWhh[d, :2 * H]))
-                                probs.append(dict(At=rg.dQ[d], Bt=hprev, M=H, N=H, lda=H, ldb=H, out=dWhh[d, 2 * H:]))
-                        elif kind == "gru":
-                            probs.append(dict(At=rg.dGH[d], Bt=hprev, M=GH, N=H, lda=GH, ldb=H, out=dWhh[d]))
-                        else:
-                            probs.append(dict(At=dGI[:, d * GH:], Bt=hprev, M=GH, N=H, lda=D * GH, ldb=H, out=dWhh[d]))
-                    if WGRAD_WITH_DX and wstream is main and len(probs) < 6 and ops.gemm8_nt_ok(dGI, WihT, R, WihT.shape[0], D * GH, D * GH,
-                                                                                                WihT.stride(0)):
-                        _, dXh_fused = ops.gemm8_tn_grouped(probs, R, dx=(dGI, WihT))   # + the layer's dX in the same launch
-                    else:
-                        ops.gemm8_tn_grouped(probs, R)
-                    if first:
-                        dWih = torch.cat([_perm_cols_to_reference(dWih[d * GH:(d + 1) * GH]) for d in range(D)], 0)
-                    if rg.bacc is not None:
-                        dBih, dBhh_all = ops.rnn_bias_grads(kind, rg.bacc, D, N, H)          # one launch: [D*G*H], [D][G*H]
-                        dBhh_l = [dBhh_all[d] for d in range(D)]
-                    else:
-                        dBih = ops.colsum(dGI)
-                        dBhh_all = None
-                        if kind == "gru":
-                            dBhh_l = [ops.colsum(rg.dGH[d].reshape(R, GH)) for d in range(D)]
-                        else:
-                            dBhh_l = [dBih[d * GH:(d + 1) * GH] for d in range(D)]
-                    for d in range(D):
-                        grads[po + 4 * d:po + 4 * d + 4] = [dWih[d * GH:(d + 1) * GH], dWhh[d], dBih[d * GH:(d + 1) * GH], dBhh_l[d]]
-                    sync = getattr(mod, "_grad_sync", None)
-                    if sync is not None and H == Ht:
-                        own = [dWih, dWhh, dBih] + ([dBhh_all] if dBhh_all is not None else
-                                                    [dBhh_l[d] for d in range(D)] if kind == "gru" else [])
-                        sync.layer_ready(own, params[po:po + 4 * D])
-                    _unpad_layer_grads(grads, po, D, G, Ht, H, It, first)
-                    if wstream is not main:
-                        wgrad_done = torch.cuda.Event()
-                        wgrad_done.record(wstream)
-            # ---- dependent chain (caller's stream): dX -> BatchNorm backward
-            dXh = dXh_fused if dXh_fused is not None else ops.gemm_nt(dGI, WihT)                                # [R][I]
-            if has_bn:
-                dX = torch.empty_like(dXh)
-                grads[offs[li]], grads[offs[li] + 1] = _bn_seq_bwd(dXh, X, dX, sv, R, It, I)
-            else:
-                dX = dXh
-            if fast:
-                dout = dX
-                continue
-            # the second stream starts this layer's weight gradients only once dX / BatchNorm backward are through, i.e. together
-            # with the next layer's sweep: the dependent chain never competes with them for the CUs
-            ready = torch.cuda.Event()
-            ready.record(main)
-            # ---- weight gradients (second stream, under the next layer's sweep): contraction over the T'*N rows.  Layer 0's run
-            # under the conv backward instead, where no persistent sweep needs most of every CU's registers: the full-size tiles
-            cores = li > 0
-            with torch.cuda.stream(side):
-                side.wait_event(ready)
-                for t in rg.tensors() + [Xh, hext]:
-                    t.record_stream(side)
-                dGI_T = ops.transpose(dGI)                              # [D*G*H][ldT]
-                Xh_T = ops.transpose(Xh)                                # [I][ldT]
-                ldT = dGI_T.shape[1]
-                dWih = ops.gemm_nt(dGI_T, Xh_T, out_dtype=torch.float32, splitk=_wgrad_splitk(dGI_T.shape[0], Xh_T.shape[0], ldT),
-                                   coresident=cores)
-                del Xh_T
-                if first:
-                    dWih = torch.cat([_perm_cols_to_reference(dWih[d * GH:(d + 1) * GH]) for d in range(D)], 0)
-                # bias gradients: from the sweep's own per-sample sums (persistent kernels: a [N][NB*H] reduction instead of
-                # column sums over the T'*N rows of dGI / dGH), else column sums
-                bsum = None
-                if rg.bacc is not None:
-                    NB = rg.bacc.shape[2] // H
-                    bsum = [ops.colsum(rg.bacc[d]) for d in range(D)]                   # [NB*H] per direction
-                    dBih = torch.cat([b[:GH] for b in bsum], 0)
-                else:
-                    dBih = ops.colsum(dGI)
-                for d in range(D):
-                    # h_{t-1} of the forward direction is slot t of the guarded buffer, h_{t+1} of the reverse direction slot t+2
-                    hprev = hext[d, 0:Tp] if d == 0 else hext[d, 2:Tp + 2]
-                    Hp_T = ops.transpose(hprev.reshape(R, H))           # [H][ldT]
-                    if kind == "gru" and rg.dQ is not None:
-                        # hidden-side gate gradient = [dr, dz (rows of dGI^T) | dQ^T]: one GEMM whose A operand is two row blocks
-                        dQ_T = ops.transpose(rg.dQ[d].reshape(R, H))   # [H][ldT]
-                        dWhh = ops.gemm_nt_rows2(dGI_T[d * GH:d * GH + 2 * H], dQ_T, 2 * H, Hp_T, GH, H, ldT, ldT, ldT,
-                                                 splitk=_wgrad_splitk(GH, H, ldT), coresident=cores)
-                        dBhh = torch.cat([bsum[d][:2 * H], bsum[d][3 * H:4 * H]], 0) if bsum is not None else \
-                            torch.cat([dBih[d * GH:d * GH + 2 * H], ops.colsum(rg.dQ[d].reshape(R, H))], 0)
-                    else:
-                        if kind == "gru":
-                            dGH_T = ops.transpose(rg.dGH[d].reshape(R, GH))    # [G*H][ldT]
-                            dBhh = ops.colsum(rg.dGH[d].reshape(R, GH))
-                        else:
-                            dGH_T = dGI_T[d * GH:(d + 1) * GH]
-                            dBhh = dBih[d * GH:(d + 1) * GH]
-                        dWhh = ops.gemm_nt(dGH_T, Hp_T, out_dtype=torch.float32, M=GH, N=H, K=ldT, lda=ldT, ldb=ldT,
-                                           splitk=_wgrad_splitk(GH, H, ldT), coresident=cores)
-                    grads[po + 4 * d:po + 4 * d + 4] = [dWih[d * GH:(d + 1) * GH].contiguous(), dWhh,
-                                                        dBih[d * GH:(d + 1) * GH].contiguous(), dBhh.contiguous()]
-                del dGI_T
-                sync = getattr(mod, "_grad_sync", None)
-                if sync is not None and H == Ht:
-                    # data parallel with the opt-in early hand-off (dist.OverlappedGradSync): this layer's gradients start
-                    # their all-reduce now, ordered after the GEMMs above, under the sweeps of the layers below.  The
-                    # returned gradients are views of dWih / dBih (and of dBih for the biases of LSTM / RNN cells).
-                    own = [dWih, dBih] + [grads[po + 4 * d + 1] for d in range(D)]
-                    if kind == "gru":
-                        own += [grads[po + 4 * d + 3] for d in range(D)]
-                    sync.layer_ready(own, params[po:po + 4 * D])
-                _unpad_layer_grads(grads, po, D, G, Ht, H, It, first)
-            dout = dX
+            n = _layer_param_count(mod.rnns[li])
+            dout, lg, wgrad_done = _rnn_layer_backward(mod, li, ctx.meta[li], list(saved[4 * li:4 * li + 4]), params[offs[li]:offs[li] + n],
+                                                       dout, lens_dev, N, Tp, dtype, main, side, wgrad_done)
+            grads[offs[li]:offs[li] + n] = lg
+        if wgrad_done is not None:
+            main.wait_event(wgrad_done)
         if getattr(ctx, "defer_join", False):
             ctx.pending = (main, side, grads, mod)     # the composite node joins after the conv backward
         else:
@@ -986,13 +1079,33 @@ class DeepSpeech(_Base):
                 for suf in [""] + (["_reverse"] if self.bidirectional else []):
                     params += [getattr(p, "weight_ih_l0" + suf), getattr(p, "weight_hh_l0" + suf),
                                getattr(p, "bias_ih_l0" + suf), getattr(p, "bias_hh_l0" + suf)]
-            res = _FrontFn.apply(x, self, lens_dev, N, Tp, dtype, training, L, sm[0].weight, sm[0].bias, sm[1].weight, sm[1].bias,
-                                 sm[3].weight, sm[3].bias, sm[4].weight, sm[4].bias, *h0s, *c0s, *params)
-            X = res[0]
-            if self._kind == "lstm":
-                new_hs = [(res[1 + i], res[1 + L + i]) for i in range(L)]
+            if COMPOSITE_NODE:
+                res = _FrontFn.apply(x, self, lens_dev, N, Tp, dtype, training, L, sm[0].weight, sm[0].bias, sm[1].weight, sm[1].bias,
+                                     sm[3].weight, sm[3].bias, sm[4].weight, sm[4].bias, *h0s, *c0s, *params)
+                X = res[0]
+                hn_l = list(res[1:1 + L])
+                cn_l = list(res[1 + L:1 + 2 * L]) if self._kind == "lstm" else []
             else:
-                new_hs = [res[1 + i] for i in range(L)]
+                # default graph: conv stack -> one node per BatchRNN layer (a layer's gradients reach DDP's reducer as soon as the
+                # layer's backward returns, under the sweeps of the layers below)
+                X = _ConvStackFn.apply(x, sm[0].weight, sm[0].bias, sm[1].weight, sm[1].bias, sm[3].weight, sm[3].bias, sm[4].weight,
+                                       sm[4].bias, self, lens_dev, Tp, dtype, training)
+                if self._prep_done is not None:           # RNN weight re-layouts were prepared on the second stream meanwhile
+                    torch.cuda.current_stream().wait_event(self._prep_done)
+                    self._prep_done = None
+                hn_l, cn_l, pos = [], [], 0
+                for i, layer in enumerate(self.rnns):
+                    n = _layer_param_count(layer)
+                    outs = _RnnLayerFn.apply(X, self, lens_dev, N, Tp, dtype, training, i, h0s[i], c0s[i], *params[pos:pos + n])
+                    pos += n
+                    X = outs[0]
+                    hn_l.append(outs[1])
+                    if len(outs) > 2:
+                        cn_l.append(outs[2])
+            if self._kind == "lstm":
+                new_hs = [(hn_l[i], cn_l[i]) for i in range(L)]
+            else:
+                new_hs = list(hn_l)
             if not self.bidirectional:
                 X = _LookaheadFn.apply(X, self.lookahead[0].conv.weight, N, Tp)
             fcm = self.fc[0].module

@@ -100,9 +100,14 @@ def gemm8_nt_ok(A, B, M, N, K, lda, ldb):
             A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0)
 
 
-def wgrad_tn_ok(dtype, R, M, N):
-    """Weight gradients as grouped TN products (no operand transposes): bf16 activations, a long contraction, 8-aligned widths."""
-    return GEMM8_ENABLED and dtype == torch.bfloat16 and R >= 512 and M % 8 == 0 and N % 8 == 0 and M >= 256 and N >= 256
+def wgrad_tn_ok(dtype, R, M, N, lda=None, ldb=None):
+    """Weight gradients as grouped TN products (no operand transposes): bf16 activations, a long contraction, 8-aligned widths, and
+    operands whose R x ld elements stay inside the kernels' 32-bit offsets (ds2_gemm8_tn_grouped / _wgrad_dx require K * ld < 2^31:
+    beyond it -- e.g. R = T'N = 256 000 rows of a BiLSTM-1280's dGI, ld 10 240 -- the transpose + NT path takes over)."""
+    lda = M if lda is None else lda
+    ldb = N if ldb is None else ldb
+    return (GEMM8_ENABLED and dtype == torch.bfloat16 and R >= 512 and M % 8 == 0 and N % 8 == 0 and M >= 256 and N >= 256 and
+            R * lda < (1 << 31) and R * ldb < (1 << 31))
 
 
 def gemm_nt(A, B, bias=None, out_dtype=None, M=None, N=None, K=None, lda=None, ldb=None, out=None, ldc=None, splitk=1,
@@ -356,30 +361,44 @@ PERSIST_ENABLED = True   # tests flip this to run the per-time-step kernels on s
 
 
 _WARNED_CUS = set()
+_WARNED_SHAPES = set()
+PERSIST_CLIFF_MIN_H = 256      # below this width a time step is launch-bound either way: no warning
 
 
 def use_persistent(kind, dtype, D, N, H):
+    """True if a persistent sweep (one launch per layer and direction pair) takes this problem on the current device.  Never a
+    silent cliff: when the answer is no because the DEVICE exposes fewer than 256 CUs although the shape is covered (partition /
+    CU-mask modes) that is an error unless DS2_ALLOW_LAUNCH_PER_STEP=1 -- a CU-masked rank of a data-parallel job must not quietly
+    become the straggler; when no persistent kernel is instantiated for the shape (the reference leaves hidden_size free,
+    train_config.py:49) the launch-per-time-step kernels run, 5-8x slower per step, and a warning says so once per shape."""
     if not PERSIST_ENABLED:
         return False
     ok = bool(query("ds2_rnn_persist_supported", dt(dtype), CELLS[kind], D, N, H))
-    if not ok:
-        # never silent: a device that does not expose 256 CUs (partition / CU-mask modes) cannot host the persistent sweeps (one
-        # workgroup per CU, all co-resident).  That is an ERROR unless the caller opted into the launch-per-time-step kernels
-        # (several times slower): a CU-masked rank of a data-parallel job must not quietly become the straggler.
+    if ok:
+        return True
+    import os
+    import warnings
+    covered = bool(query("ds2_rnn_persist_shape_covered", dt(dtype), CELLS[kind], D, N, H))
+    if covered:
         dev = torch.cuda.current_device()
         cus = torch.cuda.get_device_properties(dev).multi_processor_count
-        if cus < 256:
-            import os
-            if os.environ.get("DS2_ALLOW_LAUNCH_PER_STEP", "0") in ("", "0"):
-                raise _lib.Ds2HipError("ds2hip: device %d exposes %d compute units (< 256): the persistent recurrent kernels need one "
-                                       "workgroup per CU, all co-resident.  Set DS2_ALLOW_LAUNCH_PER_STEP=1 to run the launch-per-time-step "
-                                       "kernels instead (several times slower)." % (dev, cus))
-            if dev not in _WARNED_CUS:
-                _WARNED_CUS.add(dev)
-                import warnings
-                warnings.warn("ds2hip: device %d exposes %d compute units (< 256): the persistent recurrent kernels are disabled, the "
-                              "recurrent sweeps use one launch per time step" % (dev, cus))
-    return ok
+        if os.environ.get("DS2_ALLOW_LAUNCH_PER_STEP", "0") in ("", "0"):
+            raise _lib.Ds2HipError("ds2hip: device %d exposes %d compute units (< 256): the persistent recurrent kernels need one "
+                                   "workgroup per CU, all co-resident.  Set DS2_ALLOW_LAUNCH_PER_STEP=1 to run the launch-per-time-step "
+                                   "kernels instead (several times slower)." % (dev, cus))
+        if dev not in _WARNED_CUS:
+            _WARNED_CUS.add(dev)
+            warnings.warn("ds2hip: device %d exposes %d compute units (< 256): the persistent recurrent kernels are disabled, the "
+                          "recurrent sweeps use one launch per time step" % (dev, cus))
+    elif H >= PERSIST_CLIFF_MIN_H:
+        key = (kind, str(dtype), D, N, H)
+        if key not in _WARNED_SHAPES:
+            _WARNED_SHAPES.add(key)
+            warnings.warn("ds2hip: no persistent recurrent kernel is instantiated for %s %s hidden=%d, %d direction(s), batch %d: the "
+                          "sweeps run one launch per time step (5-8x slower per step).  Persistent kernels exist for bf16 GRU / LSTM "
+                          "with hidden in {512, 768, 800, 1024, 1280, 1536} (LSTM: not 1536) up to 32 clips per group, bf16 hidden 1024 "
+                          "(any cell), and fp32 hidden in {800, 1024}." % (str(dtype).replace("torch.", ""), kind, H, D, N))
+    return False
 
 
 def rnn_fwd(kind, GI, Whh, bhh, lens, D, N, H, Tp, h0=None, c0=None, save=True):

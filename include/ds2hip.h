@@ -141,15 +141,26 @@ int ds2_rnn_bwd(int dtype, int cell, int D, int N, int H, int Tp, const int* len
  * registers, h exchanged between the workgroups of a group through a polled exchange buffer inside ws (pure payload in four
  * slots with an all-ones "not published yet" dword, or tagged 8-byte granules: csrc/ds2_rnn_persist_impl.h); same buffer contract as
  * ds2_rnn_fwd / ds2_rnn_bwd.  Covered (ds2_rnn_persist_supported): bf16 with H = 1024 (any cell, <= 16 samples per group of an
- * 8-group chip: BASELINE config 3), and GRU / LSTM with bf16 H in {800, 1280} or fp32 H in {800, 1024} (configs 2 and 5, the
- * 1e-3 parity mode; up to 64 samples per group for bf16 H = 1280, 16 otherwise); everything else runs ds2_rnn_fwd / _bwd.
+ * 8-group chip: BASELINE config 3); GRU / LSTM with bf16 H in {512, 768, 800, 1024, 1280, 1536} (LSTM: not 1536) and <= 32
+ * samples per group (round-4 general kernels: 32 units per workgroup, groups inside one XCD for H <= 1024 -- config 5); GRU /
+ * LSTM with fp32 H in {800, 1024} or bf16 H in {800, 1280} and <= 64 samples per group (round-2 general kernels: config 2, the 1e-3
+ * parity mode); everything else runs ds2_rnn_fwd / _bwd.
  * ws: ds2_rnn_persist_ws_bytes() bytes of scratch (reset by every call on `stream`); err: one device int that the kernel sets to 1 if a workgroup gave up
  * waiting for its peers (its outputs are then NaN). */
 /* Test hook (fault injection): the number of polls a workgroup of a persistent sweep may spend waiting for its peers on one
  * exchange before it gives up -- raises *err, NaN-poisons its outputs, ends.  0 = the built-in budget (seconds).  Returns the
  * previous value. */
 unsigned ds2_rnn_persist_set_spin_limit(unsigned polls);
+/* A/B hook: bit 0 = the shapes of the round-4 general kernels (csrc/ds2_rnn_persist3_impl.h) run on the round-2 general kernels
+ * (or one launch per time step) instead.  Process-wide; returns the previous value. */
+unsigned ds2_rnn_persist_set_variant(unsigned bits);
 int ds2_rnn_persist_supported(int dtype, int cell, int D, int N, int H);
+/* 1 if a persistent kernel exists for the problem on a FULL device (256 CUs), whatever the current device exposes: tells "this
+ * device is too small for the persistent sweeps" (the caller raises) from "no persistent kernel for this shape" (it warns). */
+int ds2_rnn_persist_shape_covered(int dtype, int cell, int D, int N, int H);
+/* Kernel family the persistent entries run for the problem on the current device: 0 none (ds2_rnn_fwd / _bwd), 1 / 2 tuned H = 1024
+ * (<= 8 / 9-16 samples per group), 3 round-4 general (k_rnn_persist3_*), 4 round-2 general (k_rnn_persist2_*). */
+int ds2_rnn_persist_kind(int dtype, int cell, int D, int N, int H);
 long ds2_rnn_persist_ws_bytes(int dtype, int cell, int D, int N, int H);
 int ds2_rnn_persist_fwd(int dtype, int cell, int D, int N, int H, int Tp, const int* lens, const void* GI, const void* Whh,
                         const float* bhh, const float* h0, const float* c0, void* Hseq, long hseq_dstride, void* S, float* hn,

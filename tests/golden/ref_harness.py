@@ -26,8 +26,27 @@ def _install_stubs():
         pl = types.ModuleType("pytorch_lightning")
 
         class LightningModule(nn.Module):  # model.py:138
-            def save_hyperparameters(self, *a, **k):  # model.py:147
-                pass
+            def save_hyperparameters(self, *a, **k):  # model.py:147: Lightning records the constructor arguments of the caller
+                import inspect
+                frame = inspect.currentframe().f_back
+                try:
+                    names = [n for n in inspect.signature(type(self).__init__).parameters if n != "self"]
+                    self._hparams = {n: frame.f_locals[n] for n in names if n in frame.f_locals}
+                finally:
+                    del frame
+
+            @property
+            def hparams(self):  # written into a checkpoint as "hyper_parameters"
+                return getattr(self, "_hparams", {})
+
+            @classmethod
+            def load_from_checkpoint(cls, checkpoint_path, map_location=None, strict=True, **overrides):  # utils.py:31
+                ckpt = torch.load(checkpoint_path, map_location=map_location or "cpu", weights_only=False)
+                hp = dict(ckpt.get("hyper_parameters", {}))
+                hp.update(overrides)
+                model = cls(**hp)
+                model.load_state_dict(ckpt["state_dict"], strict=strict)
+                return model
 
             def log(self, *a, **k):  # model.py:270-271
                 pass
