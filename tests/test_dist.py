@@ -37,15 +37,20 @@ def _free_port():
 
 
 def _worker(rank, world, port, out, use_ddp=False):
-    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                      DS2_USE_DDP="1" if use_ddp else "0")
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.pop("DS2_USE_DDP", None)
+    if use_ddp:
+        os.environ.pop("DS2_OVERLAP_ALLREDUCE", None)          # the default: torch DDP
+    else:
+        os.environ["DS2_OVERLAP_ALLREDUCE"] = "1"                # opt-in: the in-place per-layer all-reduce
     from deepspeech.pytorch_amd import dist as dsdist
     r, w, lr = dsdist.init_from_env("gloo")
     assert (r, w, lr) == (rank, world, rank)
     dev = torch.device("cpu")
     model = _StandIn()
     step_mod = dsdist.wrap_data_parallel(dsdist.StepModule(model), dev, world)
-    # default = the overlapped wrapper (a model without early hand-offs is reduced by its end-of-backward bucket); DS2_USE_DDP=1 = torch DDP
+    # default = torch DDP; DS2_OVERLAP_ALLREDUCE=1 = the overlapped wrapper (a model without early hand-offs is reduced by its
+    # end-of-backward bucket)
     assert isinstance(step_mod, torch.nn.parallel.DistributedDataParallel if use_ddp else dsdist.OverlappedDataParallel)
     g = torch.Generator().manual_seed(100 + rank)          # every rank has its own minibatch
     x = torch.randn(6, 8, generator=g)
@@ -178,6 +183,134 @@ def test_two_rank_gloo_overlapped_gradient_sync():
         assert max(out[r]["errs"]) <= 1e-5, out[r]
         assert out[r]["early"] == 2                                          # w1 and w2 went early, the BN pair through finish()
     assert np.array_equal(out[0]["w1"], out[1]["w1"])
+
+
+class _LayerNode(torch.autograd.Function):
+    """Stand-in for model._RnnLayerFn: ONE autograd node per layer whose backward returns the layer's weight gradient together with
+    dX -- the node structure of the drop-in class since round 4 (conv stack -> one node per BatchRNN layer -> head)."""
+
+    @staticmethod
+    def forward(ctx, x, w, log, li):
+        ctx.save_for_backward(x, w)
+        ctx.log, ctx.li = log, li
+        return torch.tanh(x @ w)
+
+    @staticmethod
+    def backward(ctx, dy):
+        import time
+        x, w = ctx.saved_tensors
+        ctx.log.append(("layer_bwd_start", ctx.li, time.perf_counter()))
+        y = torch.tanh(x @ w)
+        dz = dy * (1 - y * y)
+        time.sleep(0.05)                              # the layer's BPTT sweep: the time an overlapped all-reduce can hide under
+        return dz @ w.t(), x.t() @ dz, None, None
+
+
+class _CompositeNode(torch.autograd.Function):
+    """The round-1..3 structure: all layers inside ONE node -- every weight gradient leaves it together, at the end."""
+
+    @staticmethod
+    def forward(ctx, x, log, *ws):
+        acts = [x]
+        for w in ws:
+            acts.append(torch.tanh(acts[-1] @ w))
+        ctx.save_for_backward(*acts, *ws)
+        ctx.log, ctx.n = log, len(ws)
+        return acts[-1]
+
+    @staticmethod
+    def backward(ctx, dy):
+        import time
+        st = ctx.saved_tensors
+        acts, ws = st[:ctx.n + 1], st[ctx.n + 1:]
+        grads = [None] * ctx.n
+        for li in reversed(range(ctx.n)):
+            ctx.log.append(("layer_bwd_start", li, time.perf_counter()))
+            dz = dy * (1 - acts[li + 1] * acts[li + 1])
+            grads[li] = acts[li].t() @ dz
+            dy = dz @ ws[li].t()
+            time.sleep(0.05)
+        return (dy, None, *grads)
+
+
+class _LayeredStandIn(torch.nn.Module):
+    def __init__(self, per_layer_nodes, width=600, layers=3):
+        super().__init__()
+        torch.manual_seed(2)
+        self.ws = torch.nn.ParameterList([torch.nn.Parameter(torch.randn(width, width) / width ** 0.5) for _ in range(layers)])   # 1.4 MB each
+        self.per_layer_nodes, self.log = per_layer_nodes, []
+
+    def training_step(self, batch, batch_idx):
+        x = batch[0]
+        if self.per_layer_nodes:
+            for li, w in enumerate(self.ws):
+                x = _LayerNode.apply(x, w, self.log, li)
+        else:
+            x = _CompositeNode.apply(x, self.log, *self.ws)
+        return (x ** 2).sum()
+
+
+def _worker_progressive(rank, world, port, out, per_layer_nodes):
+    import time
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.pop("DS2_OVERLAP_ALLREDUCE", None)
+    os.environ.pop("DS2_USE_DDP", None)
+    from deepspeech.pytorch_amd import dist as dsdist
+    dsdist.init_from_env("gloo")
+    dev = torch.device("cpu")
+    model = _LayeredStandIn(per_layer_nodes)
+    ddp = dsdist.wrap_data_parallel(dsdist.StepModule(model), dev, world, bucket_cap_mb=1)      # one layer (1.4 MB) per bucket
+    assert isinstance(ddp, torch.nn.parallel.DistributedDataParallel)
+    log = model.log
+
+    def hook(state, bucket):                                  # what DDP's default hook does, plus a time stamp when the reducer launches it
+        log.append(("allreduce_start", bucket.index(), time.perf_counter()))
+        fut = dist.all_reduce(bucket.buffer(), async_op=True).get_future()
+        return fut.then(lambda f: f.value()[0] / world)
+    ddp.register_comm_hook(None, hook)
+    g = torch.Generator().manual_seed(300 + rank)
+    x = torch.randn(16, 600, generator=g)
+    for it in range(2):                                       # the second step runs on the rebuilt (gradient-ready-order) buckets
+        del log[:]
+        model.zero_grad()
+        loss = ddp(x, torch.zeros(1), torch.ones(16), torch.ones(16, dtype=torch.int32))
+        loss.backward()
+    starts = sorted(t for k, _, t in log if k == "allreduce_start")
+    last_layer_bwd = [t for k, li, t in log if k == "layer_bwd_start" and li == 0][0]      # layer 0 runs its backward LAST
+    out[rank] = dict(n_allreduce=len(starts), before_last_layer=sum(1 for t in starts if t < last_layer_bwd),
+                     grad=float(sum(p.grad.abs().sum() for p in model.parameters())))
+    dsdist.shutdown(world)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("per_layer_nodes", [True, False])
+def test_ddp_overlaps_with_per_layer_nodes(per_layer_nodes):
+    """Plain ``DistributedDataParallel`` -- what Lightning's ``strategy: ddp`` builds around the module (reference training.py:42-47,
+    configs/librispeech.yaml:14) -- launches a layer's bucket all-reduce BEFORE the backward of the layers below has run when every
+    layer is its own autograd node (the drop-in class's graph since round 4), and only after the whole backward when the stack is one
+    composite node (rounds 1-3: the exposed ~3 ms of VERDICT round 3, missing #2)."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_progressive, args=(world, _free_port(), out, per_layer_nodes), nprocs=world, join=True)
+    for r in range(world):
+        assert out[r]["n_allreduce"] == 3, out[r]
+        if per_layer_nodes:
+            assert out[r]["before_last_layer"] >= 2, out[r]          # layers 2 and 1 are on the wire before layer 0's backward starts
+        else:
+            assert out[r]["before_last_layer"] == 0, out[r]
+    assert abs(out[0]["grad"] - out[1]["grad"]) <= 1e-4 * abs(out[0]["grad"])      # both ranks hold the same (mean) gradients
+
+
+def test_default_wrapper_is_torch_ddp(monkeypatch):
+    from deepspeech.pytorch_amd import dist as dsdist
+    monkeypatch.delenv("DS2_OVERLAP_ALLREDUCE", raising=False)
+    monkeypatch.delenv("DS2_USE_DDP", raising=False)
+    assert dsdist.overlap_allreduce() is False
+    monkeypatch.setenv("DS2_OVERLAP_ALLREDUCE", "1")
+    assert dsdist.overlap_allreduce() is True
+    monkeypatch.setenv("DS2_USE_DDP", "1")
+    assert dsdist.overlap_allreduce() is False
 
 
 def test_single_rank_is_identity():

@@ -137,3 +137,25 @@ def test_precision16_loop_and_overflow_detection(name, precision):
     assert np.isfinite(float(l3)) and tr.skipped_steps == 1
     from deepspeech.pytorch_amd import ops
     ops.check_persistent_kernels()
+
+
+@pytest.mark.parametrize("name,precision", [("gru_bi_1024", "bf16"), ("lstm_uni_la", 32), ("cfg2_full", 32), ("lstm_bi_1280", "bf16")])
+def test_per_layer_nodes_equal_the_composite_node(name, precision):
+    """The round-4 graph (conv stack -> one autograd node per BatchRNN layer) against the round-1..3 graph (ONE composite node,
+    DS2_COMPOSITE_NODE=1): same kernels in the same order on the caller's stream -- identical loss and gradients."""
+    from deepspeech.pytorch_amd import model as M
+    fx = Fixture(name)
+    inputs, targets, pct, tsz = fx.batch()
+    batch = (torch.from_numpy(inputs).to(DEV), torch.from_numpy(targets), torch.from_numpy(pct.copy()), torch.from_numpy(tsz))
+    res = []
+    old = M.COMPOSITE_NODE
+    try:
+        for comp in (False, True):
+            M.COMPOSITE_NODE = comp
+            res.append(_grads_of_step(build(fx, precision), batch, 1.0))
+    finally:
+        M.COMPOSITE_NODE = old
+    assert res[0][0] == res[1][0]
+    for k in res[0][1]:
+        a, b = res[0][1][k], res[1][1][k]
+        assert np.abs(a - b).max() <= 1e-6 * max(np.abs(a).max(), 1e-30), k

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 here=$PWD
 timeout 300 python bench.py > $out/bench_default.json 2> $out/bench_default.err; echo "bench default rc=$?"; tail -c 600 $out/bench_default.json; echo
 for cfg in cfg2 cfg5a cfg5b; do
-  timeout 300 python bench.py --config $cfg --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_$cfg.json 2> $out/bench_$cfg.err; echo "bench $cfg rc=$?"
+  timeout 300 python bench.py --config $cfg --steps 10 --warmup 3 --no-cpu-baseline --no-stock-baseline > $out/bench_$cfg.json 2> $out/bench_$cfg.err; echo "bench $cfg rc=$?"
   grep -o '"ms_per_step": [0-9.]*' $out/bench_$cfg.json
 done
 if [ -z "$SKIP_STOCK" ]; then
@@ -19,7 +19,7 @@ if [ -z "$SKIP_STOCK" ]; then
 fi
 cd /tmp
 for cfg in cfg3 cfg2 cfg5a cfg5b; do
-  timeout 400 rocprofv3 --kernel-trace --stats -d $here/$out/prof_$cfg -o $cfg -- python $here/bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline > $here/$out/prof_$cfg.log 2>&1; echo "rocprof $cfg rc=$?"
+  timeout 400 rocprofv3 --kernel-trace --stats -d $here/$out/prof_$cfg -o $cfg -- python $here/bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline --no-stock-baseline > $here/$out/prof_$cfg.log 2>&1; echo "rocprof $cfg rc=$?"
   db=$(find $here/$out/prof_$cfg -name "*.db" | head -n 1)
   [ -n "$db" ] && python $here/tools/rocpd_stats.py $db > $here/$out/kernel_stats_$cfg.md 2>> $here/$out/prof_$cfg.log
   head -n 8 $here/$out/kernel_stats_$cfg.md | cut -c1-160
@@ -30,7 +30,7 @@ if [ -z "$SKIP_PMC" ]; then
   i=0
   for ctrs in "${sets[@]}"; do
     i=$((i+1))
-    timeout 400 rocprofv3 --kernel-trace --pmc $ctrs -d $here/$out/pmc$i -o cfg3 -- python $here/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $here/$out/pmc$i.log 2>&1; echo "pmc [$ctrs] rc=$?"
+    timeout 400 rocprofv3 --kernel-trace --pmc $ctrs -d $here/$out/pmc$i -o cfg3 -- python $here/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-stock-baseline > $here/$out/pmc$i.log 2>&1; echo "pmc [$ctrs] rc=$?"
     db=$(find $here/$out/pmc$i -name "*.db" | head -n 1)
     [ -n "$db" ] && python $here/tools/rocpd_pmc.py $db > $here/$out/pmc$i.md 2>> $here/$out/pmc$i.log
     head -n 6 $here/$out/pmc$i.md | cut -c1-160

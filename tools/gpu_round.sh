@@ -9,12 +9,12 @@ timeout 1000 python -m pytest tests -m gpu -q -s --maxfail=25 --tb=short "$@" > 
 grep -E "passed|failed|Error|FAILED" $out/pytest.log | tail -n 30
 for cfg in ${CONFIGS:-cfg3 cfg2 cfg5a cfg5b}; do
   steps=20; [ $cfg != cfg3 ] && steps=6
-  timeout 300 python bench.py --config $cfg --steps $steps --warmup 3 --no-cpu-baseline $BENCH_ARGS > $out/bench_$cfg.json 2> $out/bench_$cfg.err; echo "bench $cfg rc=$?"
+  timeout 300 python bench.py --config $cfg --steps $steps --warmup 3 --no-cpu-baseline --no-stock-baseline $BENCH_ARGS > $out/bench_$cfg.json 2> $out/bench_$cfg.err; echo "bench $cfg rc=$?"
   tail -c 1200 $out/bench_$cfg.json; echo
 done
 if [ -n "$PROFILE" ]; then
   here=$PWD; cd /tmp
-  timeout 600 rocprofv3 --kernel-trace --stats -d $here/$out/prof -o cfg3 -- python $here/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $here/$out/prof.log 2>&1; echo "rocprof rc=$?"
+  timeout 600 rocprofv3 --kernel-trace --stats -d $here/$out/prof -o cfg3 -- python $here/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-stock-baseline > $here/$out/prof.log 2>&1; echo "rocprof rc=$?"
   cd $here
   db=$(find $out/prof -name "*.db" | head -n 1)
   if [ -n "$db" ]; then python tools/rocpd_stats.py $db > $out/kernel_stats_cfg3.md 2>> $out/prof.log; fi
@@ -28,7 +28,7 @@ if [ -n "$PMC" ]; then   # PMC counters: separate passes, kernel-trace only (MI3
   i=0
   for ctrs in "${sets[@]}"; do
     i=$((i+1)); tag2=pmc$i
-    timeout 600 rocprofv3 --kernel-trace --pmc $ctrs -d $here/$out/$tag2 -o cfg3 -- python $here/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $here/$out/$tag2.log 2>&1; echo "pmc [$ctrs] rc=$?"
+    timeout 600 rocprofv3 --kernel-trace --pmc $ctrs -d $here/$out/$tag2 -o cfg3 -- python $here/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-stock-baseline > $here/$out/$tag2.log 2>&1; echo "pmc [$ctrs] rc=$?"
     db=$(find $here/$out/$tag2 -name "*.db" | head -n 1)
     [ -n "$db" ] && python $here/tools/rocpd_pmc.py $db > $here/$out/$tag2.md 2>> $here/$out/$tag2.log
     head -n 8 $here/$out/$tag2.md
