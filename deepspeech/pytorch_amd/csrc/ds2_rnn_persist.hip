@@ -260,6 +260,10 @@ int ds2_rnn_persist_fwd(int dtype, int cell, int D, int N, int H, int Tp, const 
     a.hseq_dstride = hseq_dstride; a.S = S; a.h0 = h0; a.c0 = c0; a.hn = hn; a.cn = cn;
     a.xbuf = (char*)ws + AUX_BYTES; a.xgroup_bytes = xb / p3.NG; a.err = err; a.lerr = (int*)((char*)ws + 3072);
     ra.xcc = (u64*)((char*)ws + 1024); ra.P = p3.P; ra.xmap = p3.xmap; ra.gx = p3.gx; ra.nset = p3.nset;
+#ifdef DS2_PROBE
+    ra.dbg = (unsigned long long*)ws;
+    { const char* e_ = getenv("DS2_PERSIST_DBG"); ra.dbgmask = e_ ? atoi(e_) : 0; }
+#endif
     return launch3_any(false, false, cell, H, ra, st);
   }
   Plan2 pl;
@@ -313,6 +317,10 @@ int ds2_rnn_persist_bwd(int dtype, int cell, int D, int N, int H, int Tp, const 
     a.hseq_dstride = hseq_dstride; a.S = (void*)S; a.dOut = dOut; a.dGI = dGI; a.dGH = dGH; a.dBacc = dBacc;
     a.xbuf = (char*)ws + AUX_BYTES; a.xgroup_bytes = xb / p3.NG; a.err = err; a.lerr = (int*)((char*)ws + 3072);
     ra.xcc = (u64*)((char*)ws + 1024); ra.P = p3.P; ra.xmap = p3.xmap; ra.gx = p3.gx; ra.nset = p3.nset;
+#ifdef DS2_PROBE
+    ra.dbg = (unsigned long long*)ws;
+    { const char* e_ = getenv("DS2_PERSIST_DBG"); ra.dbgmask = e_ ? atoi(e_) : 0; }
+#endif
     return launch3_any(false, true, cell, H, ra, st);
   }
   Plan2 pl;

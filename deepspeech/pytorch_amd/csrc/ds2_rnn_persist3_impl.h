@@ -34,6 +34,12 @@ struct RArgs {
   int xmap;      // 1: group g's workgroups are the blocks with blockIdx % 8 == g % 8 (one XCD, if the dispatcher keeps its habit)
   int gx;        // xmap: group slots per XCD (floor(32 / P)); the grid is 8 * gx * P blocks, groups >= NG stay empty
   int nset;      // interleaved sample sets per group (the kernel's NSET)
+#ifdef DS2_PROBE   // tools/probe_persist3.py builds its own library with -DDS2_PROBE; the shipping kernels carry none of it
+  unsigned long long* dbg;  // [NG][8] cycle counters of workgroup 0 of each group (thread 0 and thread 255)
+  int dbgmask;              // 1 skip GI / dOut / S prefetch loads, 2 skip output stores, 8 skip the gather + products (no exchange),
+                            // 32 skip the products with the LDS-resident fragments, 64 publish with plain stores whatever the placement
+                            // (timing only: results are wrong across XCDs), 128 keep the gather but skip the products
+#endif
 };
 
 struct Plan3 {
@@ -109,7 +115,7 @@ constexpr int chunk3(int KSW, int SP) { return KSW <= 12 ? (KSW + SP - 1) / SP *
 template <int RT, int KSW, int KR, int SP, bool RAGGED>
 __device__ __forceinline__ void gather_mma3(ds2_f32x4 (&acc)[RT], const uint4 (&w)[RT][KR > 0 ? KR : 1], const uint4* wl_lane,
                                             __amdgpu_buffer_rsrc_t rsrc, int base, bool need, int ks0, int cnt, int part, int* err,
-                                            int* lerr, bool& dead) {
+                                            int* lerr, bool& dead, unsigned& rounds, int dbgmask = 0) {
   constexpr int CH = chunk3(KSW, SP);
   constexpr int PER = CH / SP;
   constexpr int NCH = (KSW + CH - 1) / CH;
@@ -139,6 +145,7 @@ __device__ __forceinline__ void gather_mma3(ds2_f32x4 (&acc)[RT], const uint4 (&
       unsigned spins = 0;
       for (;;) {
         __builtin_amdgcn_s_sleep(1);
+        ++rounds;
         DS2R_LOAD(c, b)
         DS2R_CHECK(b, bad1)
         if (!__any(bad1)) break;
@@ -152,7 +159,7 @@ __device__ __forceinline__ void gather_mma3(ds2_f32x4 (&acc)[RT], const uint4 (&
 #pragma unroll
     for (int kk = 0; kk < CH; ++kk) {
       const int k_ = c * CH + kk;                    // compile-time after unrolling
-      if (k_ < KSW) {
+      if (k_ < KSW && !(dbgmask & 128) && !((dbgmask & 32) && k_ >= KR)) {
         const int i = kk / SP;
         uint4 a_ = make_uint4(v[b][i][0], v[b][i][1], v[b][i][2], v[b][i][3]);
         if (SP == 2 && (kk & 1)) a_ = row_from_plus4(a_, 8);
@@ -324,10 +331,17 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_fwd(RArgs ra) {
   for (int g = 0; g < G; ++g) gin[g] = on[0] ? X::ld(gi_ptr[0] + (long)g * H) : 0u;
   gi_ptr[0] += gi_stride;
   int hstep = 0;
+  unsigned rounds = 0;
+  DS2_PROBE_ONLY(unsigned long long c_gather = 0, c_bar = 0, c_gate = 0; const int dbgmask = ra.dbgmask;)
+#ifndef DS2_PROBE
+  constexpr int dbgmask = 0;
+#endif
+  const bool plain = local || (dbgmask & 64);
   for (int s = 0; s < Tp; ++s) {
     const int t = d == 0 ? s : Tp - 1 - s;
 #pragma unroll
     for (int q = 0; q < NSET; ++q, ++hstep) {
+      DS2_PROBE_ONLY(const unsigned long long t0 = __builtin_readcyclecounter();)
       uint32_t gi[G];
 #pragma unroll
       for (int g = 0; g < G; ++g) gi[g] = gin[g];
@@ -337,19 +351,21 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_fwd(RArgs ra) {
         const bool more = q + 1 < NSET || s + 1 < Tp;
         (void)wrap;
 #pragma unroll
-        for (int g = 0; g < G; ++g) gin[g] = (more && on[qn]) ? X::ld(gi_ptr[qn] + (long)g * H) : 0u;
+        for (int g = 0; g < G; ++g) gin[g] = (more && on[qn] && !(dbgmask & 1)) ? X::ld(gi_ptr[qn] + (long)g * H) : 0u;
         gi_ptr[qn] += gi_stride;
       }
       ds2_f32x4 acc[RT];
 #pragma unroll
       for (int tt = 0; tt < RT; ++tt) acc[tt] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
-      if (s > 0 || a.h0)
+      if ((s > 0 || a.h0) && !(dbgmask & 8))
         gather_mma3<RT, KSW, KR, SP, RAGGED>(acc, w, wl_lane, rsrc, q * SETB + ((s + 3) & 3) * SLOT + gbase, gneed[q], ks0, cnt, gpart,
-                                             a.err, a.lerr, dead);
+                                             a.err, a.lerr, dead, rounds, dbgmask);
+      DS2_PROBE_ONLY(const unsigned long long t1 = __builtin_readcyclecounter();)
       float* pp = part + (PB == 2 ? (hstep & 1) * PART_FLOATS : 0);
       if (PB == 1) __syncthreads();       // every wave is through with the previous half-step's partial sums
       store_partials3<RT>(pp, acc, wave, lane);
       __syncthreads();
+      DS2_PROBE_ONLY(const unsigned long long t2 = __builtin_readcyclecounter();)
       if (on[q]) {
         const bool act = t < len[q];
         float hn0 = 0.f, hn1 = 0.f;       // emitted h_t (0 when inactive)
@@ -407,16 +423,29 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_fwd(RArgs ra) {
         }
         if (dead) hn0 = hn1 = hprev[q][0] = hprev[q][1] = QNAN;   // fail loudly downstream
         // publish the carried state first (inactive samples republish their unchanged state), then the bookkeeping stores
-        pub32(xg + q * SETB + (s & 3) * SLOT + xoff, pay_word(hprev[q][0], hprev[q][1]), local);
-        pub32(xg + q * SETB + ((s + 2) & 3) * SLOT + xoff, XSENT2, local);     // re-arm the slot of step s + 2
-        X::st(hs_ptr[q], hn0, hn1);
+        pub32(xg + q * SETB + (s & 3) * SLOT + xoff, pay_word(hprev[q][0], hprev[q][1]), plain);
+        pub32(xg + q * SETB + ((s + 2) & 3) * SLOT + xoff, XSENT2, plain);     // re-arm the slot of step s + 2
+        if (!(dbgmask & 2)) {
+          X::st(hs_ptr[q], hn0, hn1);
 #pragma unroll
-        for (int m = 0; m < NS; ++m) X::st(sv_ptr[q] + (long)m * H, pl[m][0], pl[m][1]);
+          for (int m = 0; m < NS; ++m) X::st(sv_ptr[q] + (long)m * H, pl[m][0], pl[m][1]);
+        }
       }
       if (NS) sv_ptr[q] += sv_stride;
       hs_ptr[q] += hs_stride;
+      DS2_PROBE_ONLY(const unsigned long long t3 = __builtin_readcyclecounter(); c_gather += t1 - t0; c_bar += t2 - t1; c_gate += t3 - t2;)
     }
   }
+#ifdef DS2_PROBE
+  if (ra.dbg && p == 0 && (tid == 0 || tid == 255)) {
+    const int o = grp * 8 + (tid == 0 ? 0 : 4);
+    ra.dbg[o + 0] = c_gather;
+    ra.dbg[o + 1] = c_bar;
+    ra.dbg[o + 2] = c_gate;
+    ra.dbg[o + 3] = rounds;
+  }
+#endif
+  (void)rounds;
 #pragma unroll
   for (int q = 0; q < NSET; ++q) {
     if (on[q]) {
@@ -539,7 +568,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_bwd(RArgs ra) {
     r.dout = r.hp = r.cp = 0u;
 #pragma unroll
     for (int m = 0; m < M; ++m) r.sp[m] = 0u;
-    if (on[q]) {
+    if (on[q] && !(DS2_DBG(ra, 1))) {
       const int t = tnext[q];
       r.dout = X::ld(do_ptr[q]);
 #pragma unroll
@@ -557,12 +586,19 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_bwd(RArgs ra) {
     tnext[q] += (int)dstep;
   };
   Pre pn;
+  unsigned rounds = 0;
+  DS2_PROBE_ONLY(unsigned long long c_gather = 0, c_bar = 0, c_gate = 0; const int dbgmask = ra.dbgmask;)
+#ifndef DS2_PROBE
+  constexpr int dbgmask = 0;
+#endif
+  const bool plain = local || (dbgmask & 64);
   prefetch(pn, 0);
   int hstep = 0;
   for (int s = 0; s < Tp; ++s) {
     const int t = d == 0 ? Tp - 1 - s : s;
 #pragma unroll
     for (int q = 0; q < NSET; ++q, ++hstep) {
+      DS2_PROBE_ONLY(const unsigned long long t0 = __builtin_readcyclecounter();)
       const Pre pc = pn;
       {
         const int qn = q + 1 < NSET ? q + 1 : 0;
@@ -572,13 +608,15 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_bwd(RArgs ra) {
       ds2_f32x4 acc[RT];
 #pragma unroll
       for (int tt = 0; tt < RT; ++tt) acc[tt] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
-      if (s > 0)
+      if (s > 0 && !(dbgmask & 8))
         gather_mma3<RT, KSW, KR, SP, RAGGED>(acc, w, wl_lane, rsrc, q * SETB + ((s + 3) & 3) * SLOT + gbase, gneed[q], ks0, cnt, gpart,
-                                             a.err, a.lerr, dead);
+                                             a.err, a.lerr, dead, rounds, dbgmask);
+      DS2_PROBE_ONLY(const unsigned long long t1 = __builtin_readcyclecounter();)
       float* pp = part + (PB == 2 ? (hstep & 1) * PART_FLOATS : 0);
       if (PB == 1) __syncthreads();
       store_partials3<RT>(pp, acc, wave, lane);
       __syncthreads();
+      DS2_PROBE_ONLY(const unsigned long long t2 = __builtin_readcyclecounter();)
       if (on[q]) {
         const bool act = t < len[q];
         const float2 mp = load_partials3<RT>(pp, jl >> 4, grow, jl & 15);
@@ -640,15 +678,17 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_bwd(RArgs ra) {
         for (int g = 0; g < G; ++g) pk[g] = cvt_pk_bf16(gx[g][0], gx[g][1]);
         const uint32_t pkn = cvt_pk_bf16(gn[0], gn[1]);
 #pragma unroll
-        for (int g = 0; g < G; ++g) pub32(xo + g * GATEB, pk[g] == XSENT2 ? 0x7fc07fc0u : pk[g], local);
+        for (int g = 0; g < G; ++g) pub32(xo + g * GATEB, pk[g] == XSENT2 ? 0x7fc07fc0u : pk[g], plain);
 #pragma unroll
-        for (int g = 0; g < G; ++g) pub32(xr + g * GATEB, XSENT2, local);
+        for (int g = 0; g < G; ++g) pub32(xr + g * GATEB, XSENT2, plain);
         // stored planes: the values as exchanged (GRU: dGI = [dr, dz, dn], dQ apart), bias sums from the ROUNDED values
         if (CELL == CELL_GRU) {
-          *reinterpret_cast<uint32_t*>(dgi) = pk[0];
-          *reinterpret_cast<uint32_t*>(dgi + H) = pk[1 % G];
-          *reinterpret_cast<uint32_t*>(dgi + 2 * H) = pkn;
-          *reinterpret_cast<uint32_t*>(dgh_ptr[q]) = pk[2 % G];
+          if (!(dbgmask & 2)) {
+            *reinterpret_cast<uint32_t*>(dgi) = pk[0];
+            *reinterpret_cast<uint32_t*>(dgi + H) = pk[1 % G];
+            *reinterpret_cast<uint32_t*>(dgi + 2 * H) = pkn;
+            *reinterpret_cast<uint32_t*>(dgh_ptr[q]) = pk[2 % G];
+          }
           bsum[q][0][0] += bf_lo(pk[0]); bsum[q][0][1] += bf_hi(pk[0]);
           bsum[q][1 % NB][0] += bf_lo(pk[1 % G]); bsum[q][1 % NB][1] += bf_hi(pk[1 % G]);
           bsum[q][2 % NB][0] += bf_lo(pkn); bsum[q][2 % NB][1] += bf_hi(pkn);
@@ -656,7 +696,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_bwd(RArgs ra) {
         } else {
 #pragma unroll
           for (int g = 0; g < G; ++g) {
-            *reinterpret_cast<uint32_t*>(dgi + (long)g * H) = pk[g];
+            if (!(dbgmask & 2)) *reinterpret_cast<uint32_t*>(dgi + (long)g * H) = pk[g];
             bsum[q][g % NB][0] += bf_lo(pk[g]);
             bsum[q][g % NB][1] += bf_hi(pk[g]);
           }
@@ -664,8 +704,19 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_bwd(RArgs ra) {
       }
       dgi_ptr[q] += dstep * N * ldgi;
       if (CELL == CELL_GRU) dgh_ptr[q] += dstep * N * H;
+      DS2_PROBE_ONLY(const unsigned long long t3 = __builtin_readcyclecounter(); c_gather += t1 - t0; c_bar += t2 - t1; c_gate += t3 - t2;)
     }
   }
+#ifdef DS2_PROBE
+  if (ra.dbg && p == 0 && (tid == 0 || tid == 255)) {
+    const int o = grp * 8 + (tid == 0 ? 0 : 4);
+    ra.dbg[o + 0] = c_gather;
+    ra.dbg[o + 1] = c_bar;
+    ra.dbg[o + 2] = c_gate;
+    ra.dbg[o + 3] = rounds;
+  }
+#endif
+  (void)rounds;
   if (a.dBacc) {
 #pragma unroll
     for (int q = 0; q < NSET; ++q) {

@@ -1,12 +1,13 @@
 #!/bin/bash
 # A short GPU-box session: selected tests (pytest -k expression / files in $TESTS), then quick bench lines.
 #   gpurun --timeout 900 -- 'TESTS="tests/test_gpu_loop.py" CONFIGS="cfg5a cfg5b" bash tools/gpu_session.sh <tag>'
-#   env: TESTS (pytest args, default none), CONFIGS (bench configs, default none), STEPS (default 6), BENCH_ARGS, EXTRA (command run last)
+#   env: TESTS (pytest args, default none; or TESTS_FILE = a file holding them, for -k expressions with quotes), CONFIGS (bench configs, default none), STEPS (default 6), BENCH_ARGS, EXTRA (command run last)
 tag=${1:-s}
 out=gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
+if [ -n "$TESTS_FILE" ]; then TESTS=$(cat $TESTS_FILE); fi
 if [ -n "$TESTS" ]; then
-  timeout ${TEST_TIMEOUT:-600} python -m pytest $TESTS -m gpu -q --maxfail=40 --tb=short -p no:cacheprovider > $out/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $out/pytest.log
+  eval timeout ${TEST_TIMEOUT:-600} python -m pytest $TESTS -m gpu -q --maxfail=40 --tb=short -p no:cacheprovider > $out/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $out/pytest.log
   grep -E "passed|failed|FAILED|Error" $out/pytest.log | tail -n 45
 fi
 for cfg in $CONFIGS; do
