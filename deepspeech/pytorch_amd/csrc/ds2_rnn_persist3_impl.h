@@ -8,9 +8,9 @@
 //     group (a third of the bytes); H <= 1024 -> P <= 32 and the groups are laid out INSIDE one XCD (8 x floor(32/P) groups,
 //     block b -> XCD b % 8): publishes are plain stores that stay in that XCD's L2 (905 instead of 2 236 cycles per bare exchange
 //     step, profiles/r03k_exchange.txt) -- checked at start-up by the XCC-id handshake, correct under any placement;
-//   * the W_hh slice of 32 units x G gates (LSTM-1280: 327 KB) no longer fits the register file beside the accumulators: the last
-//     KL k-steps of every wave's K-quarter live in LDS as ready-made MFMA B fragments (one conflict-free ds_read_b128 per
-//     fragment), the first KR in registers (plan3: <= 224 weight registers per lane, LDS <= 156 KB incl. the partial sums);
+//   * the W_hh slice of 32 units x G gates (LSTM-1280: 327 KB) no longer fits the register file beside the accumulators: part of
+//     every wave's B fragments lives in LDS, ready-made (one conflict-free ds_read_b128 per fragment, read a k-step or three ahead
+//     of its MFMA), the rest in registers (plan3: <= 224-256 weight registers per lane, LDS <= 156 KB incl. the partial sums);
 //   * a group's samples are cut into NSET interleaved SETS of <= 16 (one MFMA m-tile each).  Samples are independent recurrences,
 //     so a time step is NSET half-steps, each with its own four exchange slots: while set A's hand-off is in flight the
 //     workgroup multiplies set B -- the exchange latency (the floor of a persistent sweep) hides behind the other set's work,
@@ -42,25 +42,65 @@ struct RArgs {
 #endif
 };
 
+// Which B fragments of a wave's K-quarter (RT tiles x KSW k-steps) live in LDS instead of registers.  Forward kernels (RT = 2G
+// tiles per k-step): the tiles t >= TR of EVERY k-step, so that each k-step's few LDS reads hide under the register tiles' MFMAs.
+// BPTT kernels (RT = 2): whole k-steps, spread evenly: k-step k is LDS-resident iff bit (k % 10) of kmask is set.  PB = partial-sum
+// buffers (2: one barrier per half-step; 1: a second barrier in front of the stores, when LDS is short).
 struct Plan3 {
-  int KR, PB;
+  int TR;
+  unsigned kmask;
+  int PB, nlds;      // nlds = LDS-resident fragments per wave
   bool ok;
 };
-// KR = k-steps of a wave's K-quarter whose B fragments stay in registers (the other KSW - KR live in LDS), PB = partial-sum
-// buffers (2: one barrier per half-step; 1: a second barrier before the stores, when LDS is short).
+// (scalar arguments: device code must not odr-use a constexpr Plan3 object)
+constexpr bool in_lds3(int TR, unsigned kmask, int t, int k) { return t >= TR || ((kmask >> (k % 10)) & 1u); }
+constexpr int count_lds3(int TR, unsigned kmask, int RT, int KSW) {
+  int n = 0;
+  for (int k = 0; k < KSW; ++k)
+    for (int t = 0; t < RT; ++t) n += in_lds3(TR, kmask, t, k) ? 1 : 0;
+  return n;
+}
+// index of fragment (t, k) among the LDS-resident ones, k-major: closed form (LDS k-steps before k, LDS tiles per other k-step)
+constexpr int lds_index3(int TR, unsigned kmask, int RT, int t, int k) {
+  int kl = 0;                                   // whole-LDS k-steps before k
+  for (int kk = 0; kk < k; ++kk) kl += ((kmask >> (kk % 10)) & 1u) ? 1 : 0;
+  const int before = kl * RT + (k - kl) * (RT - TR);
+  return before + (((kmask >> (k % 10)) & 1u) ? t : t - TR);
+}
+constexpr int PT3_COL = 20, PT3_TILE = 16 * PT3_COL;     // partial-sum tiles stored [col][row], column stride 20 floats (conflict-free)
+constexpr int part_bytes3(int RT, int PB) { return PB * 4 * RT * PT3_TILE * 4; }
+constexpr int FR_MAX3 = 56, FR_CAP3 = 64, LDS_MAX3 = 156 * 1024;
 constexpr Plan3 plan3(int RT, int KSW) {
-  const int krmax = 56 / RT;                         // <= 224 weight registers per lane
-  for (int pb = 2; pb >= 1; --pb) {
-    const int part_kb = pb * 4 * RT;
-    const int max_kl = (156 - part_kb) / (RT * 4);
-    const int kr = KSW < krmax ? KSW : krmax;
-    if (KSW - kr <= max_kl) return Plan3{kr, pb, true};
+  const int F = RT * KSW;
+  if (F <= FR_MAX3) {
+    Plan3 pl{RT, 0u, 2, 0, part_bytes3(RT, 2) <= LDS_MAX3};
+    return pl;
   }
-  return Plan3{0, 0, false};
+  if (RT >= 4) {
+    const int tr0 = FR_MAX3 / KSW > 0 ? FR_MAX3 / KSW : 1;
+    for (int tr = tr0; tr <= RT && tr * KSW <= FR_CAP3; ++tr)
+      for (int pb = 2; pb >= 1; --pb) {
+        Plan3 pl{tr, 0u, pb, (RT - tr) * KSW, true};
+        if (pl.nlds * 4096 + part_bytes3(RT, pb) <= LDS_MAX3) return pl;
+      }
+    return Plan3{0, 0u, 0, 0, false};
+  }
+  for (int n10 = 1; n10 <= 9; ++n10) {          // n10 of every 10 k-steps in LDS, evenly spread
+    unsigned m = 0;
+    for (int i = 0; i < n10; ++i) m |= 1u << ((i * 10 + 5) / n10);
+    Plan3 pl{RT, m, 2, 0, true};
+    pl.nlds = count_lds3(RT, m, RT, KSW);
+    if (F - pl.nlds > FR_CAP3 - 4) continue;
+    for (int pb = 2; pb >= 1; --pb) {
+      pl.PB = pb;
+      if (pl.nlds * 4096 + part_bytes3(RT, pb) <= LDS_MAX3) return pl;
+    }
+  }
+  return Plan3{0, 0u, 0, 0, false};
 }
 constexpr int lds_bytes3(int RT, int KSW) {
   const Plan3 pl = plan3(RT, KSW);
-  return (KSW - pl.KR) * RT * 4096 + pl.PB * 4 * RT * 1024;
+  return pl.nlds * 4096 + part_bytes3(RT, pl.PB);
 }
 
 // XCC-id handshake of ds2_rnn_persist_impl.h for groups of P <= 32 workgroups
@@ -105,98 +145,150 @@ __device__ __forceinline__ uint32_t pay_word(float a, float b) {
   return pk == XSENT2 ? 0x7fc07fc0u : pk;
 }
 
-constexpr int chunk3(int KSW, int SP) { return KSW <= 12 ? (KSW + SP - 1) / SP * SP : 8; }
+// k-steps per gather chunk: two chunks per K-quarter up to 16 k-steps (the products of the first overlap the arrival of the
+// second), chunks of 8 beyond (BPTT: K = G*H)
+constexpr int chunk3(int KSW, int SP) { return KSW <= 16 ? ((KSW + 1) / 2 + SP - 1) / SP * SP : 8; }
 
-// One half-step's gather + products: acc[t] += A(16 sample rows x this wave's K-quarter) * W[t](16 rows x K-quarter)^T.
-// `base` = byte offset of (set, slot) + lq * 256 + sample row * 16 inside the group's buffer; k-step k adds k * 1024.  Lanes whose
-// row carries no sample (or whose k-step lies beyond the wave's ragged share) load from beyond the resource: zeros, no branch.
-// SP == 2 (at most 8 rows in the set): lane (part, row) = (li >> 3, li & 7) loads the k-steps part, part + 2, ... of a chunk and the
-// fragment of an odd k-step is rotated into place (DPP row rotate by 8): half the load instructions per lane.
-template <int RT, int KSW, int KR, int SP, bool RAGGED>
-__device__ __forceinline__ void gather_mma3(ds2_f32x4 (&acc)[RT], const uint4 (&w)[RT][KR > 0 ? KR : 1], const uint4* wl_lane,
-                                            __amdgpu_buffer_rsrc_t rsrc, int base, bool need, int ks0, int cnt, int part, int* err,
-                                            int* lerr, bool& dead, unsigned& rounds, int dbgmask = 0) {
-  constexpr int CH = chunk3(KSW, SP);
-  constexpr int PER = CH / SP;
-  constexpr int NCH = (KSW + CH - 1) / CH;
-  constexpr int NB = NCH > 1 ? 2 : 1;
-  static_assert(CH % SP == 0, "chunk tiles into lane parts");
-  u32x4_t v[NB][PER];
-#define DS2R_LOAD(c, b)                                                                                                  \
-  _Pragma("unroll") for (int i = 0; i < PER; ++i) {                                                                     \
-    const int k_ = (c) * CH + part + SP * i;                                                                             \
-    const bool ok_ = need && k_ < KSW && (!RAGGED || k_ < cnt);                                                          \
-    v[b][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok_ ? base + (ks0 + k_) * 1024 : XOOB, 0, 16 /* sc1 */);       \
-  }
-#define DS2R_CHECK(b, bad)                                                                                               \
-  bool bad;                                                                                                              \
-  {                                                                                                                      \
-    uint32_t mx = 0;                                                                                                     \
-    _Pragma("unroll") for (int i = 0; i < PER; ++i) mx = max(max(mx, max(v[b][i][0], v[b][i][1])), max(v[b][i][2], v[b][i][3])); \
-    bad = mx == XSENT2;                                                                                                  \
-  }
-  DS2R_LOAD(0, 0)
+// The gather of one wave: a stream of chunks (CH k-steps = CH / SP 16-byte loads per lane) through TWO register buffers.  The kernel
+// keeps two chunks in flight: after the products of a chunk its buffer is refilled with the chunk two ahead -- of the same
+// half-step or, with two interleaved sample sets, of the NEXT half-step (the other set's vector was published a half-step ago), so
+// the fabric round trip of the exchange overlaps this half-step's products, barrier and gate phase instead of preceding them.
+//   issue(b, c, base...)  loads chunk c (k-steps c*CH ..) of the slot at byte offset `base` (= set + slot + lq*256 + row*16; k-step k
+//                         adds k*1024) into buffer b.  Lanes without a sample row / beyond the wave's ragged share load from
+//                         beyond the resource: zeros, no branch.  SP == 2 (<= 8 rows): lane (part, row) = (li >> 3, li & 7) loads
+//                         the k-steps part, part + 2, ...; the fragment of an odd k-step is rotated into place before its MFMA;
+//   bad(b)                some lane of the chunk still holds the all-ones "not published yet" dword;
+//   lds_prefetch(c)       starts the LDS reads of the chunk's first LA k-steps (independent of the gather: issued before the check);
+//   mma(b, c, ...)        acc[t] += A(chunk) * W[t](chunk)^T, register-resident fragments from w, LDS-resident ones through a ring
+//                         of LA + 1 k-steps of staging registers (read LA k-steps ahead of their MFMAs).
+template <int RT, int KSW, int SP, bool RAGGED, bool BWD>
+struct Gather3 {
+  static constexpr int TR = plan3(RT, KSW).TR, NLDS = plan3(RT, KSW).nlds;
+  static constexpr unsigned KM = plan3(RT, KSW).kmask;
+  static constexpr int CH = chunk3(KSW, SP), PER = CH / SP, NCH = (KSW + CH - 1) / CH;
+  static constexpr int LA = BWD ? 3 : 1;
+  static constexpr int TL = NLDS == 0 ? 1 : (BWD ? RT : (RT - TR > 0 ? RT - TR : 1));   // LDS fragments of one k-step, at most
+  static_assert(CH % SP == 0 && NCH >= 2, "two chunks at least, tiling into lane parts");
+  u32x4_t v[2][PER];
+  uint4 st[LA + 1][TL];
+
+  __device__ __forceinline__ void issue(int b, int c, __amdgpu_buffer_rsrc_t rsrc, int base, bool need, int ks0, int cnt, int part) {
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    const int b = NB > 1 ? (c & 1) : 0;
-    if (c + 1 < NCH) { DS2R_LOAD(c + 1, (NB > 1 ? (b ^ 1) : 0)) }
-    DS2R_CHECK(b, bad0)
-    if (__any(bad0) && !dead) {        // a sentinel in the chunk: poll it (bounded) before its products
-      unsigned spins = 0;
-      for (;;) {
-        __builtin_amdgcn_s_sleep(1);
-        ++rounds;
-        DS2R_LOAD(c, b)
-        DS2R_CHECK(b, bad1)
-        if (!__any(bad1)) break;
-        if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && spin_check(lerr, spins))) {
-          dead = true;
-          raise_err(err, lerr);
-          break;
-        }
-      }
+    for (int i = 0; i < PER; ++i) {
+      const int k_ = c * CH + part + SP * i;
+      const bool ok_ = need && k_ < KSW && (!RAGGED || k_ < cnt);
+      v[b][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok_ ? base + (ks0 + k_) * 1024 : XOOB, 0, 16 /* sc1 */);
     }
+  }
+  __device__ __forceinline__ bool bad(int b) const {
+    uint32_t mx = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) mx = max(max(mx, max(v[b][i][0], v[b][i][1])), max(v[b][i][2], v[b][i][3]));
+    return mx == XSENT2;
+  }
+  __device__ __forceinline__ void lds_kstep(int slot, int k_, const uint4* wl_lane) {
+    if (NLDS > 0 && k_ < KSW) {
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+        if (in_lds3(TR, KM, t, k_)) st[slot][((KM >> (k_ % 10)) & 1u) ? t : t - TR] = wl_lane[lds_index3(TR, KM, RT, t, k_) * 256];
+    }
+  }
+  __device__ __forceinline__ void lds_prefetch(int c, const uint4* wl_lane) {
+#pragma unroll
+    for (int kk = 0; kk < LA; ++kk)
+      if (kk < CH) lds_kstep(kk % (LA + 1), c * CH + kk, wl_lane);
+  }
+  __device__ __forceinline__ void mma(int b, int c, ds2_f32x4 (&acc)[RT], const uint4 (&w)[RT][KSW], const uint4* wl_lane, int dbgmask) {
 #pragma unroll
     for (int kk = 0; kk < CH; ++kk) {
       const int k_ = c * CH + kk;                    // compile-time after unrolling
-      if (k_ < KSW && !(dbgmask & 128) && !((dbgmask & 32) && k_ >= KR)) {
+      if (kk + LA < CH) lds_kstep((kk + LA) % (LA + 1), k_ + LA, wl_lane);
+      if (k_ < KSW && !(dbgmask & 128)) {
         const int i = kk / SP;
         uint4 a_ = make_uint4(v[b][i][0], v[b][i][1], v[b][i][2], v[b][i][3]);
         if (SP == 2 && (kk & 1)) a_ = row_from_plus4(a_, 8);
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
-          if (k_ < KR) {
-            Mma<bf16_t>::mma16(acc[t], a_, w[t][k_ < KR ? k_ : 0]);
+          if (in_lds3(TR, KM, t, k_)) {
+            const uint4 wv = st[kk % (LA + 1)][((KM >> (k_ % 10)) & 1u) ? t : t - TR];
+            if (!(dbgmask & 32)) Mma<bf16_t>::mma16(acc[t], a_, wv);
           } else {
-            const uint4 wv = wl_lane[((k_ - KR) * RT + t) * 256];
-            Mma<bf16_t>::mma16(acc[t], a_, wv);
+            Mma<bf16_t>::mma16(acc[t], a_, w[t][k_]);
           }
         }
       }
     }
   }
-#undef DS2R_LOAD
-#undef DS2R_CHECK
-}
+};
 
+// partial sums of the 4 K-quarters: tile t of wave w at part + (w*RT + t)*PT3_TILE, stored [col][row] with a 20-float column
+// stride: the four rows a lane holds of an accumulator are ONE conflict-free 16-byte store
 template <int RT>
 __device__ __forceinline__ void store_partials3(float* part, const ds2_f32x4 (&acc)[RT], int wave, int lane) {
 #pragma unroll
   for (int t = 0; t < RT; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) part[((wave * RT + t) * 16 + mma16_row(r, lane)) * 16 + (lane & 15)] = acc[t][r];
+    *reinterpret_cast<ds2_f32x4*>(part + (wave * RT + t) * PT3_TILE + (lane & 15) * PT3_COL + 4 * (lane >> 4)) = acc[t];
 }
+// sum over the 4 waves of the columns (col, col + 1) of row `row` of tile t
 template <int RT>
 __device__ __forceinline__ float2 load_partials3(const float* part, int t, int row, int col) {
-  float2 s = make_float2(0.f, 0.f);
-#pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    const float2 v = *reinterpret_cast<const float2*>(part + ((w * RT + t) * 16 + row) * 16 + col);
-    s.x += v.x;
-    s.y += v.y;
-  }
+  const float* p0 = part + t * PT3_TILE + col * PT3_COL + row;
+  float2 s;
+  s.x = (p0[0] + p0[RT * PT3_TILE]) + (p0[2 * RT * PT3_TILE] + p0[3 * RT * PT3_TILE]);
+  s.y = (p0[PT3_COL] + p0[RT * PT3_TILE + PT3_COL]) + (p0[2 * RT * PT3_TILE + PT3_COL] + p0[3 * RT * PT3_TILE + PT3_COL]);
   return s;
 }
+
+// The gather phase of half-step (s, q) -- shared by the forward and the BPTT kernel (local names: gx, acc, w, wl_lane, rsrc, gbase,
+// gneed, ks0, cnt, gpart, dead, rounds, dbgmask).  HAS0: the exchanged vector exists at step 0 (forward with an initial state).
+// NSET == 2: the chunks of this half-step were issued during the previous one; after its products every buffer is refilled with the
+// chunk two ahead, which for the last two chunks belongs to the NEXT half-step (the other set, published a half-step ago).
+#define DS2R_BASE(S_, Q_) ((Q_) * SETB + (((S_) + 3) & 3) * SLOT + gbase)
+#define DS2R_GATHER_PHASE(HAS0)                                                                        \
+  {                                                                                                     \
+    constexpr int NCH_ = GX::NCH;                                                                       \
+    constexpr bool PIPE_ = NSET == 2;                                                                   \
+    const bool have_ = (s > 0 || (HAS0)) && !(dbgmask & 8);                                             \
+    if (have_) {                                                                                        \
+      if (!PIPE_) {                                                                                     \
+        gx.issue(0, 0, rsrc, DS2R_BASE(s, q), gneed[q], ks0, cnt, gpart);                               \
+        gx.issue(1, 1, rsrc, DS2R_BASE(s, q), gneed[q], ks0, cnt, gpart);                               \
+      }                                                                                                 \
+      _Pragma("unroll") for (int c = 0; c < NCH_; ++c) {                                                \
+        const int b = PIPE_ ? ((q * NCH_ + c) & 1) : (c & 1);                                           \
+        gx.lds_prefetch(c, wl_lane);                                                                    \
+        if (__any(gx.bad(b)) && !dead) { /* a sentinel in the chunk: poll it (bounded) before its products */ \
+          unsigned spins = 0;                                                                           \
+          for (;;) {                                                                                    \
+            __builtin_amdgcn_s_sleep(1);                                                                \
+            ++rounds;                                                                                   \
+            gx.issue(b, c, rsrc, DS2R_BASE(s, q), gneed[q], ks0, cnt, gpart);                           \
+            if (!__any(gx.bad(b))) break;                                                               \
+            if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && spin_check(a.lerr, spins))) {          \
+              dead = true;                                                                              \
+              raise_err(a.err, a.lerr);                                                                 \
+              break;                                                                                    \
+            }                                                                                           \
+          }                                                                                             \
+        }                                                                                               \
+        gx.mma(b, c, acc, w, wl_lane, dbgmask);                                                         \
+        const int c2 = c + 2;                                                                           \
+        if (PIPE_) {                                                                                    \
+          const int dh = c2 / NCH_, cc2 = c2 % NCH_;                                                    \
+          const int q2 = (q + dh) % NSET, s2 = s + (q + dh) / NSET;                                     \
+          if (s2 < Tp) gx.issue(b, cc2, rsrc, DS2R_BASE(s2, q2), gneed[q2], ks0, cnt, gpart);           \
+        } else if (c2 < NCH_) {                                                                         \
+          gx.issue(b, c2, rsrc, DS2R_BASE(s, q), gneed[q], ks0, cnt, gpart);                            \
+        }                                                                                               \
+      }                                                                                                 \
+    } else if (PIPE_ && !(dbgmask & 8)) { /* nothing to gather yet: start the next half-step's first two chunks if it has data */ \
+      const int q2 = (q + 1) % NSET, s2 = s + (q + 1) / NSET;                                           \
+      if (s2 < Tp && (s2 > 0 || (HAS0))) {                                                              \
+        gx.issue((q2 * NCH_) & 1, 0, rsrc, DS2R_BASE(s2, q2), gneed[q2], ks0, cnt, gpart);              \
+        gx.issue((q2 * NCH_ + 1) & 1, 1, rsrc, DS2R_BASE(s2, q2), gneed[q2], ks0, cnt, gpart);          \
+      }                                                                                                 \
+    }                                                                                                   \
+  }
 
 __device__ __forceinline__ void block_map3(const RArgs& ra, int& grp, int& p) {
   if (ra.xmap) {
@@ -221,14 +313,15 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_fwd(RArgs ra) {
   constexpr int KT = H / 32, KSW = (KT + 3) / 4;
   constexpr bool RAGGED = KT % 4 != 0;
   constexpr Plan3 PL = plan3(RT, KSW);
-  constexpr int KR = PL.KR, KL = KSW - KR, PB = PL.PB;
+  constexpr int PB = PL.PB, P_TR = PL.TR, P_NLDS = PL.nlds;
+  constexpr unsigned P_KM = PL.kmask;
   constexpr int SLOT = KT * 1024, SETB = 4 * SLOT;       // bytes of one slot / of one set's four slots
   static_assert(H % 32 == 0 && PL.ok, "unsupported hidden size");
   static_assert(SP == 1 || NSET == 1, "lane sharing is instantiated for single-set groups only");
   extern __shared__ __attribute__((aligned(16))) uint4 smem3[];
-  uint4* wl = smem3;                                                   // [KL][RT][4 waves][64 lanes]
-  float* part = reinterpret_cast<float*>(smem3 + KL * RT * 256);       // [PB][4][RT][256]
-  constexpr int PART_FLOATS = 4 * RT * 256;
+  uint4* wl = smem3;                                                   // [LDS-resident fragment][4 waves][64 lanes]
+  float* part = reinterpret_cast<float*>(smem3 + P_NLDS * 256);       // [PB][4 waves][RT tiles][PT3_TILE]
+  constexpr int PART_FLOATS = 4 * RT * PT3_TILE;
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int grp, p;
@@ -243,7 +336,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_fwd(RArgs ra) {
   const int ks0 = wave * KSW;
   const int cnt = RAGGED ? max(0, min(KSW, KT - ks0)) : KSW;
 
-  uint4 w[RT][KR > 0 ? KR : 1];
+  uint4 w[RT][KSW];            // only the register-resident fragments are ever touched (the others never become registers)
   {
     const bf16_t* Wd = (const bf16_t*)a.W + (long)d * GH * H;
 #pragma unroll
@@ -252,10 +345,10 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_fwd(RArgs ra) {
 #pragma unroll
       for (int k = 0; k < KSW; ++k) {
         const uint4 f = (!RAGGED || k < cnt) ? *reinterpret_cast<const uint4*>(row + (long)(ks0 + k) * 32) : make_uint4(0, 0, 0, 0);
-        if (k < KR)
-          w[t][k < KR ? k : 0] = f;
+        if (in_lds3(P_TR, P_KM, t, k))
+          wl[lds_index3(P_TR, P_KM, RT, t, k) * 256 + tid] = f;
         else
-          wl[((k - KR) * RT + t) * 256 + tid] = f;
+          w[t][k] = f;
       }
     }
   }
@@ -337,6 +430,12 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_fwd(RArgs ra) {
   constexpr int dbgmask = 0;
 #endif
   const bool plain = local || (dbgmask & 64);
+  typedef Gather3<RT, KSW, SP, RAGGED, false> GX;
+  GX gx;
+  if (NSET == 2 && a.h0 && !(dbgmask & 8)) {      // the first half-step's first two chunks (afterwards every half-step feeds the next)
+    gx.issue(0, 0, rsrc, DS2R_BASE(0, 0), gneed[0], ks0, cnt, gpart);
+    gx.issue(1, 1, rsrc, DS2R_BASE(0, 0), gneed[0], ks0, cnt, gpart);
+  }
   for (int s = 0; s < Tp; ++s) {
     const int t = d == 0 ? s : Tp - 1 - s;
 #pragma unroll
@@ -357,9 +456,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_fwd(RArgs ra) {
       ds2_f32x4 acc[RT];
 #pragma unroll
       for (int tt = 0; tt < RT; ++tt) acc[tt] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
-      if ((s > 0 || a.h0) && !(dbgmask & 8))
-        gather_mma3<RT, KSW, KR, SP, RAGGED>(acc, w, wl_lane, rsrc, q * SETB + ((s + 3) & 3) * SLOT + gbase, gneed[q], ks0, cnt, gpart,
-                                             a.err, a.lerr, dead, rounds, dbgmask);
+      DS2R_GATHER_PHASE(a.h0 != nullptr)
       DS2_PROBE_ONLY(const unsigned long long t1 = __builtin_readcyclecounter();)
       float* pp = part + (PB == 2 ? (hstep & 1) * PART_FLOATS : 0);
       if (PB == 1) __syncthreads();       // every wave is through with the previous half-step's partial sums
@@ -475,14 +572,15 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_bwd(RArgs ra) {
   constexpr int KTH = H / 32, KT = G * KTH, KSW = (KT + 3) / 4;
   constexpr bool RAGGED = KT % 4 != 0;
   constexpr Plan3 PL = plan3(RT, KSW);
-  constexpr int KR = PL.KR, KL = KSW - KR, PB = PL.PB;
+  constexpr int PB = PL.PB, P_TR = PL.TR, P_NLDS = PL.nlds;
+  constexpr unsigned P_KM = PL.kmask;
   constexpr int SLOT = KT * 1024, SETB = 4 * SLOT, GATEB = KTH * 1024;
   static_assert(H % 32 == 0 && PL.ok, "unsupported hidden size");
   static_assert(SP == 1 || NSET == 1, "lane sharing is instantiated for single-set groups only");
   extern __shared__ __attribute__((aligned(16))) uint4 smem3[];
   uint4* wl = smem3;
-  float* part = reinterpret_cast<float*>(smem3 + KL * RT * 256);
-  constexpr int PART_FLOATS = 4 * RT * 256;
+  float* part = reinterpret_cast<float*>(smem3 + P_NLDS * 256);
+  constexpr int PART_FLOATS = 4 * RT * PT3_TILE;
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int grp, p;
@@ -497,7 +595,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_bwd(RArgs ra) {
   const int ks0 = wave * KSW;
   const int cnt = RAGGED ? max(0, min(KSW, KT - ks0)) : KSW;
 
-  uint4 w[RT][KR > 0 ? KR : 1];
+  uint4 w[RT][KSW];            // only the register-resident fragments are ever touched (the others never become registers)
   {
     const bf16_t* WT = (const bf16_t*)a.W + (long)d * H * GH;
 #pragma unroll
@@ -506,10 +604,10 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_bwd(RArgs ra) {
 #pragma unroll
       for (int k = 0; k < KSW; ++k) {
         const uint4 f = (!RAGGED || k < cnt) ? *reinterpret_cast<const uint4*>(row + (long)(ks0 + k) * 32) : make_uint4(0, 0, 0, 0);
-        if (k < KR)
-          w[t][k < KR ? k : 0] = f;
+        if (in_lds3(P_TR, P_KM, t, k))
+          wl[lds_index3(P_TR, P_KM, RT, t, k) * 256 + tid] = f;
         else
-          wl[((k - KR) * RT + t) * 256 + tid] = f;
+          w[t][k] = f;
       }
     }
   }
@@ -592,6 +690,8 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_bwd(RArgs ra) {
   constexpr int dbgmask = 0;
 #endif
   const bool plain = local || (dbgmask & 64);
+  typedef Gather3<RT, KSW, SP, RAGGED, true> GX;
+  GX gx;
   prefetch(pn, 0);
   int hstep = 0;
   for (int s = 0; s < Tp; ++s) {
@@ -608,9 +708,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_bwd(RArgs ra) {
       ds2_f32x4 acc[RT];
 #pragma unroll
       for (int tt = 0; tt < RT; ++tt) acc[tt] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
-      if (s > 0 && !(dbgmask & 8))
-        gather_mma3<RT, KSW, KR, SP, RAGGED>(acc, w, wl_lane, rsrc, q * SETB + ((s + 3) & 3) * SLOT + gbase, gneed[q], ks0, cnt, gpart,
-                                             a.err, a.lerr, dead, rounds, dbgmask);
+      DS2R_GATHER_PHASE(false)
       DS2_PROBE_ONLY(const unsigned long long t1 = __builtin_readcyclecounter();)
       float* pp = part + (PB == 2 ? (hstep & 1) * PART_FLOATS : 0);
       if (PB == 1) __syncthreads();
