@@ -46,6 +46,14 @@ struct RArgs {
 // tiles per k-step): the tiles t >= TR of EVERY k-step, so that each k-step's few LDS reads hide under the register tiles' MFMAs.
 // BPTT kernels (RT = 2): whole k-steps, spread evenly: k-step k is LDS-resident iff bit (k % 10) of kmask is set.  PB = partial-sum
 // buffers (2: one barrier per half-step; 1: a second barrier in front of the stores, when LDS is short).
+// Compile-time ablations for tools/ab_variants.py (-DDS2R_VAR=<bits>, timing only -- results are wrong): the DS2_PERSIST_DBG bits of
+// the probe build (1 no prefetch loads of the gate operands, 2 no output stores, 8 no gather and no products, 32 no products with the
+// LDS-resident fragments, 128 gather but no products) plus 256 no gate math (every frame treated as inactive) and 512 no gather loads
+// (products on zeros) -- without the probe build's counters and run-time branches, i.e. in the shipping kernels' own schedule.
+#ifndef DS2R_VAR
+#define DS2R_VAR 0
+#endif
+
 struct Plan3 {
   int TR;
   unsigned kmask;
@@ -177,7 +185,10 @@ struct Gather3 {
     for (int i = 0; i < PER; ++i) {
       const int k_ = c * CH + part + SP * i;
       const bool ok_ = need && k_ < KSW && (!RAGGED || k_ < cnt);
-      v[b][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok_ ? base + (ks0 + k_) * 1024 : XOOB, 0, 16 /* sc1 */);
+      if (DS2R_VAR & 512)
+        v[b][i] = u32x4_t{0u, 0u, 0u, 0u};
+      else
+        v[b][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok_ ? base + (ks0 + k_) * 1024 : XOOB, 0, 16 /* sc1 */);
     }
   }
   __device__ __forceinline__ bool bad(int b) const {
@@ -427,7 +438,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_fwd(RArgs ra) {
   unsigned rounds = 0;
   DS2_PROBE_ONLY(unsigned long long c_gather = 0, c_bar = 0, c_gate = 0; const int dbgmask = ra.dbgmask;)
 #ifndef DS2_PROBE
-  constexpr int dbgmask = 0;
+  constexpr int dbgmask = DS2R_VAR;
 #endif
   const bool plain = local || (dbgmask & 64);
   typedef Gather3<RT, KSW, SP, RAGGED, false> GX;
@@ -464,7 +475,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_fwd(RArgs ra) {
       __syncthreads();
       DS2_PROBE_ONLY(const unsigned long long t2 = __builtin_readcyclecounter();)
       if (on[q]) {
-        const bool act = t < len[q];
+        const bool act = t < len[q] && !(dbgmask & 256);
         float hn0 = 0.f, hn1 = 0.f;       // emitted h_t (0 when inactive)
         float2 gh[G];
 #pragma unroll
@@ -658,6 +669,10 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_bwd(RArgs ra) {
   const bool local = ra.xmap ? group_is_xcd_local3(ra.xcc + grp * 32, p, ra.P, tid, a.err, a.lerr, dead) : false;
   __syncthreads();
 
+  DS2_PROBE_ONLY(const int dbgmask = ra.dbgmask;)
+#ifndef DS2_PROBE
+  constexpr int dbgmask = DS2R_VAR;
+#endif
   // gate-phase operands of a half-step, loaded one half-step ahead (raw pairs)
   struct Pre {
     uint32_t dout, sp[M], hp, cp;
@@ -666,7 +681,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_bwd(RArgs ra) {
     r.dout = r.hp = r.cp = 0u;
 #pragma unroll
     for (int m = 0; m < M; ++m) r.sp[m] = 0u;
-    if (on[q] && !(DS2_DBG(ra, 1))) {
+    if (on[q] && !(dbgmask & 1)) {
       const int t = tnext[q];
       r.dout = X::ld(do_ptr[q]);
 #pragma unroll
@@ -685,10 +700,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_bwd(RArgs ra) {
   };
   Pre pn;
   unsigned rounds = 0;
-  DS2_PROBE_ONLY(unsigned long long c_gather = 0, c_bar = 0, c_gate = 0; const int dbgmask = ra.dbgmask;)
-#ifndef DS2_PROBE
-  constexpr int dbgmask = 0;
-#endif
+  DS2_PROBE_ONLY(unsigned long long c_gather = 0, c_bar = 0, c_gate = 0;)
   const bool plain = local || (dbgmask & 64);
   typedef Gather3<RT, KSW, SP, RAGGED, true> GX;
   GX gx;
@@ -716,7 +728,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_bwd(RArgs ra) {
       __syncthreads();
       DS2_PROBE_ONLY(const unsigned long long t2 = __builtin_readcyclecounter();)
       if (on[q]) {
-        const bool act = t < len[q];
+        const bool act = t < len[q] && !(dbgmask & 256);
         const float2 mp = load_partials3<RT>(pp, jl >> 4, grow, jl & 15);
         const float din0 = car[q][0] + mp.x, din1 = car[q][1] + mp.y;
         char* xo = xg + q * SETB + (s & 3) * SLOT + xoff;

@@ -208,6 +208,11 @@ def wrap_data_parallel(step_module, device, world, bucket_cap_mb=64, overlap=Non
     parameter; 64 MB buckets ~ one recurrent layer each), OverlappedDataParallel with overlap=True / DS2_OVERLAP_ALLREDUCE=1."""
     if world == 1 and not (force_ddp() and dist.is_initialized()):
         return step_module
+    try:      # the drop-in class then builds one autograd node per layer for every shape (the reducer sees gradients progressively)
+        from . import model as _model
+        _model.PER_LAYER_NODES_FOR_DDP[0] = True
+    except Exception:  # noqa: BLE001  (stand-in modules in the CPU tests)
+        pass
     if overlap_allreduce() if overlap is None else overlap:
         return OverlappedDataParallel(step_module, world)
     ids = [device.index] if device.type == "cuda" else None

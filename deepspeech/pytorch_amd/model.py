@@ -85,8 +85,10 @@ WGRAD_BESIDE_DX = os.environ.get("DS2_WGRAD_BESIDE_DX", "0") not in ("", "0")
 WGRAD_WITH_DX = os.environ.get("DS2_WGRAD_WITH_DX", "1") not in ("", "0")
 
 # DS2_COMPOSITE_NODE=1: conv front-end + RNN stack as ONE autograd node (the round-1..3 graph, _FrontFn): the fp32 / small-shape
-# backward then keeps its weight-gradient GEMMs on the second stream until the end of the node.  Default: one node per layer.
-COMPOSITE_NODE = os.environ.get("DS2_COMPOSITE_NODE", "0") not in ("", "0")
+# backward then keeps its weight-gradient GEMMs on the second stream until the end of the node.  =0: one node per layer always.
+# Unset (default): one node per layer in the bf16 performance mode and under any data-parallel wrapper, the composite node otherwise.
+COMPOSITE_NODE = {"": None, "0": False}.get(os.environ.get("DS2_COMPOSITE_NODE", ""), True)     # None = decide per shape (see _logits)
+PER_LAYER_NODES_FOR_DDP = [False]     # set by dist.wrap_data_parallel: under a data-parallel wrapper every shape gets per-layer nodes
 
 N_FREQ_CONV2 = 41
 RNN_INPUT = 32 * N_FREQ_CONV2  # 1312, model.py:166-169
@@ -1079,7 +1081,18 @@ class DeepSpeech(_Base):
                 for suf in [""] + (["_reverse"] if self.bidirectional else []):
                     params += [getattr(p, "weight_ih_l0" + suf), getattr(p, "weight_hh_l0" + suf),
                                getattr(p, "bias_ih_l0" + suf), getattr(p, "bias_hh_l0" + suf)]
-            if COMPOSITE_NODE:
+            # bf16 performance mode: every layer's backward runs on the caller's stream (BPTT sweep, one launch with the weight
+            # gradients + dX), so one node per layer costs nothing and lets DDP's reducer overlap.  fp32 / small / odd shapes keep
+            # their weight-gradient GEMMs on the second stream under the next layer's sweep: there the composite node (one join at
+            # the end) is 1.1 ms faster on config 2 (12.4 vs 13.6 ms, profiles/r04a), and it is used unless a data-parallel
+            # wrapper is attached (DS2_COMPOSITE_NODE=0 forces one node per layer everywhere).
+            Hh = self._Hp
+            GH = ops.GATES[self._kind] * Hh
+            Dd = 2 if self.bidirectional else 1
+            fast_bwd = (ops.wgrad_tn_ok(dtype, Tp * N, Dd * GH, Hh, lda=Dd * GH, ldb=ops.pad_ld(Hh, dtype)) and
+                        ops.wgrad_tn_ok(dtype, Tp * N, GH, Hh, lda=Dd * GH, ldb=Hh))
+            composite = COMPOSITE_NODE if COMPOSITE_NODE is not None else (not fast_bwd and not PER_LAYER_NODES_FOR_DDP[0])
+            if composite:
                 res = _FrontFn.apply(x, self, lens_dev, N, Tp, dtype, training, L, sm[0].weight, sm[0].bias, sm[1].weight, sm[1].bias,
                                      sm[3].weight, sm[3].bias, sm[4].weight, sm[4].bias, *h0s, *c0s, *params)
                 X = res[0]

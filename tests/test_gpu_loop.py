@@ -151,7 +151,7 @@ def test_per_layer_nodes_equal_the_composite_node(name, precision):
     old = M.COMPOSITE_NODE
     try:
         for comp in (False, True):
-            M.COMPOSITE_NODE = comp
+            M.COMPOSITE_NODE = comp             # False: one node per layer; True: the composite node (None = per-shape default)
             res.append(_grads_of_step(build(fx, precision), batch, 1.0))
     finally:
         M.COMPOSITE_NODE = old

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--repeat", type=int, default=2)
+    ap.add_argument("--only", default="", help="comma-separated variant names to run (default: every library found); 'shipping' always runs")
     ap.add_argument("variants", nargs="*", help="name=flags (flags separated by spaces inside the quotes)")
     args = ap.parse_args()
     from deepspeech.pytorch_amd import build
@@ -36,13 +37,13 @@ def main():
     libs = [("shipping", os.path.join(PKG, "libds2hip.so"))]
     for f in sorted(glob.glob(os.path.join(PKG, "libds2hip_*.so"))):
         name = os.path.basename(f)[len("libds2hip_"):-3]
-        if name != "probe":
+        if name != "probe" and (not args.only or name in args.only.split(",")):
             libs.append((name, f))
     res = {n: [] for n, _ in libs}
     for rep in range(args.repeat):
         for name, lib in libs:
             r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_with_lib.py"), lib, "--config", args.config, "--steps",
-                                str(args.steps), "--warmup", str(args.warmup), "--no-cpu-baseline"], capture_output=True, text=True,
+                                str(args.steps), "--warmup", str(args.warmup), "--no-cpu-baseline", "--no-stock-baseline"], capture_output=True, text=True,
                                cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT))
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             if r.returncode != 0 or not line:
