@@ -148,6 +148,28 @@ __device__ __forceinline__ void pub32(char* p, uint32_t v, bool local) {
   else
     __hip_atomic_store((uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// The four lanes of a quad (tid & 3 = dw) hold four CONSECUTIVE dwords of a sample row -- in the exchange slot and in every stored
+// plane.  quad_gather() collects them on every lane (meaningful on the quad's lane 0), so that lane 0 issues ONE 16-byte store where
+// four lanes issued four 4-byte ones: a store instruction of 16 lanes x 16 B instead of 64 x 4 B (the scattered dword stores cost a
+// forward half-step 0.44 us, profiles/r04d_ablation_cfg5a.txt).  Must run with the whole quad active (outside exec-masked regions).
+__device__ __forceinline__ u32x4_t quad_gather(uint32_t v) {
+  u32x4_t r;
+  r[0] = v;
+  r[1] = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x55 /* quad_perm [1,1,1,1] */, 0xf, 0xf, true);
+  r[2] = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xAA /* quad_perm [2,2,2,2] */, 0xf, 0xf, true);
+  r[3] = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xFF /* quad_perm [3,3,3,3] */, 0xf, 0xf, true);
+  return r;
+}
+// 16-byte publish into the group's exchange buffer (byte offset `off` inside the resource): plain policy inside one XCD, write-through
+// (sc1) across XCDs.  Dwords are what the protocol looks at (sentinel or data), so a 16-byte store need not be atomic as a whole.
+__device__ __forceinline__ void pub128(__amdgpu_buffer_rsrc_t rsrc, int off, u32x4_t v, bool local) {
+  if (local)
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, off, 0, 0);
+  else
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, off, 0, 16 /* sc1 */);
+}
+__device__ __forceinline__ void st128(bf16_t* p, u32x4_t v) { *reinterpret_cast<u32x4_t*>(p) = v; }
+
 __device__ __forceinline__ uint32_t pay_word(float a, float b) {
   const uint32_t pk = cvt_pk_bf16(a, b);
   return pk == XSENT2 ? 0x7fc07fc0u : pk;
@@ -428,12 +450,19 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_fwd(RArgs ra) {
     }
   __syncthreads();      // the LDS-resident fragments are in place
 
-  // the input projection of a half-step is loaded ONE HALF-STEP AHEAD (vmcnt retires in order: a load that is still on its way
-  // from HBM when the gather's loads come back would hold the gather up)
-  uint32_t gin[G];
+  // The input projection of a set's step is loaded DEP steps of that set ahead, right BEHIND the gather phase of a half-step (vmcnt
+  // retires in order: these are HBM misses, and a gather issued behind one would wait for it; profiles/r04d_ablation_cfg5a.txt: with
+  // the loads one half-step ahead and in front of the gather they cost 0.7 us per forward and 1.7 us per BPTT time step).
+  constexpr int DEP = NSET == 1 ? 2 : 1;
+  uint32_t gir[NSET][DEP][G];
 #pragma unroll
-  for (int g = 0; g < G; ++g) gin[g] = on[0] ? X::ld(gi_ptr[0] + (long)g * H) : 0u;
-  gi_ptr[0] += gi_stride;
+  for (int q = 0; q < NSET; ++q)
+#pragma unroll
+    for (int i = 0; i < DEP; ++i) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) gir[q][i][g] = (on[q] && i < Tp) ? X::ld(gi_ptr[q] + (long)g * H) : 0u;
+      gi_ptr[q] += gi_stride;
+    }
   int hstep = 0;
   unsigned rounds = 0;
   DS2_PROBE_ONLY(unsigned long long c_gather = 0, c_bar = 0, c_gate = 0; const int dbgmask = ra.dbgmask;)
@@ -454,35 +483,36 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_fwd(RArgs ra) {
       DS2_PROBE_ONLY(const unsigned long long t0 = __builtin_readcyclecounter();)
       uint32_t gi[G];
 #pragma unroll
-      for (int g = 0; g < G; ++g) gi[g] = gin[g];
-      {
-        constexpr bool wrap = true;
-        const int qn = q + 1 < NSET ? q + 1 : 0;
-        const bool more = q + 1 < NSET || s + 1 < Tp;
-        (void)wrap;
-#pragma unroll
-        for (int g = 0; g < G; ++g) gin[g] = (more && on[qn] && !(dbgmask & 1)) ? X::ld(gi_ptr[qn] + (long)g * H) : 0u;
-        gi_ptr[qn] += gi_stride;
-      }
+      for (int g = 0; g < G; ++g) gi[g] = gir[q][0][g];
       ds2_f32x4 acc[RT];
 #pragma unroll
       for (int tt = 0; tt < RT; ++tt) acc[tt] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
       DS2R_GATHER_PHASE(a.h0 != nullptr)
+      {   // this set's input projection DEP steps ahead
+#pragma unroll
+        for (int i = 0; i + 1 < DEP; ++i)
+#pragma unroll
+          for (int g = 0; g < G; ++g) gir[q][i][g] = gir[q][i + 1][g];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+          gir[q][DEP - 1][g] = (on[q] && s + DEP < Tp && !(dbgmask & 1)) ? X::ld(gi_ptr[q] + (long)g * H) : 0u;
+        gi_ptr[q] += gi_stride;
+      }
       DS2_PROBE_ONLY(const unsigned long long t1 = __builtin_readcyclecounter();)
       float* pp = part + (PB == 2 ? (hstep & 1) * PART_FLOATS : 0);
       if (PB == 1) __syncthreads();       // every wave is through with the previous half-step's partial sums
       store_partials3<RT>(pp, acc, wave, lane);
       __syncthreads();
       DS2_PROBE_ONLY(const unsigned long long t2 = __builtin_readcyclecounter();)
+      float hn0 = 0.f, hn1 = 0.f;         // emitted h_t (0 when inactive)
+      float pl[M][2];
+#pragma unroll
+      for (int m = 0; m < M; ++m) pl[m][0] = pl[m][1] = 0.f;
       if (on[q]) {
         const bool act = t < len[q] && !(dbgmask & 256);
-        float hn0 = 0.f, hn1 = 0.f;       // emitted h_t (0 when inactive)
         float2 gh[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) gh[g] = load_partials3<RT>(pp, 2 * g + (jl >> 4), grow, jl & 15);
-        float pl[M][2];
-#pragma unroll
-        for (int m = 0; m < M; ++m) pl[m][0] = pl[m][1] = 0.f;
         if (CELL == CELL_GRU) {
           if (act) {
             const float q0 = gh[2 % G].x + bh[2 % G][0], q1 = gh[2 % G].y + bh[2 % G][1];
@@ -530,13 +560,23 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_fwd(RArgs ra) {
           }
         }
         if (dead) hn0 = hn1 = hprev[q][0] = hprev[q][1] = QNAN;   // fail loudly downstream
-        // publish the carried state first (inactive samples republish their unchanged state), then the bookkeeping stores
-        pub32(xg + q * SETB + (s & 3) * SLOT + xoff, pay_word(hprev[q][0], hprev[q][1]), plain);
-        pub32(xg + q * SETB + ((s + 2) & 3) * SLOT + xoff, XSENT2, plain);     // re-arm the slot of step s + 2
-        if (!(dbgmask & 2)) {
-          X::st(hs_ptr[q], hn0, hn1);
+      }
+      {
+        // the quad's four dwords meet on its lane 0 (all lanes active: rows are uniform within a quad), which publishes the carried
+        // state first (inactive samples republish their unchanged state), then re-arms and stores the bookkeeping planes
+        const u32x4_t pubv = quad_gather(pay_word(hprev[q][0], hprev[q][1]));
+        const u32x4_t hsv = quad_gather(cvt_pk_bf16(hn0, hn1));
+        u32x4_t plv[M];
 #pragma unroll
-          for (int m = 0; m < NS; ++m) X::st(sv_ptr[q] + (long)m * H, pl[m][0], pl[m][1]);
+        for (int m = 0; m < M; ++m) plv[m] = quad_gather(cvt_pk_bf16(pl[m][0], pl[m][1]));
+        if (on[q] && dw == 0) {
+          pub128(rsrc, q * SETB + (s & 3) * SLOT + xoff, pubv, plain);
+          pub128(rsrc, q * SETB + ((s + 2) & 3) * SLOT + xoff, u32x4_t{XSENT2, XSENT2, XSENT2, XSENT2}, plain);   // re-arm step s + 2's slot
+          if (!(dbgmask & 2)) {
+            st128(hs_ptr[q], hsv);
+#pragma unroll
+            for (int m = 0; m < NS; ++m) st128(sv_ptr[q] + (long)m * H, plv[m]);
+          }
         }
       }
       if (NS) sv_ptr[q] += sv_stride;
@@ -677,11 +717,11 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_bwd(RArgs ra) {
   struct Pre {
     uint32_t dout, sp[M], hp, cp;
   };
-  auto prefetch = [&](Pre& r, int q) {          // reads the set's pointers (they stand at tnext[q]) and advances them
+  auto prefetch = [&](Pre& r, int q, bool valid) {   // reads the set's pointers (they stand at tnext[q]) and advances them
     r.dout = r.hp = r.cp = 0u;
 #pragma unroll
     for (int m = 0; m < M; ++m) r.sp[m] = 0u;
-    if (on[q] && !(dbgmask & 1)) {
+    if (on[q] && valid && !(dbgmask & 1)) {
       const int t = tnext[q];
       r.dout = X::ld(do_ptr[q]);
 #pragma unroll
@@ -698,45 +738,45 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_bwd(RArgs ra) {
     hs_ptr[q] += dstep * N * H;
     tnext[q] += (int)dstep;
   };
-  Pre pn;
+  // ... DEP steps of the set ahead, right behind the gather phase (see the forward kernel)
+  constexpr int DEP = NSET == 1 ? 2 : 1;
+  Pre ring[NSET][DEP];
   unsigned rounds = 0;
   DS2_PROBE_ONLY(unsigned long long c_gather = 0, c_bar = 0, c_gate = 0;)
   const bool plain = local || (dbgmask & 64);
   typedef Gather3<RT, KSW, SP, RAGGED, true> GX;
   GX gx;
-  prefetch(pn, 0);
+#pragma unroll
+  for (int q = 0; q < NSET; ++q)
+#pragma unroll
+    for (int i = 0; i < DEP; ++i) prefetch(ring[q][i], q, i < Tp);
   int hstep = 0;
   for (int s = 0; s < Tp; ++s) {
     const int t = d == 0 ? Tp - 1 - s : s;
 #pragma unroll
     for (int q = 0; q < NSET; ++q, ++hstep) {
       DS2_PROBE_ONLY(const unsigned long long t0 = __builtin_readcyclecounter();)
-      const Pre pc = pn;
-      {
-        const int qn = q + 1 < NSET ? q + 1 : 0;
-        const bool more = q + 1 < NSET || s + 1 < Tp;
-        if (more) prefetch(pn, qn);
-      }
+      const Pre pc = ring[q][0];
       ds2_f32x4 acc[RT];
 #pragma unroll
       for (int tt = 0; tt < RT; ++tt) acc[tt] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
       DS2R_GATHER_PHASE(false)
+#pragma unroll
+      for (int i = 0; i + 1 < DEP; ++i) ring[q][i] = ring[q][i + 1];
+      prefetch(ring[q][DEP - 1], q, s + DEP < Tp);
       DS2_PROBE_ONLY(const unsigned long long t1 = __builtin_readcyclecounter();)
       float* pp = part + (PB == 2 ? (hstep & 1) * PART_FLOATS : 0);
       if (PB == 1) __syncthreads();
       store_partials3<RT>(pp, acc, wave, lane);
       __syncthreads();
       DS2_PROBE_ONLY(const unsigned long long t2 = __builtin_readcyclecounter();)
+      float gx[G][2], gn[2] = {0.f, 0.f};         // gx: the exchanged planes (GRU: dr, dz, dq), gn: GRU's dn (stored, not exchanged)
+#pragma unroll
+      for (int g = 0; g < G; ++g) gx[g][0] = gx[g][1] = 0.f;
       if (on[q]) {
         const bool act = t < len[q] && !(dbgmask & 256);
         const float2 mp = load_partials3<RT>(pp, jl >> 4, grow, jl & 15);
         const float din0 = car[q][0] + mp.x, din1 = car[q][1] + mp.y;
-        char* xo = xg + q * SETB + (s & 3) * SLOT + xoff;
-        char* xr = xg + q * SETB + ((s + 2) & 3) * SLOT + xoff;      // the slot re-armed for step s + 2
-        bf16_t* dgi = dgi_ptr[q];
-        float gx[G][2], gn[2] = {0.f, 0.f};       // gx: the exchanged planes (GRU: dr, dz, dq), gn: GRU's dn (stored, not exchanged)
-#pragma unroll
-        for (int g = 0; g < G; ++g) gx[g][0] = gx[g][1] = 0.f;
         car[q][0] = din0;
         car[q][1] = din1;
         if (CELL == CELL_GRU) {
@@ -783,32 +823,52 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_bwd(RArgs ra) {
           }
         }
         if (dead) gx[0][0] = gx[0][1] = QNAN;
+      }
+      {
+        // packed planes; the quad's four dwords meet on its lane 0 (all lanes active), which publishes, re-arms and stores 16 bytes at
+        // a time; every lane keeps the bias sums of its own pair from the ROUNDED values (= the column sums of the stored planes)
         uint32_t pk[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) pk[g] = cvt_pk_bf16(gx[g][0], gx[g][1]);
         const uint32_t pkn = cvt_pk_bf16(gn[0], gn[1]);
+        u32x4_t pubv[G], stv[G];
 #pragma unroll
-        for (int g = 0; g < G; ++g) pub32(xo + g * GATEB, pk[g] == XSENT2 ? 0x7fc07fc0u : pk[g], plain);
+        for (int g = 0; g < G; ++g) {
+          stv[g] = quad_gather(pk[g]);
+          pubv[g] = quad_gather(pk[g] == XSENT2 ? 0x7fc07fc0u : pk[g]);
+        }
+        const u32x4_t nv = quad_gather(pkn);
+        if (on[q]) {
+          if (dw == 0) {
+            const int xo = q * SETB + (s & 3) * SLOT + xoff, xr = q * SETB + ((s + 2) & 3) * SLOT + xoff;   // xr: re-armed for step s + 2
 #pragma unroll
-        for (int g = 0; g < G; ++g) pub32(xr + g * GATEB, XSENT2, plain);
-        // stored planes: the values as exchanged (GRU: dGI = [dr, dz, dn], dQ apart), bias sums from the ROUNDED values
-        if (CELL == CELL_GRU) {
-          if (!(dbgmask & 2)) {
-            *reinterpret_cast<uint32_t*>(dgi) = pk[0];
-            *reinterpret_cast<uint32_t*>(dgi + H) = pk[1 % G];
-            *reinterpret_cast<uint32_t*>(dgi + 2 * H) = pkn;
-            *reinterpret_cast<uint32_t*>(dgh_ptr[q]) = pk[2 % G];
+            for (int g = 0; g < G; ++g) pub128(rsrc, xo + g * GATEB, pubv[g], plain);
+#pragma unroll
+            for (int g = 0; g < G; ++g) pub128(rsrc, xr + g * GATEB, u32x4_t{XSENT2, XSENT2, XSENT2, XSENT2}, plain);
+            if (!(dbgmask & 2)) {
+              bf16_t* dgi = dgi_ptr[q];
+              if (CELL == CELL_GRU) {     // dGI = [dr, dz, dn], dQ apart
+                st128(dgi, stv[0]);
+                st128(dgi + H, stv[1 % G]);
+                st128(dgi + 2 * H, nv);
+                st128(dgh_ptr[q], stv[2 % G]);
+              } else {
+#pragma unroll
+                for (int g = 0; g < G; ++g) st128(dgi + (long)g * H, stv[g]);
+              }
+            }
           }
-          bsum[q][0][0] += bf_lo(pk[0]); bsum[q][0][1] += bf_hi(pk[0]);
-          bsum[q][1 % NB][0] += bf_lo(pk[1 % G]); bsum[q][1 % NB][1] += bf_hi(pk[1 % G]);
-          bsum[q][2 % NB][0] += bf_lo(pkn); bsum[q][2 % NB][1] += bf_hi(pkn);
-          bsum[q][3 % NB][0] += bf_lo(pk[2 % G]); bsum[q][3 % NB][1] += bf_hi(pk[2 % G]);
-        } else {
+          if (CELL == CELL_GRU) {
+            bsum[q][0][0] += bf_lo(pk[0]); bsum[q][0][1] += bf_hi(pk[0]);
+            bsum[q][1 % NB][0] += bf_lo(pk[1 % G]); bsum[q][1 % NB][1] += bf_hi(pk[1 % G]);
+            bsum[q][2 % NB][0] += bf_lo(pkn); bsum[q][2 % NB][1] += bf_hi(pkn);
+            bsum[q][3 % NB][0] += bf_lo(pk[2 % G]); bsum[q][3 % NB][1] += bf_hi(pk[2 % G]);
+          } else {
 #pragma unroll
-          for (int g = 0; g < G; ++g) {
-            if (!(dbgmask & 2)) *reinterpret_cast<uint32_t*>(dgi + (long)g * H) = pk[g];
-            bsum[q][g % NB][0] += bf_lo(pk[g]);
-            bsum[q][g % NB][1] += bf_hi(pk[g]);
+            for (int g = 0; g < G; ++g) {
+              bsum[q][g % NB][0] += bf_lo(pk[g]);
+              bsum[q][g % NB][1] += bf_hi(pk[g]);
+            }
           }
         }
       }
