@@ -175,6 +175,35 @@ __device__ __forceinline__ uint32_t pay_word(float a, float b) {
   return pk == XSENT2 ? 0x7fc07fc0u : pk;
 }
 
+// MFMA with the B fragment read STRAIGHT from an accumulation register (AGPR).  These kernels hold 400-490 registers per lane, so the
+// compiler parks the resident W fragments in AGPRs -- and, through the builtin, copies every one of them into VGPRs in front of its
+// MFMA (4 x v_accvgpr_read_b32: 240 extra VALU-slot instructions per forward half-step at LSTM-1280, as many issue cycles as the
+// MFMAs' own pipe time).  gfx950's MFMA takes srcB from the AGPR file directly; the builtin never asks for it, inline asm does.
+// The compiler does not see an MFMA in the asm, so it pads no hazards: accumulators are reused at a distance of >= 4 MFMAs (> the 18
+// wait states any XDL result needs), and mfma_results_ready() -- an asm statement every accumulator passes through -- holds the 18
+// wait states between the last MFMA and the first reader of its result.
+__device__ __forceinline__ void mfma_breg(ds2_f32x4& acc, const uint4& a, const uint4& b) {       // b: register-resident fragment
+  const u32x4_t av = __builtin_bit_cast(u32x4_t, a), bv = __builtin_bit_cast(u32x4_t, b);
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "a"(bv));
+}
+__device__ __forceinline__ void mfma_bvgpr(ds2_f32x4& acc, const uint4& a, const uint4& b) {      // b: staged from LDS
+  const u32x4_t av = __builtin_bit_cast(u32x4_t, a), bv = __builtin_bit_cast(u32x4_t, b);
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv));
+}
+template <int NA>
+__device__ __forceinline__ void mfma_results_ready(ds2_f32x4 (&acc)[NA]) {
+  static_assert(NA == 2 || NA == 4 || NA == 6 || NA == 8, "accumulator count");
+  if constexpr (NA == 2)
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]));
+  else if constexpr (NA == 4)
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+  else if constexpr (NA == 6)
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]));
+  else
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
+                 "+v"(acc[7]));
+}
+
 // k-steps per gather chunk: two chunks per K-quarter up to 16 k-steps (the products of the first overlap the arrival of the
 // second), chunks of 8 beyond (BPTT: K = G*H)
 constexpr int chunk3(int KSW, int SP) { return KSW <= 16 ? ((KSW + 1) / 2 + SP - 1) / SP * SP : 8; }
@@ -203,14 +232,22 @@ struct Gather3 {
   uint4 st[LA + 1][TL];
 
   __device__ __forceinline__ void issue(int b, int c, __amdgpu_buffer_rsrc_t rsrc, int base, bool need, int ks0, int cnt, int part) {
+    // per-lane offset once per chunk (rows without a sample: beyond the resource for every k-step of the chunk), the k-step as the
+    // instruction's SCALAR offset: no vector arithmetic per load (it was an add and a select per load: 160 of a BPTT half-step's 670
+    // VALU instructions)
+    const int lane_off = need ? base + part * 1024 : XOOB;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      const int k_ = c * CH + part + SP * i;
-      const bool ok_ = need && k_ < KSW && (!RAGGED || k_ < cnt);
+      const int k0 = c * CH + SP * i;                                  // k-step of lane part 0 (compile-time after unrolling)
+      const bool k_ok = k0 < KSW && (!RAGGED || k0 < cnt);             // wave-uniform
+      const int soff = __builtin_amdgcn_readfirstlane(k_ok ? (ks0 + k0) * 1024 : 0);
+      int voff = k_ok ? lane_off : XOOB;
+      if (SP == 2 && k0 + 1 >= KSW) voff = part ? XOOB : voff;         // odd K-quarter: the second lane part has no k-step here
+      if (SP == 2 && RAGGED) voff = (part && k0 + 1 >= cnt) ? XOOB : voff;
       if (DS2R_VAR & 512)
         v[b][i] = u32x4_t{0u, 0u, 0u, 0u};
       else
-        v[b][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok_ ? base + (ks0 + k_) * 1024 : XOOB, 0, 16 /* sc1 */);
+        v[b][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 16 /* sc1 */);
     }
   }
   __device__ __forceinline__ bool bad(int b) const {
@@ -231,7 +268,9 @@ struct Gather3 {
     for (int kk = 0; kk < LA; ++kk)
       if (kk < CH) lds_kstep(kk % (LA + 1), c * CH + kk, wl_lane);
   }
-  __device__ __forceinline__ void mma(int b, int c, ds2_f32x4 (&acc)[RT], const uint4 (&w)[RT][KSW], const uint4* wl_lane, int dbgmask) {
+  static constexpr int NACC = BWD ? 2 * RT : RT;     // BPTT (two tiles): even and odd k-steps accumulate apart, so that an accumulator is
+                                                     // reused every 4th MFMA at the earliest (see mfma_breg)
+  __device__ __forceinline__ void mma(int b, int c, ds2_f32x4 (&acc)[NACC], const uint4 (&w)[RT][KSW], const uint4* wl_lane, int dbgmask) {
 #pragma unroll
     for (int kk = 0; kk < CH; ++kk) {
       const int k_ = c * CH + kk;                    // compile-time after unrolling
@@ -242,11 +281,12 @@ struct Gather3 {
         if (SP == 2 && (kk & 1)) a_ = row_from_plus4(a_, 8);
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
+          ds2_f32x4& ac = acc[BWD ? t + RT * (k_ & 1) : t];
           if (in_lds3(TR, KM, t, k_)) {
             const uint4 wv = st[kk % (LA + 1)][((KM >> (k_ % 10)) & 1u) ? t : t - TR];
-            if (!(dbgmask & 32)) Mma<bf16_t>::mma16(acc[t], a_, wv);
+            if (!(dbgmask & 32)) mfma_bvgpr(ac, a_, wv);
           } else {
-            Mma<bf16_t>::mma16(acc[t], a_, w[t][k_]);
+            mfma_breg(ac, a_, w[t][k_]);
           }
         }
       }
@@ -488,6 +528,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_fwd(RArgs ra) {
 #pragma unroll
       for (int tt = 0; tt < RT; ++tt) acc[tt] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
       DS2R_GATHER_PHASE(a.h0 != nullptr)
+      mfma_results_ready<RT>(acc);
       {   // this set's input projection DEP steps ahead
 #pragma unroll
         for (int i = 0; i + 1 < DEP; ++i)
@@ -757,10 +798,17 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_bwd(RArgs ra) {
     for (int q = 0; q < NSET; ++q, ++hstep) {
       DS2_PROBE_ONLY(const unsigned long long t0 = __builtin_readcyclecounter();)
       const Pre pc = ring[q][0];
+      ds2_f32x4 acc2[2 * RT];
+#pragma unroll
+      for (int tt = 0; tt < 2 * RT; ++tt) acc2[tt] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
+      {
+        ds2_f32x4 (&acc)[2 * RT] = acc2;
+        DS2R_GATHER_PHASE(false)
+      }
+      mfma_results_ready<2 * RT>(acc2);
       ds2_f32x4 acc[RT];
 #pragma unroll
-      for (int tt = 0; tt < RT; ++tt) acc[tt] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
-      DS2R_GATHER_PHASE(false)
+      for (int tt = 0; tt < RT; ++tt) acc[tt] = acc2[tt] + acc2[tt + RT];
 #pragma unroll
       for (int i = 0; i + 1 < DEP; ++i) ring[q][i] = ring[q][i + 1];
       prefetch(ring[q][DEP - 1], q, s + DEP < Tp);
