@@ -175,6 +175,11 @@ __device__ __forceinline__ uint32_t pay_word(float a, float b) {
   return pk == XSENT2 ? 0x7fc07fc0u : pk;
 }
 
+// EXPERIMENT, OFF BY DEFAULT (-DDS2R_ASM_MFMA; measured and rejected in round 4: cfg5a 111 -> 104 ms, cfg5b 58.6 -> 57.0, but WRONG
+// RESULTS on every shape whose MFMAs are not separated by LDS reads -- 15 of 32 kernel tests -- although the instruction itself is
+// fine: tools/_build/mfma_asm_test.hip reproduces the builtin bit for bit with B in AGPRs.  The compiler cannot see that an asm
+// statement is an MFMA, so it re-uses source registers inside the few cycles in which the matrix pipe still reads them; keeping the
+// fragments live across a pad was not enough).  What it is:
 // MFMA with the B fragment read STRAIGHT from an accumulation register (AGPR).  These kernels hold 400-490 registers per lane, so the
 // compiler parks the resident W fragments in AGPRs -- and, through the builtin, copies every one of them into VGPRs in front of its
 // MFMA (4 x v_accvgpr_read_b32: 240 extra VALU-slot instructions per forward half-step at LSTM-1280, as many issue cycles as the
@@ -183,24 +188,38 @@ __device__ __forceinline__ uint32_t pay_word(float a, float b) {
 // wait states any XDL result needs), and mfma_results_ready() -- an asm statement every accumulator passes through -- holds the 18
 // wait states between the last MFMA and the first reader of its result.
 __device__ __forceinline__ void mfma_breg(ds2_f32x4& acc, const uint4& a, const uint4& b) {       // b: register-resident fragment
+#ifndef DS2R_ASM_MFMA
+  Mma<bf16_t>::mma16(acc, a, b);
+  return;
+#endif
   const u32x4_t av = __builtin_bit_cast(u32x4_t, a), bv = __builtin_bit_cast(u32x4_t, b);
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "a"(bv));
 }
 __device__ __forceinline__ void mfma_bvgpr(ds2_f32x4& acc, const uint4& a, const uint4& b) {      // b: staged from LDS
+#ifndef DS2R_ASM_MFMA
+  Mma<bf16_t>::mma16(acc, a, b);
+  return;
+#endif
   const u32x4_t av = __builtin_bit_cast(u32x4_t, a), bv = __builtin_bit_cast(u32x4_t, b);
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(av), "v"(bv));
 }
+#ifndef DS2R_READY_PAD
+#define DS2R_READY_PAD "s_nop 15\n\ts_nop 3"
+#endif
 template <int NA>
 __device__ __forceinline__ void mfma_results_ready(ds2_f32x4 (&acc)[NA]) {
   static_assert(NA == 2 || NA == 4 || NA == 6 || NA == 8, "accumulator count");
+#ifndef DS2R_ASM_MFMA
+  return;
+#endif
   if constexpr (NA == 2)
-    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]));
+    asm volatile(DS2R_READY_PAD : "+v"(acc[0]), "+v"(acc[1]));
   else if constexpr (NA == 4)
-    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+    asm volatile(DS2R_READY_PAD : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
   else if constexpr (NA == 6)
-    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]));
+    asm volatile(DS2R_READY_PAD : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]));
   else
-    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
+    asm volatile(DS2R_READY_PAD : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
                  "+v"(acc[7]));
 }
 
@@ -247,7 +266,11 @@ struct Gather3 {
       if (DS2R_VAR & 512)
         v[b][i] = u32x4_t{0u, 0u, 0u, 0u};
       else
+#ifdef DS2R_NO_SOFF
+        v[b][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff == XOOB ? XOOB : voff + soff, 0, 16 /* sc1 */);
+#else
         v[b][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 16 /* sc1 */);
+#endif
     }
   }
   __device__ __forceinline__ bool bad(int b) const {
@@ -271,6 +294,7 @@ struct Gather3 {
   static constexpr int NACC = BWD ? 2 * RT : RT;     // BPTT (two tiles): even and odd k-steps accumulate apart, so that an accumulator is
                                                      // reused every 4th MFMA at the earliest (see mfma_breg)
   __device__ __forceinline__ void mma(int b, int c, ds2_f32x4 (&acc)[NACC], const uint4 (&w)[RT][KSW], const uint4* wl_lane, int dbgmask) {
+    u32x4_t rot[SP == 2 ? PER : 1];     // SP == 2: the rotated fragments of the odd k-steps
 #pragma unroll
     for (int kk = 0; kk < CH; ++kk) {
       const int k_ = c * CH + kk;                    // compile-time after unrolling
@@ -278,7 +302,11 @@ struct Gather3 {
       if (k_ < KSW && !(dbgmask & 128)) {
         const int i = kk / SP;
         uint4 a_ = make_uint4(v[b][i][0], v[b][i][1], v[b][i][2], v[b][i][3]);
-        if (SP == 2 && (kk & 1)) a_ = row_from_plus4(a_, 8);
+        if (SP == 2 && (kk & 1)) {
+          a_ = row_from_plus4(a_, 8);
+          rot[i] = u32x4_t{a_.x, a_.y, a_.z, a_.w};
+          a_ = make_uint4(rot[i][0], rot[i][1], rot[i][2], rot[i][3]);
+        }
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
           ds2_f32x4& ac = acc[BWD ? t + RT * (k_ & 1) : t];
@@ -291,6 +319,20 @@ struct Gather3 {
         }
       }
     }
+#ifdef DS2R_ASM_MFMA
+    // The compiler does not know that the asm statements above are MFMAs whose source registers are still being read for a few
+    // cycles after issue: left alone it re-uses an A-fragment register for the next VALU result right behind the last MFMA (the
+    // sentinel check's v_max landed in the fragment of the last k-step: wrong sums on every shape without LDS reads in between).
+    // So the chunk's fragments stay live across a pad behind the block.
+    asm volatile("s_nop 15\n\ts_nop 3");
+#pragma unroll
+    for (int i = 0; i < PER; ++i) asm volatile("" : : "v"(v[b][i]));
+    if (SP == 2) {
+#pragma unroll
+      for (int i = 0; i < PER; ++i)
+        if ((c * CH + SP * i + 1) < KSW && !(dbgmask & 128)) asm volatile("" : : "v"(rot[i]));
+    }
+#endif
   }
 };
 
