@@ -76,7 +76,9 @@ def test_fit_checkpoint_resume(name, precision, tmp_path):
     assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(la)), (float(la), float(lb))
     for (k, p), (_, q) in zip(m.named_parameters(), m2.named_parameters()):
         d = (p.detach() - q.detach()).abs().max().item()
-        assert d <= 1e-4 * max(p.detach().abs().max().item(), 1e-3), (k, d)      # split-K atomics of the small-shape GEMMs: run-to-run noise
+        # run-to-run noise of the small-shape GEMMs' split-K atomics reaches the parameters through AdamW's normalised update
+        # m / sqrt(v): where a gradient element is ~0 the ratio is noise, bounded by the learning rate (1.5e-4)
+        assert d <= max(1e-4 * p.detach().abs().max().item(), 0.3 * 1.5e-4), (k, d)
     from deepspeech.pytorch_amd import ops
     ops.check_persistent_kernels()
 
