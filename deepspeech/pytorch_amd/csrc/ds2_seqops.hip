@@ -513,6 +513,45 @@ __global__ void __launch_bounds__(256) k_rnn_bias_grads(const float* __restrict_
 
 }  // namespace
 
+// ---- fp32 operand -> three bf16 K-segments (fp32-class GEMMs on the bf16 matrix pipe) -------------------------------------------
+// x = hi + lo (+ a residual below 2^-17 |x|) with hi = bf16(x), lo = bf16(x - hi).  A product of two fp32 operands is then
+// a_hi b_hi + a_hi b_lo + a_lo b_hi (+ terms below 2^-17 |a b|): with the A operand laid out as [hi | hi | lo] and the B operand as
+// [hi | lo | hi] along K, ONE bf16 GEMM with K' = 3 Kp and fp32 accumulation yields the three sums.  The exact-fp32 MFMA runs at
+// 1/16 of the bf16 rate (157 vs 2 500 TFLOP/s), three bf16 products at 1/3: config 2's GEMMs (fp32 parity mode, M = 808 rows) go
+// from 37 TFLOP/s to ~5x that.  mode 0 = A pattern, 1 = B pattern; segments are Kp wide (K rounded up to the 64-element K-tile),
+// zero beyond K.
+__global__ void __launch_bounds__(256) k_split3(const float* __restrict__ src, long lds_, long rows, int K, int Kp, int mode,
+                                                uint16_t* __restrict__ dst, long ldd) {
+  const int chunks = Kp / 8;
+  const long total = rows * chunks;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long r = e / chunks;
+    const int c0 = (int)(e % chunks) * 8;
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = 0.f;
+    if (c0 + 8 <= K) {
+      const float4 a = *reinterpret_cast<const float4*>(src + r * lds_ + c0), b = *reinterpret_cast<const float4*>(src + r * lds_ + c0 + 4);
+      x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+    } else {
+      for (int i = 0; i < 8; ++i)
+        if (c0 + i < K) x[i] = src[r * lds_ + c0 + i];
+    }
+    uint32_t hi[4], lo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      hi[i] = cvt_pk_bf16(x[2 * i], x[2 * i + 1]);
+      const float h0 = __uint_as_float(hi[i] << 16), h1 = __uint_as_float(hi[i] & 0xffff0000u);
+      lo[i] = cvt_pk_bf16(x[2 * i] - h0, x[2 * i + 1] - h1);
+    }
+    const uint4 H = make_uint4(hi[0], hi[1], hi[2], hi[3]), L = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    uint16_t* d = dst + r * ldd + c0;
+    *reinterpret_cast<uint4*>(d) = H;
+    *reinterpret_cast<uint4*>(d + Kp) = mode == 0 ? H : L;
+    *reinterpret_cast<uint4*>(d + 2 * Kp) = mode == 0 ? L : H;
+  }
+}
+
 extern "C" {
 
 int ds2_version(void) { return 100; }
@@ -536,6 +575,17 @@ int ds2_add2(int dtype, const void* a, const void* b, void* out, long n, ds2_str
     hipLaunchKernelGGL(k_add2<float>, dim3(ew_grid(n / V)), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)out, n / V);
   else
     hipLaunchKernelGGL(k_add2<bf16_t>, dim3(ew_grid(n / V)), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n / V);
+  DS2_CHECK_LAUNCH();
+  return 0;
+}
+
+int ds2_split3_bf16(const float* src, long lds_, long rows, int K, int Kp, int mode, void* dst, long ldd, ds2_stream_t st_) {
+  hipStream_t st = (hipStream_t)st_;
+  DS2_REQUIRE(src != nullptr && dst != nullptr && rows > 0 && K > 0 && Kp >= K && Kp % 64 == 0 && (mode == 0 || mode == 1), DS2_ERR_ARG);
+  DS2_REQUIRE(lds_ % 4 == 0 && ldd >= 3L * Kp && ldd % 8 == 0 && (((uintptr_t)src) & 15) == 0 && (((uintptr_t)dst) & 15) == 0, DS2_ERR_ALIGN);
+  const long total = rows * (Kp / 8);
+  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(k_split3, dim3(grid), dim3(256), 0, st, src, lds_, rows, K, Kp, mode, (uint16_t*)dst, ldd);
   DS2_CHECK_LAUNCH();
   return 0;
 }

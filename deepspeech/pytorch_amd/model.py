@@ -353,7 +353,12 @@ def _rnn_layer_forward(mod, li, X, lens_dev, N, Tp, dtype, training, h0, c0, lpa
         bn = layer.batch_norm.module
         Xh = ops.empty_padded(R, I, X.dtype, X.device)       # row stride off the power of two (GEMM operand)
         sv = _bn_seq_fwd(bn, bn_w, bn_b, X, Xh, R, layer.input_size, I, training)
-    GI = ops.gemm_nt(Xh, Wih, bias=Bih)                                  # [R][D*G*H]
+    if ops.split3_ok(dtype, R, D * G * H, I):
+        # fp32 mode: one bf16 GEMM over the split operands (ops.split3); the split weights are cached like every other layout
+        Wih3 = c.get(("wih3", li), wih, lambda: ops.split3(Wih, 1))
+        GI = ops.gemm_nt(ops.split3(Xh, 0), Wih3, bias=Bih, out_dtype=torch.float32)
+    else:
+        GI = ops.gemm_nt(Xh, Wih, bias=Bih)                              # [R][D*G*H]
     if H != Ht:
         h0 = _pad_cols(h0, H) if h0 is not None else None
         c0 = _pad_cols(c0, H) if c0 is not None else None
@@ -468,7 +473,14 @@ def _rnn_layer_backward(mod, li, meta, saved, lparams, dout, lens_dev, N, Tp, dt
                 wgrad_done = torch.cuda.Event()
                 wgrad_done.record(wstream)
     # ---- dependent chain (caller's stream): dX -> BatchNorm backward
-    dXh = dXh_fused if dXh_fused is not None else ops.gemm_nt(dGI, WihT)                                # [R][I]
+    s3 = ops.split3_ok(dtype, R, H, GH)                 # fp32 mode: the slow path's GEMMs on split operands (see _rnn_layer_forward)
+    if dXh_fused is not None:
+        dXh = dXh_fused
+    elif s3:
+        WihT3 = c.get(("wihT3", li), list(wih), lambda: ops.split3(WihT, 1))
+        dXh = ops.gemm_nt(ops.split3(dGI, 0), WihT3, out_dtype=torch.float32)
+    else:
+        dXh = ops.gemm_nt(dGI, WihT)                                                                    # [R][I]
     if has_bn:
         dX = torch.empty_like(dXh)
         grads[0], grads[1] = _bn_seq_bwd(dXh, X, dX, sv, R, It, I)
@@ -490,8 +502,12 @@ def _rnn_layer_backward(mod, li, meta, saved, lparams, dout, lens_dev, N, Tp, dt
         dGI_T = ops.transpose(dGI)                              # [D*G*H][ldT]
         Xh_T = ops.transpose(Xh)                                # [I][ldT]
         ldT = dGI_T.shape[1]
-        dWih = ops.gemm_nt(dGI_T, Xh_T, out_dtype=torch.float32, splitk=_wgrad_splitk(dGI_T.shape[0], Xh_T.shape[0], ldT),
-                           coresident=cores)
+        dGI_T3 = ops.split3(dGI_T, 0) if s3 else None           # [D*G*H][3*ldT]
+        if s3:
+            dWih = ops.gemm_nt(dGI_T3, ops.split3(Xh_T, 1), out_dtype=torch.float32, coresident=cores)
+        else:
+            dWih = ops.gemm_nt(dGI_T, Xh_T, out_dtype=torch.float32, splitk=_wgrad_splitk(dGI_T.shape[0], Xh_T.shape[0], ldT),
+                               coresident=cores)
         del Xh_T
         if first:
             dWih = torch.cat([_perm_cols_to_reference(dWih[d * GH:(d + 1) * GH]) for d in range(D)], 0)
@@ -510,8 +526,14 @@ def _rnn_layer_backward(mod, li, meta, saved, lparams, dout, lens_dev, N, Tp, dt
             if kind == "gru" and rg.dQ is not None:
                 # hidden-side gate gradient = [dr, dz (rows of dGI^T) | dQ^T]: one GEMM whose A operand is two row blocks
                 dQ_T = ops.transpose(rg.dQ[d].reshape(R, H))   # [H][ldT]
-                dWhh = ops.gemm_nt_rows2(dGI_T[d * GH:d * GH + 2 * H], dQ_T, 2 * H, Hp_T, GH, H, ldT, ldT, ldT,
-                                         splitk=_wgrad_splitk(GH, H, ldT), coresident=cores)
+                if s3:
+                    A3 = torch.empty((GH, 3 * ldT), dtype=torch.bfloat16, device=dGI.device)
+                    A3[:2 * H].copy_(dGI_T3[d * GH:d * GH + 2 * H])
+                    ops.split3(dQ_T, 0, out=A3[2 * H:])
+                    dWhh = ops.gemm_nt(A3, ops.split3(Hp_T, 1), out_dtype=torch.float32, coresident=cores)
+                else:
+                    dWhh = ops.gemm_nt_rows2(dGI_T[d * GH:d * GH + 2 * H], dQ_T, 2 * H, Hp_T, GH, H, ldT, ldT, ldT,
+                                             splitk=_wgrad_splitk(GH, H, ldT), coresident=cores)
                 dBhh = torch.cat([bsum[d][:2 * H], bsum[d][3 * H:4 * H]], 0) if bsum is not None else \
                     torch.cat([dBih[d * GH:d * GH + 2 * H], ops.colsum(rg.dQ[d].reshape(R, H))], 0)
             else:
@@ -521,8 +543,12 @@ def _rnn_layer_backward(mod, li, meta, saved, lparams, dout, lens_dev, N, Tp, dt
                 else:
                     dGH_T = dGI_T[d * GH:(d + 1) * GH]
                     dBhh = dBih[d * GH:(d + 1) * GH]
-                dWhh = ops.gemm_nt(dGH_T, Hp_T, out_dtype=torch.float32, M=GH, N=H, K=ldT, lda=ldT, ldb=ldT,
-                                   splitk=_wgrad_splitk(GH, H, ldT), coresident=cores)
+                if s3:
+                    A3 = ops.split3(dGH_T, 0) if kind == "gru" else dGI_T3[d * GH:(d + 1) * GH]
+                    dWhh = ops.gemm_nt(A3, ops.split3(Hp_T, 1), out_dtype=torch.float32, coresident=cores)
+                else:
+                    dWhh = ops.gemm_nt(dGH_T, Hp_T, out_dtype=torch.float32, M=GH, N=H, K=ldT, lda=ldT, ldb=ldT,
+                                       splitk=_wgrad_splitk(GH, H, ldT), coresident=cores)
             grads[po + 4 * d:po + 4 * d + 4] = [dWih[d * GH:(d + 1) * GH].contiguous(), dWhh,
                                                 dBih[d * GH:(d + 1) * GH].contiguous(), dBhh.contiguous()]
         del dGI_T

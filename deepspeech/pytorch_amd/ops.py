@@ -196,6 +196,29 @@ def colsum(X, R=None, Cc=None, ld=None, scale=1.0):
     return out
 
 
+# fp32 (1e-3 parity) mode: the large GEMMs of the RNN stack run as ONE bf16 GEMM over three K-segments of split operands
+# (a_hi b_hi + a_hi b_lo + a_lo b_hi, fp32 accumulation: relative error ~1e-5 per product against 6e-8 of the exact-fp32 MFMA, which
+# runs at 1/16 of the bf16 rate).  DS2_FP32_GEMM=exact keeps the exact kernels everywhere.
+import os as _os
+FP32_SPLIT3 = _os.environ.get("DS2_FP32_GEMM", "split3") != "exact"
+
+
+def split3_ok(dtype, M, N, K):
+    return FP32_SPLIT3 and dtype == torch.float32 and M >= 256 and N >= 256 and K >= 256
+
+
+def split3(X, mode, out=None):
+    """fp32 [rows][K] (any row stride) -> bf16 [rows][3 * Kp], Kp = K rounded up to 64: K-segments [hi | hi | lo] (mode 0: the A
+    operand of a product) or [hi | lo | hi] (mode 1: the B operand).  `out`: a row window of a larger [.., 3 * Kp] buffer."""
+    rows, K = X.shape
+    Kp = rup(K, 64)
+    if out is None:
+        out = torch.empty((rows, 3 * Kp), dtype=torch.bfloat16, device=X.device)
+    assert out.shape[0] == rows and out.shape[1] == 3 * Kp and X.dtype == torch.float32 and X.stride(1) == 1
+    call("ds2_split3_bf16", P(X), X.stride(0), rows, K, Kp, mode, P(out), out.stride(0), S())
+    return out
+
+
 def transpose(X, R=None, Cc=None, lds=None):
     """dst[C][ldd] = X[R][C]^T with ldd = roundup(R, 64) (the K-tile of the MFMA GEMM) and zero fill of the pad columns."""
     R = X.shape[0] if R is None else R

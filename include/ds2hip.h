@@ -180,6 +180,11 @@ int ds2_rnn_persist_bwd(int dtype, int cell, int D, int N, int H, int Tp, const 
  * bwd: dx and dw (dw via ws of ds2_lookahead_ws_floats). */
 int ds2_add2(int dtype, const void* a, const void* b, void* out, long n, ds2_stream_t stream);
 int ds2_transpose(int dtype, const void* src, void* dst, long R, int C, long lds, long ldd, ds2_stream_t stream);
+/* fp32 operand [rows][K] (row stride lds) -> bf16 [rows][3 * Kp] (row stride ldd; Kp = K rounded up to 64, zero beyond K): the K
+ * segments [hi | hi | lo] (mode 0, the A operand of a product) or [hi | lo | hi] (mode 1, the B operand) with hi = bf16(x),
+ * lo = bf16(x - hi).  One bf16 GEMM over K' = 3 Kp of two such operands = a_hi b_hi + a_hi b_lo + a_lo b_hi: the fp32-mode (1e-3
+ * parity) input projections / dX / weight gradients of nn.GRU / nn.LSTM (model.py:97-99) on the bf16 matrix pipe. */
+int ds2_split3_bf16(const float* src, long lds, long rows, int K, int Kp, int mode, void* dst, long ldd, ds2_stream_t stream);
 /* Weight re-layout of the recurrent layers (what nn.GRU/LSTM/RNN.flatten_parameters + the autocast weight casts do in the
  * reference, model.py:97-99): fp32 src[R][C] -> bf16 dst[R][ldd] and/or bf16 transpose dstT[Cout][lddT] in one pass.
  * perm_c > 0: output column j = f*perm_c + c takes source column c*perm_f + f (rnns.0 reads the conv features in the

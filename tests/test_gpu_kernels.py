@@ -286,6 +286,40 @@ def test_conv2_fwd_dgrad_wgrad(dtype, N, Tp):
     assert relerr(np64(dw2).reshape(21, 11, 32, 32), dw.transpose(2, 3, 0, 1)) < 1e-4
 
 
+@pytest.mark.parametrize("M,N,K", [(808, 4800, 1344), (808, 800, 4800), (4800, 1344, 808), (300, 256, 257)])
+def test_gemm_split3_is_fp32_class(M, N, K):
+    """fp32-mode GEMMs as ONE bf16 GEMM over three K-segments of split operands (ops.split3: a_hi b_hi + a_hi b_lo + a_lo b_hi):
+    2e-5 of the product's scale against float64 -- two orders inside the 1e-3 parity bar of the fp32 mode, where a plain bf16
+    product sits at 4e-3 -- and the segments themselves bit-exact (hi = bf16(x), lo = bf16(x - hi), zero pad)."""
+    o = ops()
+    rs = np.random.RandomState(M + N + K)
+    A = rs.standard_normal((M, K)) * np.exp(rs.uniform(-3, 3, (M, 1)))       # rows of very different scale, like gradients
+    B = rs.standard_normal((N, K))
+    Ad, Bd = cu(A), cu(B)
+    A3, B3 = o.split3(Ad, 0), o.split3(Bd, 1)
+    Kp = (K + 63) // 64 * 64
+    assert A3.shape == (M, 3 * Kp) and B3.shape == (N, 3 * Kp)
+    a32 = torch.from_numpy(A.astype(np.float32))
+    hi = a32.to(torch.bfloat16)
+    lo = (a32 - hi.float()).to(torch.bfloat16)
+    got = A3.cpu()
+    assert torch.equal(got[:, :K], hi) and torch.equal(got[:, Kp:Kp + K], hi) and torch.equal(got[:, 2 * Kp:2 * Kp + K], lo)
+    assert not got[:, K:Kp].any() and not got[:, 2 * Kp + K:].any()
+    b32 = torch.from_numpy(B.astype(np.float32))
+    bhi = b32.to(torch.bfloat16)
+    blo = (b32 - bhi.float()).to(torch.bfloat16)
+    gotb = B3.cpu()
+    assert torch.equal(gotb[:, :K], bhi) and torch.equal(gotb[:, Kp:Kp + K], blo) and torch.equal(gotb[:, 2 * Kp:2 * Kp + K], bhi)
+    C = np64(o.gemm_nt(A3, B3, out_dtype=torch.float32))
+    ref = A.astype(np.float32).astype(np.float64) @ B.astype(np.float32).astype(np.float64).T
+    scale = np.sqrt((A ** 2).sum(1))[:, None] * np.sqrt((B ** 2).sum(1))[None, :]          # |a| |b| per entry
+    assert (np.abs(C - ref) / scale).max() < 2e-5, (np.abs(C - ref) / scale).max()
+    plain = np64(o.gemm_nt(Ad.to(torch.bfloat16).contiguous(), Bd.to(torch.bfloat16).contiguous(), out_dtype=torch.float32)) \
+        if K % 64 == 0 else None
+    if plain is not None:
+        assert (np.abs(plain - ref) / scale).max() > 10 * (np.abs(C - ref) / scale).max()
+
+
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("kind", ["gru", "lstm", "rnn"])
