@@ -473,10 +473,10 @@ def _rnn_layer_backward(mod, li, meta, saved, lparams, dout, lens_dev, N, Tp, dt
                 wgrad_done = torch.cuda.Event()
                 wgrad_done.record(wstream)
     # ---- dependent chain (caller's stream): dX -> BatchNorm backward
-    s3 = ops.split3_ok(dtype, R, H, GH)                 # fp32 mode: the slow path's GEMMs on split operands (see _rnn_layer_forward)
+    s3 = ops.split3_ok(dtype, GH, H, R, leaf=True)      # fp32 mode: the weight-gradient GEMMs on split operands (ops.split3_ok)
     if dXh_fused is not None:
         dXh = dXh_fused
-    elif s3:
+    elif ops.split3_ok(dtype, R, H, GH):
         WihT3 = c.get(("wihT3", li), list(wih), lambda: ops.split3(WihT, 1))
         dXh = ops.gemm_nt(ops.split3(dGI, 0), WihT3, out_dtype=torch.float32)
     else:

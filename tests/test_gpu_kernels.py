@@ -286,7 +286,7 @@ def test_conv2_fwd_dgrad_wgrad(dtype, N, Tp):
     assert relerr(np64(dw2).reshape(21, 11, 32, 32), dw.transpose(2, 3, 0, 1)) < 1e-4
 
 
-@pytest.mark.parametrize("M,N,K", [(808, 4800, 1344), (808, 800, 4800), (4800, 1344, 808), (300, 256, 257)])
+@pytest.mark.parametrize("M,N,K", [(808, 4800, 1344), (808, 800, 4800), (4800, 1344, 808), (300, 256, 328)])
 def test_gemm_split3_is_fp32_class(M, N, K):
     """fp32-mode GEMMs as ONE bf16 GEMM over three K-segments of split operands (ops.split3: a_hi b_hi + a_hi b_lo + a_lo b_hi):
     2e-5 of the product's scale against float64 -- two orders inside the 1e-3 parity bar of the fp32 mode, where a plain bf16
