@@ -338,6 +338,30 @@ __device__ __forceinline__ void publish32(void* p, uint32_t v, bool local) {
     __hip_atomic_store((uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- 16-byte merged stores of the 8-samples-per-group kernels (-DDS2_QUAD_STORES: an A/B variant) ---------------------------------
+// The even lanes 8m, 8m+2, 8m+4, 8m+6 of a wave hold four CONSECUTIVE dwords of one sample row -- in the exchange slot and in every
+// stored plane (thread bits: e, pair within the 16-byte unit (2), sample row (3), lq (2)).  row4() collects them on lane 8m, which then
+// issues ONE 16-byte store where four lanes issued four 4-byte ones (8 instead of 32 active lanes per store instruction).
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4q;
+template <int N>
+__device__ __forceinline__ uint32_t row_plus(uint32_t v) {      // lane i of every 16-lane row <- lane (i + N) mod 16
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x120 + (16 - N), 0xf, 0xf, true);
+}
+__device__ __forceinline__ u32x4q row4(uint32_t v) {
+  u32x4q r;
+  r[0] = v;
+  r[1] = row_plus<2>(v);
+  r[2] = row_plus<4>(v);
+  r[3] = row_plus<6>(v);
+  return r;
+}
+__device__ __forceinline__ void publish128(__amdgpu_buffer_rsrc_t rsrc, int off, u32x4q v, bool local) {
+  if (local)
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, off, 0, 2 /* nt: plain policy, the line stays in this XCD's L2 */);
+  else
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, off, 0, 16 /* sc1: write-through */);
+}
+
 template <int TILES, int KS, typename F = NoTouch>
 __device__ __forceinline__ void gather_mma_tf(ds2_f32x4 (&acc)[TILES], const uint4 (&w)[TILES][KS], __amdgpu_buffer_rsrc_t rsrc,
                                               int slot_off, int kstep0, int lq, int srow, int half, bool need, int* err, int* lerr,
@@ -865,6 +889,19 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd4(PArgs a) {
       float pl_o[NS ? NS : 1];
 #pragma unroll
       for (int q = 0; q < (NS ? NS : 1); ++q) pl_o[q] = dpp_xor1(pl[q]);
+#ifdef DS2_QUAD_STORES
+      const u32x4q pubv = row4(xtf_word(pack_bf16x2(hprev, hp_o))), hsv = row4(pack_bf16x2(hn, hn_o));
+      u32x4q plv[NS ? NS : 1];
+#pragma unroll
+      for (int q = 0; q < (NS ? NS : 1); ++q) plv[q] = row4(pack_bf16x2(pl[q], pl_o[q]));
+      if (gate_thread && (tid & 7) == 0) {
+        publish128(rsrc, (s & 3) * SLOT_BYTES + xoff, pubv, local);
+        publish128(rsrc, ((s + 2) & 3) * SLOT_BYTES + xoff, u32x4q{XSENT, XSENT, XSENT, XSENT}, local);   // re-arm the slot of step s + 2
+        *reinterpret_cast<u32x4q*>(hs_ptr) = hsv;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) *reinterpret_cast<u32x4q*>(sv_ptr + (long)q * H) = plv[q];
+      }
+#else
       if (gate_thread && e == 0) {
         publish32(xg + (s & 3) * SLOT_BYTES + xoff, xtf_word(pack_bf16x2(hprev, hp_o)), local);
         publish32(xg + ((s + 2) & 3) * SLOT_BYTES + xoff, XSENT, local);        // re-arm the slot of step s + 2
@@ -872,6 +909,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd4(PArgs a) {
 #pragma unroll
         for (int q = 0; q < NS; ++q) *reinterpret_cast<uint32_t*>(sv_ptr + (long)q * H) = pack_bf16x2(pl[q], pl_o[q]);
       }
+#endif
     }
     gi_ptr += gi_stride;
     if (NS) sv_ptr += sv_stride;
@@ -1348,7 +1386,33 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd4(PArgs a) {
 #pragma unroll
       for (int g = 0; g < G; ++g) pk[g] = e == 0 ? pack_bf16x2(gx[g], go[g]) : pack_bf16x2(go[g], gx[g]);
       const uint32_t pkn = e == 0 ? pack_bf16x2(gn, gn_o) : pack_bf16x2(gn_o, gn);
+#ifdef DS2_QUAD_STORES
+      u32x4q pubv[G], stv[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        stv[g] = row4(pk[g]);
+        pubv[g] = row4(xtf_word(pk[g]));
+      }
+      const u32x4q nv = row4(pkn);
+      if (gate_thread && (tid & 7) == 0) {
+        const int xo = (s & 3) * SLOT_BYTES + xoff, xr = ((s + 2) & 3) * SLOT_BYTES + xoff;
+#pragma unroll
+        for (int g = 0; g < G; ++g) publish128(rsrc, xo + g * (H / 32) * 512, pubv[g], local);
+#pragma unroll
+        for (int g = 0; g < G; ++g) publish128(rsrc, xr + g * (H / 32) * 512, u32x4q{XSENT, XSENT, XSENT, XSENT}, local);
+        if (CELL == CELL_GRU) {
+          *reinterpret_cast<u32x4q*>(dgi_ptr) = stv[0];
+          *reinterpret_cast<u32x4q*>(dgi_ptr + H) = stv[1 % G];
+          *reinterpret_cast<u32x4q*>(dgi_ptr + 2 * H) = nv;
+          *reinterpret_cast<u32x4q*>(dgh_ptr) = stv[2 % G];
+        } else {
+#pragma unroll
+          for (int g = 0; g < G; ++g) *reinterpret_cast<u32x4q*>(dgi_ptr + (long)g * H) = stv[g];
+        }
+      }
+#endif
       if (gate_thread) {
+#ifndef DS2_QUAD_STORES
         if (e == 0) {
           char* xo = xg + (s & 3) * SLOT_BYTES + xoff;         // gate g, units (j, j+1): element k = g*H + j -> k-step 32*g + p
           char* xr = xg + ((s + 2) & 3) * SLOT_BYTES + xoff;   // re-armed for step s + 2
@@ -1366,6 +1430,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd4(PArgs a) {
             for (int g = 0; g < G; ++g) *reinterpret_cast<uint32_t*>(dgi_ptr + (long)g * H) = pk[g];
           }
         }
+#endif
         // own unit's rounded values: low half of the pair word on the even lane, high half on the odd lane
         if (CELL == CELL_GRU) {
           bsum[0] += e == 0 ? bf_lo(pk[0]) : bf_hi(pk[0]);
