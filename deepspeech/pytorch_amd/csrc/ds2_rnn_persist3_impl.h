@@ -148,13 +148,19 @@ __device__ __forceinline__ void pub32(char* p, uint32_t v, bool local) {
   else
     __hip_atomic_store((uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// The four lanes of a quad (tid & 3 = dw) hold four CONSECUTIVE dwords of a sample row -- in the exchange slot and in every stored
-// plane.  quad_gather() collects them on every lane (meaningful on the quad's lane 0), so that lane 0 issues ONE 16-byte store where
-// four lanes issued four 4-byte ones: a store instruction of 16 lanes x 16 B instead of 64 x 4 B (the scattered dword stores cost a
-// forward half-step 0.44 us, profiles/r04d_ablation_cfg5a.txt).  Must run with the whole quad active (outside exec-masked regions).
+// A/B VARIANT (-DDS2R_QUAD_STORES), measured and not kept: the four lanes of a quad (tid & 3 = dw) hold four CONSECUTIVE dwords of a
+// sample row -- in the exchange slot and in every stored plane.  quad_gather() collects them on every lane (meaningful on the quad's
+// lane 0), so that lane 0 issues ONE 16-byte store where four lanes issued four 4-byte ones.  Fewer active lanes per store, but three
+// DPP moves per stored dword in front of the publish: config 5a 108.1 vs 106.2 ms with plain dword stores, 5b 58.0 vs 57.7
+// (profiles/r04g_ab_dword_stores_*.txt); the same idea loses 3 % in the tuned H = 1024 kernels (r04f_ab_quad_stores_cfg3.txt).
+// Without the flag quad_gather() is the identity on element 0 and every lane stores its own dword.
 __device__ __forceinline__ u32x4_t quad_gather(uint32_t v) {
   u32x4_t r;
   r[0] = v;
+#ifndef DS2R_QUAD_STORES
+  r[1] = r[2] = r[3] = 0u;
+  return r;
+#endif
   r[1] = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x55 /* quad_perm [1,1,1,1] */, 0xf, 0xf, true);
   r[2] = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xAA /* quad_perm [2,2,2,2] */, 0xf, 0xf, true);
   r[3] = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xFF /* quad_perm [3,3,3,3] */, 0xf, 0xf, true);
@@ -652,6 +658,17 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_fwd(RArgs ra) {
         u32x4_t plv[M];
 #pragma unroll
         for (int m = 0; m < M; ++m) plv[m] = quad_gather(cvt_pk_bf16(pl[m][0], pl[m][1]));
+#ifndef DS2R_QUAD_STORES       // A/B variant: every lane stores its own dword (the form before the quad gathers)
+        if (on[q]) {
+          pub32(xg + q * SETB + (s & 3) * SLOT + xoff, pubv[0], plain);
+          pub32(xg + q * SETB + ((s + 2) & 3) * SLOT + xoff, XSENT2, plain);
+          if (!(dbgmask & 2)) {
+            *reinterpret_cast<uint32_t*>(hs_ptr[q]) = hsv[0];
+#pragma unroll
+            for (int m = 0; m < NS; ++m) *reinterpret_cast<uint32_t*>(sv_ptr[q] + (long)m * H) = plv[m][0];
+          }
+        }
+#else
         if (on[q] && dw == 0) {
           pub128(rsrc, q * SETB + (s & 3) * SLOT + xoff, pubv, plain);
           pub128(rsrc, q * SETB + ((s + 2) & 3) * SLOT + xoff, u32x4_t{XSENT2, XSENT2, XSENT2, XSENT2}, plain);   // re-arm step s + 2's slot
@@ -661,6 +678,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_fwd(RArgs ra) {
             for (int m = 0; m < NS; ++m) st128(sv_ptr[q] + (long)m * H, plv[m]);
           }
         }
+#endif
       }
       if (NS) sv_ptr[q] += sv_stride;
       hs_ptr[q] += hs_stride;
@@ -929,10 +947,37 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_bwd(RArgs ra) {
         }
         const u32x4_t nv = quad_gather(pkn);
         if (on[q]) {
+#ifndef DS2R_QUAD_STORES
+          {
+            char* xo = xg + q * SETB + (s & 3) * SLOT + xoff;
+            char* xr = xg + q * SETB + ((s + 2) & 3) * SLOT + xoff;
+#pragma unroll
+            for (int g = 0; g < G; ++g) pub32(xo + g * GATEB, pubv[g][0], plain);
+#pragma unroll
+            for (int g = 0; g < G; ++g) pub32(xr + g * GATEB, XSENT2, plain);
+            if (!(dbgmask & 2)) {
+              bf16_t* dgi = dgi_ptr[q];
+              if (CELL == CELL_GRU) {
+                *reinterpret_cast<uint32_t*>(dgi) = pk[0];
+                *reinterpret_cast<uint32_t*>(dgi + H) = pk[1 % G];
+                *reinterpret_cast<uint32_t*>(dgi + 2 * H) = pkn;
+                *reinterpret_cast<uint32_t*>(dgh_ptr[q]) = pk[2 % G];
+              } else {
+#pragma unroll
+                for (int g = 0; g < G; ++g) *reinterpret_cast<uint32_t*>(dgi + (long)g * H) = pk[g];
+              }
+            }
+          }
+          if (false) {
+            const int xo = 0, xr = 0;
+#pragma unroll
+            for (int g = 0; g < G; ++g) pub128(rsrc, xo + g * GATEB, pubv[g], plain);
+#else
           if (dw == 0) {
             const int xo = q * SETB + (s & 3) * SLOT + xoff, xr = q * SETB + ((s + 2) & 3) * SLOT + xoff;   // xr: re-armed for step s + 2
 #pragma unroll
             for (int g = 0; g < G; ++g) pub128(rsrc, xo + g * GATEB, pubv[g], plain);
+#endif
 #pragma unroll
             for (int g = 0; g < G; ++g) pub128(rsrc, xr + g * GATEB, u32x4_t{XSENT2, XSENT2, XSENT2, XSENT2}, plain);
             if (!(dbgmask & 2)) {
