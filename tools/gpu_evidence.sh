@@ -38,3 +38,6 @@ if [ -z "$SKIP_PMC" ]; then
   done
 fi
 cd $here
+if [ -z "$SKIP_STREAM" ]; then
+  (timeout 200 python tools/bench_stream.py; timeout 200 python tools/bench_stream.py --stock) > $out/stream_inference.jsonl 2> $out/stream_inference.err; echo "stream rc=$?"; tail -n 4 $out/stream_inference.jsonl | cut -c1-300
+fi
