@@ -21,6 +21,12 @@ x 10 ms.  One JSON line is printed by rank 0; it also carries
                   when profiles/cpu_reference_<config>.json exists -- the reference's own model.py timed offline at the full
                   shape in the build container (tools/cpu_reference_baseline.py).  A reported baseline, not the target.
 
+  "stock_baseline" / "vs_baseline": stock PyTorch-ROCm (the `--stock` leg below) timed by THIS run in a subprocess on the same
+                  batch, the same parameters and the same device (N=1, rank 0; --no-stock-baseline skips it), and value / its value;
+  "ctc_loss_ref" / "ctc_loss_rel_diff": the reference's fp32 CPU loss of this very batch and parameters (generated offline from the
+                  real reference, tests/golden/) against the first timed-path loss -- the line proves it computed the same thing;
+  "ms_per_step_median", "step_time_distribution": per-step HIP-event times of the timed steps (the mean is `ms_per_step`).
+
 With `--gpus N` and no launcher environment (WORLD_SIZE unset) the script re-executes itself under torch.distributed.run
 with N ranks on 127.0.0.1.
 
