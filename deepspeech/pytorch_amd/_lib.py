@@ -24,6 +24,10 @@ SIGNATURES = {
     "ds2_gemm8_nt": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _l, _l, _l, _i, _vp]),
     "ds2_gemm8_tn_grouped": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "ds2_gemm8_set_variant": (_i, [_i]),
+    "ds2_gemm8_nt_rows": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _l, _l, _l, _i, _vp, _i, _vp]),
+    "ds2_gemm8_tn_grouped_rows": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
+    "ds2_gemm8_wgrad_dx_rows": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _l, _l, _l, _vp, _i, _vp]),
+    "ds2_zero_pad_rows": (_i, [_i, _vp, _l, _i, _vp, _i, _i, _vp]),
     "ds2_gemm8_wgrad_dx": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _l, _l, _l, _vp]),
     "ds2_norm_partials": (_i, [_l]),
     "ds2_bn_fwd": (_i, [_i, _i, _i, _vp, _vp, _l, _i, _l, _l, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp,

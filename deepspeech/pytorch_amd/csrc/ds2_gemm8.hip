@@ -42,6 +42,8 @@ struct G8Problem {
   int tiles_n, tile_end;   // tiles of this problem are [previous tile_end, tile_end)
   int out_is_f32;
   int K, tn;               // contraction length; tn != 0: both operands K-major
+  const int* rows;         // row list (null = every row): NT: tile row r is row rows[r] of A and of C (M = length of the list);
+                           // TN: contraction index k is row rows[k] of both operands (K = length of the list)
 };
 struct G8Args {
   G8Problem p[G8_MAX_GROUPS];
@@ -92,7 +94,9 @@ __device__ __forceinline__ void g8_tile(const G8Problem& P, int t_id, unsigned c
     const int chunk = (lane & 7) ^ ((rloc >> 1) & 7);
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
-      a_off[rb] = (uint32_t)(((long)min(m0 + rb * 64 + rloc, P.M - 1) * P.lda + chunk * 8) * 2);
+      int ar = min(m0 + rb * 64 + rloc, P.M - 1);
+      if (P.rows) ar = P.rows[ar];
+      a_off[rb] = (uint32_t)(((long)ar * P.lda + chunk * 8) * 2);
       b_off[rb] = (uint32_t)(((long)min(n0 + rb * 64 + rloc, P.N - 1) * P.ldb + chunk * 8) * 2);
     }
   } else {
@@ -119,10 +123,32 @@ __device__ __forceinline__ void g8_tile(const G8Problem& P, int t_id, unsigned c
   // LDS map: A of buffer b at b * 32 KiB, B of buffer b at 64 KiB + b * 32 KiB (every fragment read = one per-lane base register +
   // a 16-bit immediate)
   const long a_kstep = TN ? 128 * lda_eff : 128, b_kstep = TN ? 128 * P.ldb : 128;      // bytes per K-tile
+  // TN over a row list: the physical rows of this lane's four k-rows of the K-tile that is staged next (scalar loads: two list
+  // entries per piece and wave, selected per half-wave; indices past the list re-read its last entry and are zeroed in LDS)
+  const bool listed = TN && P.rows != nullptr;
+  typedef const __attribute__((address_space(4))) int* const_int_ptr_t;      // constant address space: wave-uniform reads become
+  const const_int_ptr_t crows = (const_int_ptr_t)(uintptr_t)P.rows;           // s_load (lgkmcnt), not vector loads behind the DMA
+  uint32_t rk[4] = {0, 0, 0, 0};
+  auto fetch_rows = [&](int kt) {
+    if (listed && kt < nkt) {
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        const int k = kt * 64 + rb * 16 + wave * 2;
+        const int r0 = crows[min(k, K_ - 1)], r1 = crows[min(k + 1, K_ - 1)];
+        rk[rb] = (uint32_t)((lane >> 5) ? r1 : r0);
+      }
+    }
+  };
+  const uint32_t lda2b = (uint32_t)(lda_eff * 2), ldb2b = (uint32_t)(P.ldb * 2);
   auto stage_a = [&](int b, int kt, int r0 = 0, int r1 = 4) {
     const unsigned char* src = (const unsigned char*)a_base + (long)kt * a_kstep;
     unsigned char* d = lds + b * 32768 + wave * 1024;
-    if (tail && kt == nkt - 1) {
+    if (listed) {
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+        if (rb >= r0 && rb < r1)
+          __builtin_amdgcn_global_load_lds((glb_ptr_t)((const unsigned char*)a_base + (size_t)(rk[rb] * lda2b + t_acol)), (lds_ptr_t)(d + rb * 8192), 16, 0, 0);
+    } else if (tail && kt == nkt - 1) {
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb)
         if (rb >= r0 && rb < r1) {
@@ -138,7 +164,12 @@ __device__ __forceinline__ void g8_tile(const G8Problem& P, int t_id, unsigned c
   auto stage_b = [&](int b, int kt, int r0 = 0, int r1 = 4) {
     const unsigned char* src = (const unsigned char*)b_base + (long)kt * b_kstep;
     unsigned char* d = lds + 65536 + b * 32768 + wave * 1024;
-    if (tail && kt == nkt - 1) {
+    if (listed) {
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+        if (rb >= r0 && rb < r1)
+          __builtin_amdgcn_global_load_lds((glb_ptr_t)((const unsigned char*)b_base + (size_t)(rk[rb] * ldb2b + t_bcol)), (lds_ptr_t)(d + rb * 8192), 16, 0, 0);
+    } else if (tail && kt == nkt - 1) {
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb)
         if (rb >= r0 && rb < r1) {
@@ -245,6 +276,7 @@ __device__ __forceinline__ void g8_tile(const G8Problem& P, int t_id, unsigned c
     const bool more_a = SPREAD && (KT) >= 1 && (KT) + 1 < nkt; \
     if (tail && (KT) == nkt - 1) zero_tail(BUF);               \
     /* phase 0 */                                              \
+    fetch_rows((KT) + 2);                                      \
     G8_READ_A(BUF, 0)                                          \
     G8_READ_B(BUF, 0, fbx)                                     \
     if (more_a) stage_a((BUF) ^ 1, (KT) + 1, 0, 2);            \
@@ -287,9 +319,11 @@ __device__ __forceinline__ void g8_tile(const G8Problem& P, int t_id, unsigned c
   }
 
   // prologue: K-tiles 0 and 1
+  fetch_rows(0);
   stage_a(0, 0);
   stage_b(0, 0);
   if (nkt > 1) {
+    fetch_rows(1);
     stage_a(1, 1);
     stage_b(1, 1);
     G8_WAIT_VM(8);
@@ -343,7 +377,7 @@ __device__ __forceinline__ void g8_tile(const G8Problem& P, int t_id, unsigned c
         const uint4 d = *reinterpret_cast<const uint4*>(ep + row_l * 144 + seg * 16);
         const int grow = m0 + wm * 128 + half * 64 + row_l, gcol = n0 + wn * 64 + seg * 8;
         if (grow < M_) {
-          bf16_t* cp = Cb + (long)grow * ldc + gcol;
+          bf16_t* cp = Cb + (long)(P.rows ? P.rows[grow] : grow) * ldc + gcol;
           if (gcol + 7 < N_) {
             *reinterpret_cast<uint4*>(cp) = d;
           } else {
@@ -371,7 +405,7 @@ __device__ __forceinline__ void g8_tile(const G8Problem& P, int t_id, unsigned c
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] + ((bias && col + e < N_) ? bias[col + e] : 0.f);
-        const long off = (long)row * ldc + col;
+        const long off = (long)((!TN && P.rows) ? P.rows[row] : row) * ldc + col;
         if (P.out_is_f32) {
           float* cp = (float*)P.C + off;
           if (col + 3 < N_ && n_vec_ok) {
@@ -431,7 +465,7 @@ int g_variant = 0;   // 0: four DMA pieces in phases 2 and 3 (default); 1: two p
                      // shapes of the step (0.289 vs 0.290 ms), slower on the grouped TN launch (0.555 vs 0.589 ms), profiles/r03d_gemm8_ab.txt
 template <int MODE>
 void g8_launch(int total, const G8Args& g, hipStream_t st) {
-  if (g_variant)
+  if (g_variant && g.p[0].rows == nullptr)
     hipLaunchKernelGGL((k_gemm8<MODE, true>), dim3(total), dim3(512), 0, st, g);
   else
     hipLaunchKernelGGL((k_gemm8<MODE, false>), dim3(total), dim3(512), 0, st, g);
@@ -449,82 +483,115 @@ int ds2_gemm8_set_variant(int v) {
   return old;
 }
 
+}  // extern "C"
+
+// The `_rows` entries take a row list (device, int32, strictly inside [0, n_phys)) and visit only the listed rows of the row dimension
+// shared by the activations of a padded [T' x batch] sequence matrix -- the frames t < length of every clip (model.py:96,100: the
+// reference packs them with pack_padded_sequence; here the matrices stay in place and the products skip the padding):
+//   NT: C[rows[r]][:] = A[rows[r]][:] * B^T (+ bias) for r < n_rows; other rows of C are NOT written.
+//   TN: C = sum over k < n_rows of At[rows[k]][m] * Bt[rows[k]][n].
+// rows == null: every row (n_rows = n_phys).  n_phys bounds the operands (n_phys * ld < 2^31 elements).
+static int g8_nt(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long lda, long ldb, long ldc, int out_f32,
+                 const int* rows, int n_phys, hipStream_t st) {
+  DS2_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && n_phys >= M, DS2_ERR_ARG);
+  DS2_REQUIRE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)B) & 15) == 0, DS2_ERR_ALIGN);
+  DS2_REQUIRE((long)n_phys * lda < (1L << 31) && (long)N * ldb < (1L << 31), DS2_ERR_ARG);
+  G8Args g{};
+  g.n_problems = 1;
+  const int tm = ds2_cdiv(M, 256), tn = ds2_cdiv(N, 256);
+  g.p[0] = G8Problem{(const bf16_t*)A, nullptr, (const bf16_t*)B, C, bias, M, N, 0, lda, 0, ldb, ldc, tn, tm * tn, out_f32, K, 0, rows};
+  g8_launch<0>(tm * tn, g, st);
+  DS2_CHECK_LAUNCH();
+  return 0;
+}
+
+static int g8_tn_fill(G8Args& g, int& total, int n, const void* const* At, const void* const* At2, const int* m_split, const void* const* Bt,
+                      void* const* C, const int* M, const int* N, const long* lda, const long* lda2, const long* ldb, const long* ldc, int K,
+                      const int* rows, int n_phys) {
+  DS2_REQUIRE(K > 0 && n_phys >= K, DS2_ERR_ARG);
+  for (int i = 0; i < n; ++i) {
+    DS2_REQUIRE(M[i] > 0 && N[i] > 0 && M[i] % 8 == 0 && N[i] % 8 == 0 && lda[i] % 8 == 0 && ldb[i] % 8 == 0, DS2_ERR_ARG);
+    DS2_REQUIRE((((uintptr_t)At[i]) & 15) == 0 && (((uintptr_t)Bt[i]) & 15) == 0, DS2_ERR_ALIGN);
+    DS2_REQUIRE((long)n_phys * lda[i] < (1L << 31) && (long)n_phys * ldb[i] < (1L << 31), DS2_ERR_ARG);
+    const void* a2 = At2 ? At2[i] : nullptr;
+    const int ms = a2 ? m_split[i] : 0;
+    DS2_REQUIRE(a2 == nullptr || (ms > 0 && ms < M[i] && ms % 256 == 0 && (((uintptr_t)a2) & 15) == 0 && lda2 && lda2[i] % 8 == 0 &&
+                                  (long)n_phys * lda2[i] < (1L << 31)), DS2_ERR_ARG);
+    const int tm = ds2_cdiv(M[i], 256), tn = ds2_cdiv(N[i], 256);
+    total += tm * tn;
+    g.p[i] = G8Problem{(const bf16_t*)At[i], (const bf16_t*)a2, (const bf16_t*)Bt[i], C[i], nullptr, M[i], N[i], ms, lda[i], a2 ? lda2[i] : 0, ldb[i], ldc[i], tn, total, 1, K, 1, rows};
+  }
+  return 0;
+}
+
+extern "C" {
+
 // C (f32 if out_f32 else bf16) [M][ldc] = A[M][lda] * B[N][ldb]^T (+ bias[N]) on the 256x256 phase-split kernel.
 // K % 64 == 0, lda/ldb % 8 == 0, 16-byte aligned operands of < 2^31 elements.
 int ds2_gemm8_nt(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long lda, long ldb, long ldc, int out_f32,
                  ds2_stream_t st) {
-  DS2_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0, DS2_ERR_ARG);
-  DS2_REQUIRE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)B) & 15) == 0, DS2_ERR_ALIGN);
-  DS2_REQUIRE((long)M * lda < (1L << 31) && (long)N * ldb < (1L << 31), DS2_ERR_ARG);
-  G8Args g{};
-  g.n_problems = 1;
-  const int tm = ds2_cdiv(M, 256), tn = ds2_cdiv(N, 256);
-  g.p[0] = G8Problem{(const bf16_t*)A, nullptr, (const bf16_t*)B, C, bias, M, N, 0, lda, 0, ldb, ldc, tn, tm * tn, out_f32, K, 0};
-  g8_launch<0>(tm * tn, g, (hipStream_t)st);
-  DS2_CHECK_LAUNCH();
-  return 0;
+  return g8_nt(A, B, C, bias, M, N, K, lda, ldb, ldc, out_f32, nullptr, M, (hipStream_t)st);
+}
+int ds2_gemm8_nt_rows(const void* A, const void* B, void* C, const float* bias, int n_phys, int N, int K, long lda, long ldb, long ldc,
+                      int out_f32, const int* rows, int n_rows, ds2_stream_t st) {
+  return g8_nt(A, B, C, bias, rows ? n_rows : n_phys, N, K, lda, ldb, ldc, out_f32, rows, n_phys, (hipStream_t)st);
 }
 
 // Grouped TN products, one launch:  for every problem i   C_i[M_i][N_i] f32 = sum_k At_i[k][m] * Bt_i[k][n],  k < K
 // (At_i [K][lda_i], Bt_i [K][ldb_i]: the contraction index is the ROW of both operands).  A problem's A operand may be two
 // column blocks: output rows >= m_split_i take their columns from A2_i (leading dimension lda2_i), m_split_i a multiple of 256.
 // Any K (a ragged last K-tile is zero-filled on chip; no row past K - 1 is read), M_i, N_i % 8 == 0, 16-byte aligned rows.
-int ds2_gemm8_tn_grouped(int n_problems, const void* const* At, const void* const* At2, const int* m_split, const void* const* Bt, void* const* C,
-                         const int* M, const int* N, const long* lda, const long* lda2, const long* ldb, const long* ldc, int K, ds2_stream_t st) {
-  DS2_REQUIRE(n_problems >= 1 && n_problems <= G8_MAX_GROUPS && K > 0, DS2_ERR_ARG);
+int ds2_gemm8_tn_grouped_rows(int n_problems, const void* const* At, const void* const* At2, const int* m_split, const void* const* Bt,
+                              void* const* C, const int* M, const int* N, const long* lda, const long* lda2, const long* ldb, const long* ldc,
+                              int n_phys, const int* rows, int n_rows, ds2_stream_t st) {
+  DS2_REQUIRE(n_problems >= 1 && n_problems <= G8_MAX_GROUPS, DS2_ERR_ARG);
   G8Args g{};
   g.n_problems = n_problems;
   int total = 0;
-  for (int i = 0; i < n_problems; ++i) {
-    DS2_REQUIRE(M[i] > 0 && N[i] > 0 && M[i] % 8 == 0 && N[i] % 8 == 0 && lda[i] % 8 == 0 && ldb[i] % 8 == 0, DS2_ERR_ARG);
-    DS2_REQUIRE((((uintptr_t)At[i]) & 15) == 0 && (((uintptr_t)Bt[i]) & 15) == 0, DS2_ERR_ALIGN);
-    DS2_REQUIRE((long)K * lda[i] < (1L << 31) && (long)K * ldb[i] < (1L << 31), DS2_ERR_ARG);
-    const void* a2 = At2 ? At2[i] : nullptr;
-    const int ms = a2 ? m_split[i] : 0;
-    DS2_REQUIRE(a2 == nullptr || (ms > 0 && ms < M[i] && ms % 256 == 0 && (((uintptr_t)a2) & 15) == 0 && lda2 && lda2[i] % 8 == 0 &&
-                                  (long)K * lda2[i] < (1L << 31)), DS2_ERR_ARG);
-    const int tm = ds2_cdiv(M[i], 256), tn = ds2_cdiv(N[i], 256);
-    total += tm * tn;
-    g.p[i] = G8Problem{(const bf16_t*)At[i], (const bf16_t*)a2, (const bf16_t*)Bt[i], C[i], nullptr, M[i], N[i], ms, lda[i], a2 ? lda2[i] : 0, ldb[i], ldc[i], tn, total, 1, K, 1};
-  }
+  const int rc = g8_tn_fill(g, total, n_problems, At, At2, m_split, Bt, C, M, N, lda, lda2, ldb, ldc, rows ? n_rows : n_phys, rows, n_phys);
+  if (rc) return rc;
   g8_launch<1>(total, g, (hipStream_t)st);
   DS2_CHECK_LAUNCH();
   return 0;
+}
+int ds2_gemm8_tn_grouped(int n_problems, const void* const* At, const void* const* At2, const int* m_split, const void* const* Bt, void* const* C,
+                         const int* M, const int* N, const long* lda, const long* lda2, const long* ldb, const long* ldc, int K, ds2_stream_t st) {
+  return ds2_gemm8_tn_grouped_rows(n_problems, At, At2, m_split, Bt, C, M, N, lda, lda2, ldb, ldc, K, nullptr, K, st);
 }
 
 // The weight gradients of a recurrent layer AND its dX product in one launch: the TN problems of ds2_gemm8_tn_grouped (contraction
 // over K_tn rows) followed by ONE NT problem (dX [M_nt][ldc_nt] bf16 = A_nt[M_nt][K_nt] * B_nt[N_nt][K_nt]^T).  Alone, the weight
 // gradients leave a quarter of the CUs idle (192 tiles of 376 K-tiles on cfg3) and the dX product half of its second round (376
-// tiles of 96 K-tiles); in one grid the long tiles start first and the short ones fill in behind them.
-int ds2_gemm8_wgrad_dx(int n_tn, const void* const* At, const void* const* At2, const int* m_split, const void* const* Bt, void* const* C,
-                       const int* M, const int* N, const long* lda, const long* lda2, const long* ldb, const long* ldc, int K_tn,
-                       const void* A_nt, const void* B_nt, void* C_nt, int M_nt, int N_nt, int K_nt, long lda_nt, long ldb_nt, long ldc_nt,
-                       ds2_stream_t st) {
+// tiles of 96 K-tiles); in one grid the long tiles start first and the short ones fill in behind them.  With a row list
+// (n_phys = K_tn = M_nt physical rows) the TN problems contract over the listed rows and the NT problem computes the listed rows.
+int ds2_gemm8_wgrad_dx_rows(int n_tn, const void* const* At, const void* const* At2, const int* m_split, const void* const* Bt, void* const* C,
+                            const int* M, const int* N, const long* lda, const long* lda2, const long* ldb, const long* ldc, int K_tn,
+                            const void* A_nt, const void* B_nt, void* C_nt, int M_nt, int N_nt, int K_nt, long lda_nt, long ldb_nt, long ldc_nt,
+                            const int* rows, int n_rows, ds2_stream_t st) {
   DS2_REQUIRE(n_tn >= 1 && n_tn < G8_MAX_GROUPS && K_tn > 0, DS2_ERR_ARG);
+  DS2_REQUIRE(rows == nullptr || (K_tn == M_nt && n_rows > 0 && n_rows <= K_tn), DS2_ERR_ARG);
   DS2_REQUIRE(M_nt > 0 && N_nt > 0 && K_nt > 0 && K_nt % 64 == 0 && lda_nt % 8 == 0 && ldb_nt % 8 == 0, DS2_ERR_ARG);
   DS2_REQUIRE((((uintptr_t)A_nt) & 15) == 0 && (((uintptr_t)B_nt) & 15) == 0, DS2_ERR_ALIGN);
   DS2_REQUIRE((long)M_nt * lda_nt < (1L << 31) && (long)N_nt * ldb_nt < (1L << 31), DS2_ERR_ARG);
   G8Args g{};
   g.n_problems = n_tn + 1;
   int total = 0;
-  for (int i = 0; i < n_tn; ++i) {
-    DS2_REQUIRE(M[i] > 0 && N[i] > 0 && M[i] % 8 == 0 && N[i] % 8 == 0 && lda[i] % 8 == 0 && ldb[i] % 8 == 0, DS2_ERR_ARG);
-    DS2_REQUIRE((((uintptr_t)At[i]) & 15) == 0 && (((uintptr_t)Bt[i]) & 15) == 0, DS2_ERR_ALIGN);
-    DS2_REQUIRE((long)K_tn * lda[i] < (1L << 31) && (long)K_tn * ldb[i] < (1L << 31), DS2_ERR_ARG);
-    const void* a2 = At2 ? At2[i] : nullptr;
-    const int ms = a2 ? m_split[i] : 0;
-    DS2_REQUIRE(a2 == nullptr || (ms > 0 && ms < M[i] && ms % 256 == 0 && (((uintptr_t)a2) & 15) == 0 && lda2 && lda2[i] % 8 == 0 &&
-                                  (long)K_tn * lda2[i] < (1L << 31)), DS2_ERR_ARG);
-    const int tm = ds2_cdiv(M[i], 256), tn = ds2_cdiv(N[i], 256);
-    total += tm * tn;
-    g.p[i] = G8Problem{(const bf16_t*)At[i], (const bf16_t*)a2, (const bf16_t*)Bt[i], C[i], nullptr, M[i], N[i], ms, lda[i], a2 ? lda2[i] : 0, ldb[i], ldc[i], tn, total, 1, K_tn, 1};
-  }
-  const int tm = ds2_cdiv(M_nt, 256), tn = ds2_cdiv(N_nt, 256);
+  const int rc = g8_tn_fill(g, total, n_tn, At, At2, m_split, Bt, C, M, N, lda, lda2, ldb, ldc, rows ? n_rows : K_tn, rows, K_tn);
+  if (rc) return rc;
+  const int m_eff = rows ? n_rows : M_nt;
+  const int tm = ds2_cdiv(m_eff, 256), tn = ds2_cdiv(N_nt, 256);
   total += tm * tn;
-  g.p[n_tn] = G8Problem{(const bf16_t*)A_nt, nullptr, (const bf16_t*)B_nt, C_nt, nullptr, M_nt, N_nt, 0, lda_nt, 0, ldb_nt, ldc_nt, tn, total, 0, K_nt, 0};
+  g.p[n_tn] = G8Problem{(const bf16_t*)A_nt, nullptr, (const bf16_t*)B_nt, C_nt, nullptr, m_eff, N_nt, 0, lda_nt, 0, ldb_nt, ldc_nt, tn, total, 0, K_nt, 0, rows};
   g8_launch<2>(total, g, (hipStream_t)st);
   DS2_CHECK_LAUNCH();
   return 0;
+}
+int ds2_gemm8_wgrad_dx(int n_tn, const void* const* At, const void* const* At2, const int* m_split, const void* const* Bt, void* const* C,
+                       const int* M, const int* N, const long* lda, const long* lda2, const long* ldb, const long* ldc, int K_tn,
+                       const void* A_nt, const void* B_nt, void* C_nt, int M_nt, int N_nt, int K_nt, long lda_nt, long ldb_nt, long ldc_nt,
+                       ds2_stream_t st) {
+  return ds2_gemm8_wgrad_dx_rows(n_tn, At, At2, m_split, Bt, C, M, N, lda, lda2, ldb, ldc, K_tn, A_nt, B_nt, C_nt, M_nt, N_nt, K_nt, lda_nt,
+                                 ldb_nt, ldc_nt, nullptr, 0, st);
 }
 
 }  // extern "C"

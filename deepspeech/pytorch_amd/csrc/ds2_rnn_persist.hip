@@ -148,6 +148,11 @@ long xbuf3_bytes(int cell, int H, const Plan3H& pl, bool bwd) {
   return (long)pl.NG * pl.nset * 4 * kt * 1024;       // per group: nset sets x four payload slots of [k-step][lq][16 rows] x 16 B
 }
 
+// XCC-id handshake words of the round-4 general kernels: 32 per group, BEHIND the exchange buffer (up to 32 groups -- 8 x gx -- do
+// not fit the 2 KB the tuned kernels' eight groups use inside the head: with 16 groups (H = 512) the words of groups 8-15 used to
+// land on the spin budget and on the first group's exchange slots -- an intermittent stale read at the second time step)
+long xcc3_bytes(const Plan3H& pl) { return (long)pl.NG * 32 * 8; }
+
 long xbuf2_bytes(int dtype, int cell, int H, const Plan2& pl, bool bwd) {
   const int ksz = dtype == DS2_BF16 ? 32 : 16;
   const long kt = (bwd ? (long)gates(cell) * H : (long)H) / ksz;
@@ -220,7 +225,7 @@ unsigned ds2_rnn_persist_set_spin_limit(unsigned polls) {
 long ds2_rnn_persist_ws_bytes(int dtype, int cell, int D, int N, int H) {
   if (tuned_ok(dtype, cell, D, N, H)) return AUX_BYTES + xbuf_bytes(cell, H, true);
   Plan3H p3;
-  if (plan3h(dtype, cell, D, N, H, cu_count(), p3)) return AUX_BYTES + xbuf3_bytes(cell, H, p3, true);
+  if (plan3h(dtype, cell, D, N, H, cu_count(), p3)) return AUX_BYTES + xbuf3_bytes(cell, H, p3, true) + xcc3_bytes(p3);
   Plan2 pl;
   if (!plan2(dtype, cell, D, N, H, pl)) return 0;
   return AUX_BYTES + xbuf2_bytes(dtype, cell, H, pl, true);
@@ -251,7 +256,7 @@ int ds2_rnn_persist_fwd(int dtype, int cell, int D, int N, int H, int Tp, const 
   Plan3H p3;
   if (plan3h(dtype, cell, D, N, H, cu_count(), p3)) {
     const long xb = xbuf3_bytes(cell, H, p3, false);
-    hipError_t e = hipMemsetAsync(ws, 0xff, AUX_BYTES + xb, st);
+    hipError_t e = hipMemsetAsync(ws, 0xff, AUX_BYTES + xb + xcc3_bytes(p3), st);
     if (e != hipSuccess) return (int)e;
     if (int r = set_spin_budget(ws, st)) return r;
     ds2r::RArgs ra{};
@@ -259,7 +264,7 @@ int ds2_rnn_persist_fwd(int dtype, int cell, int D, int N, int H, int Tp, const 
     a.N = N; a.Tp = Tp; a.D = D; a.gpd = p3.gpd; a.NG = p3.NG; a.lens = lens; a.W = Whh; a.bhh = bhh; a.GI = GI; a.Hseq = Hseq;
     a.hseq_dstride = hseq_dstride; a.S = S; a.h0 = h0; a.c0 = c0; a.hn = hn; a.cn = cn;
     a.xbuf = (char*)ws + AUX_BYTES; a.xgroup_bytes = xb / p3.NG; a.err = err; a.lerr = (int*)((char*)ws + 3072);
-    ra.xcc = (u64*)((char*)ws + 1024); ra.P = p3.P; ra.xmap = p3.xmap; ra.gx = p3.gx; ra.nset = p3.nset;
+    ra.xcc = (u64*)((char*)ws + AUX_BYTES + xb); ra.P = p3.P; ra.xmap = p3.xmap; ra.gx = p3.gx; ra.nset = p3.nset;
 #ifdef DS2_PROBE
     ra.dbg = (unsigned long long*)ws;
     { const char* e_ = getenv("DS2_PERSIST_DBG"); ra.dbgmask = e_ ? atoi(e_) : 0; }
@@ -308,7 +313,7 @@ int ds2_rnn_persist_bwd(int dtype, int cell, int D, int N, int H, int Tp, const 
   Plan3H p3;
   if (plan3h(dtype, cell, D, N, H, cu_count(), p3)) {
     const long xb = xbuf3_bytes(cell, H, p3, true);
-    hipError_t e = hipMemsetAsync(ws, 0xff, AUX_BYTES + xb, st);
+    hipError_t e = hipMemsetAsync(ws, 0xff, AUX_BYTES + xb + xcc3_bytes(p3), st);
     if (e != hipSuccess) return (int)e;
     if (int r = set_spin_budget(ws, st)) return r;
     ds2r::RArgs ra{};
@@ -316,7 +321,7 @@ int ds2_rnn_persist_bwd(int dtype, int cell, int D, int N, int H, int Tp, const 
     a.N = N; a.Tp = Tp; a.D = D; a.gpd = p3.gpd; a.NG = p3.NG; a.lens = lens; a.W = WhhT; a.Hseq = (void*)Hseq;
     a.hseq_dstride = hseq_dstride; a.S = (void*)S; a.dOut = dOut; a.dGI = dGI; a.dGH = dGH; a.dBacc = dBacc;
     a.xbuf = (char*)ws + AUX_BYTES; a.xgroup_bytes = xb / p3.NG; a.err = err; a.lerr = (int*)((char*)ws + 3072);
-    ra.xcc = (u64*)((char*)ws + 1024); ra.P = p3.P; ra.xmap = p3.xmap; ra.gx = p3.gx; ra.nset = p3.nset;
+    ra.xcc = (u64*)((char*)ws + AUX_BYTES + xb); ra.P = p3.P; ra.xmap = p3.xmap; ra.gx = p3.gx; ra.nset = p3.nset;
 #ifdef DS2_PROBE
     ra.dbg = (unsigned long long*)ws;
     { const char* e_ = getenv("DS2_PERSIST_DBG"); ra.dbgmask = e_ ? atoi(e_) : 0; }

@@ -552,6 +552,16 @@ __global__ void __launch_bounds__(256) k_split3(const float* __restrict__ src, l
   }
 }
 
+// Zero the padding rows (t >= lens[n]) of a [T' x N] sequence matrix: one workgroup per group of 4 rows, 16 bytes per lane.
+__global__ void __launch_bounds__(256) k_zero_pad_rows(unsigned char* X, long ld_bytes, int row_bytes, const int* __restrict__ lens, int N, long R) {
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const int t = (int)(r / N), n = (int)(r % N);
+  if (t < lens[n]) return;
+  unsigned char* p = X + r * ld_bytes;
+  for (int o = (threadIdx.x & 63) * 16; o < row_bytes; o += 64 * 16) *reinterpret_cast<uint4*>(p + o) = make_uint4(0, 0, 0, 0);
+}
+
 extern "C" {
 
 int ds2_version(void) { return 100; }
@@ -575,6 +585,18 @@ int ds2_add2(int dtype, const void* a, const void* b, void* out, long n, ds2_str
     hipLaunchKernelGGL(k_add2<float>, dim3(ew_grid(n / V)), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)out, n / V);
   else
     hipLaunchKernelGGL(k_add2<bf16_t>, dim3(ew_grid(n / V)), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n / V);
+  DS2_CHECK_LAUNCH();
+  return 0;
+}
+
+int ds2_zero_pad_rows(int dtype, void* X, long ld, int cols, const int* lens, int Tp, int N, ds2_stream_t st_) {
+  hipStream_t st = (hipStream_t)st_;
+  DS2_REQUIRE(dtype == DS2_F32 || dtype == DS2_BF16, DS2_ERR_DTYPE);
+  const int es = dtype == DS2_F32 ? 4 : 2;
+  DS2_REQUIRE(X != nullptr && lens != nullptr && Tp > 0 && N > 0 && cols > 0 && ld >= cols, DS2_ERR_ARG);
+  DS2_REQUIRE((ld * es) % 16 == 0 && ((long)cols * es) % 16 == 0 && (((uintptr_t)X) & 15) == 0, DS2_ERR_ALIGN);
+  const long R = (long)Tp * N;
+  hipLaunchKernelGGL(k_zero_pad_rows, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, (unsigned char*)X, ld * es, cols * es, lens, N, R);
   DS2_CHECK_LAUNCH();
   return 0;
 }

@@ -16,6 +16,7 @@ There is no CPU / torch-op fallback: CPU tensors or a missing libds2hip.so raise
 import math
 from typing import List
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -88,7 +89,11 @@ WGRAD_WITH_DX = os.environ.get("DS2_WGRAD_WITH_DX", "1") not in ("", "0")
 # backward then keeps its weight-gradient GEMMs on the second stream until the end of the node.  =0: one node per layer always.
 # Unset (default): one node per layer in the bf16 performance mode and under any data-parallel wrapper, the composite node otherwise.
 COMPOSITE_NODE = {"": None, "0": False}.get(os.environ.get("DS2_COMPOSITE_NODE", ""), True)     # None = decide per shape (see _logits)
-PER_LAYER_NODES_FOR_DDP = [False]     # set by dist.wrap_data_parallel: under a data-parallel wrapper every shape gets per-layer nodes
+PER_LAYER_NODES_FOR_DDP = [False]
+# Row lists (_frame_rows): the GEMMs over the [T' x N] frames skip the padding when less than this fraction of the frames is real
+# (DS2_ROW_LISTS=0: never; the products then run over every row, padding included, as in rounds 1-3).
+ROW_LISTS = os.environ.get("DS2_ROW_LISTS", "1") != "0"
+ROW_LIST_MIN_PADDING = 0.97     # set by dist.wrap_data_parallel: under a data-parallel wrapper every shape gets per-layer nodes
 
 N_FREQ_CONV2 = 41
 RNN_INPUT = 32 * N_FREQ_CONV2  # 1312, model.py:166-169
@@ -314,9 +319,25 @@ def _layer_param_count(layer):
     return (2 if layer.batch_norm is not None else 0) + 4 * layer.num_directions
 
 
-def _rnn_layer_forward(mod, li, X, lens_dev, N, Tp, dtype, training, h0, c0, lparams):
+def _frame_rows(output_lengths, Tp, N, dev):
+    """(lens_dev, rows): the output lengths on the device and -- when the batch carries enough padding to matter -- the list of the
+    rows t*N + n with t < length[n] of a [T' x N] sequence matrix, in storage order: the frames pack_padded_sequence keeps
+    (model.py:96).  The dense products over the frames (input projections, dX, weight gradients) visit only these rows.  One host
+    buffer, one copy: [lengths | rows]."""
+    ol = output_lengths.numpy().astype(np.int32)
+    n_valid = int(np.minimum(ol, Tp).sum())
+    if not ROW_LISTS or n_valid >= ROW_LIST_MIN_PADDING * Tp * N or n_valid == 0:
+        return output_lengths.to(dev, torch.int32, non_blocking=True), None
+    rows = np.flatnonzero(np.arange(Tp, dtype=np.int32)[:, None] < ol[None, :]).astype(np.int32)
+    both = torch.from_numpy(np.concatenate([ol, rows])).to(dev, non_blocking=True)
+    return both[:N], both[N:]
+
+
+def _rnn_layer_forward(mod, li, X, lens_dev, N, Tp, dtype, training, h0, c0, lparams, rows=None):
     """One BatchRNN layer (model.py:94-102): [SequenceWise BatchNorm1d] -> input projection GEMM -> packed bi/uni GRU/LSTM/RNN
     sweep -> direction sum.  lparams: [bn.weight, bn.bias]? + per direction (weight_ih, weight_hh, bias_ih, bias_hh).
+    rows: the batch's row list (_frame_rows) -- the input projection then skips the padding frames, whose gate pre-activations
+    no sweep reads (pack_padded_sequence, model.py:96).
     Returns (out [T'N][H], hn, cn, saved = [X, Xh or None, hext, Sv], meta)."""
     c = mod._cache
     R = Tp * N
@@ -356,9 +377,9 @@ def _rnn_layer_forward(mod, li, X, lens_dev, N, Tp, dtype, training, h0, c0, lpa
     if ops.split3_ok(dtype, R, D * G * H, I):
         # fp32 mode: one bf16 GEMM over the split operands (ops.split3); the split weights are cached like every other layout
         Wih3 = c.get(("wih3", li), wih, lambda: ops.split3(Wih, 1))
-        GI = ops.gemm_nt(ops.split3(Xh, 0), Wih3, bias=Bih, out_dtype=torch.float32)
+        GI = ops.gemm_nt(ops.split3(Xh, 0), Wih3, bias=Bih, out_dtype=torch.float32, rows=rows)
     else:
-        GI = ops.gemm_nt(Xh, Wih, bias=Bih)                              # [R][D*G*H]
+        GI = ops.gemm_nt(Xh, Wih, bias=Bih, rows=rows)                   # [R][D*G*H]; padding rows unwritten with a row list
     if H != Ht:
         h0 = _pad_cols(h0, H) if h0 is not None else None
         c0 = _pad_cols(c0, H) if c0 is not None else None
@@ -374,7 +395,7 @@ def _rnn_layer_forward(mod, li, X, lens_dev, N, Tp, dtype, training, h0, c0, lpa
     return out, hn, cn, [X, Xh if has_bn else None, hext, Sv], (kind, H, D, G, I, has_bn, sv, Ht, layer.input_size)
 
 
-def _rnn_layer_backward(mod, li, meta, saved, lparams, dout, lens_dev, N, Tp, dtype, main, side, wgrad_done):
+def _rnn_layer_backward(mod, li, meta, saved, lparams, dout, lens_dev, N, Tp, dtype, main, side, wgrad_done, rows=None):
     """Backward of one BatchRNN layer.  bf16 (the performance mode): the BPTT sweep, then ONE launch with the layer's weight
     gradients (grouped TN products over the activations as stored) and its dX, then the BatchNorm backward -- all on the caller's
     stream; nothing runs beside a sweep (a co-runner costs the latency-bound sweep the chip's clock).  fp32 /
@@ -446,9 +467,10 @@ def _rnn_layer_backward(mod, li, meta, saved, lparams, dout, lens_dev, N, Tp, dt
                     probs.append(dict(At=dGI[:, d * GH:], Bt=hprev, M=GH, N=H, lda=D * GH, ldb=H, out=dWhh[d]))
             if WGRAD_WITH_DX and wstream is main and len(probs) < 6 and ops.gemm8_nt_ok(dGI, WihT, R, WihT.shape[0], D * GH, D * GH,
                                                                                         WihT.stride(0)):
-                _, dXh_fused = ops.gemm8_tn_grouped(probs, R, dx=(dGI, WihT))   # + the layer's dX in the same launch
+                # + the layer's dX in the same launch; with a row list the padding frames are neither contracted over nor computed
+                _, dXh_fused = ops.gemm8_tn_grouped(probs, R, dx=(dGI, WihT), rows=rows, zero_pad=(lens_dev, Tp, N))
             else:
-                ops.gemm8_tn_grouped(probs, R)
+                ops.gemm8_tn_grouped(probs, R, rows=rows)
             if first:
                 dWih = torch.cat([_perm_cols_to_reference(dWih[d * GH:(d + 1) * GH]) for d in range(D)], 0)
             if rg.bacc is not None:
@@ -478,9 +500,9 @@ def _rnn_layer_backward(mod, li, meta, saved, lparams, dout, lens_dev, N, Tp, dt
         dXh = dXh_fused
     elif ops.split3_ok(dtype, R, H, GH):
         WihT3 = c.get(("wihT3", li), list(wih), lambda: ops.split3(WihT, 1))
-        dXh = ops.gemm_nt(ops.split3(dGI, 0), WihT3, out_dtype=torch.float32)
+        dXh = ops.gemm_nt(ops.split3(dGI, 0), WihT3, out_dtype=torch.float32, rows=rows, zero_pad=(lens_dev, Tp, N))
     else:
-        dXh = ops.gemm_nt(dGI, WihT)                                                                    # [R][I]
+        dXh = ops.gemm_nt(dGI, WihT, rows=rows, zero_pad=(lens_dev, Tp, N))                             # [R][I]
     if has_bn:
         dX = torch.empty_like(dXh)
         grads[0], grads[1] = _bn_seq_bwd(dXh, X, dX, sv, R, It, I)
@@ -574,7 +596,8 @@ class _RnnLayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, X, mod, lens_dev, N, Tp, dtype, training, li, h0, c0, *lparams):
-        out, hn, cn, saved, meta = _rnn_layer_forward(mod, li, X, lens_dev, N, Tp, dtype, training, h0, c0, lparams)
+        ctx.rows = mod._frame_rows                   # the row list of the batch in flight (set by _logits)
+        out, hn, cn, saved, meta = _rnn_layer_forward(mod, li, X, lens_dev, N, Tp, dtype, training, h0, c0, lparams, rows=ctx.rows)
         ctx.mod, ctx.dims, ctx.meta, ctx.li = mod, (N, Tp, dtype), meta, li
         ctx.had_state = h0 is not None
         ctx.none_mask = [t is None for t in saved]
@@ -598,7 +621,7 @@ class _RnnLayerFn(torch.autograd.Function):
         main = torch.cuda.current_stream()
         side = mod._wgrad_stream(dout.device)
         dX, grads, wgrad_done = _rnn_layer_backward(mod, ctx.li, ctx.meta, saved, lparams, dout.contiguous().to(dtype), st[0], N, Tp,
-                                                    dtype, main, side, None)
+                                                    dtype, main, side, None, rows=ctx.rows)
         # the gradients leave this node now (AccumulateGrad, DDP's reducer): whatever the second stream produced must be complete.
         # The early all-reduces of the opt-in OverlappedGradSync are NOT waited for here -- that is their point -- but at the end
         # of backward (its finish callback)
@@ -624,10 +647,12 @@ class _RnnStackFn(torch.autograd.Function):
     def forward(ctx, X, mod, lens_dev, N, Tp, dtype, training, n_layers, *rest):
         L = n_layers
         hs0, cs0, params = rest[:L], rest[L:2 * L], rest[2 * L:]
+        ctx.rows = mod._frame_rows                   # the row list of the batch in flight (set by _logits)
         saved, meta, outs_h, outs_c, pos = [], [], [], [], 0
         for li in range(L):
             n = _layer_param_count(mod.rnns[li])
-            out, hn, cn, sv4, mt = _rnn_layer_forward(mod, li, X, lens_dev, N, Tp, dtype, training, hs0[li], cs0[li], params[pos:pos + n])
+            out, hn, cn, sv4, mt = _rnn_layer_forward(mod, li, X, lens_dev, N, Tp, dtype, training, hs0[li], cs0[li], params[pos:pos + n],
+                                                      rows=ctx.rows)
             pos += n
             saved += sv4
             meta.append(mt)
@@ -662,7 +687,7 @@ class _RnnStackFn(torch.autograd.Function):
         for li in reversed(range(L)):
             n = _layer_param_count(mod.rnns[li])
             dout, lg, wgrad_done = _rnn_layer_backward(mod, li, ctx.meta[li], list(saved[4 * li:4 * li + 4]), params[offs[li]:offs[li] + n],
-                                                       dout, lens_dev, N, Tp, dtype, main, side, wgrad_done)
+                                                       dout, lens_dev, N, Tp, dtype, main, side, wgrad_done, rows=ctx.rows)
             grads[offs[li]:offs[li] + n] = lg
         if wgrad_done is not None:
             main.wait_event(wgrad_done)
@@ -934,6 +959,7 @@ class DeepSpeech(_Base):
         self._flat_bias = {}
         self._side_streams = {}
         self._prep_done = None
+        self._frame_rows = None          # row list of the batch in flight (_frame_rows)
         self._weights_dirty = False
         self._kind = kind
 
@@ -1067,7 +1093,7 @@ class DeepSpeech(_Base):
         N, T = x.shape[0], x.shape[3]
         Tp = (T + 2 * 5 - 10 - 1) // 2 + 1
         dev = x.device
-        lens_dev = output_lengths.to(dev, torch.int32, non_blocking=True)
+        lens_dev, self._frame_rows = _frame_rows(output_lengths, Tp, N, dev)
         training = self.training
         sm = self.conv.seq_module
         with torch.autocast("cuda", enabled=False):

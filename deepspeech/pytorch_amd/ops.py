@@ -110,9 +110,18 @@ def wgrad_tn_ok(dtype, R, M, N, lda=None, ldb=None):
             R * lda < (1 << 31) and R * ldb < (1 << 31))
 
 
+def zero_pad_rows(X, lens, Tp, N):
+    """X[(t*N + n)][:] = 0 for t >= lens[n]: the rows a row-list product leaves unwritten."""
+    call("ds2_zero_pad_rows", dt(X), P(X), X.stride(0), X.shape[1], P(lens), Tp, N, S())
+    return X
+
+
 def gemm_nt(A, B, bias=None, out_dtype=None, M=None, N=None, K=None, lda=None, ldb=None, out=None, ldc=None, splitk=1,
-            batch=1, sA=0, sB=0, sC=0, sBias=0, coresident=False):
-    """C[M][N] = A[M][K] * B[N][K]^T (+bias).  A, B: 2-D row-major tensors (or explicit M/N/K/ld for views)."""
+            batch=1, sA=0, sB=0, sC=0, sBias=0, coresident=False, rows=None, zero_pad=None):
+    """C[M][N] = A[M][K] * B[N][K]^T (+bias).  A, B: 2-D row-major tensors (or explicit M/N/K/ld for views).
+    rows (int32 device tensor or None): on the 256x256 kernel only the listed rows of A / C are visited (the frames of a padded
+    sequence matrix that pack_padded_sequence keeps, model.py:96); zero_pad = (lens, Tp, N): the other rows of C are then zero,
+    without it they are unspecified (unwritten by the 256x256 kernel; the kernels without row lists compute every row)."""
     M = A.shape[-2] if M is None else M
     N = B.shape[-2] if N is None else N
     K = A.shape[-1] if K is None else K
@@ -120,7 +129,10 @@ def gemm_nt(A, B, bias=None, out_dtype=None, M=None, N=None, K=None, lda=None, l
     ldb = B.stride(-2) if ldb is None else ldb
     out_dtype = out_dtype or A.dtype
     if out is None and splitk == 1 and batch == 1 and not coresident and gemm8_nt_ok(A, B, M, N, K, lda, ldb):
-        return gemm8_nt(A, B, bias=bias, out_dtype=out_dtype, M=M, N=N, K=K, lda=lda, ldb=ldb)
+        res = gemm8_nt(A, B, bias=bias, out_dtype=out_dtype, M=M, N=N, K=K, lda=lda, ldb=ldb, rows=rows)
+        if rows is not None and zero_pad is not None:
+            zero_pad_rows(res, *zero_pad)
+        return res
     if out is None:
         shape = (batch, M, N) if batch > 1 else (M, N)
         out = torch.empty(shape, dtype=out_dtype, device=A.device)       # split-K: the entry zeroes C itself
@@ -129,6 +141,8 @@ def gemm_nt(A, B, bias=None, out_dtype=None, M=None, N=None, K=None, lda=None, l
     out_f32 = 1 if out.dtype == torch.float32 else 0
     call("ds2_gemm_nt_coresident" if coresident else "ds2_gemm_nt", dt(A), P(A), P(B), P(out), PF(bias), M, N, K, lda, ldb, ldc,
          out_f32, batch, sA, sB, sC, sBias, splitk, S())
+    if rows is not None and zero_pad is not None and batch == 1:
+        zero_pad_rows(out, *zero_pad)          # same contract whichever kernel ran: unlisted rows are zero
     return out
 
 
@@ -139,22 +153,28 @@ def gemm_nt_rows2(A, A2, m_split, B, M, N, K, lda, ldb, splitk=1, coresident=Fal
     return out
 
 
-def gemm8_nt(A, B, bias=None, out_dtype=None, M=None, N=None, K=None, lda=None, ldb=None):
-    """C[M][N] = A[M][K] * B[N][K]^T (+bias) on the 256x256 phase-split kernel (bf16 operands, K % 64 == 0)."""
+def gemm8_nt(A, B, bias=None, out_dtype=None, M=None, N=None, K=None, lda=None, ldb=None, rows=None):
+    """C[M][N] = A[M][K] * B[N][K]^T (+bias) on the 256x256 phase-split kernel (bf16 operands, K % 64 == 0); rows: see gemm_nt."""
     M = A.shape[-2] if M is None else M
     N = B.shape[-2] if N is None else N
     K = A.shape[-1] if K is None else K
     lda = A.stride(-2) if lda is None else lda
     ldb = B.stride(-2) if ldb is None else ldb
     out = torch.empty((M, N), dtype=out_dtype or A.dtype, device=A.device)
+    if rows is not None:
+        call("ds2_gemm8_nt_rows", P(A), P(B), P(out), PF(bias), M, N, K, lda, ldb, N, 1 if out.dtype == torch.float32 else 0, P(rows),
+             rows.numel(), S())
+        return out
     call("ds2_gemm8_nt", P(A), P(B), P(out), PF(bias), M, N, K, lda, ldb, N, 1 if out.dtype == torch.float32 else 0, S())
     return out
 
 
-def gemm8_tn_grouped(problems, K, dx=None):
+def gemm8_tn_grouped(problems, K, dx=None, rows=None, zero_pad=None):
     """problems: list of dicts(At, Bt, M, N, lda, ldb[, At2, lda2, m_split][, out]); every product C[M][N] f32 = sum_{k<K} At[k][m] Bt[k][n]
     in one launch.  Returns the list of outputs.  dx = (A, B): additionally the NT product A[M][Kx] * B[N][Kx]^T (bf16) in the SAME
-    launch (the layer's dX beside its weight gradients); returns (outputs, dX) then."""
+    launch (the layer's dX beside its weight gradients); returns (outputs, dX) then.  rows: the contraction (and the rows of dX)
+    runs over the listed rows only; zero_pad = (lens, Tp, N) zeroes the unlisted rows of dX."""
+    rp, nr = (P(rows), rows.numel()) if rows is not None else (None, 0)
     n = len(problems)
     outs = []
     for pr in problems:
@@ -179,10 +199,12 @@ def gemm8_tn_grouped(problems, K, dx=None):
         A, B = dx
         Mx, Nx, Kx = A.shape[0], B.shape[0], A.shape[1]
         out_x = torch.empty((Mx, Nx), dtype=A.dtype, device=A.device)
-        call("ds2_gemm8_wgrad_dx", n, At, At2, ms, Bt, Cs, Ms, Ns, lda, lda2, ldb, ldc, K, P(A), P(B), P(out_x), Mx, Nx, Kx, A.stride(0),
-             B.stride(0), Nx, S())
+        call("ds2_gemm8_wgrad_dx_rows", n, At, At2, ms, Bt, Cs, Ms, Ns, lda, lda2, ldb, ldc, K, P(A), P(B), P(out_x), Mx, Nx, Kx, A.stride(0),
+             B.stride(0), Nx, rp, nr, S())
+        if rows is not None and zero_pad is not None:
+            zero_pad_rows(out_x, *zero_pad)
         return outs, out_x
-    call("ds2_gemm8_tn_grouped", n, At, At2, ms, Bt, Cs, Ms, Ns, lda, lda2, ldb, ldc, K, S())
+    call("ds2_gemm8_tn_grouped_rows", n, At, At2, ms, Bt, Cs, Ms, Ns, lda, lda2, ldb, ldc, K, rp, nr, S())
     return outs
 
 

@@ -83,6 +83,25 @@ int ds2_gemm8_wgrad_dx(int n_tn, const void* const* At, const void* const* At2, 
                        const void* A_nt, const void* B_nt, void* C_nt, int M_nt, int N_nt, int K_nt, long lda_nt, long ldb_nt, long ldc_nt,
                        ds2_stream_t stream);
 
+/* Row lists: the `_rows` forms of the three entries above visit only the listed rows of the dimension that runs over the
+ * [T' x batch] frames of a padded sequence matrix -- the frames t < length of every clip, i.e. what pack_padded_sequence keeps
+ * (model.py:96; the reference's nn.GRU / nn.LSTM never see the padding, model.py:97-100).  rows: device int32 [n_rows], values in
+ * [0, n_phys); null = every row.
+ *   ds2_gemm8_nt_rows:          C[rows[r]][:] = A[rows[r]][:] * B^T (+ bias), r < n_rows; the other rows of C are NOT written.
+ *   ds2_gemm8_tn_grouped_rows:  C_i = sum over k < n_rows of At_i[rows[k]][m] * Bt_i[rows[k]][n].
+ *   ds2_gemm8_wgrad_dx_rows:    both (K_tn == M_nt == n_phys).
+ * ds2_zero_pad_rows: X[(t*N + n)][0..cols) = 0 for t >= lens[n] (the rows a `_rows` product leaves unwritten). */
+int ds2_gemm8_nt_rows(const void* A, const void* B, void* C, const float* bias, int n_phys, int N, int K, long lda, long ldb, long ldc,
+                      int out_f32, const int* rows, int n_rows, ds2_stream_t stream);
+int ds2_gemm8_tn_grouped_rows(int n_problems, const void* const* At, const void* const* At2, const int* m_split, const void* const* Bt,
+                              void* const* C, const int* M, const int* N, const long* lda, const long* lda2, const long* ldb, const long* ldc,
+                              int n_phys, const int* rows, int n_rows, ds2_stream_t stream);
+int ds2_gemm8_wgrad_dx_rows(int n_tn, const void* const* At, const void* const* At2, const int* m_split, const void* const* Bt, void* const* C,
+                            const int* M, const int* N, const long* lda, const long* lda2, const long* ldb, const long* ldc, int K_tn,
+                            const void* A_nt, const void* B_nt, void* C_nt, int M_nt, int N_nt, int K_nt, long lda_nt, long ldb_nt, long ldc_nt,
+                            const int* rows, int n_rows, ds2_stream_t stream);
+int ds2_zero_pad_rows(int dtype, void* X, long ld, int cols, const int* lens, int Tp, int N, ds2_stream_t stream);
+
 /* ---- BatchNorm (model.py:159,162 BatchNorm2d in NFTC; model.py:28-33,86,196 SequenceWise BatchNorm1d) ---------------
  * mode 0: sequence matrix X[R][ldx], C features.   mode 1: conv activation NFTC (R = N*F*Tp rows, C = 32): output also
  * gets Hardtanh(0,20) (model.py:160,163) and the MaskConv time mask (model.py:61-68; t >= lens[n] -> 0).

@@ -146,3 +146,76 @@ def test_gemm8_race_screen_bit_identical_under_uneven_load():
         else:
             for a, b in zip(first, cur):
                 assert torch.equal(a, b), rnd
+
+
+def _frame_list(Tp, N, seed):
+    """Row list of a padded [T' x N] sequence matrix with sorted-or-not ragged lengths: (lens int32 device, rows int32 device)."""
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    lens = rs.randint(max(1, Tp // 3), Tp + 1, N).astype(np.int32)
+    lens[rs.randint(N)] = Tp
+    rows = np.flatnonzero(np.arange(Tp)[:, None] < lens[None, :]).astype(np.int32)
+    return torch.from_numpy(lens).to(DEV), torch.from_numpy(rows).to(DEV)
+
+
+@pytest.mark.parametrize("Tp,N,K,Nc,f32,bias", [
+    (37, 8, 64, 264, True, True),          # 296 physical rows, ~200 listed: edge tile in M
+    (151, 32, 320, 1344, False, True),     # five K-tiles, bf16 epilogue through LDS
+    (301, 64, 1280, 512, False, False),    # cfg5-shaped rows: 19264 physical
+])
+def test_gemm8_nt_row_list_visits_exactly_the_listed_rows(Tp, N, K, Nc, f32, bias):
+    """ds2_gemm8_nt_rows: listed rows equal the full product's rows BIT for bit (same tile arithmetic, only the row -> address map
+    differs); unlisted rows keep what the output buffer held (here: NaN poison), and ds2_zero_pad_rows zeroes exactly those."""
+    from deepspeech.pytorch_amd import ops, _lib
+    R = Tp * N
+    lens, rows = _frame_list(Tp, N, 41)
+    A, B = _rand((R, K), 42), _rand((Nc, K), 43)
+    bv = torch.linspace(-1, 1, Nc, device=DEV) if bias else None
+    full = ops.gemm8_nt(A, B, bias=bv, out_dtype=torch.float32 if f32 else None)
+    out = torch.full_like(full, float("nan"))
+    _lib.call("ds2_gemm8_nt_rows", ops.P(A), ops.P(B), ops.P(out), ops.PF(bv), R, Nc, K, K, K, Nc, 1 if f32 else 0, ops.P(rows), rows.numel(),
+              ops.S())
+    listed = torch.zeros(R, dtype=torch.bool, device=DEV)
+    listed[rows.long()] = True
+    assert torch.equal(out[listed], full[listed])
+    assert torch.isnan(out[~listed]).all()
+    ops.zero_pad_rows(out, lens, Tp, N)
+    assert torch.equal(out[listed], full[listed]) and (out[~listed] == 0).all()
+    # the wrapper: same thing in one call
+    out2 = ops.gemm_nt(A, B, bias=bv, out_dtype=torch.float32 if f32 else None, rows=rows, zero_pad=(lens, Tp, N))
+    assert torch.equal(out2[listed], full[listed]) and (out2[~listed] == 0).all()
+
+
+@pytest.mark.parametrize("Tp,N", [(37, 8), (151, 32), (203, 64)])
+def test_gemm8_tn_row_list_contracts_over_the_listed_rows(Tp, N):
+    """Grouped TN products over a row list = the products over the gathered rows (unlisted rows are poisoned with NaN: they must not
+    be read into any sum); the mixed launch's dX has the listed rows of the full product and zeros elsewhere."""
+    from deepspeech.pytorch_amd import ops
+    R, H = Tp * N, 512
+    lens, rows = _frame_list(Tp, N, 51)
+    listed = torch.zeros(R, dtype=torch.bool, device=DEV)
+    listed[rows.long()] = True
+    dG, X, Hp, dQ = _rand((R, 3 * H), 52), _rand((R, H + 64), 53)[:, :H], _rand((R, H), 54), _rand((R, H), 55)
+    W = _rand((H, 3 * H), 56)
+    dGp, Xp, Hpp, dQp = dG.clone(), X.clone(), Hp.clone(), dQ.clone()
+    for t_ in (dGp, Xp, Hpp, dQp):
+        t_[~listed] = float("nan")
+
+    def problems(g, x, hp, dq):
+        return [dict(At=g, Bt=x, M=3 * H, N=H, lda=3 * H, ldb=x.stride(0)),
+                dict(At=g, At2=dq, lda2=H, m_split=2 * H, Bt=hp, M=3 * H, N=H, lda=3 * H, ldb=H)]
+    outs = ops.gemm8_tn_grouped(problems(dGp, Xp, Hpp, dQp), R, rows=rows)
+    li = rows.long()
+    refs = [dG[li].float().t() @ X[li].float(), torch.cat([dG[li][:, :2 * H], dQ[li]], 1).float().t() @ Hp[li].float()]
+    for o, r in zip(outs, refs):
+        assert torch.isfinite(o).all()
+        assert (o - r).abs().max().item() / r.abs().max().item() < 2e-5
+    # equal, bit for bit, to the same launch over physically gathered operands (same K-tiles, same order of summation)
+    outs_g = ops.gemm8_tn_grouped(problems(dG[li].contiguous(), X[li].contiguous(), Hp[li].contiguous(), dQ[li].contiguous()), li.numel())
+    for a, b in zip(outs, outs_g):
+        assert torch.equal(a, b)
+    outs_m, dx = ops.gemm8_tn_grouped(problems(dGp, Xp, Hpp, dQp), R, dx=(dGp, W), rows=rows, zero_pad=(lens, Tp, N))
+    for a, b in zip(outs, outs_m):
+        assert torch.equal(a, b)
+    full = ops.gemm8_nt(dG, W)
+    assert torch.equal(dx[listed], full[listed]) and (dx[~listed] == 0).all()

@@ -397,6 +397,46 @@ def test_rnn_persist3_sweeps(kind, D, N, H, Tp):
             assert np.abs(a_ - b_).max() <= 2e-2 * max(1.0, np.abs(b_).max()), np.abs(a_ - b_).max()
 
 
+@pytest.mark.parametrize("kind,D", [("gru", 1), ("lstm", 2)])
+def test_rnn_persist3_sixteen_groups_repeat_bit_identically(kind, D):
+    """H = 512 runs TWO groups per XCD -- up to 16 groups, the only width with more than eight.  Their XCC-id handshake words used to
+    overflow the 2 KB of the scratch head that eight groups need, onto the spin budget and the first group's exchange slots: about
+    one launch in ten read a stale word at the second time step (found by a repeated whole-model step, round 4).  Ten forward +
+    BPTT sweeps over 451 ragged steps: every launch bit-identical to the first and equal to the launch-per-step kernels."""
+    o = ops()
+    N, H, Tp = 16, 512, 451
+    G = o.GATES[kind]
+    dev = "cuda"
+    torch.manual_seed(0)
+    GI = torch.randn(Tp * N, D * G * H, device=dev).to(torch.bfloat16)
+    Whh = ((torch.rand(D, G * H, H, device=dev) * 2 - 1) / H ** 0.5).to(torch.bfloat16)
+    WhhT = Whh.transpose(1, 2).contiguous()
+    bhh = torch.zeros(D, G * H, device=dev)
+    lens_np = np.sort(np.random.RandomState(0).randint(Tp // 3, Tp + 1, N))[::-1].copy().astype(np.int32)
+    lens_np[0] = Tp
+    lens = torch.from_numpy(lens_np).to(dev)
+    dout = torch.randn(Tp, N, H, device=dev).to(torch.bfloat16)
+    assert o.use_persistent(kind, torch.bfloat16, D, N, H)
+    o.PERSIST_ENABLED = False
+    try:
+        hext_r, Sv_r, _, _ = o.rnn_fwd(kind, GI, Whh, bhh, lens, D, N, H, Tp)
+        dGI_r = o.rnn_bwd(kind, dout, WhhT, hext_r, Sv_r, lens, D, N, H, Tp).dGI
+    finally:
+        o.PERSIST_ENABLED = True
+    first = None
+    for it in range(10):
+        hext, Sv, _, _ = o.rnn_fwd(kind, GI, Whh, bhh, lens, D, N, H, Tp)
+        dGI = o.rnn_bwd(kind, dout, WhhT, hext, Sv, lens, D, N, H, Tp).dGI
+        torch.cuda.synchronize()
+        o.check_persistent_kernels()
+        if first is None:
+            first = (hext.clone(), dGI.clone())
+            assert (hext.float() - hext_r.float()).abs().max().item() <= 2e-2
+            assert (dGI.float() - dGI_r.float()).abs().max().item() <= 2e-2 * max(1.0, dGI_r.float().abs().max().item())
+        else:
+            assert torch.equal(hext, first[0]) and torch.equal(dGI, first[1]), it
+
+
 def test_rnn_persist3_long_ragged_sweep():
     """T' = 311 ragged-length steps through the round-4 kernels and the tuned H = 1024 kernels: the four-slot wrap, the re-arm and
     the bias accumulation over hundreds of steps at KERNEL level (the whole-model tests cover them only indirectly)."""

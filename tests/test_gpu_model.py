@@ -533,3 +533,38 @@ def test_criterion_attribute_equals_training_step_loss():
     assert abs(float(l2) - float(loss)) <= 1e-5 * abs(float(loss))
     l2.backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m2.parameters())
+
+
+@pytest.mark.parametrize("kind,bi", [("gru", True), ("lstm", False)])
+def test_row_lists_change_nothing_but_the_order_of_summation(kind, bi):
+    """model._frame_rows: the dense products over the [T' x N] frames skip the padding (what pack_padded_sequence drops,
+    model.py:96).  With and without the row list: the SAME loss bit for bit (the kept rows of every product are the same tile
+    arithmetic), every gradient within fp32 summation-order noise (the weight gradients contract over fewer, differently
+    grouped rows), and dX of the padding frames exactly zero either way (checked through the conv-stack gradients being equal)."""
+    from deepspeech.pytorch_amd import configs, model as M, synth
+    rt = getattr(configs.RNNType, kind)
+    mc = configs.BiDirectionalConfig(rnn_type=rt, hidden_size=512, hidden_layers=3) if bi else \
+        configs.UniDirectionalConfig(rnn_type=rt, hidden_size=512, hidden_layers=3, lookahead_context=20)
+    lengths = synth.synth_lengths(16, 301, 901, seed=77)
+    inputs, targets, pct, tsz = synth.synth_batch(lengths, seed=77)
+    mk = lambda: (torch.from_numpy(inputs).to(DEV), torch.from_numpy(targets), torch.from_numpy(pct.copy()), torch.from_numpy(tsz))
+    torch.manual_seed(3)
+    m = M.DeepSpeech(configs.LABELS, mc, "bf16", configs.AdamConfig(), configs.SpectConfig()).to(DEV).train()
+    res = {}
+    old = M.ROW_LISTS
+    try:
+        for flag in (True, False):
+            M.ROW_LISTS = flag
+            m.zero_grad()
+            loss = m.training_step(mk(), 0)
+            assert (m._frame_rows is not None) == flag
+            loss.backward()
+            res[flag] = (float(loss.item()), {k: p.grad.detach().clone() for k, p in m.named_parameters()})
+    finally:
+        M.ROW_LISTS = old
+    assert res[True][0] == res[False][0]
+    for k, g in res[True][1].items():
+        h = res[False][1][k]
+        assert torch.isfinite(g).all(), k
+        d = float((g - h).norm() / (h.norm() + 1e-30))
+        assert d < 2e-4, (k, d)

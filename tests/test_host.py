@@ -225,3 +225,34 @@ def test_build_rejects_any_other_use_of_the_l2_touch_sink_register(tmp_path):
         assert len(build._l2_sink_misuse(str(obj))) == 1, bad
     asm.unlink()
     assert build._l2_sink_misuse(str(obj))          # no assembly to check = not verified = rejected
+
+
+def test_frame_rows_lists_the_frames_pack_padded_sequence_keeps():
+    """model._frame_rows: rows t*N + n with t < length[n], in storage order -- the same frames, in the same (time-major) order, that
+    torch's pack_padded_sequence keeps (reference model.py:96); no list when the batch carries (almost) no padding or the switch
+    is off."""
+    import numpy as np
+    import torch
+    from deepspeech.pytorch_amd import model as M
+    lens = torch.tensor([7, 5, 5, 2], dtype=torch.int32)
+    Tp, N = 7, 4
+    lens_dev, rows = M._frame_rows(lens, Tp, N, "cpu")
+    assert lens_dev.tolist() == [7, 5, 5, 2] and rows.dtype == torch.int32
+    x = torch.arange(Tp * N, dtype=torch.float32).reshape(Tp, N, 1)
+    packed = torch.nn.utils.rnn.pack_padded_sequence(x, lens.long(), enforce_sorted=True)
+    assert rows.tolist() == packed.data.reshape(-1).int().tolist()           # the packed data IS the listed rows, in order
+    assert rows.numel() == int(lens.sum())
+    # unsorted lengths: still the valid frames in storage order
+    lens2 = torch.tensor([2, 7, 5, 5], dtype=torch.int32)
+    _, rows2 = M._frame_rows(lens2, Tp, N, "cpu")
+    want = [t * N + n for t in range(Tp) for n in range(N) if t < int(lens2[n])]
+    assert rows2.tolist() == want
+    # (almost) no padding -> no list; switch off -> no list
+    _, none = M._frame_rows(torch.tensor([7, 7, 7, 7], dtype=torch.int32), Tp, N, "cpu")
+    assert none is None
+    old = M.ROW_LISTS
+    try:
+        M.ROW_LISTS = False
+        assert M._frame_rows(lens, Tp, N, "cpu")[1] is None
+    finally:
+        M.ROW_LISTS = old
