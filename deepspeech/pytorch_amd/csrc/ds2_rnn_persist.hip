@@ -153,6 +153,20 @@ long xbuf3_bytes(int cell, int H, const Plan3H& pl, bool bwd) {
 // land on the spin budget and on the first group's exchange slots -- an intermittent stale read at the second time step)
 long xcc3_bytes(const Plan3H& pl) { return (long)pl.NG * 32 * 8; }
 
+// Two-set groups execute a set's half-steps only while one of its clips is inside its sequence (ds2r::sched3): the padding rows of
+// the sweep's outputs are zeroed here instead of by the half-steps left out.  One workgroup per 4 rows of a [T' x N] matrix.
+__global__ void __launch_bounds__(256) k_zero_pad3(unsigned char* X, long ld_bytes, int row_bytes, const int* __restrict__ lens, int N, long R) {
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  if ((int)(r / N) < lens[r % N]) return;
+  unsigned char* p = X + r * ld_bytes;
+  for (int o = (threadIdx.x & 63) * 16; o < row_bytes; o += 64 * 16) *reinterpret_cast<uint4*>(p + o) = make_uint4(0, 0, 0, 0);
+}
+void zero_pad3(void* X, long ld_bytes, long row_bytes, const int* lens, int N, int Tp, hipStream_t st) {
+  const long R = (long)Tp * N;
+  hipLaunchKernelGGL(k_zero_pad3, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, (unsigned char*)X, ld_bytes, (int)row_bytes, lens, N, R);
+}
+
 long xbuf2_bytes(int dtype, int cell, int H, const Plan2& pl, bool bwd) {
   const int ksz = dtype == DS2_BF16 ? 32 : 16;
   const long kt = (bwd ? (long)gates(cell) * H : (long)H) / ksz;
@@ -205,7 +219,8 @@ int ds2_rnn_persist_shape_covered(int dtype, int cell, int D, int N, int H) {
   return launch2_any(true, false, dtype, cell, H, MT, dummy, nullptr) == 0 ? 1 : 0;
 }
 
-// A/B hook: bit 0 = route the shapes of the round-4 general kernels to the round-2 general kernels (or launch-per-step) instead.
+// A/B hook: bit 0 = route the shapes of the round-4 general kernels to the round-2 general kernels (or launch-per-step) instead;
+// bit 1 = two-set groups execute every half-step (no set schedules).
 // Returns the previous value.  Process-wide.
 unsigned ds2_rnn_persist_set_variant(unsigned bits) {
   const unsigned old = g_variant;
@@ -265,6 +280,10 @@ int ds2_rnn_persist_fwd(int dtype, int cell, int D, int N, int H, int Tp, const 
     a.hseq_dstride = hseq_dstride; a.S = S; a.h0 = h0; a.c0 = c0; a.hn = hn; a.cn = cn;
     a.xbuf = (char*)ws + AUX_BYTES; a.xgroup_bytes = xb / p3.NG; a.err = err; a.lerr = (int*)((char*)ws + 3072);
     ra.xcc = (u64*)((char*)ws + AUX_BYTES + xb); ra.P = p3.P; ra.xmap = p3.xmap; ra.gx = p3.gx; ra.nset = p3.nset;
+    ra.skip = (p3.nset == 2 && !(g_variant & 2u)) ? 1 : 0;
+    if (ra.skip)
+      for (int d = 0; d < D; ++d)       // h_t of the padding frames (Hseq points at t = 0)
+        zero_pad3((char*)Hseq + (long)d * hseq_dstride * 2, (long)H * 2, (long)H * 2, lens, N, Tp, st);
 #ifdef DS2_PROBE
     ra.dbg = (unsigned long long*)ws;
     { const char* e_ = getenv("DS2_PERSIST_DBG"); ra.dbgmask = e_ ? atoi(e_) : 0; }
@@ -322,6 +341,13 @@ int ds2_rnn_persist_bwd(int dtype, int cell, int D, int N, int H, int Tp, const 
     a.hseq_dstride = hseq_dstride; a.S = (void*)S; a.dOut = dOut; a.dGI = dGI; a.dGH = dGH; a.dBacc = dBacc;
     a.xbuf = (char*)ws + AUX_BYTES; a.xgroup_bytes = xb / p3.NG; a.err = err; a.lerr = (int*)((char*)ws + 3072);
     ra.xcc = (u64*)((char*)ws + AUX_BYTES + xb); ra.P = p3.P; ra.xmap = p3.xmap; ra.gx = p3.gx; ra.nset = p3.nset;
+    ra.skip = (p3.nset == 2 && !(g_variant & 2u)) ? 1 : 0;
+    if (ra.skip) {
+      const long GHb = (long)gates(cell) * H * 2;
+      zero_pad3(dGI, D * GHb, D * GHb, lens, N, Tp, st);
+      if (dGH)
+        for (int d = 0; d < D; ++d) zero_pad3((char*)dGH + (long)d * Tp * N * H * 2, (long)H * 2, (long)H * 2, lens, N, Tp, st);
+    }
 #ifdef DS2_PROBE
     ra.dbg = (unsigned long long*)ws;
     { const char* e_ = getenv("DS2_PERSIST_DBG"); ra.dbgmask = e_ ? atoi(e_) : 0; }

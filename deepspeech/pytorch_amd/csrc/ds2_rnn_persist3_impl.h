@@ -33,7 +33,9 @@ struct RArgs {
   int P;         // workgroups per group = H / 32
   int xmap;      // 1: group g's workgroups are the blocks with blockIdx % 8 == g % 8 (one XCD, if the dispatcher keeps its habit)
   int gx;        // xmap: group slots per XCD (floor(32 / P)); the grid is 8 * gx * P blocks, groups >= NG stay empty
-  int nset;      // interleaved sample sets per group (the kernel's NSET)
+  int nset;      // sample sets per group (the kernel's NSET)
+  int skip;      // 1: a set executes only the time steps at which one of its clips is inside its sequence (the caller zeroes the
+                 // padding rows of the outputs: they are no longer written for the steps left out); 0: every step
 #ifdef DS2_PROBE   // tools/probe_persist3.py builds its own library with -DDS2_PROBE; the shipping kernels carry none of it
   unsigned long long* dbg;  // [NG][8] cycle counters of workgroup 0 of each group (thread 0 and thread 255)
   int dbgmask;              // 1 skip GI / dOut / S prefetch loads, 2 skip output stores, 8 skip the gather + products (no exchange),
@@ -362,18 +364,35 @@ __device__ __forceinline__ float2 load_partials3(const float* part, int t, int r
 
 // The gather phase of half-step (s, q) -- shared by the forward and the BPTT kernel (local names: gx, acc, w, wl_lane, rsrc, gbase,
 // gneed, ks0, cnt, gpart, dead, rounds, dbgmask).  HAS0: the exchanged vector exists at step 0 (forward with an initial state).
-// NSET == 2: the chunks of this half-step were issued during the previous one; after its products every buffer is refilled with the
-// chunk two ahead, which for the last two chunks belongs to the NEXT half-step (the other set, published a half-step ago).
+// NSET == 2: the first two chunks of a half-step are normally issued during the previous one (`pre`): after its products every buffer
+// is refilled with the chunk two ahead, which for the last two chunks belongs to the half-step executed NEXT -- normally the other set's,
+// published a half-step ago.  Sets whose clips are all outside their sequences at a time step do not execute it (lo / hi).
 #define DS2R_BASE(S_, Q_) ((Q_) * SETB + (((S_) + 3) & 3) * SLOT + gbase)
 #define DS2R_GATHER_PHASE(HAS0)                                                                        \
   {                                                                                                     \
     constexpr int NCH_ = GX::NCH;                                                                       \
     constexpr bool PIPE_ = NSET == 2;                                                                   \
-    const bool have_ = (s > 0 || (HAS0)) && !(dbgmask & 8);                                             \
+    const bool have_ = (s > lo[q] || (HAS0)) && !(dbgmask & 8);                                         \
+    /* the half-step executed next (sets leave / join the schedule: see `lo`, `hi`), and whether its first two chunks may be  \
+       started from here: it has data, and its buffer parity continues this one's ((q2 - q - 1) * NCH even) */               \
+    int s2 = s, q2 = q;                                                                                 \
+    bool pre_next = false;                                                                              \
+    if (PIPE_ && have_) {                                                                               \
+      bool found_ = false;                                                                              \
+      _Pragma("unroll") for (int k_ = 1; k_ < 2 * NSET; ++k_) {                                         \
+        const int qq_ = (q + k_) % NSET, ss_ = s + (q + k_) / NSET;                                     \
+        if (!found_ && ss_ >= lo[qq_] && ss_ < hi[qq_]) {                                               \
+          found_ = true;                                                                                \
+          s2 = ss_;                                                                                     \
+          q2 = qq_;                                                                                     \
+        }                                                                                               \
+      }                                                                                                 \
+      pre_next = found_ && (s2 > lo[q2] || (HAS0)) && (NCH_ % 2 == 0 || ((q2 - q - 1) & 1) == 0);       \
+    }                                                                                                   \
     if (have_) {                                                                                        \
-      if (!PIPE_) {                                                                                     \
-        gx.issue(0, 0, rsrc, DS2R_BASE(s, q), gneed[q], ks0, cnt, gpart);                               \
-        gx.issue(1, 1, rsrc, DS2R_BASE(s, q), gneed[q], ks0, cnt, gpart);                               \
+      if (!pre) {                                                                                       \
+        gx.issue(PIPE_ ? ((q * NCH_) & 1) : 0, 0, rsrc, DS2R_BASE(s, q), gneed[q], ks0, cnt, gpart);    \
+        gx.issue(PIPE_ ? ((q * NCH_ + 1) & 1) : 1, 1, rsrc, DS2R_BASE(s, q), gneed[q], ks0, cnt, gpart); \
       }                                                                                                 \
       _Pragma("unroll") for (int c = 0; c < NCH_; ++c) {                                                \
         const int b = PIPE_ ? ((q * NCH_ + c) & 1) : (c & 1);                                           \
@@ -394,22 +413,36 @@ __device__ __forceinline__ float2 load_partials3(const float* part, int t, int r
         }                                                                                               \
         gx.mma(b, c, acc, w, wl_lane, dbgmask);                                                         \
         const int c2 = c + 2;                                                                           \
-        if (PIPE_) {                                                                                    \
-          const int dh = c2 / NCH_, cc2 = c2 % NCH_;                                                    \
-          const int q2 = (q + dh) % NSET, s2 = s + (q + dh) / NSET;                                     \
-          if (s2 < Tp) gx.issue(b, cc2, rsrc, DS2R_BASE(s2, q2), gneed[q2], ks0, cnt, gpart);           \
-        } else if (c2 < NCH_) {                                                                         \
+        if (c2 < NCH_) {                                                                                \
           gx.issue(b, c2, rsrc, DS2R_BASE(s, q), gneed[q], ks0, cnt, gpart);                            \
+        } else if (PIPE_ && pre_next) {                                                                 \
+          gx.issue(b, c2 - NCH_, rsrc, DS2R_BASE(s2, q2), q2 == 0 ? gneed[0] : gneed[NSET - 1], ks0, cnt, gpart); \
         }                                                                                               \
       }                                                                                                 \
-    } else if (PIPE_ && !(dbgmask & 8)) { /* nothing to gather yet: start the next half-step's first two chunks if it has data */ \
-      const int q2 = (q + 1) % NSET, s2 = s + (q + 1) / NSET;                                           \
-      if (s2 < Tp && (s2 > 0 || (HAS0))) {                                                              \
-        gx.issue((q2 * NCH_) & 1, 0, rsrc, DS2R_BASE(s2, q2), gneed[q2], ks0, cnt, gpart);              \
-        gx.issue((q2 * NCH_ + 1) & 1, 1, rsrc, DS2R_BASE(s2, q2), gneed[q2], ks0, cnt, gpart);          \
-      }                                                                                                 \
     }                                                                                                   \
+    pre = pre_next;                                                                                     \
   }
+
+// Samples of a group: i < Ns (clip n = slice + gpd * i); set q owns the CONSECUTIVE samples i = q * RPS + row, RPS = ceil(Ns / NSET):
+// with the batch sorted by length (the reference's loader does that, data_loader.py:249) set 0 holds the group's long clips and
+// set 1 its short ones.  sched3: the step range [lo, hi) of the sweep's step counter s in which set q has a clip inside its
+// sequence, for a sweep that visits t = s (ascending = true) or t = T' - 1 - s (false): outside it the set's half-steps are not
+// executed at all -- no gather, no products, no publish (the carried state of every clip is its initial one there).
+template <int NSET>
+__device__ __forceinline__ void sched3(const int* lens, int slice, int gpd, int Ns, int Tp, bool ascending, bool skip, int (&lo)[NSET],
+                                       int (&hi)[NSET], int& RPS) {
+  RPS = (Ns + NSET - 1) / NSET;
+#pragma unroll
+  for (int q = 0; q < NSET; ++q) {
+    int mx = 0;
+    const int rows = min(RPS, Ns - q * RPS);
+    for (int r = 0; r < rows; ++r) mx = max(mx, min(lens[slice + gpd * (q * RPS + r)], Tp));
+    if (!skip && rows > 0) mx = Tp;
+    mx = __builtin_amdgcn_readfirstlane(mx);
+    lo[q] = ascending ? 0 : Tp - mx;
+    hi[q] = ascending ? mx : Tp;
+  }
+}
 
 __device__ __forceinline__ void block_map3(const RArgs& ra, int& grp, int& p) {
   if (ra.xmap) {
@@ -479,9 +512,11 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_fwd(RArgs ra) {
   // gather identity of this lane
   const int srow = SP == 2 ? (li & 7) : li, gpart = SP == 2 ? (li >> 3) : 0;
   const int gbase = lq * 256 + srow * 16;
+  int lo[NSET], hi[NSET], RPS;
+  sched3<NSET>(a.lens, slice, a.gpd, Ns, Tp, d == 0, ra.skip != 0, lo, hi, RPS);
   bool gneed[NSET];
 #pragma unroll
-  for (int q = 0; q < NSET; ++q) gneed[q] = srow * NSET + q < Ns;
+  for (int q = 0; q < NSET; ++q) gneed[q] = srow < RPS && q * RPS + srow < Ns;
 
   // ---- gate identity: thread bits (dw: unit pair of the 16-byte unit (2), sample row (4), lq (2)) = the exchange layout's order
   const int lqw = tid >> 6, grow = (tid >> 2) & 15, dw = tid & 3;
@@ -494,13 +529,13 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_fwd(RArgs ra) {
   bf16_t* sv_ptr[NSET];
   bf16_t* hs_ptr[NSET];
   const long dstep = d == 0 ? 1 : -1;
-  const int t_first = d == 0 ? 0 : Tp - 1;
   constexpr long NSH_ = (long)M * H;
   int nsmp[NSET];
 #pragma unroll
   for (int q = 0; q < NSET; ++q) {
-    const int i = grow * NSET + q;
-    on[q] = i < Ns && grow < 16 / SP;
+    const int t_first = d == 0 ? lo[q] : Tp - 1 - lo[q];      // the set's first executed step
+    const int i = q * RPS + grow;
+    on[q] = grow < RPS && i < Ns && grow < 16 / SP;
     const int n = on[q] ? slice + a.gpd * i : 0;
     nsmp[q] = n;
     len[q] = on[q] ? a.lens[n] : 0;
@@ -534,7 +569,8 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_fwd(RArgs ra) {
       bf16_t* hb = (bf16_t*)a.Hseq + (long)d * a.hseq_dstride + (long)nsmp[q] * H + j;
       X::st(hb - (long)N * H, 0.f, 0.f);
       X::st(hb + (long)Tp * N * H, 0.f, 0.f);
-      if (a.h0) pub32(xg + q * SETB + 3 * SLOT + xoff, pay_word(hprev[q][0], hprev[q][1]), local);   // "step -1": slot 3
+      // the step "before the set's first": slot (lo + 3) & 3
+      if (a.h0) pub32(xg + q * SETB + ((lo[q] + 3) & 3) * SLOT + xoff, pay_word(hprev[q][0], hprev[q][1]), local);
     }
   __syncthreads();      // the LDS-resident fragments are in place
 
@@ -548,7 +584,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_fwd(RArgs ra) {
 #pragma unroll
     for (int i = 0; i < DEP; ++i) {
 #pragma unroll
-      for (int g = 0; g < G; ++g) gir[q][i][g] = (on[q] && i < Tp) ? X::ld(gi_ptr[q] + (long)g * H) : 0u;
+      for (int g = 0; g < G; ++g) gir[q][i][g] = (on[q] && lo[q] + i < hi[q]) ? X::ld(gi_ptr[q] + (long)g * H) : 0u;
       gi_ptr[q] += gi_stride;
     }
   int hstep = 0;
@@ -560,14 +596,18 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_fwd(RArgs ra) {
   const bool plain = local || (dbgmask & 64);
   typedef Gather3<RT, KSW, SP, RAGGED, false> GX;
   GX gx;
-  if (NSET == 2 && a.h0 && !(dbgmask & 8)) {      // the first half-step's first two chunks (afterwards every half-step feeds the next)
-    gx.issue(0, 0, rsrc, DS2R_BASE(0, 0), gneed[0], ks0, cnt, gpart);
-    gx.issue(1, 1, rsrc, DS2R_BASE(0, 0), gneed[0], ks0, cnt, gpart);
+  bool pre = false;             // the first two chunks of the half-step about to run are in flight (NSET == 2)
+  int s_lo = lo[0], s_hi = hi[0];
+#pragma unroll
+  for (int q = 1; q < NSET; ++q) {
+    s_lo = min(s_lo, lo[q]);
+    s_hi = max(s_hi, hi[q]);
   }
-  for (int s = 0; s < Tp; ++s) {
+  for (int s = s_lo; s < s_hi; ++s) {
     const int t = d == 0 ? s : Tp - 1 - s;
 #pragma unroll
-    for (int q = 0; q < NSET; ++q, ++hstep) {
+    for (int q = 0; q < NSET; ++q) {
+      if (s < lo[q] || s >= hi[q]) continue;     // no clip of this set is inside its sequence at t
       DS2_PROBE_ONLY(const unsigned long long t0 = __builtin_readcyclecounter();)
       uint32_t gi[G];
 #pragma unroll
@@ -584,7 +624,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_fwd(RArgs ra) {
           for (int g = 0; g < G; ++g) gir[q][i][g] = gir[q][i + 1][g];
 #pragma unroll
         for (int g = 0; g < G; ++g)
-          gir[q][DEP - 1][g] = (on[q] && s + DEP < Tp && !(dbgmask & 1)) ? X::ld(gi_ptr[q] + (long)g * H) : 0u;
+          gir[q][DEP - 1][g] = (on[q] && s + DEP < hi[q] && !(dbgmask & 1)) ? X::ld(gi_ptr[q] + (long)g * H) : 0u;
         gi_ptr[q] += gi_stride;
       }
       DS2_PROBE_ONLY(const unsigned long long t1 = __builtin_readcyclecounter();)
@@ -683,6 +723,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_fwd(RArgs ra) {
       if (NS) sv_ptr[q] += sv_stride;
       hs_ptr[q] += hs_stride;
       DS2_PROBE_ONLY(const unsigned long long t3 = __builtin_readcyclecounter(); c_gather += t1 - t0; c_bar += t2 - t1; c_gate += t3 - t2;)
+      ++hstep;
     }
   }
 #ifdef DS2_PROBE
@@ -768,9 +809,11 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_bwd(RArgs ra) {
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, NSET * SETB, 0x00020000);
   const int srow = SP == 2 ? (li & 7) : li, gpart = SP == 2 ? (li >> 3) : 0;
   const int gbase = lq * 256 + srow * 16;
+  int lo[NSET], hi[NSET], RPS;
+  sched3<NSET>(a.lens, slice, a.gpd, Ns, Tp, d != 0, ra.skip != 0, lo, hi, RPS);      // BPTT visits t = T' - 1 - s for direction 0
   bool gneed[NSET];
 #pragma unroll
-  for (int q = 0; q < NSET; ++q) gneed[q] = srow * NSET + q < Ns;
+  for (int q = 0; q < NSET; ++q) gneed[q] = srow < RPS && q * RPS + srow < Ns;
 
   const int lqw = tid >> 6, grow = (tid >> 2) & 15, dw = tid & 3;
   const int jl = lqw * 8 + dw * 2, j = p * 32 + jl;
@@ -786,13 +829,13 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_bwd(RArgs ra) {
   bf16_t* dgi_ptr[NSET];
   bf16_t* dgh_ptr[NSET];
   const long dstep = d == 0 ? -1 : 1;                       // BPTT walks the direction's time axis backwards
-  const int t_first = d == 0 ? Tp - 1 : 0;
   const long prev_off = d == 0 ? -1 : 1;                    // previous step in FORWARD order of this direction
   constexpr long NSH_ = (long)M * H;
 #pragma unroll
   for (int q = 0; q < NSET; ++q) {
-    const int i = grow * NSET + q;
-    on[q] = i < Ns && grow < 16 / SP;
+    const int t_first = d == 0 ? Tp - 1 - lo[q] : lo[q];      // the set's first executed step
+    const int i = q * RPS + grow;
+    on[q] = grow < RPS && i < Ns && grow < 16 / SP;
     const int n = on[q] ? slice + a.gpd * i : 0;
     nsmp[q] = n;
     len[q] = on[q] ? a.lens[n] : 0;
@@ -850,12 +893,20 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_bwd(RArgs ra) {
 #pragma unroll
   for (int q = 0; q < NSET; ++q)
 #pragma unroll
-    for (int i = 0; i < DEP; ++i) prefetch(ring[q][i], q, i < Tp);
+    for (int i = 0; i < DEP; ++i) prefetch(ring[q][i], q, lo[q] + i < hi[q]);
   int hstep = 0;
-  for (int s = 0; s < Tp; ++s) {
+  bool pre = false;             // the first two chunks of the half-step about to run are in flight (NSET == 2)
+  int s_lo = lo[0], s_hi = hi[0];
+#pragma unroll
+  for (int q = 1; q < NSET; ++q) {
+    s_lo = min(s_lo, lo[q]);
+    s_hi = max(s_hi, hi[q]);
+  }
+  for (int s = s_lo; s < s_hi; ++s) {
     const int t = d == 0 ? Tp - 1 - s : s;
 #pragma unroll
-    for (int q = 0; q < NSET; ++q, ++hstep) {
+    for (int q = 0; q < NSET; ++q) {
+      if (s < lo[q] || s >= hi[q]) continue;     // no clip of this set is inside its sequence at t
       DS2_PROBE_ONLY(const unsigned long long t0 = __builtin_readcyclecounter();)
       const Pre pc = ring[q][0];
       ds2_f32x4 acc2[2 * RT];
@@ -871,7 +922,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_bwd(RArgs ra) {
       for (int tt = 0; tt < RT; ++tt) acc[tt] = acc2[tt] + acc2[tt + RT];
 #pragma unroll
       for (int i = 0; i + 1 < DEP; ++i) ring[q][i] = ring[q][i + 1];
-      prefetch(ring[q][DEP - 1], q, s + DEP < Tp);
+      prefetch(ring[q][DEP - 1], q, s + DEP < hi[q]);
       DS2_PROBE_ONLY(const unsigned long long t1 = __builtin_readcyclecounter();)
       float* pp = part + (PB == 2 ? (hstep & 1) * PART_FLOATS : 0);
       if (PB == 1) __syncthreads();
@@ -1010,6 +1061,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_bwd(RArgs ra) {
       dgi_ptr[q] += dstep * N * ldgi;
       if (CELL == CELL_GRU) dgh_ptr[q] += dstep * N * H;
       DS2_PROBE_ONLY(const unsigned long long t3 = __builtin_readcyclecounter(); c_gather += t1 - t0; c_bar += t2 - t1; c_gate += t3 - t2;)
+      ++hstep;
     }
   }
 #ifdef DS2_PROBE

@@ -437,6 +437,58 @@ def test_rnn_persist3_sixteen_groups_repeat_bit_identically(kind, D):
             assert torch.equal(hext, first[0]) and torch.equal(dGI, first[1]), it
 
 
+@pytest.mark.parametrize("kind,D,N,H,Tp,sort_lens", [
+    ("lstm", 2, 64, 1280, 61, True),       # config 5a's groups: 22 clips in two sets of 11, groups span XCDs
+    ("gru", 2, 128, 1024, 45, True),       # XCD-local groups, two sets of 16
+    ("lstm", 2, 128, 800, 37, False),      # lengths in loader order NOT sorted: set 1 may outlast set 0
+    ("gru", 1, 96, 1536, 33, True),        # one direction, 18 clips per group
+])
+def test_rnn_persist3_set_schedules(kind, D, N, H, Tp, sort_lens):
+    """Two-set groups execute a set's half-steps only while one of its clips is inside its sequence (ds2r::sched3; with the batch
+    sorted by length set 1 holds a group's short clips and drops out early / joins late).  Ragged lengths over tens of steps:
+    forward and BPTT against the oracle on every row -- padding rows included, which the half-steps left out no longer write
+    (ds2_rnn_persist_fwd / _bwd zero them) -- and against the same kernels with every half-step executed (variant bit 1):
+    bit-identical, the schedule changes which half-steps run, not what the executed ones compute."""
+    from deepspeech.pytorch_amd._lib import query
+    o = ops()
+    assert o.use_persistent(kind, torch.bfloat16, D, N, H)
+    assert query("ds2_rnn_persist_kind", o.dt(torch.bfloat16), o.CELLS[kind], D, N, H) == 3
+    res = _rnn_sweep_case(torch.bfloat16, kind, D, N, H, Tp, 0.7 / np.sqrt(H), tol_scale=2.0, sort_lens=sort_lens, min_len=Tp // 4)
+    o.check_persistent_kernels()
+    old = query("ds2_rnn_persist_set_variant", 2)
+    try:
+        res_all = _rnn_sweep_case(torch.bfloat16, kind, D, N, H, Tp, 0.7 / np.sqrt(H), tol_scale=2.0, sort_lens=sort_lens, min_len=Tp // 4)
+        o.check_persistent_kernels()
+    finally:
+        query("ds2_rnn_persist_set_variant", old)
+    for a_, b_ in zip(res, res_all):
+        assert np.array_equal(a_, b_)
+
+
+def test_rnn_persist3_set_schedule_with_initial_state():
+    """h0 / c0 carry (reference inference.py:86-96) into a two-set group whose second set joins the reverse direction late: its
+    initial state is published in the slot before ITS first executed step."""
+    rs = np.random.RandomState(17)
+    kind, D, N, H, Tp = "lstm", 2, 64, 1280, 9
+    G = O.GATES[kind]
+    GI = rs.standard_normal((Tp * N, D * G * H))
+    Whh, bhh = rs.uniform(-0.03, 0.03, (D, G * H, H)), rs.uniform(-0.2, 0.2, (D, G * H))
+    h0, c0 = rs.standard_normal((D, N, H)), rs.standard_normal((D, N, H))
+    lens = np.sort(rs.randint(2, Tp + 1, size=N))[::-1].astype(np.int32).copy()
+    lens[0] = Tp
+    dt_ = torch.bfloat16
+    GI_r, Whh_r = rnd(GI, dt_), rnd(Whh, dt_)
+    o = ops()
+    hext, Sv, hn, cn = o.rnn_fwd(kind, cu(GI, dt_), cu(Whh, dt_), cu(bhh), torch.from_numpy(lens).to(DEV), D, N, H, Tp, h0=cu(h0), c0=cu(c0))
+    o.check_persistent_kernels()
+    for d in range(D):
+        out, hn_ref, cn_ref, _ = O.rnn_dir_fwd(kind, GI_r.reshape(Tp, N, D, G * H)[:, :, d], lens, np.eye(G * H), Whh_r[d],
+                                               np.zeros(G * H), bhh[d], reverse=(d == 1), h0=h0[d], c0=c0[d])
+        assert np.abs(np64(hext[d, 1:Tp + 1]) - out).max() < 4e-2
+        assert np.abs(np64(hn[d]) - hn_ref).max() < 4e-2
+        assert np.abs(np64(cn[d]) - cn_ref).max() < 6e-2
+
+
 def test_rnn_persist3_long_ragged_sweep():
     """T' = 311 ragged-length steps through the round-4 kernels and the tuned H = 1024 kernels: the four-slot wrap, the re-arm and
     the bias accumulation over hundreds of steps at KERNEL level (the whole-model tests cover them only indirectly)."""
@@ -491,12 +543,16 @@ def test_rnn_persistent_general_initial_state():
                 assert np.abs(np64(cn[d]) - cn_ref).max() < tol * 1.5
 
 
-def _rnn_sweep_case(dtype, kind, D, N, H, Tp, wscale, tol_scale=1.0):
+def _rnn_sweep_case(dtype, kind, D, N, H, Tp, wscale, tol_scale=1.0, sort_lens=True, min_len=1):
     rs = np.random.RandomState(D * 100 + N + H + Tp)
     G = O.GATES[kind]
     I = 24
-    lens = np.sort(rs.randint(1, Tp + 1, size=N))[::-1].copy()
-    lens[0] = Tp
+    lens = rs.randint(min_len, Tp + 1, size=N)
+    if sort_lens:
+        lens = np.sort(lens)[::-1].copy()
+        lens[0] = Tp
+    else:
+        lens[N // 2] = Tp
     x = rs.standard_normal((Tp, N, I))
     for i, ln in enumerate(lens):
         x[ln:, i] = 0
