@@ -70,10 +70,19 @@ long xbuf_bytes(int cell, int H, bool bwd) {
   return (long)NGROUPS * 2 * MAXS * X2 * 8;
 }
 
+// ds2_rnn_persist_set_variant (A/B runs on one box): bit 0 = do not use the round-4 general kernels; 1 = two-set groups execute every
+// half-step; 2 = every lane gathers at every step; 3 = the general kernels take H = 1024 too; 4 = the tuned kernels keep 9-16 clips per group
+unsigned g_variant = 0;
+
 bool tuned_ok(int dtype, int cell, int D, int N, int H) {
   if (dtype != DS2_BF16 || H != 1024 || (D != 1 && D != 2)) return false;
   const int gpd = NGROUPS / D;
-  return N >= 1 && (N + gpd - 1) / gpd <= MAXS && cu_count() >= NGROUPS * 32;   // one workgroup per CU, all 256 co-resident
+  if (g_variant & 8u) return false;                     // A/B: the general kernels take H = 1024 too
+  const int ns = N >= 1 ? (N + gpd - 1) / gpd : MAXS + 1;
+  // 9-16 clips per group: the round-4 general kernels are faster (GRU bi, 64 clips: 2.7 vs 3.4 us per forward step,
+  // profiles/r04n_time_sweeps.txt) unless A/B bit 4 asks for the tuned ones; RNN cells only exist here
+  const int cap = ((g_variant & 16u) || cell == CELL_RNN) ? MAXS : 8;
+  return ns <= cap && cu_count() >= NGROUPS * 32;       // one workgroup per CU, all 256 co-resident
 }
 
 // Geometry of the general kernels: P = H/16 workgroups per group, as many groups per direction as the chip holds.
@@ -102,7 +111,6 @@ bool plan2(int dtype, int cell, int D, int N, int H, Plan2& pl) {
   return launch2_any(true, false, dtype, cell, H, pl.MT, dummy, nullptr) == 0;
 }
 // ---- round-4 general kernels (bf16, 32 units per workgroup) -----------------------------------------------------------------
-unsigned g_variant = 0;      // ds2_rnn_persist_set_variant: bit 0 = do not use the round-4 general kernels (A/B runs on one box)
 struct Plan3H {
   int gpd, NG, P, xmap, gx, nset;
 };
@@ -220,7 +228,9 @@ int ds2_rnn_persist_shape_covered(int dtype, int cell, int D, int N, int H) {
 }
 
 // A/B hook: bit 0 = route the shapes of the round-4 general kernels to the round-2 general kernels (or launch-per-step) instead;
-// bit 1 = two-set groups execute every half-step (no set schedules).
+// bit 1 = two-set groups execute every half-step (no set schedules); bit 2 = every lane gathers at every step (also for clips outside
+// their sequences); bit 3 = the round-4 general kernels also take H = 1024 (instead of the tuned kernels); bit 4 = the tuned kernels
+// keep groups of 9-16 clips (round 3's routing).
 // Returns the previous value.  Process-wide.
 unsigned ds2_rnn_persist_set_variant(unsigned bits) {
   const unsigned old = g_variant;
@@ -280,8 +290,8 @@ int ds2_rnn_persist_fwd(int dtype, int cell, int D, int N, int H, int Tp, const 
     a.hseq_dstride = hseq_dstride; a.S = S; a.h0 = h0; a.c0 = c0; a.hn = hn; a.cn = cn;
     a.xbuf = (char*)ws + AUX_BYTES; a.xgroup_bytes = xb / p3.NG; a.err = err; a.lerr = (int*)((char*)ws + 3072);
     ra.xcc = (u64*)((char*)ws + AUX_BYTES + xb); ra.P = p3.P; ra.xmap = p3.xmap; ra.gx = p3.gx; ra.nset = p3.nset;
-    ra.skip = (p3.nset == 2 && !(g_variant & 2u)) ? 1 : 0;
-    if (ra.skip)
+    ra.skip = ((p3.nset == 2 && !(g_variant & 2u)) ? 1 : 0) | ((g_variant & 4u) ? 0 : 2);
+    if (ra.skip & 1)
       for (int d = 0; d < D; ++d)       // h_t of the padding frames (Hseq points at t = 0)
         zero_pad3((char*)Hseq + (long)d * hseq_dstride * 2, (long)H * 2, (long)H * 2, lens, N, Tp, st);
 #ifdef DS2_PROBE
@@ -341,8 +351,8 @@ int ds2_rnn_persist_bwd(int dtype, int cell, int D, int N, int H, int Tp, const 
     a.hseq_dstride = hseq_dstride; a.S = (void*)S; a.dOut = dOut; a.dGI = dGI; a.dGH = dGH; a.dBacc = dBacc;
     a.xbuf = (char*)ws + AUX_BYTES; a.xgroup_bytes = xb / p3.NG; a.err = err; a.lerr = (int*)((char*)ws + 3072);
     ra.xcc = (u64*)((char*)ws + AUX_BYTES + xb); ra.P = p3.P; ra.xmap = p3.xmap; ra.gx = p3.gx; ra.nset = p3.nset;
-    ra.skip = (p3.nset == 2 && !(g_variant & 2u)) ? 1 : 0;
-    if (ra.skip) {
+    ra.skip = ((p3.nset == 2 && !(g_variant & 2u)) ? 1 : 0) | ((g_variant & 4u) ? 0 : 2);
+    if (ra.skip & 1) {
       const long GHb = (long)gates(cell) * H * 2;
       zero_pad3(dGI, D * GHb, D * GHb, lens, N, Tp, st);
       if (dGH)

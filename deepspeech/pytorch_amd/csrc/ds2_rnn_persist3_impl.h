@@ -34,8 +34,9 @@ struct RArgs {
   int xmap;      // 1: group g's workgroups are the blocks with blockIdx % 8 == g % 8 (one XCD, if the dispatcher keeps its habit)
   int gx;        // xmap: group slots per XCD (floor(32 / P)); the grid is 8 * gx * P blocks, groups >= NG stay empty
   int nset;      // sample sets per group (the kernel's NSET)
-  int skip;      // 1: a set executes only the time steps at which one of its clips is inside its sequence (the caller zeroes the
-                 // padding rows of the outputs: they are no longer written for the steps left out); 0: every step
+  int skip;      // bit 0: a set executes only the time steps at which one of its clips is inside its sequence (the caller zeroes the
+                 // padding rows of the outputs: they are no longer written for the steps left out); bit 1: a lane gathers its clip's
+                 // exchanged vector only while that clip is inside its sequence
 #ifdef DS2_PROBE   // tools/probe_persist3.py builds its own library with -DDS2_PROBE; the shipping kernels carry none of it
   unsigned long long* dbg;  // [NG][8] cycle counters of workgroup 0 of each group (thread 0 and thread 255)
   int dbgmask;              // 1 skip GI / dOut / S prefetch loads, 2 skip output stores, 8 skip the gather + products (no exchange),
@@ -363,11 +364,16 @@ __device__ __forceinline__ float2 load_partials3(const float* part, int t, int r
 }
 
 // The gather phase of half-step (s, q) -- shared by the forward and the BPTT kernel (local names: gx, acc, w, wl_lane, rsrc, gbase,
-// gneed, ks0, cnt, gpart, dead, rounds, dbgmask).  HAS0: the exchanged vector exists at step 0 (forward with an initial state).
+// glen, asc, ks0, cnt, gpart, dead, rounds, dbgmask).  HAS0: the exchanged vector exists at step 0 (forward with an initial state).
 // NSET == 2: the first two chunks of a half-step are normally issued during the previous one (`pre`): after its products every buffer
 // is refilled with the chunk two ahead, which for the last two chunks belongs to the half-step executed NEXT -- normally the other set's,
 // published a half-step ago.  Sets whose clips are all outside their sequences at a time step do not execute it (lo / hi).
 #define DS2R_BASE(S_, Q_) ((Q_) * SETB + (((S_) + 3) & 3) * SLOT + gbase)
+// A lane gathers the exchanged vector of ONE clip (row `srow` of the set): only while that clip is inside its sequence at the step's
+// time index -- a clip outside it keeps its state and its gate results are discarded, so its row of the product may be anything;
+// the lane's loads then go out of range (no fabric request, zeros returned).  glen[q] = that clip's length (0: no such row).
+#define DS2R_T(S_) (asc ? (S_) : Tp - 1 - (S_))
+#define DS2R_NEED(S_, Q_) (DS2R_T(S_) < glen[Q_])
 #define DS2R_GATHER_PHASE(HAS0)                                                                        \
   {                                                                                                     \
     constexpr int NCH_ = GX::NCH;                                                                       \
@@ -391,8 +397,8 @@ __device__ __forceinline__ float2 load_partials3(const float* part, int t, int r
     }                                                                                                   \
     if (have_) {                                                                                        \
       if (!pre) {                                                                                       \
-        gx.issue(PIPE_ ? ((q * NCH_) & 1) : 0, 0, rsrc, DS2R_BASE(s, q), gneed[q], ks0, cnt, gpart);    \
-        gx.issue(PIPE_ ? ((q * NCH_ + 1) & 1) : 1, 1, rsrc, DS2R_BASE(s, q), gneed[q], ks0, cnt, gpart); \
+        gx.issue(PIPE_ ? ((q * NCH_) & 1) : 0, 0, rsrc, DS2R_BASE(s, q), DS2R_NEED(s, q), ks0, cnt, gpart);    \
+        gx.issue(PIPE_ ? ((q * NCH_ + 1) & 1) : 1, 1, rsrc, DS2R_BASE(s, q), DS2R_NEED(s, q), ks0, cnt, gpart); \
       }                                                                                                 \
       _Pragma("unroll") for (int c = 0; c < NCH_; ++c) {                                                \
         const int b = PIPE_ ? ((q * NCH_ + c) & 1) : (c & 1);                                           \
@@ -402,7 +408,7 @@ __device__ __forceinline__ float2 load_partials3(const float* part, int t, int r
           for (;;) {                                                                                    \
             __builtin_amdgcn_s_sleep(1);                                                                \
             ++rounds;                                                                                   \
-            gx.issue(b, c, rsrc, DS2R_BASE(s, q), gneed[q], ks0, cnt, gpart);                           \
+            gx.issue(b, c, rsrc, DS2R_BASE(s, q), DS2R_NEED(s, q), ks0, cnt, gpart);                           \
             if (!__any(gx.bad(b))) break;                                                               \
             if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && spin_check(a.lerr, spins))) {          \
               dead = true;                                                                              \
@@ -414,9 +420,9 @@ __device__ __forceinline__ float2 load_partials3(const float* part, int t, int r
         gx.mma(b, c, acc, w, wl_lane, dbgmask);                                                         \
         const int c2 = c + 2;                                                                           \
         if (c2 < NCH_) {                                                                                \
-          gx.issue(b, c2, rsrc, DS2R_BASE(s, q), gneed[q], ks0, cnt, gpart);                            \
+          gx.issue(b, c2, rsrc, DS2R_BASE(s, q), DS2R_NEED(s, q), ks0, cnt, gpart);                            \
         } else if (PIPE_ && pre_next) {                                                                 \
-          gx.issue(b, c2 - NCH_, rsrc, DS2R_BASE(s2, q2), q2 == 0 ? gneed[0] : gneed[NSET - 1], ks0, cnt, gpart); \
+          gx.issue(b, c2 - NCH_, rsrc, DS2R_BASE(s2, q2), DS2R_T(s2) < (q2 == 0 ? glen[0] : glen[NSET - 1]), ks0, cnt, gpart); \
         }                                                                                               \
       }                                                                                                 \
     }                                                                                                   \
@@ -513,10 +519,12 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_fwd(RArgs ra) {
   const int srow = SP == 2 ? (li & 7) : li, gpart = SP == 2 ? (li >> 3) : 0;
   const int gbase = lq * 256 + srow * 16;
   int lo[NSET], hi[NSET], RPS;
-  sched3<NSET>(a.lens, slice, a.gpd, Ns, Tp, d == 0, ra.skip != 0, lo, hi, RPS);
-  bool gneed[NSET];
+  const bool asc = d == 0;                              // the sweep's step s visits t = s (else t = T' - 1 - s)
+  sched3<NSET>(a.lens, slice, a.gpd, Ns, Tp, asc, (ra.skip & 1) != 0, lo, hi, RPS);
+  int glen[NSET];
 #pragma unroll
-  for (int q = 0; q < NSET; ++q) gneed[q] = srow < RPS && q * RPS + srow < Ns;
+  for (int q = 0; q < NSET; ++q)
+    glen[q] = (srow < RPS && q * RPS + srow < Ns) ? ((ra.skip & 2) ? a.lens[slice + a.gpd * (q * RPS + srow)] : Tp) : 0;
 
   // ---- gate identity: thread bits (dw: unit pair of the 16-byte unit (2), sample row (4), lq (2)) = the exchange layout's order
   const int lqw = tid >> 6, grow = (tid >> 2) & 15, dw = tid & 3;
@@ -810,10 +818,12 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_bwd(RArgs ra) {
   const int srow = SP == 2 ? (li & 7) : li, gpart = SP == 2 ? (li >> 3) : 0;
   const int gbase = lq * 256 + srow * 16;
   int lo[NSET], hi[NSET], RPS;
-  sched3<NSET>(a.lens, slice, a.gpd, Ns, Tp, d != 0, ra.skip != 0, lo, hi, RPS);      // BPTT visits t = T' - 1 - s for direction 0
-  bool gneed[NSET];
+  const bool asc = d != 0;                              // BPTT visits t = T' - 1 - s for direction 0
+  sched3<NSET>(a.lens, slice, a.gpd, Ns, Tp, asc, (ra.skip & 1) != 0, lo, hi, RPS);
+  int glen[NSET];
 #pragma unroll
-  for (int q = 0; q < NSET; ++q) gneed[q] = srow < RPS && q * RPS + srow < Ns;
+  for (int q = 0; q < NSET; ++q)
+    glen[q] = (srow < RPS && q * RPS + srow < Ns) ? ((ra.skip & 2) ? a.lens[slice + a.gpd * (q * RPS + srow)] : Tp) : 0;
 
   const int lqw = tid >> 6, grow = (tid >> 2) & 15, dw = tid & 3;
   const int jl = lqw * 8 + dw * 2, j = p * 32 + jl;
