@@ -429,15 +429,16 @@ __device__ __forceinline__ float2 load_partials3(const float* part, int t, int r
     pre = pre_next;                                                                                     \
   }
 
-// Samples of a group: i < Ns (clip n = slice + gpd * i); set q owns the CONSECUTIVE samples i = q * RPS + row, RPS = ceil(Ns / NSET):
-// with the batch sorted by length (the reference's loader does that, data_loader.py:249) set 0 holds the group's long clips and
-// set 1 its short ones.  sched3: the step range [lo, hi) of the sweep's step counter s in which set q has a clip inside its
+// Samples of a group: i < Ns (clip n = slice + gpd * i); set q owns the CONSECUTIVE samples i = q * RPS + row.  RPS = 16 for two
+// sets: set 0 is a full m-tile, set 1 the remainder -- with the batch sorted by length (the reference's loader does that,
+// data_loader.py:249) set 1 holds the group's SHORTEST clips and is scheduled for as few steps as possible (a half-step costs the
+// same for 6 rows as for 16: it is a latency chain).  sched3: the step range [lo, hi) of the sweep's step counter s in which set q has a clip inside its
 // sequence, for a sweep that visits t = s (ascending = true) or t = T' - 1 - s (false): outside it the set's half-steps are not
 // executed at all -- no gather, no products, no publish (the carried state of every clip is its initial one there).
 template <int NSET>
 __device__ __forceinline__ void sched3(const int* lens, int slice, int gpd, int Ns, int Tp, bool ascending, bool skip, int (&lo)[NSET],
                                        int (&hi)[NSET], int& RPS) {
-  RPS = (Ns + NSET - 1) / NSET;
+  RPS = NSET == 1 ? Ns : min(16, Ns);
 #pragma unroll
   for (int q = 0; q < NSET; ++q) {
     int mx = 0;
