@@ -71,7 +71,7 @@ long xbuf_bytes(int cell, int H, bool bwd) {
 }
 
 // ds2_rnn_persist_set_variant (A/B runs on one box): bit 0 = do not use the round-4 general kernels; 1 = two-set groups execute every
-// half-step; 2 = every lane gathers at every step; 3 = the general kernels take H = 1024 too; 4 = the tuned kernels keep 9-16 clips per group
+// half-step; 2 = unused; 3 = the general kernels take H = 1024 too; 4 = the tuned kernels keep 9-16 clips per group
 unsigned g_variant = 0;
 
 bool tuned_ok(int dtype, int cell, int D, int N, int H) {
@@ -228,8 +228,7 @@ int ds2_rnn_persist_shape_covered(int dtype, int cell, int D, int N, int H) {
 }
 
 // A/B hook: bit 0 = route the shapes of the round-4 general kernels to the round-2 general kernels (or launch-per-step) instead;
-// bit 1 = two-set groups execute every half-step (no set schedules); bit 2 = every lane gathers at every step (also for clips outside
-// their sequences); bit 3 = the round-4 general kernels also take H = 1024 (instead of the tuned kernels); bit 4 = the tuned kernels
+// bit 1 = two-set groups execute every half-step (no set schedules); bit 2 unused; bit 3 = the round-4 general kernels also take H = 1024 (instead of the tuned kernels); bit 4 = the tuned kernels
 // keep groups of 9-16 clips (round 3's routing).
 // Returns the previous value.  Process-wide.
 unsigned ds2_rnn_persist_set_variant(unsigned bits) {
@@ -290,7 +289,7 @@ int ds2_rnn_persist_fwd(int dtype, int cell, int D, int N, int H, int Tp, const 
     a.hseq_dstride = hseq_dstride; a.S = S; a.h0 = h0; a.c0 = c0; a.hn = hn; a.cn = cn;
     a.xbuf = (char*)ws + AUX_BYTES; a.xgroup_bytes = xb / p3.NG; a.err = err; a.lerr = (int*)((char*)ws + 3072);
     ra.xcc = (u64*)((char*)ws + AUX_BYTES + xb); ra.P = p3.P; ra.xmap = p3.xmap; ra.gx = p3.gx; ra.nset = p3.nset;
-    ra.skip = ((p3.nset == 2 && !(g_variant & 2u)) ? 1 : 0) | ((g_variant & 4u) ? 0 : 2);
+    ra.skip = (p3.nset == 2 && !(g_variant & 2u)) ? 1 : 0;
     if (ra.skip & 1)
       for (int d = 0; d < D; ++d)       // h_t of the padding frames (Hseq points at t = 0)
         zero_pad3((char*)Hseq + (long)d * hseq_dstride * 2, (long)H * 2, (long)H * 2, lens, N, Tp, st);
@@ -351,7 +350,7 @@ int ds2_rnn_persist_bwd(int dtype, int cell, int D, int N, int H, int Tp, const 
     a.hseq_dstride = hseq_dstride; a.S = (void*)S; a.dOut = dOut; a.dGI = dGI; a.dGH = dGH; a.dBacc = dBacc;
     a.xbuf = (char*)ws + AUX_BYTES; a.xgroup_bytes = xb / p3.NG; a.err = err; a.lerr = (int*)((char*)ws + 3072);
     ra.xcc = (u64*)((char*)ws + AUX_BYTES + xb); ra.P = p3.P; ra.xmap = p3.xmap; ra.gx = p3.gx; ra.nset = p3.nset;
-    ra.skip = ((p3.nset == 2 && !(g_variant & 2u)) ? 1 : 0) | ((g_variant & 4u) ? 0 : 2);
+    ra.skip = (p3.nset == 2 && !(g_variant & 2u)) ? 1 : 0;
     if (ra.skip & 1) {
       const long GHb = (long)gates(cell) * H * 2;
       zero_pad3(dGI, D * GHb, D * GHb, lens, N, Tp, st);

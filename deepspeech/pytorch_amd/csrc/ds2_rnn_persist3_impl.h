@@ -34,9 +34,8 @@ struct RArgs {
   int xmap;      // 1: group g's workgroups are the blocks with blockIdx % 8 == g % 8 (one XCD, if the dispatcher keeps its habit)
   int gx;        // xmap: group slots per XCD (floor(32 / P)); the grid is 8 * gx * P blocks, groups >= NG stay empty
   int nset;      // sample sets per group (the kernel's NSET)
-  int skip;      // bit 0: a set executes only the time steps at which one of its clips is inside its sequence (the caller zeroes the
-                 // padding rows of the outputs: they are no longer written for the steps left out); bit 1: a lane gathers its clip's
-                 // exchanged vector only while that clip is inside its sequence
+  int skip;      // 1: a set executes only the time steps at which one of its clips is inside its sequence (the caller zeroes the
+                 // padding rows of the outputs: they are no longer written for the steps left out)
 #ifdef DS2_PROBE   // tools/probe_persist3.py builds its own library with -DDS2_PROBE; the shipping kernels carry none of it
   unsigned long long* dbg;  // [NG][8] cycle counters of workgroup 0 of each group (thread 0 and thread 255)
   int dbgmask;              // 1 skip GI / dOut / S prefetch loads, 2 skip output stores, 8 skip the gather + products (no exchange),
@@ -369,9 +368,13 @@ __device__ __forceinline__ float2 load_partials3(const float* part, int t, int r
 // is refilled with the chunk two ahead, which for the last two chunks belongs to the half-step executed NEXT -- normally the other set's,
 // published a half-step ago.  Sets whose clips are all outside their sequences at a time step do not execute it (lo / hi).
 #define DS2R_BASE(S_, Q_) ((Q_) * SETB + (((S_) + 3) & 3) * SLOT + gbase)
-// A lane gathers the exchanged vector of ONE clip (row `srow` of the set): only while that clip is inside its sequence at the step's
-// time index -- a clip outside it keeps its state and its gate results are discarded, so its row of the product may be anything;
-// the lane's loads then go out of range (no fabric request, zeros returned).  glen[q] = that clip's length (0: no such row).
+// A lane gathers the exchanged vector of ONE clip (row `srow` of the set) at EVERY executed step, also while that clip is outside its
+// sequence (glen[q] = T' for a row that exists, 0 otherwise: the loads of a lane without a row go out of range -- zeros, no fabric
+// request).  Gathering only the clips inside their sequences (glen = the clip's length) was tried: it saves a fifth to a third of
+// the requests on configs 5a / 5b, gains nothing (the half-step is a latency chain) -- and it is WRONG: a workgroup none of whose
+// rows is needed stops waiting for its peers, runs ahead of them and re-arms slots they have not read yet (the four-slot protocol
+// relies on the lock-step that "every workgroup reads every peer's publish of the step before" enforces).  A group of two short
+// clips hit exactly that: peers timed out on a slot its owner had passed (round 4, tests/test_gpu_loop.py lstm_bi_1280).
 #define DS2R_T(S_) (asc ? (S_) : Tp - 1 - (S_))
 #define DS2R_NEED(S_, Q_) (DS2R_T(S_) < glen[Q_])
 #define DS2R_GATHER_PHASE(HAS0)                                                                        \
@@ -525,7 +528,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_fwd(RArgs ra) {
   int glen[NSET];
 #pragma unroll
   for (int q = 0; q < NSET; ++q)
-    glen[q] = (srow < RPS && q * RPS + srow < Ns) ? ((ra.skip & 2) ? a.lens[slice + a.gpd * (q * RPS + srow)] : Tp) : 0;
+    glen[q] = (srow < RPS && q * RPS + srow < Ns) ? Tp : 0;
 
   // ---- gate identity: thread bits (dw: unit pair of the 16-byte unit (2), sample row (4), lq (2)) = the exchange layout's order
   const int lqw = tid >> 6, grow = (tid >> 2) & 15, dw = tid & 3;
@@ -824,7 +827,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_bwd(RArgs ra) {
   int glen[NSET];
 #pragma unroll
   for (int q = 0; q < NSET; ++q)
-    glen[q] = (srow < RPS && q * RPS + srow < Ns) ? ((ra.skip & 2) ? a.lens[slice + a.gpd * (q * RPS + srow)] : Tp) : 0;
+    glen[q] = (srow < RPS && q * RPS + srow < Ns) ? Tp : 0;
 
   const int lqw = tid >> 6, grow = (tid >> 2) & 15, dw = tid & 3;
   const int jl = lqw * 8 + dw * 2, j = p * 32 + jl;

@@ -329,7 +329,13 @@ def _frame_rows(output_lengths, Tp, N, dev):
     if not ROW_LISTS or n_valid >= ROW_LIST_MIN_PADDING * Tp * N or n_valid == 0:
         return output_lengths.to(dev, torch.int32, non_blocking=True), None
     rows = np.flatnonzero(np.arange(Tp, dtype=np.int32)[:, None] < ol[None, :]).astype(np.int32)
-    both = torch.from_numpy(np.concatenate([ol, rows])).to(dev, non_blocking=True)
+    # staged in pinned memory: the copy is asynchronous AND the allocator keeps the block until it is done (a pageable temporary
+    # would be freed on return from .to())
+    host = torch.empty(N + rows.size, dtype=torch.int32, pin_memory=torch.device(dev).type == "cuda" and not os.environ.get("DS2_DBG_PAGEABLE"))
+    hv = host.numpy()
+    hv[:N] = ol
+    hv[N:] = rows
+    both = host.to(dev, non_blocking=True)
     return both[:N], both[N:]
 
 
@@ -843,7 +849,10 @@ class _CtcFn(torch.autograd.Function):
         max_tl = int(tsz.max().item()) if N > 0 else 0
         # one host staging buffer, one host-to-device copy: [target offsets | target sizes | targets] as int32
         tg = targets.cpu() if targets.is_cuda else targets
-        meta = torch.cat([offs.to(torch.int32), tsz.to(torch.int32), tg.reshape(-1).to(torch.int32)]).to(dev, non_blocking=True)
+        parts = [offs.to(torch.int32), tsz.to(torch.int32), tg.reshape(-1).to(torch.int32)]
+        host = torch.empty(sum(p.numel() for p in parts), dtype=torch.int32, pin_memory=dev.type == "cuda")     # pinned: see _frame_rows
+        torch.cat(parts, out=host)
+        meta = host.to(dev, non_blocking=True)
         loss, nll, dl = ops.ctc_loss_grad(logits, meta[2 * N:], meta[:N], out_lens_dev, meta[N:2 * N], Tp, N, Cc, blank, max_tl)
         ctx.save_for_backward(dl)
         ctx.consumed = False

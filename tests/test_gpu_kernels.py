@@ -397,14 +397,10 @@ def test_rnn_persist3_sweeps(kind, D, N, H, Tp):
             assert np.abs(a_ - b_).max() <= 2e-2 * max(1.0, np.abs(b_).max()), np.abs(a_ - b_).max()
 
 
-@pytest.mark.parametrize("kind,D", [("gru", 1), ("lstm", 2)])
-def test_rnn_persist3_sixteen_groups_repeat_bit_identically(kind, D):
-    """H = 512 runs TWO groups per XCD -- up to 16 groups, the only width with more than eight.  Their XCC-id handshake words used to
-    overflow the 2 KB of the scratch head that eight groups need, onto the spin budget and the first group's exchange slots: about
-    one launch in ten read a stale word at the second time step (found by a repeated whole-model step, round 4).  Ten forward +
-    BPTT sweeps over 451 ragged steps: every launch bit-identical to the first and equal to the launch-per-step kernels."""
+def _repeat_sweeps_bit_identically(kind, D, N, H, Tp, lens_np, rounds):
+    """`rounds` forward + BPTT sweeps on the same operands: every launch bit-identical to the first, no time-out, and the first equal
+    to the launch-per-step kernels."""
     o = ops()
-    N, H, Tp = 16, 512, 451
     G = o.GATES[kind]
     dev = "cuda"
     torch.manual_seed(0)
@@ -412,9 +408,7 @@ def test_rnn_persist3_sixteen_groups_repeat_bit_identically(kind, D):
     Whh = ((torch.rand(D, G * H, H, device=dev) * 2 - 1) / H ** 0.5).to(torch.bfloat16)
     WhhT = Whh.transpose(1, 2).contiguous()
     bhh = torch.zeros(D, G * H, device=dev)
-    lens_np = np.sort(np.random.RandomState(0).randint(Tp // 3, Tp + 1, N))[::-1].copy().astype(np.int32)
-    lens_np[0] = Tp
-    lens = torch.from_numpy(lens_np).to(dev)
+    lens = torch.from_numpy(lens_np.astype(np.int32)).to(dev)
     dout = torch.randn(Tp, N, H, device=dev).to(torch.bfloat16)
     assert o.use_persistent(kind, torch.bfloat16, D, N, H)
     o.PERSIST_ENABLED = False
@@ -424,7 +418,7 @@ def test_rnn_persist3_sixteen_groups_repeat_bit_identically(kind, D):
     finally:
         o.PERSIST_ENABLED = True
     first = None
-    for it in range(10):
+    for it in range(rounds):
         hext, Sv, _, _ = o.rnn_fwd(kind, GI, Whh, bhh, lens, D, N, H, Tp)
         dGI = o.rnn_bwd(kind, dout, WhhT, hext, Sv, lens, D, N, H, Tp).dGI
         torch.cuda.synchronize()
@@ -437,56 +431,36 @@ def test_rnn_persist3_sixteen_groups_repeat_bit_identically(kind, D):
             assert torch.equal(hext, first[0]) and torch.equal(dGI, first[1]), it
 
 
-@pytest.mark.parametrize("kind,D,N,H,Tp,sort_lens", [
-    ("lstm", 2, 64, 1280, 61, True),       # config 5a's groups: 22 clips in two sets of 11, groups span XCDs
-    ("gru", 2, 128, 1024, 45, True),       # XCD-local groups, two sets of 16
-    ("lstm", 2, 128, 800, 37, False),      # lengths in loader order NOT sorted: set 1 may outlast set 0
-    ("gru", 1, 96, 1536, 33, True),        # one direction, 18 clips per group
+@pytest.mark.parametrize("kind,D", [("gru", 1), ("lstm", 2)])
+def test_rnn_persist3_sixteen_groups_repeat_bit_identically(kind, D):
+    """H = 512 runs TWO groups per XCD -- up to 16 groups, the only width with more than eight.  Their XCC-id handshake words used to
+    overflow the 2 KB of the scratch head that eight groups need, onto the spin budget and the first group's exchange slots: about
+    one launch in ten read a stale word at the second time step (found by a repeated whole-model step, round 4).  Ten forward +
+    BPTT sweeps over 451 ragged steps: every launch bit-identical to the first and equal to the launch-per-step kernels."""
+    N, Tp = 16, 451
+    lens_np = np.sort(np.random.RandomState(0).randint(Tp // 3, Tp + 1, N))[::-1].copy()
+    lens_np[0] = Tp
+    _repeat_sweeps_bit_identically(kind, D, N, 512, Tp, lens_np, 10)
+
+
+@pytest.mark.parametrize("kind,D,N,H,lens", [
+    ("lstm", 2, 5, 1280, [66, 60, 51, 39, 30]),        # groups of 2, 2 and 1 clips; the last group's only clip ends at step 39 of 66
+    ("gru", 2, 9, 1024, [90, 90, 80, 33, 31, 30, 12, 11, 10]),
+    ("lstm", 1, 64, 1280, None),                       # config 5b's groups (11 clips), lengths spread over [T'/3, T']
 ])
-def test_rnn_persist3_set_schedules(kind, D, N, H, Tp, sort_lens):
-    """Two-set groups execute a set's half-steps only while one of its clips is inside its sequence (ds2r::sched3; with the batch
-    sorted by length set 1 holds a group's short clips and drops out early / joins late).  Ragged lengths over tens of steps:
-    forward and BPTT against the oracle on every row -- padding rows included, which the half-steps left out no longer write
-    (ds2_rnn_persist_fwd / _bwd zero them) -- and against the same kernels with every half-step executed (variant bit 1):
-    bit-identical, the schedule changes which half-steps run, not what the executed ones compute."""
-    from deepspeech.pytorch_amd._lib import query
-    o = ops()
-    assert o.use_persistent(kind, torch.bfloat16, D, N, H)
-    assert query("ds2_rnn_persist_kind", o.dt(torch.bfloat16), o.CELLS[kind], D, N, H) == 3
-    res = _rnn_sweep_case(torch.bfloat16, kind, D, N, H, Tp, 0.7 / np.sqrt(H), tol_scale=2.0, sort_lens=sort_lens, min_len=Tp // 4)
-    o.check_persistent_kernels()
-    old = query("ds2_rnn_persist_set_variant", 2)
-    try:
-        res_all = _rnn_sweep_case(torch.bfloat16, kind, D, N, H, Tp, 0.7 / np.sqrt(H), tol_scale=2.0, sort_lens=sort_lens, min_len=Tp // 4)
-        o.check_persistent_kernels()
-    finally:
-        query("ds2_rnn_persist_set_variant", old)
-    for a_, b_ in zip(res, res_all):
-        assert np.array_equal(a_, b_)
-
-
-def test_rnn_persist3_set_schedule_with_initial_state():
-    """h0 / c0 carry (reference inference.py:86-96) into a two-set group whose second set joins the reverse direction late: its
-    initial state is published in the slot before ITS first executed step."""
-    rs = np.random.RandomState(17)
-    kind, D, N, H, Tp = "lstm", 2, 64, 1280, 9
-    G = O.GATES[kind]
-    GI = rs.standard_normal((Tp * N, D * G * H))
-    Whh, bhh = rs.uniform(-0.03, 0.03, (D, G * H, H)), rs.uniform(-0.2, 0.2, (D, G * H))
-    h0, c0 = rs.standard_normal((D, N, H)), rs.standard_normal((D, N, H))
-    lens = np.sort(rs.randint(2, Tp + 1, size=N))[::-1].astype(np.int32).copy()
-    lens[0] = Tp
-    dt_ = torch.bfloat16
-    GI_r, Whh_r = rnd(GI, dt_), rnd(Whh, dt_)
-    o = ops()
-    hext, Sv, hn, cn = o.rnn_fwd(kind, cu(GI, dt_), cu(Whh, dt_), cu(bhh), torch.from_numpy(lens).to(DEV), D, N, H, Tp, h0=cu(h0), c0=cu(c0))
-    o.check_persistent_kernels()
-    for d in range(D):
-        out, hn_ref, cn_ref, _ = O.rnn_dir_fwd(kind, GI_r.reshape(Tp, N, D, G * H)[:, :, d], lens, np.eye(G * H), Whh_r[d],
-                                               np.zeros(G * H), bhh[d], reverse=(d == 1), h0=h0[d], c0=c0[d])
-        assert np.abs(np64(hext[d, 1:Tp + 1]) - out).max() < 4e-2
-        assert np.abs(np64(hn[d]) - hn_ref).max() < 4e-2
-        assert np.abs(np64(cn[d]) - cn_ref).max() < 6e-2
+def test_rnn_persist3_groups_of_short_clips_stay_in_lock_step(kind, D, N, H, lens):
+    """The four-slot exchange relies on LOCK-STEP: a workgroup reads every peer's publish of the step before, so none can run more
+    than a step ahead and re-arm a slot somebody still needs.  A variant of these kernels gathered only the rows of clips inside
+    their sequences; a workgroup of a group whose clips had all ended then stopped waiting, ran ahead, and its peers timed out on
+    a slot it had passed (caught once in a whole suite run, round 4).  Groups whose clips end long before T', thirty launches:
+    no time-out, bit-identical results."""
+    if lens is None:
+        Tp = 151
+        lens_np = np.sort(np.random.RandomState(3).randint(Tp // 3, Tp + 1, N))[::-1].copy()
+        lens_np[0] = Tp
+    else:
+        lens_np, Tp = np.array(lens), max(lens)
+    _repeat_sweeps_bit_identically(kind, D, N, H, Tp, lens_np, 30)
 
 
 def test_rnn_persist3_long_ragged_sweep():
