@@ -128,15 +128,24 @@ __device__ __forceinline__ void g8_tile(const G8Problem& P, int t_id, unsigned c
   const bool listed = TN && P.rows != nullptr;
   typedef const __attribute__((address_space(4))) int* const_int_ptr_t;      // constant address space: wave-uniform reads become
   const const_int_ptr_t crows = (const_int_ptr_t)(uintptr_t)P.rows;           // s_load (lgkmcnt), not vector loads behind the DMA
+  // fetch_rows issues the scalar loads (phase 0 of the K-tile two ahead of the one they belong to); select_rows consumes them two
+  // phases later, right in front of the DMA that needs them -- so the loads' latency never sits in front of a phase's LDS reads
   uint32_t rk[4] = {0, 0, 0, 0};
+  int sr0[4] = {0, 0, 0, 0}, sr1[4] = {0, 0, 0, 0};
   auto fetch_rows = [&](int kt) {
     if (listed && kt < nkt) {
 #pragma unroll
       for (int rb = 0; rb < 4; ++rb) {
         const int k = kt * 64 + rb * 16 + wave * 2;
-        const int r0 = crows[min(k, K_ - 1)], r1 = crows[min(k + 1, K_ - 1)];
-        rk[rb] = (uint32_t)((lane >> 5) ? r1 : r0);
+        sr0[rb] = crows[min(k, K_ - 1)];
+        sr1[rb] = crows[min(k + 1, K_ - 1)];
       }
+    }
+  };
+  auto select_rows = [&]() {
+    if (listed) {
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) rk[rb] = (uint32_t)((lane >> 5) ? sr1[rb] : sr0[rb]);
     }
   };
   const uint32_t lda2b = (uint32_t)(lda_eff * 2), ldb2b = (uint32_t)(P.ldb * 2);
@@ -294,6 +303,7 @@ __device__ __forceinline__ void g8_tile(const G8Problem& P, int t_id, unsigned c
     G8_BARRIER();                                              \
     /* phase 2 */                                              \
     G8_READ_A(BUF, 1)                                          \
+    select_rows();                                             \
     if (more) stage_b(BUF, (KT) + 2, 0, SPREAD ? 2 : 4);       \
     G8_WAIT_LGKM0();                                           \
     G8_BARRIER();                                              \
@@ -320,10 +330,12 @@ __device__ __forceinline__ void g8_tile(const G8Problem& P, int t_id, unsigned c
 
   // prologue: K-tiles 0 and 1
   fetch_rows(0);
+  select_rows();
   stage_a(0, 0);
   stage_b(0, 0);
   if (nkt > 1) {
     fetch_rows(1);
+    select_rows();
     stage_a(1, 1);
     stage_b(1, 1);
     G8_WAIT_VM(8);
