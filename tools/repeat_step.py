@@ -1,3 +1,11 @@
+#!/usr/bin/env python
+"""Flake screen of a whole training step: N fresh models of the lstm_bi_1280 fixture (groups of 2, 2 and 1 clips in the round-4 general
+sweeps), upstream gradient 1 / 65 536 alternating, device memory polluted with NaN between the steps; reports every step whose
+gradients are not finite / differ from the first step's, and a raised sweep time-out.  (Found the lock-step violation of the
+active-rows-only gather)
+
+    gpurun -- 'python tools/repeat_step.py 60 > gpurun_out/repeat_step.txt'
+"""
 import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

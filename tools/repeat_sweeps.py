@@ -1,4 +1,10 @@
-"""Determinism / correctness of the sweeps at H = 512, 16 clips, T' = 451 (the shape of tests/test_gpu_model.py::test_row_lists...)."""
+#!/usr/bin/env python
+"""Race screen of the persistent sweeps at kernel level: twelve forward + BPTT launches per shape on the same operands (every third
+with NaN in the padding rows of the input projection, as a row-list product leaves them), each compared with the launch-per-step
+kernels and bit for bit with the first launch.  Found the handshake-word overflow of H = 512 (profiles/r04i_*, r04j_*).
+
+    gpurun -- 'DS2_ALLOW_LAUNCH_PER_STEP=1 python tools/repeat_sweeps.py [gru1 lstm2 ...] > gpurun_out/repeat_sweeps.txt'
+"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
