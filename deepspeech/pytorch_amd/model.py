@@ -331,7 +331,7 @@ def _frame_rows(output_lengths, Tp, N, dev):
     rows = np.flatnonzero(np.arange(Tp, dtype=np.int32)[:, None] < ol[None, :]).astype(np.int32)
     # staged in pinned memory: the copy is asynchronous AND the allocator keeps the block until it is done (a pageable temporary
     # would be freed on return from .to())
-    host = torch.empty(N + rows.size, dtype=torch.int32, pin_memory=torch.device(dev).type == "cuda" and not os.environ.get("DS2_DBG_PAGEABLE"))
+    host = torch.empty(N + rows.size, dtype=torch.int32, pin_memory=torch.device(dev).type == "cuda")
     hv = host.numpy()
     hv[:N] = ol
     hv[N:] = rows
