@@ -3,7 +3,7 @@
 //                   8 XCD-local groups of 32 workgroups, <= 16 samples per group -- BASELINE.json config 3;
 //   general kernels, round 4 (ds2_rnn_persist3_impl.h, instantiated in ds2_rnn_persist3_*.hip): bf16, GRU / LSTM, H in {512, 768,
 //                   800, 1024, 1280, 1536}: 32 units per workgroup, XCD-local groups for H <= 1024, up to 32 samples per group in
-//                   two interleaved sets -- config 5 and every bf16 width / batch the tuned kernels do not take;
+//                   two sample sets with their own step schedules -- config 5 and every bf16 width / batch the tuned kernels do not take;
 //   general kernels, round 2 (ds2_rnn_persist2_impl.h, instantiated in ds2_rnn_persist2_*.hip): H in {800, 1024, 1280}, bf16 and fp32
 //                   storage, GRU / LSTM, up to 64 samples per group -- config 2 (the fp32 parity mode) and bf16 groups of > 32 samples.
 #include "ds2_rnn_persist3_impl.h"

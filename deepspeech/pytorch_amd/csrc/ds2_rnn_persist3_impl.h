@@ -11,10 +11,12 @@
 //   * the W_hh slice of 32 units x G gates (LSTM-1280: 327 KB) no longer fits the register file beside the accumulators: part of
 //     every wave's B fragments lives in LDS, ready-made (one conflict-free ds_read_b128 per fragment, read a k-step or three ahead
 //     of its MFMA), the rest in registers (plan3: <= 224-256 weight registers per lane, LDS <= 156 KB incl. the partial sums);
-//   * a group's samples are cut into NSET interleaved SETS of <= 16 (one MFMA m-tile each).  Samples are independent recurrences,
-//     so a time step is NSET half-steps, each with its own four exchange slots: while set A's hand-off is in flight the
-//     workgroup multiplies set B -- the exchange latency (the floor of a persistent sweep) hides behind the other set's work,
-//     and only ONE m-tile of accumulators, gather buffers and gate state is live at a time;
+//   * a group's samples are cut into NSET SETS of <= 16 consecutive samples (one MFMA m-tile each).  Samples are independent
+//     recurrences, so a time step is NSET half-steps, each with its own four exchange slots: while set A's hand-off is in flight
+//     the workgroup multiplies set B -- the exchange latency (the floor of a persistent sweep) hides behind the other set's work,
+//     and only ONE m-tile of accumulators, gather buffers and gate state is live at a time.  A set's half-steps are executed only
+//     while one of its clips is inside its sequence (sched3): with the batch sorted by length the second set holds the group's
+//     shortest clips and drops out of the schedule early (joins it late in a descending sweep);
 //   * all 256 threads run the gate phase (one sample row x one pair of hidden units each), thread bits in the order of the
 //     exchange layout so that a wave publishes one contiguous 1 KiB run.
 // Exchange: payload-only bf16 in MFMA A-fragment order, four slots per set, the all-ones dword = "not published yet", publishers
@@ -237,7 +239,7 @@ constexpr int chunk3(int KSW, int SP) { return KSW <= 16 ? ((KSW + 1) / 2 + SP -
 
 // The gather of one wave: a stream of chunks (CH k-steps = CH / SP 16-byte loads per lane) through TWO register buffers.  The kernel
 // keeps two chunks in flight: after the products of a chunk its buffer is refilled with the chunk two ahead -- of the same
-// half-step or, with two interleaved sample sets, of the NEXT half-step (the other set's vector was published a half-step ago), so
+// half-step or, with two sample sets, of the half-step executed NEXT (normally the other set's, published a half-step ago), so
 // the fabric round trip of the exchange overlaps this half-step's products, barrier and gate phase instead of preceding them.
 //   issue(b, c, base...)  loads chunk c (k-steps c*CH ..) of the slot at byte offset `base` (= set + slot + lq*256 + row*16; k-step k
 //                         adds k*1024) into buffer b.  Lanes without a sample row / beyond the wave's ragged share load from
@@ -1126,7 +1128,7 @@ int launch3_one(bool bwd, const RArgs& ra, hipStream_t st) {
   }
 }
 
-// nset = interleaved sets (1 or 2); single-set groups of <= 8 samples share the gather loads between lane pairs (SP = 2)
+// nset = sample sets (1 or 2); single-set groups of <= 8 samples share the gather loads between lane pairs (SP = 2)
 template <int CELL, int H>
 int launch3(bool probe, bool bwd, const RArgs& ra, hipStream_t st) {
   if (!covered3<CELL, H>()) return DS2_ERR_ARG;

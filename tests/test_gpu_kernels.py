@@ -358,7 +358,7 @@ GENERAL_PERSISTENT_CASES = [
 ]
 
 
-# round-4 general kernels (ds2_rnn_persist3_impl.h: bf16, 32 units per workgroup): one / two interleaved sample sets, lane-shared
+# round-4 general kernels (ds2_rnn_persist3_impl.h: bf16, 32 units per workgroup): one / two sample sets, lane-shared
 # gathers (<= 8 samples per group), XCD-local groups (H <= 1024) and groups that span XCDs (1280, 1536), ragged K splits (800:
 # 25 k-steps over 4 waves), LDS-resident weight tails (LSTM-1280 forward 3 of 10 k-steps, BPTT 12 of 40), empty group slots (N = 3)
 PERSIST3_CASES = [

@@ -38,7 +38,7 @@ def main():
     rows = [
         ("k_rnn_persist_bwd", "BPTT sweep (W_hh^T resident), one launch per layer", "mfma (latency-bound)", sweep, peak, "TFLOP/s"),
         ("k_rnn_persist_fwd", "forward sweep (W_hh resident)", "mfma (latency-bound)", sweep, peak, "TFLOP/s"),
-        ("k_rnn_persist3_bwd", "BPTT sweep, round-4 general kernel (32 units per workgroup, interleaved sample sets)",
+        ("k_rnn_persist3_bwd", "BPTT sweep, round-4 general kernel (32 units per workgroup, two sample sets with their own step schedules)",
          "mfma (latency / exchange-volume bound)", sweep, peak, "TFLOP/s"),
         ("k_rnn_persist3_fwd", "forward sweep, round-4 general kernel", "mfma (latency / exchange-volume bound)", sweep, peak, "TFLOP/s"),
         ("k_rnn_persist2_bwd", "BPTT sweep, general kernel", "mfma (latency / exchange-volume bound)", sweep, peak, "TFLOP/s"),
