@@ -16,10 +16,12 @@ x 10 ms.  One JSON line is printed by rank 0; it also carries
                   sweep): algorithmic h2h FLOPs of a sweep over valid frames / average launch duration measured live with
                   HIP events on the launch stream, against the dense MFMA peak of the compute dtype (bf16 2.5 PFLOP/s, fp32
                   157.3 TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md);
-  "cpu_baseline": oracle/ds2_torch_port.py (the same torch calls the reference makes) timed on the host cores of this
-                  box on a bounded sample of the same model AT THE SAME BATCH SIZE (short clips; rank 0, N=1 only), plus --
-                  when profiles/cpu_reference_<config>.json exists -- the reference's own model.py timed offline at the full
-                  shape in the build container (tools/cpu_reference_baseline.py).  A reported baseline, not the target.
+  "cpu_baseline": oracle/ds2_torch_port.py (a port of the reference's model.py:214-249: the same torch calls in the same order)
+                  timed on the host cores of THIS box (rank 0, N=1 only), fp32, all usable cores.  For cfg3 -- the metric's
+                  configuration -- `value` is ONE training step at the bench's own full batch (32 clips of 12-15 s; minutes of CPU
+                  time, no same-shape warm-up); `short_sample` is the bounded sample (same model and batch size, 3-s clips) and
+                  `reference_offline` the reference's own model.py timed offline in the build container
+                  (tools/cpu_reference_baseline.py, profiles/cpu_reference_<config>.json).  A reported baseline, not the target.
 
   "stock_baseline" / "vs_baseline": stock PyTorch-ROCm (the `--stock` leg below) timed by THIS run in a subprocess on the same
                   batch, the same parameters and the same device (N=1, rank 0; --no-stock-baseline skips it), and value / its value;
@@ -267,21 +269,39 @@ def log(msg):
 _T0 = time.perf_counter()
 
 
-def cpu_baseline_subprocess(args):
-    """Runs the CPU leg in a child process under a hard time limit so that it can never stall the GPU bench."""
-    import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--config", args.config,
-           "--cpu-clips", str(args.cpu_clips), "--cpu-frames", str(args.cpu_frames)]
-    try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_timeout)
-        for line in r.stdout.splitlines()[::-1]:
-            if line.startswith("{"):
+def _last_json_line(text):
+    for line in (text or "").splitlines()[::-1]:
+        if line.startswith("{"):
+            try:
                 return json.loads(line)
+            except ValueError:
+                continue
+    return None
+
+
+def cpu_baseline_subprocess(args):
+    """Runs the CPU leg in a child process under a hard time limit so that it can never stall the GPU bench.  The child prints a
+    line per leg (short sample, then the full shape); the last complete one counts, also when the limit cuts the child off."""
+    import subprocess
+    full = args.cpu_full
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--config", args.config,
+           "--cpu-clips", str(args.cpu_clips), "--cpu-frames", str(args.cpu_frames), "--cpu-full", "1" if full else "0"]
+    limit = args.cpu_timeout if args.cpu_timeout > 0 else (1200 if full else 170)
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=limit)
+        j = _last_json_line(r.stdout)
+        if j is not None:
+            return j
         return {"value": None, "unit": "audio-seconds/sec", "cores": usable_cores(), "kind": "port",
                 "sample": "cpu leg failed: " + (r.stderr.strip().splitlines() or ["?"])[-1][:200]}
-    except subprocess.TimeoutExpired:
+    except subprocess.TimeoutExpired as e:
+        so = e.stdout.decode() if isinstance(e.stdout, bytes) else e.stdout
+        j = _last_json_line(so)
+        if j is not None:
+            j["note"] = "the full-shape leg exceeded the %d s limit: this is the short sample" % limit
+            return j
         return {"value": None, "unit": "audio-seconds/sec", "cores": usable_cores(), "kind": "port",
-                "sample": "cpu leg exceeded its %d s limit" % args.cpu_timeout}
+                "sample": "cpu leg exceeded its %d s limit" % limit}
 
 
 def stock_baseline_subprocess(args):
@@ -309,17 +329,27 @@ def stock_baseline_subprocess(args):
 
 
 def cpu_baseline(args):
-    """oracle/ds2_torch_port.py on the host cores: same model, bounded sample (a few short clips), fp32."""
+    """oracle/ds2_torch_port.py -- a port of the reference's forward / training_step (model.py:214-249: the same torch calls in the
+    same order) -- on the host cores of THIS box, fp32, all usable cores.  Two legs, each printed as its own JSON line (the parent
+    takes the last one it got, so a full-shape leg that outlives the time limit still leaves the short sample):
+      1. a bounded sample: the configuration's model and batch size on short clips (--cpu-frames), best of <= 4 steps;
+      2. (--cpu-full, default for cfg3) the metric's own configuration: rank 0's FULL batch of the bench (the same clips the GPU
+         leg trains on: 32 clips of 12-15 s for cfg3), ONE timed step, no same-shape warm-up (a step is minutes of CPU time; the
+         thread pool and allocator are warm from leg 1).  This is `value`; leg 1 moves to `short_sample`."""
     from deepspeech.pytorch_amd import synth
     from oracle import ds2_torch_port as TP
     kind, H, L, bi, N, tmin, tmax, dtype = CONFIGS[args.config]
     cores = usable_cores()
     torch.set_num_threads(cores)
     cfg = dict(rnn_type=kind, hidden_size=H, hidden_layers=L, bidirectional=bi, lookahead_context=20)
-    port = TP.Port(cfg, TP.random_state(cfg, 0), "cpu")
+    st0 = TP.random_state(cfg, 0)
+    st0 = synth.synth_params({k: tuple(np.asarray(v).shape) for k, v in st0.items()}, PARAM_SEED[args.config])   # the native leg's parameters
+    port = TP.Port(cfg, st0, "cpu")
     n = args.cpu_clips if args.cpu_clips > 0 else N          # default: the configuration's own batch size (the CPU path is
     t = args.cpu_frames                                      # weight-bandwidth-bound per time step, so the batch size matters)
     opt = port.make_optimizer()
+    what = "oracle/ds2_torch_port.py (port of the reference's model.py:214-249: the same torch op sequence) fp32, same model (%s H=%d L=%d %s)" % (
+        kind, H, L, "bi" if bi else "uni")
 
     def make(n_, t_, seed):
         lengths = synth.synth_lengths(n_, max(41, t_ - t_ // 5), t_, seed=seed)
@@ -336,15 +366,30 @@ def cpu_baseline(args):
     best = min(times)
     secs = synth.audio_seconds(lengths)
     out = {"value": round(secs / best, 3), "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
-           "sample": "oracle/ds2_torch_port.py (the reference's torch op sequence) fp32, same model (%s H=%d L=%d %s), %d clips of "
-                     "%.2f-%.2f s, best of %d steps (%.2f s/step), torch %s, %d threads" % (
-                         kind, H, L, "bi" if bi else "uni", n, lengths.min() * 0.01, lengths.max() * 0.01, len(times), best,
-                         torch.__version__, cores)}
+           "sample": "%s, %d clips of %.2f-%.2f s, best of %d steps (%.2f s/step), torch %s, %d threads" % (
+               what, n, lengths.min() * 0.01, lengths.max() * 0.01, len(times), best, torch.__version__, cores)}
     try:   # the reference's own model.py at the FULL shape, timed offline in the build container (no reference on this box)
         ref = json.load(open(os.path.join(ROOT, "profiles", "cpu_reference_%s.json" % args.config)))
         out["reference_offline"] = {k: ref[k] for k in ("value", "unit", "cores", "kind", "sample") if k in ref}
     except Exception:
         pass
+    if not args.cpu_full:
+        return out
+    print(json.dumps(out), flush=True)                 # what the parent falls back to if the full-shape leg runs out of time
+    short = {k: out[k] for k in ("value", "unit", "sample")}
+    # ---- the metric's own configuration: rank 0's batch of the bench, fresh parameters and optimizer state (the fixture's)
+    port = TP.Port(cfg, st0, "cpu")
+    opt = port.make_optimizer()
+    lengths, batch = build_batch(args.config, 0, "cpu")
+    t0 = time.perf_counter()
+    loss = port.train_step(batch, opt)
+    dt = time.perf_counter() - t0
+    secs = synth.audio_seconds(lengths)
+    out.update(value=round(secs / dt, 4), short_sample=short, seconds_per_step=round(dt, 2), ctc_loss_first_step=float(loss.detach().item()),
+               sample="%s, the bench's own rank-0 batch: %d clips of %.2f-%.2f s (%.1f s of audio, the metric's configuration %s), ONE timed "
+                      "training step (forward + CTC + backward + clip_grad_norm(400) + AdamW) of %.1f s with 0 same-shape warm-up steps "
+                      "(thread pool / allocator warm from the short sample), torch %s, %d threads on this box's host cores" % (
+                          what, len(lengths), lengths.min() * 0.01, lengths.max() * 0.01, secs, args.config, dt, torch.__version__, cores))
     return out
 
 
@@ -359,13 +404,17 @@ def main():
     ap.add_argument("--torch-optimizer", action="store_true", help="clip_grad_norm_ + torch AdamW(fused=True) instead of the HIP optimizer kernels")
     ap.add_argument("--cpu-clips", type=int, default=0, help="clips of the CPU sample (0 = the configuration's batch size)")
     ap.add_argument("--cpu-frames", type=int, default=301)
-    ap.add_argument("--cpu-timeout", type=int, default=170)
+    ap.add_argument("--cpu-timeout", type=int, default=0, help="limit of the CPU leg in seconds (0: 1200 with the full-shape step, 170 without)")
+    ap.add_argument("--cpu-full", type=int, default=-1, help="1: time ONE training step of the port at the configuration's full batch on the "
+                    "host cores (minutes); 0: the short sample only; default: 1 for cfg3 (the metric's configuration), 0 otherwise")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--no-stock-baseline", action="store_true", help="skip the stock PyTorch-ROCm leg of the N=1 run")
     ap.add_argument("--stock-steps", type=int, default=3)
     ap.add_argument("--stock-warmup", type=int, default=2)
     ap.add_argument("--stock-timeout", type=int, default=150)
     args = ap.parse_args()
+    if args.cpu_full < 0:
+        args.cpu_full = 1 if args.config == "cfg3" else 0
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args)))
         return
@@ -445,7 +494,7 @@ def main():
                                        "model, batch and precision) measured on the same GPU right after the timed region; BASELINE.md "
                                        "holds no published number for this metric")
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.stock:
-        log("cpu baseline leg (subprocess, <= %d s)" % args.cpu_timeout)
+        log("cpu baseline leg (subprocess%s)" % (": short sample, then ONE full-shape step on the host cores -- minutes" if args.cpu_full else ""))
         out["cpu_baseline"] = cpu_baseline_subprocess(args)
     if rank == 0:
         print(json.dumps(out))

@@ -9,9 +9,9 @@
 #include "ds2_rnn_persist3_impl.h"
 
 namespace ds2p {
-int launch_gru(bool bwd, int H, const PArgs& a, hipStream_t st);
-int launch_lstm(bool bwd, int H, const PArgs& a, hipStream_t st);
-int launch_rnn(bool bwd, int H, const PArgs& a, hipStream_t st);
+int launch_gru(bool bwd, int H, const PArgs& a, hipStream_t st, bool dense);
+int launch_lstm(bool bwd, int H, const PArgs& a, hipStream_t st, bool dense);
+int launch_rnn(bool bwd, int H, const PArgs& a, hipStream_t st, bool dense);
 }  // namespace ds2p
 namespace ds2q {
 // 0 on success, DS2_ERR_ARG if the combination is not instantiated; `probe` only asks whether it is
@@ -41,11 +41,16 @@ int cu_count() {   // of the CURRENT device (cached per device)
   return n[dev];
 }
 
+// ds2_rnn_persist_set_variant (A/B runs on one box): bit 0 = do not use the round-4 general kernels; 1 = two-set groups execute every
+// half-step; 2 = unused; 3 = the general kernels take H = 1024 too; 4 = the tuned kernels keep 9-16 clips per group;
+// 5 = the 8-clip tuned kernels use dense products (round 4's form) instead of the structured-sparse ones
+unsigned g_variant = 0;
 int dispatch(bool bwd, int cell, int H, const PArgs& a, hipStream_t st) {
+  const bool dense = (g_variant & 32u) != 0;    // A/B: the 8-clip kernels without the structured-sparse products (round 4's form)
   switch (cell) {
-    case CELL_GRU: return launch_gru(bwd, H, a, st);
-    case CELL_LSTM: return launch_lstm(bwd, H, a, st);
-    case CELL_RNN: return launch_rnn(bwd, H, a, st);
+    case CELL_GRU: return launch_gru(bwd, H, a, st, dense);
+    case CELL_LSTM: return launch_lstm(bwd, H, a, st, dense);
+    case CELL_RNN: return launch_rnn(bwd, H, a, st, dense);
   }
   return DS2_ERR_ARG;
 }
@@ -70,9 +75,6 @@ long xbuf_bytes(int cell, int H, bool bwd) {
   return (long)NGROUPS * 2 * MAXS * X2 * 8;
 }
 
-// ds2_rnn_persist_set_variant (A/B runs on one box): bit 0 = do not use the round-4 general kernels; 1 = two-set groups execute every
-// half-step; 2 = unused; 3 = the general kernels take H = 1024 too; 4 = the tuned kernels keep 9-16 clips per group
-unsigned g_variant = 0;
 
 bool tuned_ok(int dtype, int cell, int D, int N, int H) {
   if (dtype != DS2_BF16 || H != 1024 || (D != 1 && D != 2)) return false;

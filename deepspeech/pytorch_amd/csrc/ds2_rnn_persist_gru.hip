@@ -3,8 +3,8 @@
 #include "ds2_rnn_persist_impl.h"
 
 namespace ds2p {
-int launch_gru(bool bwd, int H, const PArgs& a, hipStream_t st) {
-  if (H == 1024) return launch<CELL_GRU, 1024, 32>(bwd, a, st);
+int launch_gru(bool bwd, int H, const PArgs& a, hipStream_t st, bool dense) {
+  if (H == 1024) return launch<CELL_GRU, 1024, 32>(bwd, a, st, dense);
   return DS2_ERR_ARG;
 }
 }  // namespace ds2p

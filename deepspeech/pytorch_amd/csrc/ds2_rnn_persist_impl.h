@@ -338,6 +338,40 @@ __device__ __forceinline__ void publish32(void* p, uint32_t v, bool local) {
     __hip_atomic_store((uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- 8 clips on all 16 MFMA rows: the structured-sparse form (round 5) ---------------------------------------------------------
+// A group of <= 8 clips fills half of the 16 rows of a dense 16x16x32 tile: half of every product of the sweeps was padding.
+// v_smfmac_f32_16x16x64_bf16 multiplies a 2:4-sparse A (two non-zeros in every four consecutive k, their positions in an index word)
+// with a dense B over K = 64 at the cost of a dense K = 32 instruction.  Rows s and s + 8 of the tile both belong to clip s: row s
+// carries its k = 0, 1 (mod 4) elements, row s + 8 its k = 2, 3 (mod 4) ones -- each row is 2:4 sparse by construction (index words
+// 0x4444 / 0xEEEE), and D[s] + D[s + 8] is the full dot product: 24 instead of 48 matrix instructions per wave and step.
+// (Layout of the operands measured by tools/probe_smfmac.py, profiles/r05a_smfmac.txt: lane 16*lq + i holds A row i, compressed
+// elements 8*lq .. 8*lq + 7 = logical k 16*lq + 4*(e/2) + index(e); B column i as TWO dense 16x16x32 fragments, elements e = 0..7:
+// k = 8*lq + e, elements 8..15: k = 32 + 8*lq + (e - 8) -- the weights stay in the registers of the dense kernels, fragment pairs
+// (2*kb, 2*kb + 1) feed one instruction.)
+// Exchange slot: [k-block (K/64)][lq (4)][tile row (16)] x 16 bytes; the unit of (kb, lq, row) = that lane's compressed A fragment =
+// the four pairs k = 64*kb + 16*lq + 4*g + 2*(row >> 3) + {0, 1}, g = 0..3, of clip row & 7: ONE 16-byte load per lane and k-block.
+typedef __attribute__((ext_vector_type(16))) __bf16 ds2_bf16x16;
+__device__ __forceinline__ int xsp_unit_bytes(int kb, int lq, int row16) { return ((kb * 4 + lq) * 16 + row16) * 16; }
+// byte offset of the dword that carries elements (k, k+1), k even, of clip `row`
+__device__ __forceinline__ int xsp_pair_bytes(int k, int row) {
+  const int kk = k & 63, r = kk & 15;
+  return xsp_unit_bytes(k >> 6, kk >> 4, row + 8 * ((r & 3) >> 1)) + (r >> 2) * 4;
+}
+// The sparse instruction has no C operand: the sums of a chunk start from zeros IN the destination.  Left to itself the compiler keeps
+// one zero tuple in accumulation registers, multiplies the first k-block there and copies the result out (s_nop + 8 reads in front of
+// the second k-block); zeros it must produce in vector registers make the whole chain run in place.
+__device__ __forceinline__ ds2_f32x4 zero_in_vgprs() {
+  ds2_f32x4 z;
+  asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0" : "=v"(z[0]), "=v"(z[1]), "=v"(z[2]), "=v"(z[3]));
+  return z;
+}
+__device__ __forceinline__ void smma16(ds2_f32x4& acc, const uint4& a, const uint4& b0, const uint4& b1, int idx) {
+  struct {
+    uint4 lo, hi;
+  } bb{b0, b1};
+  acc = __builtin_amdgcn_smfmac_f32_16x16x64_bf16(__builtin_bit_cast(ds2_bf16x8, a), __builtin_bit_cast(ds2_bf16x16, bb), acc, idx, 0, 0);
+}
+
 // ---- 16-byte merged stores of the 8-samples-per-group kernels (-DDS2_QUAD_STORES: an A/B variant) ---------------------------------
 // The even lanes 8m, 8m+2, 8m+4, 8m+6 of a wave hold four CONSECUTIVE dwords of one sample row -- in the exchange slot and in every
 // stored plane (thread bits: e, pair within the 16-byte unit (2), sample row (3), lq (2)).  row4() collects them on lane 8m, which then
@@ -362,12 +396,15 @@ __device__ __forceinline__ void publish128(__amdgpu_buffer_rsrc_t rsrc, int off,
     __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, off, 0, 16 /* sc1: write-through */);
 }
 
-template <int TILES, int KS, typename F = NoTouch>
+// SP: the structured-sparse form (see smma16): srow = the lane's tile row (0..15), `half` is unused, w[t][2*kb], w[t][2*kb + 1] (the
+// dense fragments of k-steps 2*kb, 2*kb + 1) are the B operand of k-block kb, `spidx` the lane's index word.
+template <int TILES, int KS, bool SP = false, typename F = NoTouch>
 __device__ __forceinline__ void gather_mma_tf(ds2_f32x4 (&acc)[TILES], const uint4 (&w)[TILES][KS], __amdgpu_buffer_rsrc_t rsrc,
                                               int slot_off, int kstep0, int lq, int srow, int half, bool need, int* err, int* lerr,
-                                              bool& dead, unsigned& rounds, F after_issue = F()) {
+                                              bool& dead, unsigned& rounds, F after_issue = F(), int spidx = 0) {
   constexpr int CH = chunk_ksteps_tf(KS);
-  constexpr int PER = CH / 2;       // k-steps a lane loads per chunk (the other half arrives by the DPP row rotate)
+  constexpr int PER = CH / 2;       // loads of a lane per chunk: half of the chunk's k-steps (the other half arrives by the DPP row
+                                    // rotate), or (SP) its fragment of each of the chunk's CH / 2 k-blocks
   static_assert(KS % CH == 0 && CH % 2 == 0, "k-steps per wave must tile into poll chunks");
   typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 #pragma unroll
@@ -379,18 +416,27 @@ __device__ __forceinline__ void gather_mma_tf(ds2_f32x4 (&acc)[TILES], const uin
     // conditional block would end in the copies of its first result, i.e. in a wait, ahead of after_issue)
 #define DS2_TF_LOAD(FIRST)                                                                                             \
     _Pragma("unroll") for (int i = 0; i < PER; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(                      \
-        rsrc, need ? slot_off + xtf_unit_bytes(kstep0 + c * CH + half * PER + i, lq, srow) : 0x7ffffff0, 0, 16 /* sc1 */); \
+        rsrc, need ? slot_off + (SP ? xsp_unit_bytes((kstep0 + c * CH) / 2 + i, lq, srow)                              \
+                                    : xtf_unit_bytes(kstep0 + c * CH + half * PER + i, lq, srow)) : 0x7ffffff0, 0, 16 /* sc1 */); \
     if (FIRST && c == 0 && !std::is_same<F, NoTouch>::value) {                                                         \
       after_issue();                     /* scalar work that hides under the first round trip (l2_touch) */            \
       __builtin_amdgcn_sched_barrier(0); /* nothing that waits for the loads may be scheduled above it   */            \
     }
 #define DS2_TF_MMA()                                                                                                   \
-    _Pragma("unroll") for (int t = 0; t < TILES; ++t) part[t] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};                        \
-    _Pragma("unroll") for (int k = 0; k < CH; ++k) {                                                                   \
-      const int i = k % PER;                                                                                           \
-      uint4 a = make_uint4(v[i][0], v[i][1], v[i][2], v[i][3]);                                                        \
-      if (k >= PER) a = make_uint4(ror8(a.x), ror8(a.y), ror8(a.z), ror8(a.w));                                        \
-      _Pragma("unroll") for (int t = 0; t < TILES; ++t) Mma<bf16_t>::mma16(part[t], a, w[t][c * CH + k]);              \
+    _Pragma("unroll") for (int t = 0; t < TILES; ++t) part[t] = (SP && KS != CH) ? zero_in_vgprs() : ds2_f32x4{0.f, 0.f, 0.f, 0.f}; \
+    if (SP) {                                                                                                          \
+      _Pragma("unroll") for (int i = 0; i < PER; ++i) {                                                                \
+        const uint4 a = make_uint4(v[i][0], v[i][1], v[i][2], v[i][3]);                                                \
+        _Pragma("unroll") for (int t = 0; t < TILES; ++t)                                                              \
+            smma16(part[t], a, w[t][c * CH + 2 * i], w[t][c * CH + 2 * i + 1], spidx);                                 \
+      }                                                                                                                \
+    } else {                                                                                                           \
+      _Pragma("unroll") for (int k = 0; k < CH; ++k) {                                                                 \
+        const int i = k % PER;                                                                                         \
+        uint4 a = make_uint4(v[i][0], v[i][1], v[i][2], v[i][3]);                                                      \
+        if (k >= PER) a = make_uint4(ror8(a.x), ror8(a.y), ror8(a.z), ror8(a.w));                                      \
+        _Pragma("unroll") for (int t = 0; t < TILES; ++t) Mma<bf16_t>::mma16(part[t], a, w[t][c * CH + k]);            \
+      }                                                                                                                \
     }
 #define DS2_TF_CHECK(bad)                                                                                              \
     bool bad = false;                                                                                                  \
@@ -704,7 +750,7 @@ __device__ __forceinline__ float dpp_xor1(float v) {      // value of the neighb
   return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true));
 }
 
-template <int CELL, int H, int P>
+template <int CELL, int H, int P, bool SP>
 __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd4(PArgs a) {
   constexpr int G = CellInfo<CELL>::G, NS = CellInfo<CELL>::NS;
   constexpr int U = H / P;
@@ -712,6 +758,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd4(PArgs a) {
   constexpr int KS = H / 128;
   constexpr int X2 = H / 2;
   static_assert(U == 32 && H % 128 == 0, "the one-unit-per-thread gate map assumes 32 hidden units per workgroup");
+  static_assert(!SP || H % 256 == 0, "a wave's K-quarter is whole k-blocks of 64");
   __shared__ __attribute__((aligned(16))) float part[2][4 * TILES * PT_TILE];
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -731,22 +778,24 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd4(PArgs a) {
       const int r = 16 * t + li;
       const bf16_t* row = Wd + ((long)(r / U) * H + p * U + (r % U)) * H + wave * (H / 4) + lq * 8;
 #pragma unroll
-      for (int k = 0; k < KS; ++k) w[t][k] = *reinterpret_cast<const uint4*>(row + 32 * k);
+      for (int k = 0; k < KS; ++k) w[t][k] = *reinterpret_cast<const uint4*>(row + 32 * k);   // SP: the same fragments (see smma16)
     }
   }
   // tag-free exchange: 4 slots of [H/32 k-steps][4][8 rows] x 16 bytes inside this group's share of the scratch
   constexpr int SLOT_BYTES = (H / 32) * 512;
   static_assert(4 * SLOT_BYTES <= 2 * MAXS * X2 * 8, "four payload slots fit where the two tagged parities lived");
   char* xg = (char*)(a.xbuf + (long)grp * 2 * MAXS * X2);
-  const int srow = li & 7, half = li >> 3;
-  const bool need = srow < Ns;
+  const int srow = SP ? li : (li & 7), half = li >> 3;
+  const bool need = (li & 7) < Ns;
+  const int spidx = (li & 8) ? 0xEEEE : 0x4444;      // SP: rows 8..15 carry the k = 2, 3 (mod 4) elements
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, 4 * SLOT_BYTES, 0x00020000);
 
   // ---- gate identity: thread bits = (e: unit of the pair, pair within the 16-byte unit (2), sample row (3), lq (2)) -- the pair
   // index (tid >> 1) has the bit order of the exchange layout, so the even lanes of a wave publish one contiguous 128-byte run
+  // (SP: (e, pair within the unit (2), tile-row half (1), sample row (3), 16-k block of the workgroup's 32 units (1)): two 64-byte runs)
   const int e = tid & 1, pid = tid >> 1;
-  const int gi_i = (pid >> 2) & 7;
-  const int up = ((pid >> 5) & 3) * 4 + (pid & 3);
+  const int gi_i = SP ? (pid >> 3) & 7 : (pid >> 2) & 7;
+  const int up = SP ? (pid >> 6) * 8 + (pid & 3) * 2 + ((pid >> 2) & 1) : ((pid >> 5) & 3) * 4 + (pid & 3);
   const bool gate_thread = gi_i < Ns;
   const int n = slice + a.gpd * gi_i;
   const int j = p * U + 2 * up;              // first unit of the pair
@@ -781,7 +830,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd4(PArgs a) {
     *reinterpret_cast<uint32_t*>(hb - (long)N * H) = 0u;
     *reinterpret_cast<uint32_t*>(hb + (long)Tp * N * H) = 0u;
   }
-  const int xoff = xtf_pair_bytes(j, gi_i);     // this pair's dword inside a slot
+  const int xoff = SP ? xsp_pair_bytes(j, gi_i) : xtf_pair_bytes(j, gi_i);     // this pair's dword inside a slot
   if (a.h0) {                    // initial state as "step -1": slot 3
     const float other = dpp_xor1(hprev);
     if (gate_thread && e == 0) publish32(xg + 3 * SLOT_BYTES + xoff, xtf_word(pack_bf16x2(hprev, other)), local);
@@ -838,7 +887,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd4(PArgs a) {
 #pragma unroll
     for (int tt = 0; tt < TILES; ++tt) acc[tt] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
     if (s > 0 || a.h0)
-      gather_mma_tf<TILES, KS>(acc, w, rsrc, ((s + 3) & 3) * SLOT_BYTES, wave * KS, lq, srow, half, need, a.err, a.lerr, dead, rounds, touch);
+      gather_mma_tf<TILES, KS, SP>(acc, w, rsrc, ((s + 3) & 3) * SLOT_BYTES, wave * KS, lq, srow, half, need, a.err, a.lerr, dead, rounds, touch, spidx);
     else
       touch();
     DS2_PROBE_ONLY(const unsigned long long t1 = __builtin_readcyclecounter();)
@@ -856,6 +905,8 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd4(PArgs a) {
       for (int g = 0; g < G; ++g) {
         const float* pp = part[par] + pidx[g];
         gh[g] = (pp[0] + pp[TILES * PT_TILE]) + (pp[2 * TILES * PT_TILE] + pp[3 * TILES * PT_TILE]);
+        if (SP)      // the clip's second tile row (k = 2, 3 mod 4), 8 floats on in the [col][row] tile
+          gh[g] += (pp[8] + pp[TILES * PT_TILE + 8]) + (pp[2 * TILES * PT_TILE + 8] + pp[3 * TILES * PT_TILE + 8]);
       }
       if (act) {
         if (CELL == CELL_GRU) {
@@ -1169,7 +1220,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd(PArgs a) {
 // ------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float ld_bf16(const bf16_t* p) { return __uint_as_float((uint32_t)p->v << 16); }
 
-template <int CELL, int H, int P>
+template <int CELL, int H, int P, bool SP>
 __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd4(PArgs a) {
   constexpr int G = CellInfo<CELL>::G, NS = CellInfo<CELL>::NS;
   constexpr int U = H / P;
@@ -1177,6 +1228,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd4(PArgs a) {
   constexpr int KS = G * H / 128;
   constexpr int X2 = G * H / 2;
   static_assert(U == 32 && (G * H) % 128 == 0, "the one-unit-per-thread gate map assumes 32 hidden units per workgroup");
+  static_assert(!SP || ((G * H) % 256 == 0 && H % 64 == 0), "a wave's K-quarter is whole k-blocks of 64; a gate starts on a k-block");
   __shared__ __attribute__((aligned(16))) float part[2][4 * TILES * PT_TILE];
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1195,20 +1247,21 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd4(PArgs a) {
     for (int t = 0; t < TILES; ++t) {
       const bf16_t* row = WT + (long)(p * U + 16 * t + li) * GH + wave * (GH / 4) + lq * 8;
 #pragma unroll
-      for (int k = 0; k < KS; ++k) w[t][k] = *reinterpret_cast<const uint4*>(row + 32 * k);
+      for (int k = 0; k < KS; ++k) w[t][k] = *reinterpret_cast<const uint4*>(row + 32 * k);   // SP: the same fragments (see smma16)
     }
   }
   // tag-free exchange (see gather_mma_tf): 4 slots of [G*H/32 k-steps][4][8 rows] x 16 bytes
   constexpr int SLOT_BYTES = (G * H / 32) * 512;
   static_assert(4 * SLOT_BYTES <= 2 * MAXS * X2 * 8, "four payload slots fit where the two tagged parities lived");
   char* xg = (char*)(a.xbuf + (long)grp * 2 * MAXS * X2);
-  const int srow = li & 7, half = li >> 3;
-  const bool need = srow < Ns;
+  const int srow = SP ? li : (li & 7), half = li >> 3;
+  const bool need = (li & 7) < Ns;
+  const int spidx = (li & 8) ? 0xEEEE : 0x4444;
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, 4 * SLOT_BYTES, 0x00020000);
 
   const int e = tid & 1, pid = tid >> 1;      // thread bits as in k_rnn_persist_fwd4
-  const int gi_i = (pid >> 2) & 7;
-  const int up = ((pid >> 5) & 3) * 4 + (pid & 3);
+  const int gi_i = SP ? (pid >> 3) & 7 : (pid >> 2) & 7;
+  const int up = SP ? (pid >> 6) * 8 + (pid & 3) * 2 + ((pid >> 2) & 1) : ((pid >> 5) & 3) * 4 + (pid & 3);
   const bool gate_thread = gi_i < Ns;
   const int n = slice + a.gpd * gi_i;
   const int j = p * U + 2 * up, ju = j + e;
@@ -1233,7 +1286,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd4(PArgs a) {
   const bool local = group_is_xcd_local(a.xcc + grp * 32, p, tid, a.err, a.lerr, dead);
   unsigned rounds = 0;
   const int pidx = partial_t_index((2 * up + e) / 16, gi_i, (2 * up + e) % 16);
-  const int xoff = xtf_pair_bytes(j, gi_i);     // this pair's dword of gate 0 inside a slot
+  const int xoff = SP ? xsp_pair_bytes(j, gi_i) : xtf_pair_bytes(j, gi_i);     // this pair's dword of gate 0 inside a slot
 
   DS2_PROBE_ONLY(unsigned long long c_gather = 0, c_bar = 0, c_gate = 0;)
   // Everything the gate phase of a step needs (2-byte loads of this thread's unit: dOut, the saved planes, h_prev, c_prev) is
@@ -1311,7 +1364,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd4(PArgs a) {
 #pragma unroll
     for (int tt = 0; tt < TILES; ++tt) acc[tt] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
     if (s > 0)
-      gather_mma_tf<TILES, KS>(acc, w, rsrc, ((s + 3) & 3) * SLOT_BYTES, wave * KS, lq, srow, half, need, a.err, a.lerr, dead, rounds, touch);
+      gather_mma_tf<TILES, KS, SP>(acc, w, rsrc, ((s + 3) & 3) * SLOT_BYTES, wave * KS, lq, srow, half, need, a.err, a.lerr, dead, rounds, touch, spidx);
     else
       touch();
     // this step's values first (loaded two steps ago; the gather has just drained vmcnt), THEN the new loads: converted after
@@ -1340,7 +1393,9 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd4(PArgs a) {
     if (gate_thread) {
       const bool act = t < len;
       const float* pp = part[par] + pidx;
-      const float din = car + ((pp[0] + pp[TILES * PT_TILE]) + (pp[2 * TILES * PT_TILE] + pp[3 * TILES * PT_TILE]));
+      float psum = (pp[0] + pp[TILES * PT_TILE]) + (pp[2 * TILES * PT_TILE] + pp[3 * TILES * PT_TILE]);
+      if (SP) psum += (pp[8] + pp[TILES * PT_TILE + 8]) + (pp[2 * TILES * PT_TILE + 8] + pp[3 * TILES * PT_TILE + 8]);   // tile row s + 8
+      const float din = car + psum;
       car = din;
       if (CELL == CELL_GRU) {
         if (act) {
@@ -1473,17 +1528,22 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd4(PArgs a) {
   }
 }
 
+// dense = the round-2..4 form of the 8-clip kernels (half of every 16-row tile is padding); default: the structured-sparse form
 template <int CELL, int H, int P>
-int launch(bool bwd, const PArgs& a, hipStream_t st) {
+int launch(bool bwd, const PArgs& a, hipStream_t st, bool dense) {
   const bool split = (a.N + a.gpd - 1) / a.gpd <= 8;   // <= 8 samples per group: lane pairs share the gather
   if (bwd) {
-    if (split)
-      hipLaunchKernelGGL((k_rnn_persist_bwd4<CELL, H, P>), dim3(NGROUPS * P), dim3(256), 0, st, a);
+    if (split && dense)
+      hipLaunchKernelGGL((k_rnn_persist_bwd4<CELL, H, P, false>), dim3(NGROUPS * P), dim3(256), 0, st, a);
+    else if (split)
+      hipLaunchKernelGGL((k_rnn_persist_bwd4<CELL, H, P, true>), dim3(NGROUPS * P), dim3(256), 0, st, a);
     else
       hipLaunchKernelGGL((k_rnn_persist_bwd<CELL, H, P, 1>), dim3(NGROUPS * P), dim3(256), 0, st, a);
   } else {
-    if (split)
-      hipLaunchKernelGGL((k_rnn_persist_fwd4<CELL, H, P>), dim3(NGROUPS * P), dim3(256), 0, st, a);
+    if (split && dense)
+      hipLaunchKernelGGL((k_rnn_persist_fwd4<CELL, H, P, false>), dim3(NGROUPS * P), dim3(256), 0, st, a);
+    else if (split)
+      hipLaunchKernelGGL((k_rnn_persist_fwd4<CELL, H, P, true>), dim3(NGROUPS * P), dim3(256), 0, st, a);
     else
       hipLaunchKernelGGL((k_rnn_persist_fwd<CELL, H, P, 1>), dim3(NGROUPS * P), dim3(256), 0, st, a);
   }

@@ -347,6 +347,28 @@ def test_rnn_persistent_sweeps(kind, D, N, H, Tp):
         assert np.abs(a - b).max() <= 2e-2 * max(1.0, np.abs(b).max()), np.abs(a - b).max()
 
 
+@pytest.mark.parametrize("kind,D,N,H,Tp", [("gru", 2, 32, 1024, 9), ("gru", 2, 11, 1024, 13), ("lstm", 1, 5, 1024, 6), ("rnn", 2, 9, 1024, 11),
+                                           ("gru", 2, 1, 1024, 7)])
+def test_rnn_persistent_sparse_and_dense_forms_agree(kind, D, N, H, Tp):
+    """Groups of <= 8 clips (round 5): the sweeps' products run on the structured-sparse instruction -- a clip's k = 0, 1 (mod 4)
+    elements on tile row s, its k = 2, 3 (mod 4) elements on row s + 8 -- instead of leaving half of the dense tile to padding.
+    Both forms multiply the same bf16 operands and are held to the oracle by _rnn_sweep_case; against each other only the fp32
+    summation order may differ."""
+    o = ops()
+    from deepspeech.pytorch_amd._lib import query
+    assert o.use_persistent(kind, torch.bfloat16, D, N, H)
+    res_sp = _rnn_sweep_case(torch.bfloat16, kind, D, N, H, Tp, 1.0 / np.sqrt(H))
+    o.check_persistent_kernels()
+    old = query("ds2_rnn_persist_set_variant", 32)         # bit 5: dense products (round 4's form)
+    try:
+        res_de = _rnn_sweep_case(torch.bfloat16, kind, D, N, H, Tp, 1.0 / np.sqrt(H))
+        o.check_persistent_kernels()
+    finally:
+        query("ds2_rnn_persist_set_variant", old)
+    for a, b in zip(res_sp, res_de):
+        assert np.abs(a - b).max() <= 2e-2 * max(1.0, np.abs(b).max()), np.abs(a - b).max()
+
+
 GENERAL_PERSISTENT_CASES = [
     # fp32 storage (the 1e-3 parity mode): BASELINE config 2's width (H = 800; 25 / 150 k-steps: ragged K split) and 1024
     (torch.float32, "gru", 2, 8, 800, 9), (torch.float32, "lstm", 1, 5, 800, 7), (torch.float32, "gru", 2, 32, 1024, 6),
