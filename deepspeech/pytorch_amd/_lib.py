@@ -61,6 +61,7 @@ SIGNATURES = {
     "ds2_cast_transpose_bf16": (_i, [_vp, _l, _i, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp]),
     "ds2_small_weight_layouts": (_i, [_i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ds2_scale_by": (_i, [_vp, _vp, _l, _vp]),
+    "ds2_copy_words": (_i, [_vp, _vp, _l, _vp]),
     "ds2_lookahead_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ds2_lookahead_ws_floats": (_l, [_i, _i, _i, _i]),
     "ds2_lookahead_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),

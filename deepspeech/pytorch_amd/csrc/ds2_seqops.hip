@@ -562,9 +562,28 @@ __global__ void __launch_bounds__(256) k_zero_pad_rows(unsigned char* X, long ld
   for (int o = (threadIdx.x & 63) * 16; o < row_bytes; o += 64 * 16) *reinterpret_cast<uint4*>(p + o) = make_uint4(0, 0, 0, 0);
 }
 
+// Word copy between any two device-visible buffers -- the pinned host staging slots of the per-step int32 tables -> device memory,
+// the persistent kernels' error word -> its pinned host mirror.  An in-stream kernel instead of hipMemcpyAsync: the runtime sends
+// pinned copies to the SDMA engines, and with the host thread a few steps ahead of the device those transfers run UNDER the kernels of
+// earlier steps -- a recurrent sweep hit by one took 2.1-3.0 ms instead of 1.0-1.3 (tools/step_jitter.py, profiles/r05d_*).
+__global__ void __launch_bounds__(256) k_copy_words(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = src[i];
+}
+
 extern "C" {
 
 int ds2_version(void) { return 100; }
+
+int ds2_copy_words(const void* src, void* dst, long n_words, ds2_stream_t st_) {
+  hipStream_t st = (hipStream_t)st_;
+  DS2_REQUIRE(n_words >= 0 && (n_words == 0 || (src != nullptr && dst != nullptr)), DS2_ERR_ARG);
+  DS2_REQUIRE((((uintptr_t)src) & 3) == 0 && (((uintptr_t)dst) & 3) == 0, DS2_ERR_ALIGN);
+  if (n_words == 0) return 0;
+  const long blocks = (n_words + 255) / 256;
+  hipLaunchKernelGGL(k_copy_words, dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(256), 0, st, (const uint32_t*)src, (uint32_t*)dst, n_words);
+  DS2_CHECK_LAUNCH();
+  return 0;
+}
 
 const char* ds2_error_string(int code) {
   switch (code) {

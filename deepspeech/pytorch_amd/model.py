@@ -319,6 +319,9 @@ def _layer_param_count(layer):
     return (2 if layer.batch_norm is not None else 0) + 4 * layer.num_directions
 
 
+_ROWS_STAGING, _CTC_STAGING = ops.PinnedRing(), ops.PinnedRing()
+
+
 def _frame_rows(output_lengths, Tp, N, dev):
     """(lens_dev, rows): the output lengths on the device and -- when the batch carries enough padding to matter -- the list of the
     rows t*N + n with t < length[n] of a [T' x N] sequence matrix, in storage order: the frames pack_padded_sequence keeps
@@ -329,13 +332,9 @@ def _frame_rows(output_lengths, Tp, N, dev):
     if not ROW_LISTS or n_valid >= ROW_LIST_MIN_PADDING * Tp * N or n_valid == 0:
         return output_lengths.to(dev, torch.int32, non_blocking=True), None
     rows = np.flatnonzero(np.arange(Tp, dtype=np.int32)[:, None] < ol[None, :]).astype(np.int32)
-    # staged in pinned memory: the copy is asynchronous AND the allocator keeps the block until it is done (a pageable temporary
-    # would be freed on return from .to())
-    host = torch.empty(N + rows.size, dtype=torch.int32, pin_memory=torch.device(dev).type == "cuda")
-    hv = host.numpy()
-    hv[:N] = ol
-    hv[N:] = rows
-    both = host.to(dev, non_blocking=True)
+    # staged in pinned memory (an asynchronous copy must not read a pageable temporary that is freed on return from .to()), in a
+    # slot of a ring allocated once: see ops.PinnedRing for what a fresh pinned allocation per step costs the kernel in flight
+    both = _ROWS_STAGING.stage(dev, [ol, rows])
     return both[:N], both[N:]
 
 
@@ -849,10 +848,8 @@ class _CtcFn(torch.autograd.Function):
         max_tl = int(tsz.max().item()) if N > 0 else 0
         # one host staging buffer, one host-to-device copy: [target offsets | target sizes | targets] as int32
         tg = targets.cpu() if targets.is_cuda else targets
-        parts = [offs.to(torch.int32), tsz.to(torch.int32), tg.reshape(-1).to(torch.int32)]
-        host = torch.empty(sum(p.numel() for p in parts), dtype=torch.int32, pin_memory=dev.type == "cuda")     # pinned: see _frame_rows
-        torch.cat(parts, out=host)
-        meta = host.to(dev, non_blocking=True)
+        parts = [offs.to(torch.int32).numpy(), tsz.to(torch.int32).numpy(), tg.reshape(-1).to(torch.int32).numpy()]
+        meta = _CTC_STAGING.stage(dev, parts)       # pinned ring slot: see _frame_rows
         loss, nll, dl = ops.ctc_loss_grad(logits, meta[2 * N:], meta[:N], out_lens_dev, meta[N:2 * N], Tp, N, Cc, blank, max_tl)
         ctx.save_for_backward(dl)
         ctx.consumed = False

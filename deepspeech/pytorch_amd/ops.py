@@ -3,6 +3,7 @@ memory and streams; every computation is a ds2hip kernel.  All tensors must be C
 path (a CPU tensor raises)."""
 import ctypes as C
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -403,10 +404,61 @@ def poll_persistent_error(dev):
         if int(m[0][0]) != 0:
             raise _lib.Ds2HipError("a persistent recurrent kernel timed out on device %d waiting for its peer workgroups "
                                    "(are other kernels occupying CUs?); its outputs were NaN-poisoned" % key)
-    m[0].copy_(t[:1], non_blocking=True)
+    call("ds2_copy_words", P(t), C.c_void_p(m[0].data_ptr()), 1, S())      # in-stream kernel -> pinned host word (no SDMA transfer)
     ev = torch.cuda.Event()
     ev.record()
     m[1] = ev
+
+
+class PinnedRing:
+    """Host staging for the small per-step int32 tables (lengths + row list, CTC target table): ONE pinned allocation per ring, made at
+    first use, cut into `depth` slots that are reused round-robin behind an event each.
+
+    Why not ``torch.empty(..., pin_memory=True)`` per step: torch's pinned-block cache hands a block out again only after the copy
+    that read it has finished.  A training loop's host thread runs several steps ahead of the device until the hardware queue is
+    full, so during the first second of a run every step allocated FRESH pinned blocks (hipHostMalloc: device page-table edits under
+    the running kernels), and the copies themselves went to the SDMA engines, where the transfers of LATER steps run under the
+    kernels of earlier ones: a recurrent sweep (latency-bound, all 256 CUs polling L2) hit by one took 2.1-3.0 ms instead of 1.0-1.3
+    -- 11 of the first 19 timed steps of a bench run, i.e. most of the window the driver times (tools/step_jitter.py,
+    profiles/r05c_step_jitter.txt, r05d_step_jitter_env.txt).  The slot is therefore copied by an in-stream kernel (ds2_copy_words)."""
+
+    def __init__(self, depth=32):
+        self.depth, self.cap, self.buf, self.events, self.i = depth, 0, None, None, 0
+
+    def stage(self, dev, parts):
+        """parts: 1-D int32 numpy arrays -> their concatenation as ONE int32 device tensor (asynchronous copy)."""
+        n = int(sum(p.size for p in parts))
+        dev = torch.device(dev)
+        if dev.type != "cuda":
+            return torch.from_numpy(np.concatenate([np.asarray(p, dtype=np.int32).reshape(-1) for p in parts]) if parts else np.zeros(0, np.int32))
+        if self.buf is None or n > self.cap:
+            if self.events is not None:
+                for e in self.events:               # the old buffer must outlive the copies that still read it
+                    if e is not None:
+                        e.synchronize()
+            self.cap = max(1024, 1 << (max(n, 1) - 1).bit_length())
+            self.buf = torch.empty(self.depth * self.cap, dtype=torch.int32, pin_memory=True)
+            self.events = [None] * self.depth
+            self.i = 0
+        k = self.i
+        self.i = (k + 1) % self.depth
+        if self.events[k] is not None and not self.events[k].query():
+            self.events[k].synchronize()            # the host is a whole ring ahead of the device: wait for the slot's last copy
+        slot = self.buf[k * self.cap:k * self.cap + n]
+        hv = slot.numpy()
+        o = 0
+        for p in parts:
+            hv[o:o + p.size] = np.asarray(p).reshape(-1)
+            o += p.size
+        out = torch.empty(n, dtype=torch.int32, device=dev)
+        if n:
+            # a kernel that reads the (device-mapped) pinned slot, not hipMemcpyAsync: see ds2_copy_words for what SDMA transfers of
+            # later steps cost the sweeps of earlier ones
+            call("ds2_copy_words", C.c_void_p(slot.data_ptr()), P(out), n, S())
+        if self.events[k] is None:
+            self.events[k] = torch.cuda.Event()
+        self.events[k].record()
+        return out
 
 
 PERSIST_ENABLED = True   # tests flip this to run the per-time-step kernels on shapes the persistent kernels cover

@@ -218,6 +218,13 @@ int ds2_cast_transpose_bf16(const float* src, long lds, int R, int C, int perm_c
 int ds2_small_weight_layouts(int dtype, const float* w1, const float* w2, const float* wfc, int C, int H, float* w1k, void* w2t,
                              void* w2d0, void* w2d1, void* wfcp, void* wfcT, ds2_stream_t stream);
 int ds2_scale_by(float* x, const float* s, long n, ds2_stream_t stream);
+
+/* ds2_copy_words: dst[0..n_words) = src[0..n_words) (4-byte words), as a kernel on `stream`.  Either pointer may be pinned
+ * (device-mapped) host memory.  Replaces the reference's implicit host->device transfers of the per-step index tables -- the
+ * lengths `.cpu()` / BoolTensor masks `.cuda()` of MaskConv (model.py:61-68,215) and the CTC target table (model.py:248) -- and the
+ * device->host read of the persistent sweeps' error word: hipMemcpyAsync would hand these to the SDMA engines, whose transfers run
+ * under the kernels of earlier steps when the host thread is ahead and cost a latency-bound sweep 1-2 ms each. */
+int ds2_copy_words(const void* src, void* dst, long n_words, ds2_stream_t stream);
 int ds2_lookahead_fwd(int dtype, const void* x, const float* w, void* y, void* pre, int Tp, int N, int H, int ctx,
                       ds2_stream_t stream);
 long ds2_lookahead_ws_floats(int Tp, int N, int H, int ctx);
