@@ -249,6 +249,9 @@ unsigned ds2_rnn_persist_set_spin_limit(unsigned polls) {
 
 // scratch bytes of one sweep (exchange buffer for the larger of the forward / BPTT needs + the head described above)
 long ds2_rnn_persist_ws_bytes(int dtype, int cell, int D, int N, int H) {
+#ifdef DS2_PROBE
+  if (tuned_ok(dtype, cell, D, N, H)) return AUX_BYTES + xbuf_bytes(cell, H, true) + 32 * ds2p::TL_N * ds2p::TL_K * 8;   // + timeline
+#endif
   if (tuned_ok(dtype, cell, D, N, H)) return AUX_BYTES + xbuf_bytes(cell, H, true);
   Plan3H p3;
   if (plan3h(dtype, cell, D, N, H, cu_count(), p3)) return AUX_BYTES + xbuf3_bytes(cell, H, p3, true) + xcc3_bytes(p3);
@@ -275,6 +278,7 @@ int ds2_rnn_persist_fwd(int dtype, int cell, int D, int N, int H, int Tp, const 
     a.xcc = (u64*)((char*)ws + 1024); a.lerr = (int*)((char*)ws + 3072);
 #ifdef DS2_PROBE
     a.dbg = (unsigned long long*)ws;
+    a.tl = (unsigned long long*)((char*)ws + AUX_BYTES + xbuf_bytes(cell, H, true));
     { const char* e_ = getenv("DS2_PERSIST_DBG"); a.dbgmask = e_ ? atoi(e_) : 0; }
 #endif
     return dispatch(false, cell, H, a, st);
@@ -336,6 +340,7 @@ int ds2_rnn_persist_bwd(int dtype, int cell, int D, int N, int H, int Tp, const 
     a.xcc = (u64*)((char*)ws + 1024); a.lerr = (int*)((char*)ws + 3072);
 #ifdef DS2_PROBE
     a.dbg = (unsigned long long*)ws;
+    a.tl = (unsigned long long*)((char*)ws + AUX_BYTES + xbuf_bytes(cell, H, true));
     { const char* e_ = getenv("DS2_PERSIST_DBG"); a.dbgmask = e_ ? atoi(e_) : 0; }
 #endif
     return dispatch(true, cell, H, a, st);

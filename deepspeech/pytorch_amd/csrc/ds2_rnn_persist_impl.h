@@ -81,15 +81,20 @@ struct PArgs {
   u64* xcc;                 // [NGROUPS][32] start-up exchange of the workgroups' XCC ids, reset (0xFF bytes) before the launch
 #ifdef DS2_PROBE            // tools/probe_rnn_persist.py builds its own library with -DDS2_PROBE; the shipping kernels carry none of it
   unsigned long long* dbg;  // [NGROUPS][8] cycle counters of workgroup 0 of each group
+  unsigned long long* tl;   // [32 workgroups of group 0][TL_N steps][TL_K stamps]: s_memtime of wave 0 (see DS2_TL)
   int dbgmask;              // 1 skip GI/dOut/S prefetch loads, 2 skip output stores, 8 skip the gather (no exchange), 16 no L2 warm-up
 #endif
 };
 #ifdef DS2_PROBE
 #define DS2_PROBE_ONLY(...) __VA_ARGS__
 #define DS2_DBG(a, bit) ((a).dbgmask & (bit))
+// timeline of a few steps: stamps 0 step top, 1 gather issued, 2 gather + products done, 3 barrier passed, 4 publish issued, 5 step end
+constexpr int TL_S0 = 300, TL_N = 8, TL_K = 6;
+#define DS2_TL(k) do { if (grp == 0 && tid == 0 && s >= TL_S0 && s < TL_S0 + TL_N) tl_[s - TL_S0][k] = __builtin_readcyclecounter(); } while (0)
 #else
 #define DS2_PROBE_ONLY(...)
 #define DS2_DBG(a, bit) 0
+#define DS2_TL(k) do { } while (0)
 #endif
 
 __device__ __forceinline__ u64 g_load(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -169,6 +174,22 @@ __device__ __forceinline__ uint32_t ror8(uint32_t v) {   // lane i <- lane i^8 w
 #define DS2_L2_AHEAD 3        // steps; a build flag for A/B runs (tools/ab_variants.py)
 #endif
 constexpr int L2_AHEAD = DS2_L2_AHEAD;
+// A/B knobs of the 8-clip sweeps (tools/ab_sweeps.py, profiles/r05h_ab_sweep_timing.txt).  Forward: the input-projection loads of
+// step s + 1 are issued at the END of step s (behind the publish, raw 16-bit values converted after the next gather) and a short pause
+// stands in front of the gather where their wait used to pace it: GRU 1.345 -> 1.315-1.32 us per time step with a pause of 2-3 (no
+// pause: 1.37-1.39, re-polls; 6: 1.38), LSTM unchanged.  BPTT: a pause in front of the gather costs its own length (1 / 2 / 4:
+// +0.00 / +0.03 / +0.07 us per step).
+#ifndef DS2_FWD_GI_AHEAD
+#define DS2_FWD_GI_AHEAD 1
+#endif
+#ifndef DS2_FWD_SLEEP
+#define DS2_FWD_SLEEP 2
+#endif
+// (rejected, profiles/r05h_ab_sweep_timing.txt: all 12 partial-sum reads of the forward gate phase issued before the first add -- 1.72
+// instead of 1.33 us per step; the compiler's own order overlaps the first gate's exp / rcp chain with the remaining reads)
+#ifndef DS2_BWD_SLEEP
+#define DS2_BWD_SLEEP 0
+#endif
 __device__ __forceinline__ uint64_t uniform64(uint64_t v) {   // uniform values may still live in vector registers (64-bit multiplies do)
   return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) |
          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);          // the builtin returns int: no sign extension
@@ -760,6 +781,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd4(PArgs a) {
   static_assert(U == 32 && H % 128 == 0, "the one-unit-per-thread gate map assumes 32 hidden units per workgroup");
   static_assert(!SP || H % 256 == 0, "a wave's K-quarter is whole k-blocks of 64");
   __shared__ __attribute__((aligned(16))) float part[2][4 * TILES * PT_TILE];
+  DS2_PROBE_ONLY(__shared__ unsigned long long tl_[TL_N][TL_K];)
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = blockIdx.x % NGROUPS, p = blockIdx.x / NGROUPS;
@@ -861,11 +883,22 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd4(PArgs a) {
     pf_p[i] = uniform64(a.GI + ((long)(d == 0 ? pf_s0 : Tp - 1 - pf_s0) * N + nr) * ldgi + (long)d * GH + p * U);
   }
   const uint64_t pf_step = uniform64((uint64_t)(dstep * N * ldgi * 2));
+#if DS2_FWD_GI_AHEAD
+  uint32_t gi_raw[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) gi_raw[g] = 0u;
+  if (gate_thread) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) gi_raw[g] = gi_ptr[(long)g * H];
+  }
+#endif
   for (int s = 0; s < Tp; ++s) {
     DS2_PROBE_ONLY(const unsigned long long t0 = __builtin_readcyclecounter();)
+    DS2_TL(0);
     const int t = d == 0 ? s : Tp - 1 - s;
     const int par = s & 1;
     auto touch = [&]() {
+      DS2_TL(1);
       if (DS2_DBG(a, 16)) return;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -879,10 +912,15 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd4(PArgs a) {
     float gi[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) gi[g] = 0.f;
+#if !DS2_FWD_GI_AHEAD
     if (gate_thread && !DS2_DBG(a, 1)) {
 #pragma unroll
       for (int g = 0; g < G; ++g) gi[g] = __uint_as_float((uint32_t)gi_ptr[(long)g * H] << 16);
     }
+#endif
+#if DS2_FWD_SLEEP
+    if (s > 0) __builtin_amdgcn_s_sleep(DS2_FWD_SLEEP);
+#endif
     ds2_f32x4 acc[TILES];
 #pragma unroll
     for (int tt = 0; tt < TILES; ++tt) acc[tt] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -890,10 +928,22 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd4(PArgs a) {
       gather_mma_tf<TILES, KS, SP>(acc, w, rsrc, ((s + 3) & 3) * SLOT_BYTES, wave * KS, lq, srow, half, need, a.err, a.lerr, dead, rounds, touch, spidx);
     else
       touch();
+#if DS2_FWD_GI_AHEAD
+    {   // loaded at the end of the step before (the gather's waits have drained them: vmcnt retires in order)
+      if (s == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        gi[g] = __uint_as_float(gi_raw[g] << 16);
+        asm volatile("" : "+v"(gi[g]));
+      }
+    }
+#endif
     DS2_PROBE_ONLY(const unsigned long long t1 = __builtin_readcyclecounter();)
+    DS2_TL(2);
     store_partials_t<TILES>(part[par], acc, wave, lane);
     __syncthreads();
     DS2_PROBE_ONLY(const unsigned long long t2 = __builtin_readcyclecounter();)
+    DS2_TL(3);
     float hn = 0.f;                 // emitted h_t (0 when inactive)
     float pl[NS ? NS : 1];
 #pragma unroll
@@ -956,6 +1006,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd4(PArgs a) {
       if (gate_thread && e == 0) {
         publish32(xg + (s & 3) * SLOT_BYTES + xoff, xtf_word(pack_bf16x2(hprev, hp_o)), local);
         publish32(xg + ((s + 2) & 3) * SLOT_BYTES + xoff, XSENT, local);        // re-arm the slot of step s + 2
+        DS2_TL(4);
         *reinterpret_cast<uint32_t*>(hs_ptr) = pack_bf16x2(hn, hn_o);
 #pragma unroll
         for (int q = 0; q < NS; ++q) *reinterpret_cast<uint32_t*>(sv_ptr + (long)q * H) = pack_bf16x2(pl[q], pl_o[q]);
@@ -963,12 +1014,21 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd4(PArgs a) {
 #endif
     }
     gi_ptr += gi_stride;
+#if DS2_FWD_GI_AHEAD
+    if (gate_thread && s + 1 < Tp) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) gi_raw[g] = gi_ptr[(long)g * H];
+    }
+#endif
     if (NS) sv_ptr += sv_stride;
     hs_ptr += hs_stride;
     l2_touch_retire();
     DS2_PROBE_ONLY(const unsigned long long t3 = __builtin_readcyclecounter(); c_gather += t1 - t0; c_bar += t2 - t1; c_gate += t3 - t2;)
+    DS2_TL(5);
   }
 #ifdef DS2_PROBE
+  if (a.tl && grp == 0 && tid == 0)
+    for (int i = 0; i < TL_N * TL_K; ++i) a.tl[(long)p * TL_N * TL_K + i] = tl_[i / TL_K][i % TL_K];
   if (a.dbg && p == 0 && (tid == 0 || tid == 255)) {
     const int o = grp * 8 + (tid == 0 ? 0 : 4);
     a.dbg[o + 0] = c_gather;
@@ -1230,6 +1290,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd4(PArgs a) {
   static_assert(U == 32 && (G * H) % 128 == 0, "the one-unit-per-thread gate map assumes 32 hidden units per workgroup");
   static_assert(!SP || ((G * H) % 256 == 0 && H % 64 == 0), "a wave's K-quarter is whole k-blocks of 64; a gate starts on a k-block");
   __shared__ __attribute__((aligned(16))) float part[2][4 * TILES * PT_TILE];
+  DS2_PROBE_ONLY(__shared__ unsigned long long tl_[TL_N][TL_K];)
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = blockIdx.x % NGROUPS, p = blockIdx.x / NGROUPS;
@@ -1340,9 +1401,11 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd4(PArgs a) {
   const uint64_t pf_step_h = uniform64((uint64_t)(dstep * N * H * 2)), pf_step_s = uniform64((uint64_t)(dstep * N * NSH_ * 2));
   auto body = [&](int s, Pre& pu, Pre& pn) {
     DS2_PROBE_ONLY(const unsigned long long t0 = __builtin_readcyclecounter();)
+    DS2_TL(0);
     const int t = d == 0 ? Tp - 1 - s : s;
     const int par = s & 1;
     auto touch = [&]() {
+      DS2_TL(1);
       if (DS2_DBG(a, 16)) return;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -1363,6 +1426,9 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd4(PArgs a) {
     ds2_f32x4 acc[TILES];
 #pragma unroll
     for (int tt = 0; tt < TILES; ++tt) acc[tt] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
+#if DS2_BWD_SLEEP
+    if (s > 0) __builtin_amdgcn_s_sleep(DS2_BWD_SLEEP);
+#endif
     if (s > 0)
       gather_mma_tf<TILES, KS, SP>(acc, w, rsrc, ((s + 3) & 3) * SLOT_BYTES, wave * KS, lq, srow, half, need, a.err, a.lerr, dead, rounds, touch, spidx);
     else
@@ -1383,9 +1449,11 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd4(PArgs a) {
     if (s + 2 < Tp) prefetch(pn, s + 2, 2);
     __builtin_amdgcn_sched_barrier(0);
     DS2_PROBE_ONLY(const unsigned long long t1 = __builtin_readcyclecounter();)
+    DS2_TL(2);
     store_partials_t<TILES>(part[par], acc, wave, lane);
     __syncthreads();
     DS2_PROBE_ONLY(const unsigned long long t2 = __builtin_readcyclecounter();)
+    DS2_TL(3);
     // gate gradients of this thread's unit (zeros when inactive); gq[] = what is exchanged, gs[] = what is stored in dGI
     float gx[G], gn = 0.f, gq = 0.f;        // gx: the G exchanged planes; GRU: gx = {dr, dz, dq}, gn = dn (stored), gq = dq
 #pragma unroll
@@ -1475,6 +1543,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd4(PArgs a) {
           for (int g = 0; g < G; ++g) publish32(xo + g * (H / 32) * 512, xtf_word(pk[g]), local);
 #pragma unroll
           for (int g = 0; g < G; ++g) publish32(xr + g * (H / 32) * 512, XSENT, local);
+          DS2_TL(4);
           if (CELL == CELL_GRU) {
             *reinterpret_cast<uint32_t*>(dgi_ptr) = pk[0];
             *reinterpret_cast<uint32_t*>(dgi_ptr + H) = pk[1 % G];
@@ -1505,6 +1574,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd4(PArgs a) {
     if (CELL == CELL_GRU) dgh_ptr += dstep * N * H;
     l2_touch_retire();
     DS2_PROBE_ONLY(const unsigned long long t3 = __builtin_readcyclecounter(); c_gather += t1 - t0; c_bar += t2 - t1; c_gate += t3 - t2;)
+    DS2_TL(5);
   };
   for (int s = 0; s < Tp; s += 3) {
     body(s, pra, prc);
@@ -1512,6 +1582,8 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd4(PArgs a) {
     if (s + 2 < Tp) body(s + 2, prc, prb);
   }
 #ifdef DS2_PROBE
+  if (a.tl && grp == 0 && tid == 0)
+    for (int i = 0; i < TL_N * TL_K; ++i) a.tl[(long)p * TL_N * TL_K + i] = tl_[i / TL_K][i % TL_K];
   if (a.dbg && p == 0 && (tid == 0 || tid == 255)) {
     const int o = grp * 8 + (tid == 0 ? 0 : 4);
     a.dbg[o + 0] = c_gather;

@@ -4,7 +4,7 @@
 (seed cfg_id*1000) and parameters regenerated from a seed (``synth.synth_params``) -- dumping what fits in a small fixture:
 
     loss (fp32 run = the reference as shipped), output lengths, logits on every LOGIT_STRIDE-th frame, and for EVERY parameter
-    gradient a strided sample (stride below), its L2 norm and its sum;  with --autocast also the reference under
+    gradient a strided sample (stride below; small tensors whole, as gradfull.<param>), its L2 norm and its sum;  with --autocast also the reference under
     ``torch.autocast(bfloat16)``: loss_ac and ``acnoise.<param>`` = relative L2 distance of its gradient from the fp32 run
     (the yard-stick of the bf16 bars in tests/test_gpu_model.py).
 
@@ -33,6 +33,8 @@ import ref_harness  # noqa: E402
 from deepspeech.pytorch_amd import synth  # noqa: E402
 
 GRAD_STRIDE = 997       # prime: no resonance with the 1024 / 1280 / 3072 ... row lengths
+FULL_BELOW = 16384      # gradients of at most this many elements (BatchNorm weights / biases, conv and RNN biases, the conv1 kernel)
+                        # are stored whole as gradfull.<param>: a stride-997 sample of a 32-element tensor is ONE number
 LOGIT_STRIDE = 16
 PARAM_SEED = {"cfg2": 2202, "cfg3": 3303, "cfg5a": 5505, "cfg5b": 6606}
 CFG_ID = {"cfg2": 2, "cfg3": 3, "cfg5a": 5, "cfg5b": 6}
@@ -83,6 +85,8 @@ def main():
         g = p.grad.detach().numpy().astype(np.float64)
         g32[k] = g
         out["gradsub." + k] = g.reshape(-1)[::GRAD_STRIDE].astype(np.float32)
+        if g.size <= FULL_BELOW:
+            out["gradfull." + k] = g.reshape(-1).astype(np.float32)
         out["gradl2." + k] = np.float64(np.sqrt((g ** 2).sum()))
         out["gradsum." + k] = np.float64(g.sum())
     secs_ac = None

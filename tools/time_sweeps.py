@@ -14,6 +14,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deepspeech.pytorch_amd import _lib, ops  # noqa: E402
 
+if os.environ.get("DS2_AB_LIB"):          # tools/ab_sweeps.py: another build of the library (A/B runs only)
+    _lib.LIB_PATH = os.environ["DS2_AB_LIB"]
+
 dev = "cuda"
 shapes = sys.argv[1:] or ["lstm,1,88,1024,401", "lstm,1,66,1280,401", "lstm,2,128,1024,401", "lstm,2,64,1280,401", "lstm,2,64,1280,401,ragged"]
 for spec in shapes:
