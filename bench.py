@@ -173,6 +173,38 @@ def run_native(args, rank, world, device):
                   "how": "HIP events at every step start on the step's stream (device time between consecutive steps)"} if per_step else None
     log("timed region done: %.1f ms/step" % (dt / args.steps * 1e3))
     last_loss = float(last.detach().item())
+    # ---- data-parallel evidence (world > 1, or DS2_FORCE_DDP=1 on one GPU): what the exchange costs, and that the ranks are N GPUs
+    dp_info = None
+    is_ddp = isinstance(step_mod, torch.nn.parallel.DistributedDataParallel)
+    if world > 1 or is_ddp:
+        import torch.distributed as dist_
+        dp_info = {"wrapper": type(step_mod).__name__}
+        if is_ddp:
+            # the same step with the gradient exchange switched off (DDP.no_sync): step time with - without = what the all-reduce
+            # costs the step after overlap (exposed tail + contention under the sweeps), measured, not modelled
+            k2 = max(3, min(args.steps, 10))
+            with step_mod.no_sync():              # (ops.SWEEP_EVENTS is None again: step() records no events in this leg)
+                for _ in range(2):
+                    step()
+                dt_ns, _ = dsdist.timed_steps(step, k2, device, world)
+            t = torch.tensor([dt / args.steps, dt_ns / k2], dtype=torch.float64, device=device)
+            if dist_.is_initialized():
+                dist_.all_reduce(t, op=dist_.ReduceOp.MAX)
+            dp_info.update(ms_per_step_with_allreduce=round(float(t[0]) * 1e3, 3), ms_per_step_no_sync=round(float(t[1]) * 1e3, 3),
+                           comm_exposed_ms=round(float(t[0] - t[1]) * 1e3, 3), no_sync_steps=k2,
+                           comm_exposed_how="max-over-ranks step time of the timed region minus the same step under DDP.no_sync() "
+                                            "(%d steps right after it): exposed all-reduce tail + its contention with the sweeps" % k2)
+        mine = {"rank": rank, "device": torch.cuda.get_device_name(device), "uuid": str(getattr(torch.cuda.get_device_properties(device), "uuid", "?")),
+                "pci_bus_id": getattr(torch.cuda.get_device_properties(device), "pci_bus_id", None),
+                "step_ms_min": step_stats["min_ms"] if step_stats else None, "step_ms_median": step_stats["median_ms"] if step_stats else None,
+                "step_ms_max": step_stats["max_ms"] if step_stats else None, "seconds_timed_region": round(dt, 4)}
+        if dist_.is_initialized() and world > 1:
+            gathered = [None] * world
+            dist_.all_gather_object(gathered, mine)
+        else:
+            gathered = [mine]
+        dp_info["ranks"] = gathered
+        dp_info["distinct_devices"] = len({g["uuid"] for g in gathered})
 
     ops.check_persistent_kernels()
     # ---- roofline of the dominant kernel: the recurrent sweep (persistent kernel: ONE launch per layer and sweep; the
@@ -221,6 +253,7 @@ def run_native(args, rank, world, device):
                 "whole_step_frac_of_mfma_roofline": None}
     roofline["_step_stats"] = step_stats
     roofline["_loss_ref"] = ref
+    roofline["_dp_info"] = dp_info
     return lengths, dt, first_loss, last_loss, roofline
 
 
@@ -267,6 +300,32 @@ def log(msg):
 
 
 _T0 = time.perf_counter()
+
+
+def other_config_subprocess(args, cfg):
+    """`bench.py --config <cfg>` (native path, a few steps, no baselines) in a child process under a time limit: the configurations
+    the driver does not time itself (cfg2: the fp32 parity configuration; cfg5a / cfg5b: 7 x LSTM-1280, batch 64) ride along with the
+    headline line as `other_configs`, timed after it and outside `value`."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", str(args.other_steps), "--warmup", "3",
+           "--no-cpu-baseline", "--no-stock-baseline", "--no-other-configs"]
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.other_timeout, env=env)
+        j = _last_json_line(r.stdout)
+        if j is None:
+            return {"error": (r.stderr.strip().splitlines() or ["?"])[-1][:200]}
+        rf = j.get("roofline") or {}
+        return {"ms_per_step": j["ms_per_step"], "ms_per_step_median": j.get("ms_per_step_median"), "value": j["value"], "unit": j["unit"],
+                "steps": j["steps"], "dtype": j["dtype"], "workload": j["config"]["workload"],
+                "ctc_loss_first_step": j.get("ctc_loss_first_step"), "ctc_loss_ref": j.get("ctc_loss_ref"),
+                "ctc_loss_rel_diff": j.get("ctc_loss_rel_diff"),
+                "roofline_kernel": rf.get("kernel"), "roofline_frac": rf.get("frac"), "us_per_time_step": rf.get("us_per_time_step"),
+                "recurrent_kernels": rf.get("recurrent_kernels"), "whole_step_frac_of_mfma_roofline": rf.get("whole_step_frac_of_mfma_roofline")}
+    except subprocess.TimeoutExpired:
+        return {"error": "exceeded its %d s limit" % args.other_timeout}
 
 
 def _last_json_line(text):
@@ -412,6 +471,10 @@ def main():
     ap.add_argument("--stock-steps", type=int, default=3)
     ap.add_argument("--stock-warmup", type=int, default=2)
     ap.add_argument("--stock-timeout", type=int, default=150)
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the cfg2 / cfg5a / cfg5b legs of the default N=1 run")
+    ap.add_argument("--other-configs", default="cfg5a,cfg5b,cfg2", help="configurations timed after the headline (N=1, --config cfg3 only)")
+    ap.add_argument("--other-steps", type=int, default=10)
+    ap.add_argument("--other-timeout", type=int, default=120)
     args = ap.parse_args()
     if args.cpu_full < 0:
         args.cpu_full = 1 if args.config == "cfg3" else 0
@@ -458,6 +521,7 @@ def main():
                                                              PEAK_TFLOPS[dtype], 6)
     step_stats = roofline.pop("_step_stats", None) if roofline is not None else None
     loss_ref = roofline.pop("_loss_ref", None) if roofline is not None else None
+    dp_info = roofline.pop("_dp_info", None) if roofline is not None else None
     out = {
         "metric": "audio-seconds/sec (train step)", "value": round(value, 2), "unit": "audio-seconds/sec", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
@@ -484,6 +548,8 @@ def main():
                                       "(synth.synth_params seed %d), rank 0's batch" % (args.config, PARAM_SEED[args.config]))
     if roofline is not None:
         out["roofline"] = roofline
+    if dp_info is not None:
+        out["data_parallel"] = dp_info
     if rank == 0 and world == 1 and not args.stock and not args.no_stock_baseline:
         log("stock PyTorch-ROCm leg (subprocess, <= %d s)" % args.stock_timeout)
         sb = stock_baseline_subprocess(args)
@@ -493,6 +559,13 @@ def main():
             out["vs_baseline_kind"] = ("this run's audio-s/s over stock PyTorch-ROCm's (MIOpen conv / BatchNorm / RNN + ATen CTC, same "
                                        "model, batch and precision) measured on the same GPU right after the timed region; BASELINE.md "
                                        "holds no published number for this metric")
+    if args.no_cpu_baseline and args.no_stock_baseline:
+        args.no_other_configs = True          # "just the number" runs (tools/*.sh, A/B scripts) skip every extra leg
+    if rank == 0 and world == 1 and not args.stock and not args.no_other_configs and args.config == "cfg3":
+        out["other_configs"] = {}
+        for cfg in [c for c in args.other_configs.split(",") if c in CONFIGS and c != args.config]:
+            log("other configuration %s (subprocess, <= %d s)" % (cfg, args.other_timeout))
+            out["other_configs"][cfg] = other_config_subprocess(args, cfg)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.stock:
         log("cpu baseline leg (subprocess%s)" % (": short sample, then ONE full-shape step on the host cores -- minutes" if args.cpu_full else ""))
         out["cpu_baseline"] = cpu_baseline_subprocess(args)

@@ -131,9 +131,9 @@ __device__ __forceinline__ bool group_is_xcd_local3(u64* slots, int p, int P, in
         same = !(tid < P) || ((unsigned)v == my);
         break;
       }
-      if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && spin_check(lerr, spins))) {
+      if (++spins > STARTUP_SPIN_LIMIT || ((spins & 1023u) == 0 && spin_check(lerr, spins))) {
         dead = true;
-        raise_err(err, lerr);
+        raise_err_startup(err, lerr);
         same = false;
         break;
       }

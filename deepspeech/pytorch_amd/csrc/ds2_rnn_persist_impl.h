@@ -119,7 +119,18 @@ __device__ __forceinline__ bool spin_check(int* lerr, unsigned spins) {
          spins > (unsigned)__hip_atomic_load(lerr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void raise_err(int* err, int* lerr) {
-  __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_max(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // max: never hides a start-up failure (code 2) -- the healthy
+  __hip_atomic_store(lerr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // groups of the same launch stop with code 1 when they see lerr
+}
+// The start-up handshake is where a sweep finds out that its workgroups are NOT all resident: every workgroup needs a whole CU (512
+// registers per lane), so a kernel of another process on this GPU -- or a long kernel on another stream -- that holds CUs keeps some
+// of the 256 from starting while the others wait here.  That wait gets its own, much shorter budget (~0.3 s: an RCCL collective
+// beside the sweep ends within milliseconds) and its own code in the sticky error word, so that the host can NAME the cause
+// (ops.check_persistent_kernels) instead of reporting a generic time-out after seconds.  max: a later mid-sweep time-out of the
+// same launch must not hide it.
+constexpr unsigned STARTUP_SPIN_LIMIT = 1000000;   // measured: 1e5 polls = 0.03 s (tests/test_gpu_persist_safety.py)
+__device__ __forceinline__ void raise_err_startup(int* err, int* lerr) {
+  __hip_atomic_fetch_max(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_store(lerr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ bool group_is_xcd_local(u64* slots /* this group's [32] */, int p, int tid, int* err, int* lerr, bool& dead) {
@@ -137,9 +148,9 @@ __device__ __forceinline__ bool group_is_xcd_local(u64* slots /* this group's [3
         same = !(tid < 32) || ((unsigned)v == my);
         break;
       }
-      if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && spin_check(lerr, spins))) {
+      if (++spins > STARTUP_SPIN_LIMIT || ((spins & 1023u) == 0 && spin_check(lerr, spins))) {
         dead = true;
-        raise_err(err, lerr);
+        raise_err_startup(err, lerr);
         same = false;
         break;
       }

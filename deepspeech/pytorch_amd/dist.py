@@ -78,6 +78,12 @@ class OverlappedGradSync:
         self._params = list(params)
 
     def begin_step(self):
+        if (self._handles or self._deferred) and not self._done:
+            # gradients were handed over early (all-reduces in flight, some withheld from autograd) but the end-of-backward reduction
+            # never ran: the arm hook did not fire (the loss that was backpropagated did not depend on the wrapper's outputs?) and
+            # finish_backward() was not called -- the previous step's gradients would be silently missing / unreduced
+            raise RuntimeError("OverlappedGradSync: the previous step's gradient reduction never finished -- call finish_backward() "
+                               "after loss.backward(), or use torch DDP (DS2_OVERLAP_ALLREDUCE=0)")
         self._handles, self._early, self._deferred = [], set(), []
         self._queued = self._done = False
 
@@ -148,18 +154,17 @@ class OverlappedGradSync:
         self._done = True
 
 
-def _first_grad_tensor(out):
-    """First tensor that requires grad in a (nested) tuple / list / dict of outputs."""
+def _grad_tensors(out):
+    """Every tensor that requires grad in a (nested) tuple / list / dict of outputs."""
     if torch.is_tensor(out):
-        return out if out.requires_grad else None
+        return [out] if out.requires_grad else []
     if isinstance(out, dict):
         out = list(out.values())
+    found = []
     if isinstance(out, (tuple, list)):
         for o in out:
-            t = _first_grad_tensor(o)
-            if t is not None:
-                return t
-    return None
+            found += _grad_tensors(o)
+    return found
 
 
 class OverlappedDataParallel(torch.nn.Module):
@@ -180,11 +185,12 @@ class OverlappedDataParallel(torch.nn.Module):
         self.sync.begin_step()
         out = self.module(*args)
         if torch.is_grad_enabled():
-            t = _first_grad_tensor(out)
-            if t is None:
+            ts = _grad_tensors(out)
+            if not ts:
                 raise RuntimeError("OverlappedDataParallel: the wrapped module returned nothing that requires grad -- the end-of-backward "
                                    "gradient reduction cannot be armed (use torch DDP: DS2_OVERLAP_ALLREDUCE=0)")
-            t.register_hook(self.sync.arm)         # fires when backward reaches it: the end-of-backward reduction is queued
+            for t in ts:                           # EVERY such output: whichever of them the loss depends on arms the reduction when
+                t.register_hook(self.sync.arm)     # backward reaches it (arm is idempotent)
         return out
 
     def finish_backward(self):

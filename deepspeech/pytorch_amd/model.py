@@ -89,11 +89,26 @@ WGRAD_WITH_DX = os.environ.get("DS2_WGRAD_WITH_DX", "1") not in ("", "0")
 # backward then keeps its weight-gradient GEMMs on the second stream until the end of the node.  =0: one node per layer always.
 # Unset (default): one node per layer in the bf16 performance mode and under any data-parallel wrapper, the composite node otherwise.
 COMPOSITE_NODE = {"": None, "0": False}.get(os.environ.get("DS2_COMPOSITE_NODE", ""), True)     # None = decide per shape (see _logits)
+# Set by dist.wrap_data_parallel; _data_parallel_active() also sees a wrapper this module was not told about (Lightning's own
+# `strategy: ddp` wraps the LightningModule itself): under any data-parallel wrapper every shape gets per-layer nodes, so that the
+# reducer receives a layer's gradients when the layer's backward returns.
 PER_LAYER_NODES_FOR_DDP = [False]
+
+
+def _data_parallel_active():
+    if PER_LAYER_NODES_FOR_DDP[0]:
+        return True
+    try:
+        import torch.distributed as _dist
+        return _dist.is_available() and _dist.is_initialized() and _dist.get_world_size() > 1
+    except Exception:  # noqa: BLE001
+        return False
+
+
 # Row lists (_frame_rows): the GEMMs over the [T' x N] frames skip the padding when less than this fraction of the frames is real
 # (DS2_ROW_LISTS=0: never; the products then run over every row, padding included, as in rounds 1-3).
 ROW_LISTS = os.environ.get("DS2_ROW_LISTS", "1") != "0"
-ROW_LIST_MIN_PADDING = 0.97     # set by dist.wrap_data_parallel: under a data-parallel wrapper every shape gets per-layer nodes
+ROW_LIST_MIN_PADDING = 0.97
 
 N_FREQ_CONV2 = 41
 RNN_INPUT = 32 * N_FREQ_CONV2  # 1312, model.py:166-169
@@ -1149,7 +1164,7 @@ class DeepSpeech(_Base):
             Dd = 2 if self.bidirectional else 1
             fast_bwd = (ops.wgrad_tn_ok(dtype, Tp * N, Dd * GH, Hh, lda=Dd * GH, ldb=ops.pad_ld(Hh, dtype)) and
                         ops.wgrad_tn_ok(dtype, Tp * N, GH, Hh, lda=Dd * GH, ldb=Hh))
-            composite = COMPOSITE_NODE if COMPOSITE_NODE is not None else (not fast_bwd and not PER_LAYER_NODES_FOR_DDP[0])
+            composite = COMPOSITE_NODE if COMPOSITE_NODE is not None else (not fast_bwd and not _data_parallel_active())
             if composite:
                 res = _FrontFn.apply(x, self, lens_dev, N, Tp, dtype, training, L, sm[0].weight, sm[0].bias, sm[1].weight, sm[1].bias,
                                      sm[3].weight, sm[3].bias, sm[4].weight, sm[4].bias, *h0s, *c0s, *params)

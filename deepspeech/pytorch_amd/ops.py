@@ -375,11 +375,23 @@ def _persist_err(dev):
     return t
 
 
+def _persist_error_message(code, key):
+    """The sticky error word of the persistent sweeps: 1 = a workgroup gave up waiting for a peer's data in the middle of a sweep,
+    2 = the start-up handshake never completed, i.e. the sweep's 256 workgroups (one whole CU each) were not all resident."""
+    if code == 2:
+        return ("a persistent recurrent sweep on device %d could not start: its 256 workgroups never became co-resident within ~0.3 s -- "
+                "another kernel holds compute units (a second process on this GPU, e.g. a validation job or two ranks with the same "
+                "LOCAL_RANK; or a long-running kernel on another stream).  The sweep gave up, its outputs were NaN-poisoned" % key)
+    return ("a persistent recurrent kernel timed out on device %d waiting for its peer workgroups in the middle of a sweep "
+            "(are other kernels occupying CUs?); its outputs were NaN-poisoned" % key)
+
+
 def check_persistent_kernels():
     """Synchronises and raises if any persistent recurrent kernel launched so far gave up waiting for its peers."""
     for key, t in _PERSIST_ERR.items():
-        if int(t[0].item()) != 0:
-            raise _lib.Ds2HipError("a persistent recurrent kernel timed out on device %d (outputs were NaN-poisoned)" % key)
+        code = int(t[0].item())
+        if code != 0:
+            raise _lib.Ds2HipError(_persist_error_message(code, key))
 
 
 _ERR_MIRROR = {}   # device index -> [pinned host int32 tensor, event of the copy in flight or None]
@@ -402,8 +414,7 @@ def poll_persistent_error(dev):
             return                                   # the previous copy has not landed yet: look again next step
         m[1] = None
         if int(m[0][0]) != 0:
-            raise _lib.Ds2HipError("a persistent recurrent kernel timed out on device %d waiting for its peer workgroups "
-                                   "(are other kernels occupying CUs?); its outputs were NaN-poisoned" % key)
+            raise _lib.Ds2HipError(_persist_error_message(int(m[0][0]), key))
     call("ds2_copy_words", P(t), C.c_void_p(m[0].data_ptr()), 1, S())      # in-stream kernel -> pinned host word (no SDMA transfer)
     ev = torch.cuda.Event()
     ev.record()

@@ -76,9 +76,14 @@ def test_fit_checkpoint_resume(name, precision, tmp_path):
     assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(la)), (float(la), float(lb))
     for (k, p), (_, q) in zip(m.named_parameters(), m2.named_parameters()):
         d = (p.detach() - q.detach()).abs().max().item()
-        # run-to-run noise of the small-shape GEMMs' split-K atomics reaches the parameters through AdamW's normalised update
-        # m / sqrt(v): where a gradient element is ~0 the ratio is noise, bounded by the learning rate (1.5e-4)
-        assert d <= max(1e-4 * p.detach().abs().max().item(), 0.3 * 1.5e-4), (k, d)
+        # Both runs start the 4th step from identical parameters, so they can differ only through what is not run-to-run
+        # deterministic INSIDE a step: the split-K atomics of the small-shape weight-gradient GEMMs (model._wgrad_splitk: the
+        # recurrent weight matrices and the head's Linear).  Their noise reaches the parameters through AdamW's normalised update
+        # m / sqrt(v): where a gradient element is ~0 the ratio is noise, bounded by the learning rate (1.5e-4).  Every other
+        # parameter (convolutions, BatchNorm, biases, lookahead) is held to the tight bound.
+        splitk_fed = any(t in k for t in ("weight_ih", "weight_hh", "fc.0.module.1.weight"))
+        floor = 0.3 * 1.5e-4 if splitk_fed else 1e-7
+        assert d <= max(1e-4 * p.detach().abs().max().item(), floor), (k, d)
     from deepspeech.pytorch_amd import ops
     ops.check_persistent_kernels()
 

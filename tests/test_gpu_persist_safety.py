@@ -140,11 +140,11 @@ def test_sweep_that_cannot_get_its_cus_times_out_loudly_and_recovers():
         with torch.cuda.stream(torch.cuda.Stream()):
             release.fill_(1)                                   # the squatters leave; the rest of the sweep's workgroups start, see the
         torch.cuda.synchronize()                               # launch's error word and end at once
-        with pytest.raises(_lib.Ds2HipError):
+        with pytest.raises(_lib.Ds2HipError, match="co-resident"):   # the message names the cause: the start-up handshake never completed
             ops.poll_persistent_error(torch.device(DEV, 0))    # the copy has landed: raises now, without a host synchronisation
             ops.poll_persistent_error(torch.device(DEV, 0))
         assert not torch.isfinite(hext.float()).all()          # poisoned, never silently wrong
-        with pytest.raises(_lib.Ds2HipError):
+        with pytest.raises(_lib.Ds2HipError, match="another kernel holds compute units"):
             ops.check_persistent_kernels()
     finally:
         lib.ds2_rnn_persist_set_spin_limit(old)
@@ -156,3 +156,56 @@ def test_sweep_that_cannot_get_its_cus_times_out_loudly_and_recovers():
     again = ops.rnn_fwd(p["kind"], p["GI"], p["Whh"], p["bhh"], p["lens"], p["D"], p["N"], p["H"], p["Tp"])[0]
     ops.check_persistent_kernels()
     assert torch.equal(again, ref)
+
+
+def test_sweep_without_its_cus_gives_up_within_a_fraction_of_a_second_by_itself():
+    """Round 5: the start-up handshake has its own budget (~0.1 s instead of the seconds a mid-sweep wait may take) -- with NO test hook
+    lowering the spin limit, a sweep whose workgroups cannot all become resident ends by itself while the squatters are still there,
+    and the error names the cause."""
+    from deepspeech.pytorch_amd import _lib, ops
+    if not ops.use_persistent("gru", torch.bfloat16, 2, 32, 1024):
+        pytest.skip("persistent sweeps need all 256 CUs")
+    L = _compile(SQUAT_SRC, "squat")
+    L.run_squat.argtypes = [ctypes.c_int, ctypes.c_ulonglong, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    p = _problem(Tp=64)
+    ops.check_persistent_kernels()
+    ops._PERSIST_ERR.clear()
+    ops._ERR_MIRROR.clear()
+    side = torch.cuda.Stream()
+    release = torch.zeros(1, dtype=torch.int32, device=DEV)
+    sink = torch.zeros(256, dtype=torch.int32, device=DEV)
+    try:
+        torch.cuda.synchronize()
+        rc = L.run_squat(128, ctypes.c_ulonglong(300_000_000), ctypes.c_void_p(release.data_ptr()), ctypes.c_void_p(sink.data_ptr()),
+                         ctypes.c_void_p(side.cuda_stream))                     # squatters stay for up to 3 s unless released
+        assert rc == 0
+        t0 = time.perf_counter()
+        hext = ops.rnn_fwd(p["kind"], p["GI"], p["Whh"], p["bhh"], p["lens"], p["D"], p["N"], p["H"], p["Tp"])[0]
+        err = ops._persist_err(torch.device(DEV, 0))
+        done = torch.cuda.Event()
+        done.record()                                                           # behind the sweep on the caller's stream
+        gave_up_after = None
+        while time.perf_counter() - t0 < 2.0:
+            time.sleep(0.02)
+            # the resident workgroups have raised the word although the launch cannot end before the squatters leave
+            with torch.cuda.stream(side):
+                pass
+            probe = torch.empty(1, dtype=torch.int32).pin_memory()
+            with torch.cuda.stream(torch.cuda.Stream()):
+                probe.copy_(err[:1], non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+            if int(probe[0]) != 0:
+                gave_up_after = time.perf_counter() - t0
+                break
+        assert gave_up_after is not None and gave_up_after < 1.0, gave_up_after
+        assert int(probe[0]) == 2
+    finally:
+        with torch.cuda.stream(torch.cuda.Stream()):
+            release.fill_(1)
+        torch.cuda.synchronize()
+    with pytest.raises(_lib.Ds2HipError, match="co-resident"):
+        ops.check_persistent_kernels()
+    assert not torch.isfinite(hext.float()).all()
+    print("a sweep with half of the CUs taken gave up by itself after %.2f s" % gave_up_after)
+    ops._PERSIST_ERR.clear()
+    ops._ERR_MIRROR.clear()
