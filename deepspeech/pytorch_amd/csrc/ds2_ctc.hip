@@ -451,6 +451,148 @@ __global__ void __launch_bounds__(GRAD_WAVES * 64) k_ctc_gradient(const int* __r
   }
 }
 
+// ---- label sets of more than 256 classes (the reference takes any labels file, model.py:139,154-155,203) -----------------------
+// Class rows no longer fit the LDS staging of the kernels above (a chunk of 8 rows of 1024 classes is 32 KB per buffer), and the
+// recursion needs only the log-probabilities of the target's own extended labels: every state reads lp[t][ext[s]] straight from the
+// scratch (L2-resident: written by the log-softmax pass just before), one step ahead of its use.  ldp = class stride (a multiple of
+// 64).  Same formulas, same zero_infinity / NaN behaviour as k_ctc_recursion / k_ctc_gradient.
+__global__ void __launch_bounds__(256) k_ctc_logsoftmax_big(const float* __restrict__ logits, long ldl, const int* __restrict__ in_len,
+                                                            int Tp, int N, int C, int ldp, float* __restrict__ ws_lp) {
+  const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);     // frame row t*N + n: one wave per frame
+  const int lane = threadIdx.x & 63;
+  if (i >= (long)Tp * N) return;
+  const int t = (int)(i / N), n = (int)(i % N);
+  if (t >= in_len[n]) return;
+  const float* x = logits + i * ldl;
+  float* lp = ws_lp + ((long)n * Tp + t) * ldp;
+  float m = -INFINITY;
+  for (int c = lane; c < C; c += 64) m = fmaxf(m, x[c]);
+  m = wave_max(m);
+  float sum = 0.f;
+  for (int c = lane; c < C; c += 64) sum += expf(x[c] - m);
+  sum = wave_sum(sum);
+  const float lz = m + logf(sum);
+  for (int c = lane; c < C; c += 64) lp[c] = x[c] - lz;
+}
+
+__global__ void __launch_bounds__(REC_THREADS) k_ctc_recursion_big(const int* __restrict__ targets, const int* __restrict__ toff,
+                                                                   const int* __restrict__ in_len, const int* __restrict__ tg_len,
+                                                                   int Tp, int blank, int Lmax, int ldp, float* __restrict__ nll_out,
+                                                                   const float* __restrict__ ws_lp, float* __restrict__ ws_alpha,
+                                                                   float* __restrict__ ws_beta, float* __restrict__ ws_ll) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* prev = reinterpret_cast<float*>(smem);
+  float* cur = prev + Lmax;
+  int* ext = reinterpret_cast<int*>(cur + Lmax);
+  const int tid = threadIdx.x, n = blockIdx.x;
+  const bool is_beta = blockIdx.y != 0;
+  int Ti = in_len[n];
+  if (Ti > Tp) Ti = Tp;
+  const int S = tg_len[n], L = 2 * S + 1;
+  if (Ti <= 0) {
+    if (!is_beta && tid == 0) {
+      nll_out[n] = 0.f;
+      ws_ll[n] = INFINITY;
+    }
+    return;
+  }
+  const int* tg = targets + toff[n];
+  const float* lp = ws_lp + (long)n * Tp * ldp;
+  float* dst = (is_beta ? ws_beta : ws_alpha) + (long)n * Tp * Lmax;
+  for (int s = tid; s < L; s += REC_THREADS) ext[s] = (s & 1) ? tg[s >> 1] : blank;
+  __syncthreads();
+  for (int i = 0; i < Ti; ++i) {
+    const int t = is_beta ? Ti - 1 - i : i;
+    const float* lpt = lp + (long)t * ldp;
+    for (int s = tid; s < L; s += REC_THREADS) {
+      const int e = ext[s];
+      float v;
+      if (i == 0) {
+        const bool entry = is_beta ? s >= L - 2 : s <= 1;
+        v = entry ? lpt[e] : -INFINITY;
+      } else if (!is_beta) {
+        const float a0 = prev[s];
+        const float a1 = s >= 1 ? prev[s - 1] : -INFINITY;
+        const float a2 = (s >= 2 && e != blank && e != ext[s - 2]) ? prev[s - 2] : -INFINITY;
+        v = lse3(a0, a1, a2) + lpt[e];
+      } else {
+        const float b0 = prev[s];
+        const float b1 = s + 1 < L ? prev[s + 1] : -INFINITY;
+        const float b2 = (s + 2 < L && ext[s + 2] != blank && ext[s + 2] != e) ? prev[s + 2] : -INFINITY;
+        v = lse3(b0, b1, b2) + lpt[e];
+      }
+      cur[s] = v;
+      dst[(long)t * Lmax + s] = v;
+    }
+    lds_barrier();
+    float* tmp = prev;
+    prev = cur;
+    cur = tmp;
+  }
+  if (!is_beta && tid == 0) {
+    const float l1 = prev[L - 1];
+    const float l2 = L > 1 ? prev[L - 2] : -INFINITY;
+    const float ll = lse3(l1, l2, -INFINITY);
+    const bool feasible = L <= 2 * Ti + 1 && ll != -INFINITY;      // zero_infinity: see k_ctc_recursion
+    nll_out[n] = feasible ? -ll : 0.f;
+    ws_ll[n] = feasible ? ll : INFINITY;
+  }
+}
+
+// grid (ceil(Tp / GRAD_FRAMES), N); one wave per frame; dynamic LDS: GRAD_WAVES x ldp floats
+__global__ void __launch_bounds__(GRAD_WAVES * 64) k_ctc_gradient_big(const int* __restrict__ targets, const int* __restrict__ toff,
+                                                                      const int* __restrict__ in_len, const int* __restrict__ tg_len,
+                                                                      int Tp, int N, int C, int blank, int Lmax, int ldp, float grad_scale,
+                                                                      float* __restrict__ dlogits, long ldg, const float* __restrict__ ws_lp,
+                                                                      const float* __restrict__ ws_alpha, const float* __restrict__ ws_beta,
+                                                                      const float* __restrict__ ws_ll) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* wacc = reinterpret_cast<float*>(smem) + (long)wave * ldp;
+  const int n = blockIdx.y;
+  int Ti = in_len[n];
+  if (Ti > Tp) Ti = Tp;
+  const int L = 2 * tg_len[n] + 1;
+  const int* tg = targets + toff[n];
+  const float ll = ws_ll[n];
+  const bool live = ll != INFINITY;
+  const int t_end = min((int)(blockIdx.x + 1) * GRAD_FRAMES, Tp);
+  for (int t = blockIdx.x * GRAD_FRAMES + wave; t < t_end; t += GRAD_WAVES) {
+    float* dl = dlogits + ((long)t * N + n) * ldg;
+    if (!live || t >= Ti) {                          // wave-uniform
+      for (int c = lane; c < ldg; c += 64) dl[c] = 0.f;
+      continue;
+    }
+    const float* lpt = ws_lp + ((long)n * Tp + t) * ldp;
+    const float* al = ws_alpha + ((long)n * Tp + t) * Lmax;
+    const float* be = ws_beta + ((long)n * Tp + t) * Lmax;
+    for (int c = lane; c < ldp; c += 64) wacc[c] = 0.f;
+    __builtin_amdgcn_wave_barrier();
+    float blank_part = 0.f;
+    for (int s = lane; s < L; s += 64) {
+      const float w = expf(al[s] + be[s] - ll);      // <= 1
+      if (s & 1)
+        atomicAdd(&wacc[tg[s >> 1]], w);             // LDS atomics of one wave; a class that occurs in several states of one
+      else                                           // 64-state pass is summed in the hardware's lane order (fixed)
+        blank_part += w;
+    }
+    blank_part = wave_sum(blank_part);
+    __builtin_amdgcn_wave_barrier();
+    float gpart = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      float a = wacc[c];
+      if (c == blank) a += blank_part;
+      const float y = expf(lpt[c]);
+      const float g = a > 0.f ? -a / y : 0.f;
+      wacc[c] = g;                                   // the lane's own class: reused as its g
+      gpart += g;
+    }
+    const float gs = wave_sum(gpart);
+    for (int c = lane; c < ldg; c += 64) dl[c] = c < C ? (wacc[c] - expf(lpt[c]) * gs) * grad_scale : 0.f;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 __global__ void k_sum_small(const float* __restrict__ v, int n, float* __restrict__ out) {
   float s = 0.f;
   for (int i = threadIdx.x; i < n; i += 64) s += v[i];
@@ -473,7 +615,8 @@ int ds2_ctc_set_variant(int mode) {
   return old;
 }
 
-static int ctc_class_stride(int C) { return C <= 32 ? 32 : C <= 64 ? 64 : C <= 128 ? 128 : 256; }
+constexpr int CTC_MAX_CLASSES = 8192;     // the gradient pass keeps one row of per-class sums per wave in LDS (4 x 32 KB at 8192)
+static int ctc_class_stride(int C) { return C <= 32 ? 32 : C <= 64 ? 64 : C <= 128 ? 128 : C <= 256 ? 256 : (C + 63) / 64 * 64; }
 
 long ds2_ctc_ws_floats(int Tp, int N, int C, int max_target_len) {
   const long Lmax = 2L * max_target_len + 1;
@@ -484,12 +627,10 @@ int ds2_ctc_loss_grad(const float* logits, long ldl, const int* targets, const i
                       const int* target_lengths, int Tp, int N, int C, int blank, int max_target_len, float grad_scale,
                       float* nll, float* loss_sum, float* dlogits, long ldg, float* ws, ds2_stream_t st_) {
   hipStream_t st = (hipStream_t)st_;
-  DS2_REQUIRE(Tp > 0 && N > 0 && C > 0 && C <= 256 && blank >= 0 && blank < C && max_target_len >= 0, DS2_ERR_ARG);
+  DS2_REQUIRE(Tp > 0 && N > 0 && C > 0 && C <= CTC_MAX_CLASSES && blank >= 0 && blank < C && max_target_len >= 0, DS2_ERR_ARG);
   DS2_REQUIRE(ldg >= C && ldl >= C, DS2_ERR_ARG);
   const int CP = ctc_class_stride(C);
   const int Lmax = 2 * max_target_len + 1;
-  const size_t shm = (size_t)Lmax * 12 + 2 * LP_CHUNK * CP * 4;
-  DS2_REQUIRE(shm <= 160 * 1024, DS2_ERR_ARG);
   int dev = 0;
   (void)hipGetDevice(&dev);
   dev = dev >= 0 && dev < DS2_MAX_DEVICES ? dev : 0;
@@ -497,6 +638,32 @@ int ds2_ctc_loss_grad(const float* logits, long ldl, const int* targets, const i
   float* ws_alpha = ws + (long)N * Tp * CP;
   float* ws_beta = ws_alpha + (long)N * Tp * Lmax;
   float* ws_ll = ws_beta + (long)N * Tp * Lmax;
+  if (C > 256) {      // large label sets: no class rows in LDS (see k_ctc_recursion_big)
+    const size_t shm_r = (size_t)Lmax * 12, shm_g = (size_t)GRAD_WAVES * CP * 4;
+    DS2_REQUIRE(shm_r <= 160 * 1024 && shm_g <= 160 * 1024, DS2_ERR_ARG);
+    static size_t attr_r[DS2_MAX_DEVICES], attr_g[DS2_MAX_DEVICES];
+    if (attr_r[dev] < shm_r) {
+      (void)hipFuncSetAttribute((const void*)k_ctc_recursion_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_r);
+      attr_r[dev] = shm_r;
+    }
+    if (attr_g[dev] < shm_g) {
+      (void)hipFuncSetAttribute((const void*)k_ctc_gradient_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_g);
+      attr_g[dev] = shm_g;
+    }
+    hipLaunchKernelGGL(k_ctc_logsoftmax_big, dim3(ds2_cdiv((long)Tp * N, 4)), dim3(256), 0, st, logits, ldl, input_lengths, Tp, N, C, CP, ws_lp);
+    DS2_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_ctc_recursion_big, dim3(N, 2), dim3(REC_THREADS), shm_r, st, targets, target_offsets, input_lengths, target_lengths,
+                       Tp, blank, Lmax, CP, nll, ws_lp, ws_alpha, ws_beta, ws_ll);
+    DS2_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_ctc_gradient_big, dim3(ds2_cdiv(Tp, GRAD_FRAMES), N), dim3(GRAD_WAVES * 64), shm_g, st, targets, target_offsets,
+                       input_lengths, target_lengths, Tp, N, C, blank, Lmax, CP, grad_scale, dlogits, ldg, ws_lp, ws_alpha, ws_beta, ws_ll);
+    DS2_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_sum_small, dim3(1), dim3(64), 0, st, nll, N, loss_sum);
+    DS2_CHECK_LAUNCH();
+    return 0;
+  }
+  const size_t shm = (size_t)Lmax * 12 + 2 * LP_CHUNK * CP * 4;
+  DS2_REQUIRE(shm <= 160 * 1024, DS2_ERR_ARG);
 #define DS2_CTC_LAUNCH(CPT, SLOT)                                                                                                   \
   {                                                                                                                                 \
     static size_t attr[DS2_MAX_DEVICES]; /* per device: the attribute belongs to the device's copy of the kernel */                 \

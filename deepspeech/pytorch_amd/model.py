@@ -937,8 +937,8 @@ class DeepSpeech(_Base):
         num_classes = len(self.labels)
         kind = rnn_kind(model_cfg.rnn_type)
         H, L = int(model_cfg.hidden_size), int(model_cfg.hidden_layers)
-        if num_classes > 256:
-            raise ValueError("the CTC kernels hold the log-probabilities of a frame in a 256-class row, got %d classes" % num_classes)
+        if num_classes > 8192:      # the reference takes any labels file; ds2_ctc_loss_grad keeps per-class sums of a frame in LDS
+            raise ValueError("the CTC gradient kernel holds one row of per-class sums per wave in LDS: at most 8192 classes, got %d" % num_classes)
         # Internal, tile-aligned sizes (never visible in the state_dict): the recurrent kernels tile the hidden units by 16 and
         # the head / CTC kernels the classes by 32.  Extra hidden units carry zero weights and biases (they stay exactly 0 in
         # GRU, LSTM and tanh cells), extra classes zero weight rows that nothing reads.

@@ -85,6 +85,9 @@ CASES = [
     # train_config.py:55 is a free int), hidden size 50
     dict(name="gru_uni_h50_la40_c45", rnn_type="gru", hidden_size=50, hidden_layers=2, bidirectional=False,
          lookahead_context=40, n_labels=45, lengths=[141, 120, 93, 66], data_seed=32, param_seed=132),
+    # a label set beyond 256 classes (round 5: the CTC kernels no longer stage class rows in LDS for such sets)
+    dict(name="gru_bi_h32_c300", rnn_type="gru", hidden_size=32, hidden_layers=2, bidirectional=True, n_labels=300,
+         lengths=[121, 100, 77], data_seed=34, param_seed=134),
     dict(name="rnn_bi_h24_c40", rnn_type="rnn", hidden_size=24, hidden_layers=2, bidirectional=True, n_labels=40,
          lengths=[99, 80, 55], data_seed=33, param_seed=133),
     # configs[4] at its own DEPTH (7 layers) and width (LSTM-1280), bi-directional and uni-directional + Lookahead, 18 clips (two

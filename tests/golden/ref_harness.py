@@ -137,6 +137,7 @@ def extended_labels(n):
     punctuation -- for models with more output classes than the English set (the reference takes any labels file, model.py:154)."""
     base = ["_", "'"] + [chr(ord("A") + i) for i in range(26)] + [" "]
     extra = list("0123456789.,?!-:;()[]{}<>/\\@#$%^&*+=~|abcdefghijklmnopqrstuvwxyz")
+    extra += [chr(c) for c in range(0x4E00, 0x4E00 + max(0, n - len(base) - len(extra)))]     # then CJK ideographs (a Mandarin-sized set)
     assert n <= len(base) + len(extra)
     return (base + extra)[:n] if n > len(base) else base[:n]
 

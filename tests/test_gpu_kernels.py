@@ -729,28 +729,41 @@ def test_ctc_recursion_kernels_agree_bit_for_bit():
         assert torch.equal(a, b)
 
 
-def _ctc_check(N, Tp, lens, tlens):
-    logits, targets = _ctc_case(N, Tp, lens, tlens, seed=Tp + N)
+def _ctc_check(N, Tp, lens, tlens, Cc=29, blank=0):
+    logits, targets = _ctc_case(N, Tp, lens, tlens, seed=Tp + N, Cc=Cc)
+    if blank != 0:                      # labels avoid the blank index, wherever it sits
+        targets = np.where(targets == blank, 0, targets)
     lp = O.log_softmax(logits)
     # (the vectorised oracle recursion for the long cases: it is held to the loop version in tests/test_oracle_vs_golden.py)
-    loss_ref, nll_ref, dlp = (O.ctc_loss_and_grad_fast if Tp > 100 else O.ctc_loss_and_grad)(lp, targets, np.asarray(lens), np.asarray(tlens))
+    loss_ref, nll_ref, dlp = (O.ctc_loss_and_grad_fast if Tp > 100 else O.ctc_loss_and_grad)(lp, targets, np.asarray(lens), np.asarray(tlens), blank=blank)
     dlogits_ref = dlp - np.exp(lp) * dlp.sum(-1, keepdims=True)
     o = ops()
-    ld = 32
+    ld = (Cc + 31) // 32 * 32
     lg = torch.zeros((Tp * N, ld), dtype=torch.float32, device=DEV)
-    lg[:, :29] = cu(logits.reshape(Tp * N, 29))
+    lg[:, :Cc] = cu(logits.reshape(Tp * N, Cc))
     offs = np.concatenate([[0], np.cumsum(tlens)[:-1]]).astype(np.int32)
     loss, nll, dl = o.ctc_loss_grad(lg, torch.from_numpy(targets.astype(np.int32)).to(DEV), torch.from_numpy(offs).to(DEV),
                                     torch.from_numpy(np.asarray(lens, np.int32)).to(DEV),
-                                    torch.from_numpy(np.asarray(tlens, np.int32)).to(DEV), Tp, N, 29, 0, int(max(tlens)))
+                                    torch.from_numpy(np.asarray(tlens, np.int32)).to(DEV), Tp, N, Cc, blank, int(max(tlens)))
     assert np.allclose(np64(nll), nll_ref, rtol=2e-5, atol=1e-4), (np64(nll), nll_ref)
     assert abs(float(loss.item()) - loss_ref) <= 2e-5 * max(1.0, abs(loss_ref))
     got = np64(dl).reshape(Tp, N, ld)
     # fp32 log-space recursion: alpha/beta reach magnitude ~3*T', whose fp32 ulp (6e-8 * 3T') bounds the precision of
     # exp(alpha + beta - ll); torch's fp32 CTC has the same noise.  Stated bar: 2e-6 * T' absolute (4e-6 * T' for the > 200-label
     # cases, whose nearly forced alignments run the log-space values to ~5 T').
-    assert np.abs(got[:, :, :29] - dlogits_ref).max() < max(2e-5, (4e-6 if max(tlens) > 200 else 2e-6) * Tp)
-    assert np.all(got[:, :, 29:] == 0)
+    # larger label sets: log-probabilities ~ -log C, so the log-space values (and their fp32 ulp) grow by log C / log 29
+    scale_c = 1.0 if Cc == 29 else 1.25 * np.log(Cc) / np.log(29.0)
+    assert np.abs(got[:, :, :Cc] - dlogits_ref).max() < max(2e-5, (4e-6 if max(tlens) > 200 else 2e-6) * Tp) * scale_c
+    assert np.all(got[:, :, Cc:] == 0)
+
+
+@pytest.mark.parametrize("Cc,blank", [(257, 0), (300, 299), (1000, 0), (5000, 17)])
+@pytest.mark.parametrize("N,Tp,lens,tlens", [(3, 31, [31, 25, 19], [7, 6, 4]), (4, 40, [40, 39, 15, 11], [9, 9, 3, 21]),
+                                             (2, 300, [300, 150], [140, 1]), (2, 9, [9, 5], [0, 2])])
+def test_ctc_loss_and_grad_large_label_sets(Cc, blank, N, Tp, lens, tlens):
+    """More than 256 classes (the reference's labels file is unbounded, model.py:139,203; a Mandarin model has thousands): the class
+    rows are no longer staged in LDS, every state reads the log-probability of its own label (k_ctc_recursion_big)."""
+    _ctc_check(N, Tp, lens, tlens, Cc=Cc, blank=blank)
 
 
 def test_softmax_rows():

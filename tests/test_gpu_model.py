@@ -114,15 +114,15 @@ def test_fp32_logits_eval_transcripts_and_carry(name):
 
 BF16_CASES = ["gru_bi_tiny", "lstm_bi_tiny", "gru_uni_la", "gru_bi_mid", "gru_bi_1024", "lstm_uni_1024_la", "rnn_bi_1024", "lstm_bi_1024",
               "cfg2_full", "lstm_bi_1280", "lstm_uni_1280_la", "gru_bi_1024_l5_n32", "lstm_bi_1280_l7_n18", "lstm_uni_1280_la_l7_n18",
-              "lstm_bi_h10_n10", "gru_uni_h50_la40_c45", "rnn_bi_h24_c40"]
+              "lstm_bi_h10_n10", "gru_uni_h50_la40_c45", "rnn_bi_h24_c40", "gru_bi_h32_c300"]
 # Stated bf16 bounds.  The comparator is the REFERENCE ITSELF under torch.autocast(bfloat16) (fixture keys loss_ac /
 # logits_ac / grad_ac.* / acnoise.*, tests/golden/make_golden.py leg C) next to the reference in float64:
-#   loss     within 3e-3 relative of the reference's autocast loss AND of its float64 loss
+#   loss     within 1e-3 relative of the reference's autocast loss AND of its float64 loss
 #   logits   within 0.12 absolute of the float64 logits (the reference's own autocast logits deviate by up to ~0.08)
 #   gradient relative L2 distance from the float64 gradient <= max(BF16_GRAD_FACTOR x the reference-autocast's own distance
 #            from float64 ("acnoise"), BF16_GRAD_FLOOR), for EVERY parameter except the two conv biases in front of BatchNorm
 #            (exactly zero in exact arithmetic: pure rounding noise in any implementation)
-BF16_LOSS_RTOL, BF16_LOGITS_ATOL, BF16_GRAD_FACTOR, BF16_GRAD_FLOOR = 3e-3, 0.12, 2.0, 4e-2
+BF16_LOSS_RTOL, BF16_LOGITS_ATOL, BF16_GRAD_FACTOR, BF16_GRAD_FLOOR = 1e-3, 0.12, 2.0, 4e-2     # loss: the north star's 1e-3 (measured <= 9e-5)
 
 
 def bf16_step(fx):
@@ -295,15 +295,15 @@ def test_full_size_step_matches_the_reference_itself(cfg_name):
     """The same full-size step against THE REFERENCE'S OWN model.py run on the CPU at that full shape (fp32 as shipped, and under
     torch.autocast(bfloat16); tests/golden/make_fullsize_golden.py -> tests/golden/full/<config>.npz: loss, logits on every 16th
     frame, a strided sample + L2 norm of every parameter gradient).  Bars as for the small fixtures: fp32 mode (cfg2) -- loss
-    1e-3 relative, logits 1e-3, every gradient sample within 1e-3 of the tensor's max; bf16 mode -- loss within 3e-3 of the
+    1e-3 relative, logits 1e-3, every gradient sample within 1e-3 of the tensor's max; bf16 mode -- loss within 1e-3 of the
     reference's fp32 AND autocast losses, logits within 0.12, every gradient's relative L2 distance from the reference's fp32
     gradient <= max(2 x the reference-autocast's own distance (CPU), 1.5 x the distance of stock PyTorch-ROCm under bf16 autocast
     on this device -- measured here, against the same reference gradient --, 4e-2).  The second yard-stick is needed at this
     size: the conv-block BatchNorm gradients are sums of ~2e6 cancelling terms per channel, and a GPU bf16 pipeline (stock or
-    ours) sits 3-4 x further from fp32 than the CPU autocast run does (tools/diag_fullsize.py prints the whole table:
-    profiles/r03c_diag_fullsize_cfg3.txt -- ours 0.345 / stock 0.262 / CPU autocast 0.084 on conv.seq_module.1.weight, while ours
-    is closer than stock on 24 of the 59 tensors).  A tensor beyond its bar is accepted only if its absolute error is < 2e-3 of the
-    whole gradient's norm (at most three such tensors; cfg5b: the BatchNorm bias of layer 4, 0.13 % of the gradient norm)."""
+    ours) sits further from fp32 than the CPU autocast run does.  Round 5: tensors of <= 16 384 elements are compared WHOLE
+    (fixture key gradfull.*): the stride-997 sample of a 32-element BatchNorm weight used until round 4 was a single number, and the
+    "0.345 vs stock 0.262" of conv.seq_module.1.weight was that one channel -- over whole tensors and six batches ours and stock's
+    distances are 7.5e-2 and 6.3e-2 rms (tools/diag_conv_bn.py, profiles/r05i_diag_conv_bn_seeds.txt).  No tensor is excused."""
     from deepspeech.pytorch_amd import configs, ops, synth
     from deepspeech.pytorch_amd.model import DeepSpeech
     z, meta = _full_fixture(cfg_name)
@@ -349,8 +349,10 @@ def test_full_size_step_matches_the_reference_itself(cfg_name):
         assert np.isfinite(g).all(), k
         if k in ("conv.seq_module.0.bias", "conv.seq_module.3.bias"):
             continue                                   # exactly zero in exact arithmetic: rounding noise in any implementation
-        sub, l2 = z["gradsub." + k].astype(np.float64), float(z["gradl2." + k])
-        mine = g[::st]
+        l2 = float(z["gradl2." + k])
+        whole = ("gradfull." + k) in z.files      # small tensors are stored whole (round 5): a stride-997 sample of a 32-element
+        sub = z[("gradfull." if whole else "gradsub.") + k].astype(np.float64)      # BatchNorm weight was ONE number
+        mine = g if whole else g[::st]
         if fp32:
             scale = max(np.abs(sub).max(), 1e-3)
             err = np.abs(mine - sub).max() / scale
@@ -360,23 +362,17 @@ def test_full_size_step_matches_the_reference_itself(cfg_name):
         else:
             den = max(np.sqrt((sub ** 2).sum()), 1e-30)
             err = float(np.sqrt(((mine - sub) ** 2).sum()) / den)
-            d_stock = float(np.sqrt(((stock[k][::st] - sub) ** 2).sum()) / den)
+            d_stock = float(np.sqrt((((stock[k] if whole else stock[k][::st]) - sub) ** 2).sum()) / den)
             bound = max(BF16_GRAD_FACTOR * float(z["acnoise." + k]), FULL_SIZE_FACTOR * d_stock, BF16_GRAD_FLOOR)
             if err > bound:
-                # an ill-conditioned small tensor (a bias-type gradient = a sum of ~5e4 cancelling rows; even the fp32 GPU run is
-                # 2e-2 away from the fp32 CPU run on these): accepted only while its ABSOLUTE error is a negligible share of the
-                # step's whole gradient, and for at most three tensors
-                share = err * l2 / total_l2
-                assert share <= 2e-3 and err <= 1.5, "grad %s: relative L2 distance %.3e from the reference's fp32 gradient > %.3e (reference autocast: %.3e, stock bf16 on this device: %.3e) and %.2e of the whole gradient's norm" % (
-                    k, err, bound, float(z["acnoise." + k]), d_stock, share)
-                outliers.append("%s (rel %.2f, stock %.2f, %.1e of the gradient norm)" % (k, err, d_stock, share))
+                outliers.append("%s (relative L2 distance %.3e from the reference's fp32 gradient > %.3e; reference autocast %.3e, stock bf16 on "
+                                "this device %.3e; %.1e of the whole gradient's norm)" % (k, err, bound, float(z["acnoise." + k]), d_stock,
+                                                                                         err * l2 / total_l2))
                 continue
             assert abs(np.sqrt((g ** 2).sum()) - l2) <= 2 * bound * max(l2, 1e-3), k
         if err / bound > worst[1]:
             worst = (k, err / bound, err)
-    assert len(outliers) <= 3, outliers
-    if outliers:
-        print("%s: beyond the per-tensor bar, accepted as negligible: %s" % (cfg_name, "; ".join(outliers)))
+    assert outliers == [], outliers          # round 5: no tensor is excused (small tensors are compared whole)
     # logits of a second model (fresh BatchNorm buffers), every LOGIT_STRIDE-th frame
     m2 = DeepSpeech(configs.LABELS, mc, 32 if fp32 else "bf16", configs.AdamConfig(), configs.SpectConfig())
     m2.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in P.items()}, strict=True)
