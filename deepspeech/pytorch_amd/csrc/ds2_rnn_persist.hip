@@ -22,6 +22,11 @@ int launch_f32_1024(bool probe, bool bwd, int cell, int MT, const QArgs& a, hipS
 }  // namespace ds2q
 
 namespace ds2r {
+int launch3_384(bool probe, bool bwd, int cell, const RArgs& a, hipStream_t st);
+int launch3_640(bool probe, bool bwd, int cell, const RArgs& a, hipStream_t st);
+int launch3_896(bool probe, bool bwd, int cell, const RArgs& a, hipStream_t st);
+int launch3_1152(bool probe, bool bwd, int cell, const RArgs& a, hipStream_t st);
+int launch3_1408(bool probe, bool bwd, int cell, const RArgs& a, hipStream_t st);
 int launch3_512(bool probe, bool bwd, int cell, const RArgs& a, hipStream_t st);
 int launch3_768(bool probe, bool bwd, int cell, const RArgs& a, hipStream_t st);
 int launch3_800(bool probe, bool bwd, int cell, const RArgs& a, hipStream_t st);
@@ -118,6 +123,11 @@ struct Plan3H {
 };
 int launch3_any(bool probe, bool bwd, int cell, int H, const ds2r::RArgs& a, hipStream_t st) {
   switch (H) {
+    case 384: return ds2r::launch3_384(probe, bwd, cell, a, st);
+    case 640: return ds2r::launch3_640(probe, bwd, cell, a, st);
+    case 896: return ds2r::launch3_896(probe, bwd, cell, a, st);
+    case 1152: return ds2r::launch3_1152(probe, bwd, cell, a, st);
+    case 1408: return ds2r::launch3_1408(probe, bwd, cell, a, st);
     case 512: return ds2r::launch3_512(probe, bwd, cell, a, st);
     case 768: return ds2r::launch3_768(probe, bwd, cell, a, st);
     case 800: return ds2r::launch3_800(probe, bwd, cell, a, st);

@@ -95,6 +95,34 @@ COMPOSITE_NODE = {"": None, "0": False}.get(os.environ.get("DS2_COMPOSITE_NODE",
 PER_LAYER_NODES_FOR_DDP = [False]
 
 
+# DS2_PAD_HIDDEN=0: round the hidden size up to the 16-unit tile only (rounds 3-4); default: up to the nearest width a persistent
+# recurrent kernel is instantiated for, when that costs at most 1.5x the units
+PAD_HIDDEN = os.environ.get("DS2_PAD_HIDDEN", "1") != "0"
+
+
+def _padded_hidden(H, kind, precision):
+    """Internal width of the recurrent stack: `hidden_size` rounded up to the 16-unit MFMA tile -- and, from 200 units on, further up to
+    the nearest width the persistent sweeps are instantiated for (bf16: every 128 from 384 to 1280 / 1536, plus 800; fp32: 800 and
+    1024), if that is at most 1.5x as wide.  The extra units carry zero weights and biases and stay exactly 0 (GRU, LSTM and tanh
+    cells, forward and backward); the padding lives in the weight cache and the activations, never in the state_dict.  Why: a width
+    one notch off the instantiated set used to fall to the launch-per-time-step kernels at 5-8x the time per step (the reference
+    leaves hidden_size free, train_config.py:49); zero units in a latency-bound sweep cost next to nothing."""
+    base = (int(H) + 15) // 16 * 16
+    if not PAD_HIDDEN or base < 200 or kind not in ("gru", "lstm"):
+        return base
+    try:
+        from ._lib import query
+        # compute_dtype()'s rule; a model built for fp32 and run under autocast lands on 800 / 1024, which the bf16 kernels cover too
+        dt_ = ops.dt(torch.bfloat16 if str(precision) in ("16", "bf16", "16-mixed", "bf16-mixed") else torch.float32)
+        cell = ops.CELLS[kind]
+        for w in range(base, int(base * 1.5) + 1, 16):
+            if query("ds2_rnn_persist_shape_covered", dt_, cell, 2, 1, w) or query("ds2_rnn_persist_shape_covered", dt_, cell, 1, 1, w):
+                return w
+    except Exception:  # noqa: BLE001  (library not built: the constructor must still work on a CPU-only box)
+        pass
+    return base
+
+
 def _data_parallel_active():
     if PER_LAYER_NODES_FOR_DDP[0]:
         return True
@@ -942,7 +970,7 @@ class DeepSpeech(_Base):
         # Internal, tile-aligned sizes (never visible in the state_dict): the recurrent kernels tile the hidden units by 16 and
         # the head / CTC kernels the classes by 32.  Extra hidden units carry zero weights and biases (they stay exactly 0 in
         # GRU, LSTM and tanh cells), extra classes zero weight rows that nothing reads.
-        self._Hp = (H + 15) // 16 * 16
+        self._Hp = _padded_hidden(H, kind, precision)
         self._Cp = (num_classes + 31) // 32 * 32
 
         self.conv = MaskConv(nn.Sequential(

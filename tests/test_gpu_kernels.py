@@ -388,6 +388,9 @@ PERSIST3_CASES = [
     ("gru", 2, 7, 1280, 8), ("gru", 2, 8, 800, 9), ("lstm", 2, 13, 800, 6), ("lstm", 2, 128, 800, 4), ("gru", 2, 3, 512, 7),
     ("lstm", 1, 100, 512, 5), ("gru", 2, 96, 1024, 4), ("lstm", 2, 128, 1024, 3), ("gru", 1, 20, 768, 6), ("lstm", 2, 50, 768, 5),
     ("gru", 2, 30, 1536, 4), ("gru", 1, 9, 1536, 5),
+    # round 5: the widths in between (every bf16 hidden size up to 1536 is at most 128 zero units away from a persistent kernel)
+    ("gru", 2, 9, 384, 6), ("lstm", 1, 40, 384, 5), ("gru", 2, 33, 640, 5), ("lstm", 2, 8, 640, 6), ("gru", 1, 7, 896, 6),
+    ("lstm", 2, 64, 896, 4), ("gru", 2, 64, 1152, 4), ("lstm", 2, 11, 1152, 5), ("gru", 2, 16, 1408, 5), ("gru", 1, 40, 1408, 4),
 ]
 
 

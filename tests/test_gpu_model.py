@@ -564,3 +564,41 @@ def test_row_lists_change_nothing_but_the_order_of_summation(kind, bi):
         assert torch.isfinite(g).all(), k
         d = float((g - h).norm() / (h.norm() + 1e-30))
         assert d < 2e-4, (k, d)
+
+
+@pytest.mark.parametrize("kind,H,precision,want", [("gru", 600, "bf16", 640), ("lstm", 1100, "bf16", 1152), ("gru", 700, 32, 800)])
+def test_hidden_sizes_between_the_instantiated_widths_ride_the_persistent_sweeps(kind, H, precision, want, monkeypatch):
+    """Round 5: a hidden size one notch off the widths the persistent sweeps are instantiated for (the reference leaves hidden_size free,
+    train_config.py:49) is padded with zero units up to the next such width inside the weight cache, instead of falling to the
+    launch-per-time-step kernels.  The padded model computes the same step as the same model on the per-step kernels (DS2_PAD_HIDDEN=0's
+    path): the extra units are exactly zero, only the summation order inside the products differs."""
+    import warnings
+    from deepspeech.pytorch_amd import configs, model as M, ops, synth
+    lengths = np.array([121, 100, 77, 64])
+    inputs, targets, pct, tsz = synth.synth_batch(lengths, seed=5)
+    rt = getattr(configs.RNNType, kind)
+    mc = configs.BiDirectionalConfig(rnn_type=rt, hidden_size=H, hidden_layers=2)
+
+    def step(pad):
+        monkeypatch.setattr(M, "PAD_HIDDEN", pad)
+        torch.manual_seed(3)
+        m = M.DeepSpeech(configs.LABELS, mc, precision, configs.AdamConfig(), configs.SpectConfig()).to(DEV).train()
+        assert m._Hp == (want if pad else (H + 15) // 16 * 16)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            loss = m.training_step((torch.from_numpy(inputs).to(DEV), torch.from_numpy(targets), torch.from_numpy(pct.copy()), torch.from_numpy(tsz)), 0)
+            loss.backward()
+        ops.check_persistent_kernels()
+        slow = [x for x in w if "launch per time step" in str(x.message) or "one launch per time step" in str(x.message)]
+        return float(loss.item()), {k: p.grad.detach().double().cpu().numpy() for k, p in m.named_parameters()}, slow, list(m.state_dict())
+
+    la, ga, slow_a, keys_a = step(True)
+    lb, gb, slow_b, keys_b = step(False)
+    assert not slow_a, [str(x.message) for x in slow_a]              # the padded model stays on the persistent kernels
+    assert keys_a == keys_b                                          # the padding never shows in the state_dict
+    tol_l, tol_g = (2e-3, 4e-2) if precision == "bf16" else (2e-5, 2e-4)
+    assert abs(la - lb) <= tol_l * abs(lb), (la, lb)
+    for k in ga:
+        assert ga[k].shape == gb[k].shape
+        den = max(np.sqrt((gb[k] ** 2).sum()), 1e-12)
+        assert np.sqrt(((ga[k] - gb[k]) ** 2).sum()) / den <= tol_g, (k, np.sqrt(((ga[k] - gb[k]) ** 2).sum()) / den)
