@@ -34,14 +34,15 @@ SIGNATURES = {
                         _vp, _vp, _vp, _vp]),
     "ds2_bn_bwd": (_i, [_i, _i, _vp, _vp, _vp, _l, _i, _l, _l, _l, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ds2_colsum": (_i, [_i, _vp, _l, _i, _l, _vp, _f, _vp, _vp]),
-    "ds2_conv1_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
-    "ds2_conv1_wgrad_ws_floats": (_l, [_i, _i]),
-    "ds2_conv1_wgrad": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
-    "ds2_conv2_fwd_ws_bytes": (_l, [_i, _i, _i]),
-    "ds2_conv2_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
-    "ds2_conv2_dgrad": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "ds2_conv_rows": (_i, [_i, _vp, _vp]),
+    "ds2_conv1_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ds2_conv1_wgrad_ws_floats": (_l, [_i, _i, _i]),
+    "ds2_conv1_wgrad": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "ds2_conv2_fwd_ws_bytes": (_l, [_i, _i, _i, _i]),
+    "ds2_conv2_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ds2_conv2_dgrad": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "ds2_conv2_wgrad_ws_floats": (_l, [_i, _i]),
-    "ds2_conv2_wgrad": (_i, [_i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "ds2_conv2_wgrad": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "ds2_rnn_gates": (_i, [_i]),
     "ds2_rnn_saved_planes": (_i, [_i]),
     "ds2_rnn_state_bytes": (_l, [_i, _i, _i]),

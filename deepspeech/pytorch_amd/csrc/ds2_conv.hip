@@ -30,13 +30,13 @@ constexpr int C1_PC = (C1_TB - 1) * 2 + K1T;               // 137 input cols
 constexpr int C1_PCP = C1_PC + 1;
 
 __device__ __forceinline__ void conv1_load_patch(float* patch, const float* __restrict__ xn, int T, int f_base, int t_base,
-                                                 int tid, int nthreads) {
+                                                 int tid, int nthreads, int f0) {
   for (int i = tid; i < C1_PR * C1_PC; i += nthreads) {
     const int pr = i / C1_PC, pc = i - pr * C1_PC;
     const int fi = f_base + pr, ti = t_base + pc;
     // unconditional load from a clamped address, zeroed by a select afterwards: keeps all of a thread's ~25 loads in flight
-    const bool ok = fi >= 0 && fi < F0 && ti >= 0 && ti < T;
-    const float v = xn[(long)min(max(fi, 0), F0 - 1) * T + min(max(ti, 0), T - 1)];
+    const bool ok = fi >= 0 && fi < f0 && ti >= 0 && ti < T;
+    const float v = xn[(long)min(max(fi, 0), f0 - 1) * T + min(max(ti, 0), T - 1)];
     patch[pr * C1_PCP + pc] = ok ? v : 0.f;
   }
 }
@@ -44,11 +44,12 @@ __device__ __forceinline__ void conv1_load_patch(float* patch, const float* __re
 template <typename T>
 __global__ void __launch_bounds__(256) k_conv1_fwd(const float* __restrict__ x, const float* __restrict__ w1k,
                                                     const float* __restrict__ b1, const int* __restrict__ lens,
-                                                    T* __restrict__ y1, int N, int Tin, int Tp) {
+                                                    T* __restrict__ y1, int N, int Tin, int Tp, int f0, int f1) {
+  // f0 / f1: input frequency bins / output rows (runtime: the reference derives them from SpectConfig, model.py:166-169)
   __shared__ float patch[C1_PR * C1_PCP];
   const int tid = threadIdx.x;
   const int to0 = blockIdx.x * C1_TB, fo0 = blockIdx.y * C1_FB, n = blockIdx.z;
-  conv1_load_patch(patch, x + (long)n * F0 * Tin, Tin, 2 * fo0 - 20, 2 * to0 - 5, tid, 256);
+  conv1_load_patch(patch, x + (long)n * f0 * Tin, Tin, 2 * fo0 - 20, 2 * to0 - 5, tid, 256, f0);
   __syncthreads();
   const int r = tid >> 6, c = tid & 63;
   const int fo = fo0 + r, to = to0 + c;
@@ -65,9 +66,9 @@ __global__ void __launch_bounds__(256) k_conv1_fwd(const float* __restrict__ x, 
       for (int co = 0; co < CH; ++co) acc[co] = fmaf(xv, wk[kt * CH + co], acc[co]);
     }
   }
-  if (fo < F1 && to < Tp) {
+  if (fo < f1 && to < Tp) {
     const bool live = to < lens[n];
-    T* dst = y1 + (((long)n * F1 + fo) * Tp + to) * CH;
+    T* dst = y1 + (((long)n * f1 + fo) * Tp + to) * CH;
     constexpr int V = Vec16<T>::N;
 #pragma unroll
     for (int v = 0; v < CH / V; ++v) {
@@ -106,7 +107,7 @@ __device__ __forceinline__ void load_dy32<bf16_t>(const bf16_t* __restrict__ p, 
 template <typename T>
 __global__ void __launch_bounds__(C1W_THREADS) k_conv1_wgrad(const float* __restrict__ x, const T* __restrict__ dy1,
                                                              float* __restrict__ partial, int N, int Tin, int Tp,
-                                                             int nchunk_t, int nchunk_f) {
+                                                             int nchunk_t, int nchunk_f, int f0, int f1) {
   // TWO kernel taps per thread (tid and tid + 256): the output-gradient channels arrive through scalar loads and are
   // unpacked bf16 -> fp32 on the scalar ALU, one unit per CU shared by all waves -- with one tap per thread that unpack
   // (32 SALU ops per position and wave) outran the 32 v_fmac it feeds; two taps per thread halve the SALU work per FMA.
@@ -125,11 +126,11 @@ __global__ void __launch_bounds__(C1W_THREADS) k_conv1_wgrad(const float* __rest
     const int ct = chunk % nchunk_t, cf = (chunk / nchunk_t) % nchunk_f, n = chunk / (nchunk_t * nchunk_f);
     const int to0 = ct * C1_TB, fo0 = cf * C1_FB;
     __syncthreads();
-    conv1_load_patch(patch, x + (long)n * F0 * Tin, Tin, 2 * fo0 - 20, 2 * to0 - 5, tid, C1W_THREADS);
+    conv1_load_patch(patch, x + (long)n * f0 * Tin, Tin, 2 * fo0 - 20, 2 * to0 - 5, tid, C1W_THREADS, f0);
     __syncthreads();
-    const int rmax = min(C1_FB, F1 - fo0), cmax = min(C1_TB, Tp - to0);
+    const int rmax = min(C1_FB, f1 - fo0), cmax = min(C1_TB, Tp - to0);
     for (int r = 0; r < rmax; ++r) {
-      const T* dyrow = dy1 + (((long)n * F1 + fo0 + r) * Tp + to0) * CH;
+      const T* dyrow = dy1 + (((long)n * f1 + fo0 + r) * Tp + to0) * CH;
       const float* prow0 = patch + (2 * r + kf0) * C1_PCP + kt0;
       const float* prow1 = patch + (2 * r + kf1) * C1_PCP + kt1;
       for (int c = 0; c < cmax; ++c) {
@@ -523,7 +524,7 @@ constexpr int CW_SPLITS = 64;
 
 template <typename T>
 __global__ void __launch_bounds__(256, 1) k_conv2_wgrad(const T* __restrict__ dY, const T* __restrict__ A1,
-                                                         float* __restrict__ partial, int N, int Tp) {
+                                                         float* __restrict__ partial, int N, int Tp, int f1, int f2) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[(CW_TB + (CW_TB + K2T - 1)) * CH * sizeof(float)];
   T* sdy = reinterpret_cast<T*>(smem);                      // [CW_TB][32]
   T* sx = sdy + CW_TB * CH;                                 // [CW_TB + 10][32]
@@ -537,13 +538,13 @@ __global__ void __launch_bounds__(256, 1) k_conv2_wgrad(const T* __restrict__ dY
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
 
-  const int nrows = N * F2;
+  const int nrows = N * f2;
   for (int rr = split; rr < nrows; rr += gridDim.y) {
-    const int n = rr / F2, fo = rr - n * F2;
+    const int n = rr / f2, fo = rr - n * f2;
     const int fi = 2 * fo - 10 + kf;
-    if (fi < 0 || fi >= F1) continue;   // uniform per block
-    const T* dyrow = dY + ((long)n * F2 + fo) * Tp * CH;
-    const T* xrow = A1 + ((long)n * F1 + fi) * Tp * CH;
+    if (fi < 0 || fi >= f1) continue;   // uniform per block
+    const T* dyrow = dY + ((long)n * f2 + fo) * Tp * CH;
+    const T* xrow = A1 + ((long)n * f1 + fi) * Tp * CH;
     for (int t0 = 0; t0 < Tp; t0 += CW_TB) {
       __syncthreads();
       for (int i = tid; i < CW_TB * (CH / V); i += 256) {
@@ -989,16 +990,37 @@ int conv_tap_launch(const ConvTapArgs& a, hipStream_t st) {
 
 }  // namespace
 
+// Frequency geometry (reference model.py:166-169): F0 = sample_rate * window_size / 2 + 1 input bins (161 at 16 kHz / 20 ms), F1 and
+// F2 the rows after the two convolutions.  The matrix-pipe kernels of the bf16 path (k_conv1_*_mfma, k_conv_rtap, k_conv2_wgrad_bf16r)
+// are specialised for 161 / 81 / 41; any other geometry runs the general kernels (k_conv1_fwd / _wgrad, k_conv_tap, k_conv2_wgrad)
+// in the same storage type: same results, 2-3x the time of the layer.
+static bool conv_geometry(int f0, int& f1, int& f2) {
+  f1 = (f0 + 2 * 20 - K1F) / 2 + 1;
+  f2 = (f1 + 2 * 10 - K2F) / 2 + 1;
+  return f0 >= 1 && f1 >= 1 && f2 >= 1;
+}
+
 extern "C" {
 
-int ds2_conv1_fwd(int dtype, const float* x, const float* w1k, const float* b1, const int* lens, void* y1, int N, int T,
+int ds2_conv_rows(int F0, int* F1_out, int* F2_out) {
+  int f1, f2;
+  DS2_REQUIRE(conv_geometry(F0, f1, f2), DS2_ERR_ARG);
+  if (F1_out) *F1_out = f1;
+  if (F2_out) *F2_out = f2;
+  return 0;
+}
+
+int ds2_conv1_fwd(int dtype, const float* x, const float* w1k, const float* b1, const int* lens, void* y1, int N, int F0_, int T,
                   int Tp, ds2_stream_t st_) {
   hipStream_t st = (hipStream_t)st_;
   DS2_REQUIRE(dtype == DS2_F32 || dtype == DS2_BF16, DS2_ERR_DTYPE);
-  DS2_REQUIRE(N > 0 && T > 0 && Tp == (T + 2 * 5 - 10 - 1) / 2 + 1, DS2_ERR_ARG);
-  dim3 grid(ds2_cdiv(Tp, C1_TB), ds2_cdiv(F1, C1_FB), N);
+  int f1, f2;
+  DS2_REQUIRE(N > 0 && T > 0 && Tp == (T + 2 * 5 - 10 - 1) / 2 + 1 && conv_geometry(F0_, f1, f2), DS2_ERR_ARG);
+  dim3 grid(ds2_cdiv(Tp, C1_TB), ds2_cdiv(f1, C1_FB), N);
   if (dtype == DS2_F32) {
-    hipLaunchKernelGGL(k_conv1_fwd<float>, grid, dim3(256), 0, st, x, w1k, b1, lens, (float*)y1, N, T, Tp);
+    hipLaunchKernelGGL(k_conv1_fwd<float>, grid, dim3(256), 0, st, x, w1k, b1, lens, (float*)y1, N, T, Tp, F0_, f1);
+  } else if (F0_ != F0) {
+    hipLaunchKernelGGL(k_conv1_fwd<bf16_t>, grid, dim3(256), 0, st, x, w1k, b1, lens, (bf16_t*)y1, N, T, Tp, F0_, f1);
   } else {   // matrix pipes: persistent workgroups over the (sample, frame block, row block) tiles
     const int ntb = ds2_cdiv(Tp, M1_TB);
     const long total = (long)N * ntb * 9;
@@ -1010,8 +1032,8 @@ int ds2_conv1_fwd(int dtype, const float* x, const float* w1k, const float* b1, 
   return 0;
 }
 
-static int conv1_wgrad_blocks(int N, int Tp) {
-  long total = (long)N * ds2_cdiv(F1, C1_FB) * ds2_cdiv(Tp, C1_TB);
+static int conv1_wgrad_blocks(int N, int f1, int Tp) {
+  long total = (long)N * ds2_cdiv(f1, C1_FB) * ds2_cdiv(Tp, C1_TB);
   return (int)(total < C1W_MAXBLOCKS ? total : C1W_MAXBLOCKS);
 }
 static int conv1_wgrad_mfma_blocks(int N, int Tp) {   // never more than conv1_wgrad_blocks (the workspace is sized for that)
@@ -1019,18 +1041,24 @@ static int conv1_wgrad_mfma_blocks(int N, int Tp) {   // never more than conv1_w
   const int cus = ds2_cu_count();
   return (int)(total < cus ? total : cus);
 }
-long ds2_conv1_wgrad_ws_floats(int N, int Tp) {
-  const long P = conv1_wgrad_blocks(N, Tp);
+long ds2_conv1_wgrad_ws_floats(int N, int F0_, int Tp) {
+  int f1, f2;
+  if (!conv_geometry(F0_, f1, f2)) return 0;
+  const long P = conv1_wgrad_blocks(N, f1, Tp);
   return P * (K1F * K1T * CH) + (long)ds2_norm_partials(P) * (K1F * K1T * CH);
 }
-int ds2_conv1_wgrad(int dtype, const float* x, const void* dy1, float* dw1k, int N, int T, int Tp, float* ws,
+int ds2_conv1_wgrad(int dtype, const float* x, const void* dy1, float* dw1k, int N, int F0_, int T, int Tp, float* ws,
                     ds2_stream_t st_) {
   hipStream_t st = (hipStream_t)st_;
   DS2_REQUIRE(dtype == DS2_F32 || dtype == DS2_BF16, DS2_ERR_DTYPE);
-  int P = conv1_wgrad_blocks(N, Tp);
-  const int ncf = ds2_cdiv(F1, C1_FB), nct = ds2_cdiv(Tp, C1_TB);
+  int f1, f2;
+  DS2_REQUIRE(conv_geometry(F0_, f1, f2), DS2_ERR_ARG);
+  int P = conv1_wgrad_blocks(N, f1, Tp);
+  const int ncf = ds2_cdiv(f1, C1_FB), nct = ds2_cdiv(Tp, C1_TB);
   if (dtype == DS2_F32) {
-    hipLaunchKernelGGL(k_conv1_wgrad<float>, dim3(P), dim3(C1W_THREADS), 0, st, x, (const float*)dy1, ws, N, T, Tp, nct, ncf);
+    hipLaunchKernelGGL(k_conv1_wgrad<float>, dim3(P), dim3(C1W_THREADS), 0, st, x, (const float*)dy1, ws, N, T, Tp, nct, ncf, F0_, f1);
+  } else if (F0_ != F0) {
+    hipLaunchKernelGGL(k_conv1_wgrad<bf16_t>, dim3(P), dim3(C1W_THREADS), 0, st, x, (const bf16_t*)dy1, ws, N, T, Tp, nct, ncf, F0_, f1);
   } else {
     static bool attr[DS2_MAX_DEVICES];
     if (ds2_first_use_on_device(attr))
@@ -1043,17 +1071,18 @@ int ds2_conv1_wgrad(int dtype, const float* x, const void* dy1, float* dw1k, int
   return ds2_colsum(DS2_F32, ws, P, C, C, dw1k, 1.0f, ws + (long)P * C, st_);
 }
 
-// scratch of ds2_conv2_fwd: bf16 storage runs the layer as two register-resident tap correlations (even / odd kernel rows)
-// whose fp32 partial sums [N][41][Tp][32] pass through it; fp32 storage needs none
-long ds2_conv2_fwd_ws_bytes(int dtype, int N, int Tp) { return dtype == DS2_BF16 ? (long)N * F2 * Tp * CH * 4 : 0; }
-int ds2_conv2_fwd(int dtype, const void* a1, const void* w2t, const float* b2, const int* lens, void* y2, int N, int Tp, void* ws,
+// scratch of ds2_conv2_fwd: bf16 storage at 161 bins runs the layer as two register-resident tap correlations (even / odd kernel
+// rows) whose fp32 partial sums [N][41][Tp][32] pass through it; fp32 storage and other geometries need none
+long ds2_conv2_fwd_ws_bytes(int dtype, int N, int F0_, int Tp) { return (dtype == DS2_BF16 && F0_ == F0) ? (long)N * F2 * Tp * CH * 4 : 0; }
+int ds2_conv2_fwd(int dtype, const void* a1, const void* w2t, const float* b2, const int* lens, void* y2, int N, int F0_, int Tp, void* ws,
                   ds2_stream_t st_) {
   hipStream_t st = (hipStream_t)st_;
   DS2_REQUIRE(dtype == DS2_F32 || dtype == DS2_BF16, DS2_ERR_DTYPE);
-  DS2_REQUIRE(N > 0 && Tp > 0, DS2_ERR_ARG);
-  if (dtype == DS2_F32) {
-    ConvTapArgs a{a1, w2t, b2, lens, y2, N, Tp, F1, F2, K2F, 2, 10, F2, 1, 0};
-    return conv_tap_launch<float>(a, st);
+  int f1, f2;
+  DS2_REQUIRE(N > 0 && Tp > 0 && conv_geometry(F0_, f1, f2), DS2_ERR_ARG);
+  if (dtype == DS2_F32 || F0_ != F0) {
+    ConvTapArgs a{a1, w2t, b2, lens, y2, N, Tp, f1, f2, K2F, 2, 10, f2, 1, 0};
+    return dtype == DS2_F32 ? conv_tap_launch<float>(a, st) : conv_tap_launch<bf16_t>(a, st);
   }
   DS2_REQUIRE(ws != nullptr, DS2_ERR_ARG);
   // kernel rows kf = 2m (11 of them), then kf = 2m + 1 (10): input row of (u, m) = 2*(u + m - 5) + q
@@ -1067,21 +1096,27 @@ int ds2_conv2_fwd(int dtype, const void* a1, const void* w2t, const float* b2, c
 // f = 2u+q: kf = q + 2m ->  input row u + 5 - m, i.e. a stride-1 correlation with the flipped taps m' = M_q-1-m
 // (M_0 = 11, M_1 = 10), top padding M_q - 6, and kt' = 10 - kt with padding 5.
 //   w2d_q [M_q*11][32 ci][32 co] = w2[co][ci][q + 2*(M_q-1-m')][10 - kt']        (prepared by the binding)
-int ds2_conv2_dgrad(int dtype, const void* dy2, const void* w2d_even, const void* w2d_odd, void* da1, int N, int Tp,
+int ds2_conv2_dgrad(int dtype, const void* dy2, const void* w2d_even, const void* w2d_odd, void* da1, int N, int F0_, int Tp,
                     ds2_stream_t st_) {
   hipStream_t st = (hipStream_t)st_;
   DS2_REQUIRE(dtype == DS2_F32 || dtype == DS2_BF16, DS2_ERR_DTYPE);
-  DS2_REQUIRE(N > 0 && Tp > 0, DS2_ERR_ARG);
-  if (dtype == DS2_BF16) {
+  int f1, f2;
+  DS2_REQUIRE(N > 0 && Tp > 0 && conv_geometry(F0_, f1, f2), DS2_ERR_ARG);
+  if (dtype == DS2_BF16 && F0_ == F0) {
     RTapArgs e{(const bf16_t*)dy2, (const bf16_t*)w2d_even, nullptr, nullptr, nullptr, nullptr, (bf16_t*)da1, N, Tp, F2, F1, 11, 1, 0, 1, 0, 5, 41, 2, 0};
     RTapArgs o{(const bf16_t*)dy2, (const bf16_t*)w2d_odd, nullptr, nullptr, nullptr, nullptr, (bf16_t*)da1, N, Tp, F2, F1, 10, 1, 0, 1, 0, 4, 40, 2, 1};
     const int rc = conv_rtap_launch(e, st);
     return rc ? rc : conv_rtap_launch(o, st);
   }
-  ConvTapArgs e{dy2, w2d_even, nullptr, nullptr, da1, N, Tp, F2, F1, 11, 1, 5, 41, 2, 0};
-  ConvTapArgs o{dy2, w2d_odd, nullptr, nullptr, da1, N, Tp, F2, F1, 10, 1, 4, 40, 2, 1};
-  const int rc = conv_tap_launch<float>(e, st);
-  return rc ? rc : conv_tap_launch<float>(o, st);
+  // rows f = 2u + q of da1: (f1 + 1) / 2 even ones, f1 / 2 odd ones
+  ConvTapArgs e{dy2, w2d_even, nullptr, nullptr, da1, N, Tp, f2, f1, 11, 1, 5, (f1 + 1) / 2, 2, 0};
+  ConvTapArgs o{dy2, w2d_odd, nullptr, nullptr, da1, N, Tp, f2, f1, 10, 1, 4, f1 / 2, 2, 1};
+  if (dtype == DS2_F32) {
+    const int rc = conv_tap_launch<float>(e, st);
+    return (rc || f1 / 2 == 0) ? rc : conv_tap_launch<float>(o, st);
+  }
+  const int rc = conv_tap_launch<bf16_t>(e, st);
+  return (rc || f1 / 2 == 0) ? rc : conv_tap_launch<bf16_t>(o, st);
 }
 
 long ds2_conv2_wgrad_ws_floats(int N, int Tp) {
@@ -1090,18 +1125,23 @@ long ds2_conv2_wgrad_ws_floats(int N, int Tp) {
   static_assert(CWR_SPLITS >= CW_SPLITS, "sized for the larger split count of the two kernels");
   return (long)CWR_SPLITS * C + (long)ds2_norm_partials(CWR_SPLITS) * C;
 }
-int ds2_conv2_wgrad(int dtype, const void* dy2, const void* a1, float* dw2t, int N, int Tp, float* ws, ds2_stream_t st_) {
+int ds2_conv2_wgrad(int dtype, const void* dy2, const void* a1, float* dw2t, int N, int F0_, int Tp, float* ws, ds2_stream_t st_) {
   hipStream_t st = (hipStream_t)st_;
   DS2_REQUIRE(dtype == DS2_F32 || dtype == DS2_BF16, DS2_ERR_DTYPE);
+  int f1, f2;
+  DS2_REQUIRE(conv_geometry(F0_, f1, f2), DS2_ERR_ARG);
   dim3 grid(K2F, CW_SPLITS);
+  const bool general = dtype == DS2_F32 || F0_ != F0;
   if (dtype == DS2_F32) {
-    hipLaunchKernelGGL(k_conv2_wgrad<float>, grid, dim3(256), 0, st, (const float*)dy2, (const float*)a1, ws, N, Tp);
+    hipLaunchKernelGGL(k_conv2_wgrad<float>, grid, dim3(256), 0, st, (const float*)dy2, (const float*)a1, ws, N, Tp, f1, f2);
+  } else if (general) {
+    hipLaunchKernelGGL(k_conv2_wgrad<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dy2, (const bf16_t*)a1, ws, N, Tp, f1, f2);
   } else {
     hipLaunchKernelGGL(k_conv2_wgrad_bf16r<4>, dim3(CWR_SPLITS, 6), dim3(256), 0, st, (const bf16_t*)dy2, (const bf16_t*)a1, ws, N, Tp);
   }
   DS2_CHECK_LAUNCH();
   const int C = K2F * K2T * CH * CH;
-  const int splits = dtype == DS2_F32 ? CW_SPLITS : CWR_SPLITS;
+  const int splits = general ? CW_SPLITS : CWR_SPLITS;
   return ds2_colsum(DS2_F32, ws, splits, C, C, dw2t, 1.0f, ws + (long)splits * C, st_);
 }
 

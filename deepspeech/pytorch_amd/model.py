@@ -138,9 +138,13 @@ def _data_parallel_active():
 ROW_LISTS = os.environ.get("DS2_ROW_LISTS", "1") != "0"
 ROW_LIST_MIN_PADDING = 0.97
 
-N_FREQ_CONV2 = 41
+N_FREQ_CONV2 = 41              # the 16 kHz / 20 ms defaults (161 bins); a model holds its own geometry: _F0/_F1/_F2/_rnn_in/_rnn_ld
 RNN_INPUT = 32 * N_FREQ_CONV2  # 1312, model.py:166-169
 RNN_INPUT_LD = 1344            # leading dimension of the conv-stack output: 1312 rounded up to the GEMM K-tile (64); pad = 0
+
+
+def _round64(n):
+    return (n + 63) // 64 * 64
 
 
 # ==================================================================================================================
@@ -289,16 +293,17 @@ def _bn_seq_bwd(G, X, DX, sv, R, Ct, Cp):
 
 
 def _perm_cols_to_internal(w):
-    """rnns.0 weight_ih columns: reference feature c*41+f -> internal f*32+c, zero-padded to RNN_INPUT_LD columns."""
-    g = w.shape[0]
-    out = w.new_zeros((g, RNN_INPUT_LD))
-    out[:, :RNN_INPUT] = w.reshape(g, 32, N_FREQ_CONV2).permute(0, 2, 1).reshape(g, RNN_INPUT)
+    """rnns.0 weight_ih columns: reference feature c*F2+f -> internal f*32+c (F2 = columns / 32: 41 at 161 bins), zero-padded to the
+    GEMM K-tile (1312 -> 1344)."""
+    g, rin = w.shape
+    out = w.new_zeros((g, _round64(rin)))
+    out[:, :rin] = w.reshape(g, 32, rin // 32).permute(0, 2, 1).reshape(g, rin)
     return out
 
 
-def _perm_cols_to_reference(w):
+def _perm_cols_to_reference(w, rin=RNN_INPUT):
     g = w.shape[0]
-    return w[:, :RNN_INPUT].reshape(g, N_FREQ_CONV2, 32).permute(0, 2, 1).reshape(g, RNN_INPUT)
+    return w[:, :rin].reshape(g, rin // 32, 32).permute(0, 2, 1).reshape(g, rin)
 
 
 # ==================================================================================================================
@@ -316,18 +321,23 @@ class _ConvStackFn(torch.autograd.Function):
         w1k = c.get("w1k", [w1], lambda: w1.detach().reshape(32, 451).t().contiguous())
         w2t = c.get(("w2t", dtype), [w2], lambda: w2.detach().permute(2, 3, 0, 1).contiguous().to(dtype))
         x = x.contiguous().float()
+        F0, F1, F2, rin, rld = mod._F0, mod._F1, mod._F2, mod._rnn_in, mod._rnn_ld
+        if x.shape[2] != F0:
+            raise ValueError("this model was built for %d frequency bins (SpectConfig: sample_rate * window_size / 2 + 1), got input "
+                             "with %d" % (F0, x.shape[2]))
         y1 = ops.conv1_fwd(x, w1k, b1.detach(), lens_dev, Tp, dtype)
-        R1 = N * 81 * Tp
+        R1 = N * F1 * Tp
         a1 = torch.empty_like(y1)
         sv1 = ops.bn_fwd(y1, 1, training, g1.detach(), be1.detach(), bn1.running_mean, bn1.running_var,
-                         bn1.num_batches_tracked, R1, 32, 32, a1, 32, F=81, Tp=Tp, N=N, lens=lens_dev, eps=bn1.eps,
+                         bn1.num_batches_tracked, R1, 32, 32, a1, 32, F=F1, Tp=Tp, N=N, lens=lens_dev, eps=bn1.eps,
                          momentum=bn1.momentum)
-        y2 = ops.conv2_fwd(a1, w2t, b2.detach(), lens_dev)
-        R2 = N * 41 * Tp
-        x0 = torch.empty((Tp * N, RNN_INPUT_LD), dtype=dtype, device=x.device)
-        x0[:, RNN_INPUT:].zero_()
+        y2 = ops.conv2_fwd(a1, w2t, b2.detach(), lens_dev, F0)
+        R2 = N * F2 * Tp
+        x0 = torch.empty((Tp * N, rld), dtype=dtype, device=x.device)
+        if rld > rin:
+            x0[:, rin:].zero_()
         sv2 = ops.bn_fwd(y2, 2, training, g2.detach(), be2.detach(), bn2.running_mean, bn2.running_var,
-                         bn2.num_batches_tracked, R2, 32, 32, x0, RNN_INPUT_LD, F=41, Tp=Tp, N=N, lens=lens_dev, eps=bn2.eps,
+                         bn2.num_batches_tracked, R2, 32, 32, x0, rld, F=F2, Tp=Tp, N=N, lens=lens_dev, eps=bn2.eps,
                          momentum=bn2.momentum)
         ctx.mod, ctx.dims, ctx.sv = mod, (N, T, Tp, dtype), (sv1, sv2)
         ctx.save_for_backward(x, y1, a1, y2, lens_dev, w2)
@@ -340,21 +350,22 @@ class _ConvStackFn(torch.autograd.Function):
         sv1, sv2 = ctx.sv
         c = ctx.mod._cache
         dx0 = dx0.contiguous().to(dtype)
-        R1, R2 = N * 81 * Tp, N * 41 * Tp
+        F0, F1, F2, rld = ctx.mod._F0, ctx.mod._F1, ctx.mod._F2, ctx.mod._rnn_ld
+        R1, R2 = N * F1 * Tp, N * F2 * Tp
         dy2 = torch.empty_like(y2)
-        dg2, dbe2 = ops.bn_bwd(dx0, y2, dy2, 2, sv2, R2, 32, RNN_INPUT_LD, 32, 32, F=41, Tp=Tp, N=N, lens=lens_dev)
+        dg2, dbe2 = ops.bn_bwd(dx0, y2, dy2, 2, sv2, R2, 32, rld, 32, 32, F=F2, Tp=Tp, N=N, lens=lens_dev)
         w2d = c.get(("w2d", dtype), [w2], lambda: [
             w2.detach()[:, :, q::2, :].flip(2, 3).permute(2, 3, 1, 0).contiguous().to(dtype) for q in (0, 1)])
-        da1 = ops.conv2_dgrad(dy2, w2d[0], w2d[1])
+        da1 = ops.conv2_dgrad(dy2, w2d[0], w2d[1], F0)
         dy1 = torch.empty_like(y1)
-        dg1, dbe1 = ops.bn_bwd(da1, y1, dy1, 1, sv1, R1, 32, 32, 32, 32, F=81, Tp=Tp, N=N, lens=lens_dev)
+        dg1, dbe1 = ops.bn_bwd(da1, y1, dy1, 1, sv1, R1, 32, 32, 32, 32, F=F1, Tp=Tp, N=N, lens=lens_dev)
         db1 = ops.colsum(dy1.view(R1, 32))
         dw1k = ops.conv1_wgrad(x, dy1, Tp)
         dw1 = dw1k.t().reshape(32, 1, 41, 11).contiguous()
         # conv2's parameter gradients are off the dependent chain (dgrad -> BatchNorm backward -> conv1 weight gradient), so last;
         # on this stream: the second one is busy with the layer-0 weight-gradient GEMMs of the RNN stack for longer than this one
         db2 = ops.colsum(dy2.view(R2, 32))
-        dw2 = ops.conv2_wgrad(dy2, a1).view(21, 11, 32, 32).permute(2, 3, 0, 1).contiguous()
+        dw2 = ops.conv2_wgrad(dy2, a1, F0).view(21, 11, 32, 32).permute(2, 3, 0, 1).contiguous()
         return (None, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, None, None, None, None, None)
 
 
@@ -394,7 +405,7 @@ def _rnn_layer_forward(mod, li, X, lens_dev, N, Tp, dtype, training, h0, c0, lpa
     H = mod._Hp                                         # internal width: hidden_size rounded up to the 16-unit MFMA tile
     G = ops.GATES[kind]
     first = li == 0
-    I = RNN_INPUT_LD if first else H                    # layer 0 sees the zero-padded conv-stack output
+    I = mod._rnn_ld if first else H                     # layer 0 sees the zero-padded conv-stack output
     has_bn = layer.batch_norm is not None
     bn_w, bn_b = (lparams[0], lparams[1]) if has_bn else (None, None)
     wts = lparams[2 if has_bn else 0:]
@@ -520,7 +531,7 @@ def _rnn_layer_backward(mod, li, meta, saved, lparams, dout, lens_dev, N, Tp, dt
             else:
                 ops.gemm8_tn_grouped(probs, R, rows=rows)
             if first:
-                dWih = torch.cat([_perm_cols_to_reference(dWih[d * GH:(d + 1) * GH]) for d in range(D)], 0)
+                dWih = torch.cat([_perm_cols_to_reference(dWih[d * GH:(d + 1) * GH], mod._rnn_in) for d in range(D)], 0)
             if rg.bacc is not None:
                 dBih, dBhh_all = ops.rnn_bias_grads(kind, rg.bacc, D, N, H)          # one launch: [D*G*H], [D][G*H]
                 dBhh_l = [dBhh_all[d] for d in range(D)]
@@ -580,7 +591,7 @@ def _rnn_layer_backward(mod, li, meta, saved, lparams, dout, lens_dev, N, Tp, dt
                                coresident=cores)
         del Xh_T
         if first:
-            dWih = torch.cat([_perm_cols_to_reference(dWih[d * GH:(d + 1) * GH]) for d in range(D)], 0)
+            dWih = torch.cat([_perm_cols_to_reference(dWih[d * GH:(d + 1) * GH], mod._rnn_in) for d in range(D)], 0)
         # bias gradients: from the sweep's own per-sample sums (persistent kernels: a [N][NB*H] reduction instead of
         # column sums over the T'*N rows of dGI / dGH), else column sums
         bsum = None
@@ -985,8 +996,13 @@ class DeepSpeech(_Base):
         rnn_input_size = int(math.floor(rnn_input_size + 2 * 20 - 41) / 2 + 1)
         rnn_input_size = int(math.floor(rnn_input_size + 2 * 10 - 21) / 2 + 1)
         rnn_input_size *= 32
-        if rnn_input_size != RNN_INPUT:
-            raise ValueError("the conv kernels are specialised for 161 frequency bins (16 kHz, 20 ms window)")
+        # frequency geometry (model.py:166-169): any SpectConfig the reference accepts.  161 bins (16 kHz / 20 ms) run the tuned
+        # matrix-pipe kernels of the bf16 path; other geometries the general conv kernels (ds2hip.h, conv front-end)
+        self._F0 = int(math.floor((self.spect_cfg.sample_rate * self.spect_cfg.window_size) / 2) + 1)
+        self._F1, self._F2 = ops.conv_rows(self._F0)
+        self._rnn_in, self._rnn_ld = 32 * self._F2, _round64(32 * self._F2)
+        if rnn_input_size != self._rnn_in or self._F2 < 1:
+            raise ValueError("unsupported spectrogram geometry: %d frequency bins" % self._F0)
         self.rnns = nn.Sequential(
             BatchRNN(rnn_input_size, H, kind, bidirectional=self.bidirectional, batch_norm=False),
             *(BatchRNN(H, H, kind, bidirectional=self.bidirectional) for _ in range(L - 1))
@@ -1035,8 +1051,8 @@ class DeepSpeech(_Base):
                 if not all(c.valid(k, wih if k[0].startswith("wih") else whh) for k in keys):
                     GH, H = whh[0].shape
                     I = wih[0].shape[1]
-                    Io = RNN_INPUT_LD if first else I
-                    perm = (32, N_FREQ_CONV2) if first else None
+                    Io = self._rnn_ld if first else I
+                    perm = (32, self._F2) if first else None
                     dev = wih[0].device
                     Wih = ops.empty_padded(D * GH, Io, dtype, dev)
                     Whh = torch.empty((D, GH, H), dtype=dtype, device=dev)

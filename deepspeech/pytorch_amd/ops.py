@@ -322,42 +322,50 @@ def bn_bwd(G, X, DX, mode, sv, R, Cc, ldg, ldx, lddx, F=0, Tp=0, N=0, lens=None)
 
 
 # ---------------------------------------------------------------------------------------------------------------
+def conv_rows(F0):
+    """(F1, F2): frequency rows after conv1 / conv2 for F0 input bins (reference model.py:166-168): 161 -> (81, 41), 81 -> (41, 21)."""
+    F1 = (F0 + 2 * 20 - 41) // 2 + 1
+    return F1, (F1 + 2 * 10 - 21) // 2 + 1
+
+
 def conv1_fwd(x, w1k, b1, lens, Tp, dtype):
-    N, _, F, T = x.shape
-    y1 = torch.empty((N, 81, Tp, 32), dtype=dtype, device=x.device)
-    call("ds2_conv1_fwd", dt(dtype), PF(x), PF(w1k), PF(b1), P(lens), P(y1), N, T, Tp, S())
+    N, _, F0, T = x.shape
+    y1 = torch.empty((N, conv_rows(F0)[0], Tp, 32), dtype=dtype, device=x.device)
+    call("ds2_conv1_fwd", dt(dtype), PF(x), PF(w1k), PF(b1), P(lens), P(y1), N, F0, T, Tp, S())
     return y1
 
 
 def conv1_wgrad(x, dy1, Tp):
-    N, _, F, T = x.shape
+    N, _, F0, T = x.shape
     dw = torch.empty((451, 32), dtype=torch.float32, device=x.device)
-    ws = torch.empty(query("ds2_conv1_wgrad_ws_floats", N, Tp), dtype=torch.float32, device=x.device)
-    call("ds2_conv1_wgrad", dt(dy1), P(x), P(dy1), P(dw), N, T, Tp, P(ws), S())
+    ws = torch.empty(query("ds2_conv1_wgrad_ws_floats", N, F0, Tp), dtype=torch.float32, device=x.device)
+    call("ds2_conv1_wgrad", dt(dy1), P(x), P(dy1), P(dw), N, F0, T, Tp, P(ws), S())
     return dw
 
 
-def conv2_fwd(a1, w2t, b2, lens):
-    N, _, Tp, _ = a1.shape
-    y2 = torch.empty((N, 41, Tp, 32), dtype=a1.dtype, device=a1.device)
-    nws = query("ds2_conv2_fwd_ws_bytes", dt(a1), N, Tp)
+def conv2_fwd(a1, w2t, b2, lens, F0=161):
+    N, F1, Tp, _ = a1.shape
+    assert F1 == conv_rows(F0)[0]
+    y2 = torch.empty((N, conv_rows(F0)[1], Tp, 32), dtype=a1.dtype, device=a1.device)
+    nws = query("ds2_conv2_fwd_ws_bytes", dt(a1), N, F0, Tp)
     ws = torch.empty(nws, dtype=torch.uint8, device=a1.device) if nws else None
-    call("ds2_conv2_fwd", dt(a1), P(a1), P(w2t), PF(b2), P(lens), P(y2), N, Tp, P(ws), S())
+    call("ds2_conv2_fwd", dt(a1), P(a1), P(w2t), PF(b2), P(lens), P(y2), N, F0, Tp, P(ws), S())
     return y2
 
 
-def conv2_dgrad(dy2, w2d_even, w2d_odd):
-    N, _, Tp, _ = dy2.shape
-    da1 = torch.empty((N, 81, Tp, 32), dtype=dy2.dtype, device=dy2.device)
-    call("ds2_conv2_dgrad", dt(dy2), P(dy2), P(w2d_even), P(w2d_odd), P(da1), N, Tp, S())
+def conv2_dgrad(dy2, w2d_even, w2d_odd, F0=161):
+    N, F2, Tp, _ = dy2.shape
+    assert F2 == conv_rows(F0)[1]
+    da1 = torch.empty((N, conv_rows(F0)[0], Tp, 32), dtype=dy2.dtype, device=dy2.device)
+    call("ds2_conv2_dgrad", dt(dy2), P(dy2), P(w2d_even), P(w2d_odd), P(da1), N, F0, Tp, S())
     return da1
 
 
-def conv2_wgrad(dy2, a1):
+def conv2_wgrad(dy2, a1, F0=161):
     N, _, Tp, _ = dy2.shape
     dw = torch.empty((231, 32, 32), dtype=torch.float32, device=dy2.device)
     ws = torch.empty(query("ds2_conv2_wgrad_ws_floats", N, Tp), dtype=torch.float32, device=dy2.device)
-    call("ds2_conv2_wgrad", dt(dy2), P(dy2), P(a1), P(dw), N, Tp, P(ws), S())
+    call("ds2_conv2_wgrad", dt(dy2), P(dy2), P(a1), P(dw), N, F0, Tp, P(ws), S())
     return dw
 
 

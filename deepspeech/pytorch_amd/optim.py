@@ -50,13 +50,12 @@ class _FusedStep:
         plan = {}
         m = self._model
         if m is not None:
-            from .model import N_FREQ_CONV2, RNN_INPUT_LD
             for li, layer in enumerate(m.rnns):
                 D = layer.num_directions
                 for d, suf in enumerate([""] + (["_reverse"] if D == 2 else [])):
                     wih, whh = getattr(layer.rnn, "weight_ih_l0" + suf), getattr(layer.rnn, "weight_hh_l0" + suf)
                     first = li == 0
-                    plan[id(wih)] = ("ih", li, d, D, (32, N_FREQ_CONV2) if first else None, RNN_INPUT_LD if first else wih.shape[1])
+                    plan[id(wih)] = ("ih", li, d, D, (32, m._F2) if first else None, m._rnn_ld if first else wih.shape[1])
                     plan[id(whh)] = ("hh", li, d, D, None, whh.shape[1])
         self._matrix_plan = plan
         return plan

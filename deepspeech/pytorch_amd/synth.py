@@ -29,15 +29,15 @@ def synth_lengths(n, t_min, t_max, seed, linear=False):
     return np.sort(ln)[::-1].copy()
 
 
-def synth_batch(lengths, seed, chars_per_second=12.0, n_labels=29):
-    """Returns numpy arrays (inputs f32 (N,1,161,Tmax), targets i64 [sum S], input_percentages f32 [N],
-    target_sizes i32 [N]) -- the reference 4-tuple."""
+def synth_batch(lengths, seed, chars_per_second=12.0, n_labels=29, n_freq=N_FREQ):
+    """Returns numpy arrays (inputs f32 (N,1,n_freq,Tmax), targets i64 [sum S], input_percentages f32 [N],
+    target_sizes i32 [N]) -- the reference 4-tuple.  n_freq = sample_rate * window_size / 2 + 1 (161 at 16 kHz / 20 ms)."""
     lengths = np.asarray(lengths, dtype=np.int64)
     n, t_max = len(lengths), int(lengths.max())
     rs = np.random.RandomState(seed)
-    inputs = np.zeros((n, 1, N_FREQ, t_max), dtype=np.float32)
+    inputs = np.zeros((n, 1, n_freq, t_max), dtype=np.float32)
     for i, t in enumerate(lengths):
-        inputs[i, 0, :, :t] = rs.standard_normal((N_FREQ, int(t))).astype(np.float32)
+        inputs[i, 0, :, :t] = rs.standard_normal((n_freq, int(t))).astype(np.float32)
     target_sizes = np.maximum(1, np.floor(chars_per_second * lengths * FRAME_SECONDS)).astype(np.int32)
     targets = rs.randint(1, n_labels, size=int(target_sizes.sum())).astype(np.int64)
     input_percentages = (lengths / float(t_max)).astype(np.float32)

@@ -123,27 +123,31 @@ int ds2_bn_bwd(int dtype, int mode, const void* G, const void* X, void* DX, long
 int ds2_colsum(int dtype, const void* X, long R, int C, long ld, float* out, float scale, float* ws, ds2_stream_t stream);
 
 /* ---- conv front-end (MaskConv over model.py:157-164) ------------------------------------------------------------------
- * conv1: Conv2d(1,32,(41,11),stride (2,2),pad (20,5)) on x (N,1,161,T) f32 -> y1 NFTC [N][81][Tp][32] (T), bias added,
+ * F0 = input frequency bins = sample_rate * window_size / 2 + 1 (model.py:166: 161 at 16 kHz / 20 ms, 81 at 8 kHz); F1, F2 = rows
+ *      after the two convolutions (model.py:167-168; ds2_conv_rows: 161 -> 81 -> 41).  The bf16 matrix-pipe kernels are specialised
+ *      for 161 bins; every other geometry runs the general kernels of the same storage type.
+ * conv1: Conv2d(1,32,(41,11),stride (2,2),pad (20,5)) on x (N,1,F0,T) f32 -> y1 NFTC [N][F1][Tp][32] (T), bias added,
  *        time mask applied.  w1k = weight re-laid as [41*11][32] f32 (tap-major, out-channel fastest).
- * conv2: Conv2d(32,32,(21,11),stride (2,1),pad (10,5)) on a1 NFTC [N][81][Tp][32] -> y2 NFTC [N][41][Tp][32];
+ * conv2: Conv2d(32,32,(21,11),stride (2,1),pad (10,5)) on a1 NFTC [N][F1][Tp][32] -> y2 NFTC [N][F2][Tp][32];
  *        w2t = weight re-laid as [21*11][32 out][32 in] (T).
  * dgrad: da1 = conv2^T(dy2) with w2d = the two stride-parity sub-kernels, layout documented in _lib.py/prep. */
-int ds2_conv1_fwd(int dtype, const float* x, const float* w1k, const float* b1, const int* lens, void* y1, int N, int T,
+int ds2_conv_rows(int F0, int* F1, int* F2);
+int ds2_conv1_fwd(int dtype, const float* x, const float* w1k, const float* b1, const int* lens, void* y1, int N, int F0, int T,
                   int Tp, ds2_stream_t stream);
-/* dw1k [451][32] f32 = sum over positions of dy1 (NFTC, T) x input taps.  ws: ds2_conv1_wgrad_ws_floats(N,Tp) floats. */
-long ds2_conv1_wgrad_ws_floats(int N, int Tp);
-int ds2_conv1_wgrad(int dtype, const float* x, const void* dy1, float* dw1k, int N, int T, int Tp, float* ws,
+/* dw1k [451][32] f32 = sum over positions of dy1 (NFTC, T) x input taps.  ws: ds2_conv1_wgrad_ws_floats(N,F0,Tp) floats. */
+long ds2_conv1_wgrad_ws_floats(int N, int F0, int Tp);
+int ds2_conv1_wgrad(int dtype, const float* x, const void* dy1, float* dw1k, int N, int F0, int T, int Tp, float* ws,
                     ds2_stream_t stream);
-/* ws: ds2_conv2_fwd_ws_bytes(dtype,N,Tp) bytes (bf16 storage: fp32 partial sums of the even-kernel-row half of the layer pass
- * through it; 0 and ws may be NULL for fp32 storage). */
-long ds2_conv2_fwd_ws_bytes(int dtype, int N, int Tp);
-int ds2_conv2_fwd(int dtype, const void* a1, const void* w2t, const float* b2, const int* lens, void* y2, int N, int Tp, void* ws,
-                  ds2_stream_t stream);
-int ds2_conv2_dgrad(int dtype, const void* dy2, const void* w2d_even, const void* w2d_odd, void* da1, int N, int Tp,
+/* ws: ds2_conv2_fwd_ws_bytes(dtype,N,F0,Tp) bytes (bf16 storage at 161 bins: fp32 partial sums of the even-kernel-row half of the
+ * layer pass through it; 0 and ws may be NULL otherwise). */
+long ds2_conv2_fwd_ws_bytes(int dtype, int N, int F0, int Tp);
+int ds2_conv2_fwd(int dtype, const void* a1, const void* w2t, const float* b2, const int* lens, void* y2, int N, int F0, int Tp,
+                  void* ws, ds2_stream_t stream);
+int ds2_conv2_dgrad(int dtype, const void* dy2, const void* w2d_even, const void* w2d_odd, void* da1, int N, int F0, int Tp,
                     ds2_stream_t stream);
 /* dw2t [231][32 out][32 in] f32.  ws: ds2_conv2_wgrad_ws_floats(N,Tp) floats. */
 long ds2_conv2_wgrad_ws_floats(int N, int Tp);
-int ds2_conv2_wgrad(int dtype, const void* dy2, const void* a1, float* dw2t, int N, int Tp, float* ws, ds2_stream_t stream);
+int ds2_conv2_wgrad(int dtype, const void* dy2, const void* a1, float* dw2t, int N, int F0, int Tp, float* ws, ds2_stream_t stream);
 
 /* ---- recurrent sweeps (BatchRNN, model.py:94-102; nn.GRU / nn.LSTM / nn.RNN(tanh), enums.py:17-21) ---------------------
  * See csrc/ds2_rnn.hip for the buffer shapes.  H % 16 == 0. */

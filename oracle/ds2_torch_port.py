@@ -19,6 +19,7 @@ Reference lines restated: mask after every conv-stack module (model.py:53-69), c
 (189-193), head BN + bias-free Linear (195-201), training step incl. the float32 percentage round trip (241-249),
 AdamW hyper-parameters (283-289), Lightning's ``gradient_clip_val: 400`` (configs/an4.yaml:12).
 """
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -53,7 +54,9 @@ class Port:
             elif not (k.startswith("rnns.") and ".rnn." in k):
                 self.P[k] = t.clone().float().requires_grad_(True)
         for l in range(L):
-            m = RNN_CLASSES[cfg["rnn_type"]](input_size=1312 if l == 0 else H, hidden_size=H, bidirectional=self.bi, bias=True)
+            # layer 0: 32 channels x the frequency rows after the two convolutions (model.py:166-169: 1312 at 161 bins), from the state
+            m = RNN_CLASSES[cfg["rnn_type"]](input_size=int(np.asarray(state["rnns.0.rnn.weight_ih_l0"]).shape[1]) if l == 0 else H,
+                                             hidden_size=H, bidirectional=self.bi, bias=True)
             m = m.to(self.device)
             with torch.no_grad():
                 for n, p in m.named_parameters():

@@ -36,12 +36,14 @@ class Fixture:
         self.cfg = dict(rnn_type=m["rnn_type"], hidden_size=m["hidden_size"], hidden_layers=m["hidden_layers"],
                         bidirectional=m["bidirectional"], lookahead_context=m.get("lookahead_context", 20))
         self.lengths = np.asarray(m["lengths"], dtype=np.int64)
+        self.sample_rate = m.get("sample_rate", 16000)      # SpectConfig.sample_rate: 161 frequency bins at 16 kHz, 81 at 8 kHz
         self.labels = m.get("labels") or (["_", "'"] + [chr(ord("A") + i) for i in range(26)] + [" "])   # reference labels.json
 
     def batch(self):
         m = self.meta
         inputs, targets, pct, tsz = synth.synth_batch(self.lengths, m["data_seed"],
-                                                      chars_per_second=m.get("chars_per_second", 12.0), n_labels=m.get("n_labels", 29))
+                                                      chars_per_second=m.get("chars_per_second", 12.0), n_labels=m.get("n_labels", 29),
+                                                      n_freq=m.get("sample_rate", 16000) // 100 + 1)
         if "long_target_sample" in m:
             i = m["long_target_sample"]
             rs = np.random.RandomState(m["data_seed"] + 999)

@@ -88,6 +88,12 @@ CASES = [
     # a label set beyond 256 classes (round 5: the CTC kernels no longer stage class rows in LDS for such sets)
     dict(name="gru_bi_h32_c300", rnn_type="gru", hidden_size=32, hidden_layers=2, bidirectional=True, n_labels=300,
          lengths=[121, 100, 77], data_seed=34, param_seed=134),
+    # another spectrogram geometry (round 5): 8 kHz audio = 81 frequency bins -> 41 -> 21 rows, 672 RNN input features
+    # (SpectConfig.sample_rate, model.py:166-169); and 129 bins (an odd row count after conv1: 65 -> 33)
+    dict(name="gru_bi_8khz", rnn_type="gru", hidden_size=32, hidden_layers=2, bidirectional=True, sample_rate=8000,
+         lengths=[131, 101, 88, 60], data_seed=36, param_seed=136),
+    dict(name="lstm_uni_12k8", rnn_type="lstm", hidden_size=32, hidden_layers=2, bidirectional=False, lookahead_context=20,
+         sample_rate=12800, lengths=[97, 80, 41], data_seed=37, param_seed=137),
     dict(name="rnn_bi_h24_c40", rnn_type="rnn", hidden_size=24, hidden_layers=2, bidirectional=True, n_labels=40,
          lengths=[99, 80, 55], data_seed=33, param_seed=133),
     # configs[4] at its own DEPTH (7 layers) and width (LSTM-1280), bi-directional and uni-directional + Lookahead, 18 clips (two
@@ -102,7 +108,8 @@ CASES = [
 def make_batch(case):
     lengths = np.asarray(case["lengths"], dtype=np.int64)
     inputs, targets, pct, tsz = synth.synth_batch(lengths, case["data_seed"],
-                                                  chars_per_second=case.get("chars_per_second", 12.0), n_labels=case.get("n_labels", 29))
+                                                  chars_per_second=case.get("chars_per_second", 12.0), n_labels=case.get("n_labels", 29),
+                                                  n_freq=case.get("sample_rate", 16000) // 100 + 1)
     if "long_target_sample" in case:   # make one sample infeasible: more labels than output frames
         i = case["long_target_sample"]
         rs = np.random.RandomState(case["data_seed"] + 999)
@@ -134,7 +141,8 @@ def case_labels(ns, case):
 
 def fresh_model(ns, case, P, double=False):
     model = ref_harness.build_reference_model(ns, case["rnn_type"], case["hidden_size"], case["hidden_layers"],
-                                              case["bidirectional"], case.get("lookahead_context", 20), labels=case_labels(ns, case))
+                                              case["bidirectional"], case.get("lookahead_context", 20), labels=case_labels(ns, case),
+                                              sample_rate=case.get("sample_rate", 16000))
     model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in P.items()}, strict=True)
     return model.double() if double else model
 
@@ -162,7 +170,8 @@ def main():
             continue
         stride = case.get("stride", STRIDE)
         probe = ref_harness.build_reference_model(ns, case["rnn_type"], case["hidden_size"], case["hidden_layers"],
-                                                  case["bidirectional"], case.get("lookahead_context", 20), labels=case_labels(ns, case))
+                                                  case["bidirectional"], case.get("lookahead_context", 20), labels=case_labels(ns, case),
+                                              sample_rate=case.get("sample_rate", 16000))
         shapes = {k: tuple(v.shape) for k, v in probe.state_dict().items()}
         P = make_params(case, shapes)
         inputs, targets, pct, tsz = make_batch(case)

@@ -143,7 +143,7 @@ def extended_labels(n):
 
 
 def build_reference_model(ns, rnn_type="gru", hidden_size=32, hidden_layers=2, bidirectional=True,
-                          lookahead_context=20, seed=0, labels=None):
+                          lookahead_context=20, seed=0, labels=None, sample_rate=16000):
     torch.manual_seed(seed)
     rt = getattr(ns.RNNType, rnn_type)
     if bidirectional:
@@ -152,5 +152,5 @@ def build_reference_model(ns, rnn_type="gru", hidden_size=32, hidden_layers=2, b
         mcfg = ns.UniDirectionalConfig(rnn_type=rt, hidden_size=hidden_size, hidden_layers=hidden_layers,
                                        lookahead_context=lookahead_context)
     model = ns.DeepSpeech(labels=labels if labels is not None else ns.labels, model_cfg=mcfg, precision=32, optim_cfg=ns.AdamConfig(),
-                          spect_cfg=ns.SpectConfig())
+                          spect_cfg=ns.SpectConfig(sample_rate=sample_rate))
     return model

@@ -224,10 +224,11 @@ def test_bn_conv_modes(dtype, seq_out):
 
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("N,T", [(2, 37), (3, 150), (2, 523)])          # 523 frames: three 128-frame blocks, ragged tail
-def test_conv1_fwd_and_wgrad(dtype, N, T):
+@pytest.mark.parametrize("N,T,F0", [(2, 37, 161), (3, 150, 161), (2, 523, 161),          # 523 frames: three 128-frame blocks, ragged tail
+                                    (2, 70, 81), (3, 41, 129), (1, 33, 257), (2, 29, 41)])  # other SpectConfig geometries (general kernels)
+def test_conv1_fwd_and_wgrad(dtype, N, T, F0):
     rs = np.random.RandomState(7 + T)
-    x = rs.standard_normal((N, 1, 161, T))
+    x = rs.standard_normal((N, 1, F0, T))
     w, b = rs.uniform(-0.05, 0.05, (32, 1, 41, 11)), rs.uniform(-0.1, 0.1, 32)
     lens_in = np.array([T, max(T - 9, 1), max(T // 2, 1)][:N])
     lens = O.seq_lens(lens_in)
@@ -248,16 +249,19 @@ def test_conv1_fwd_and_wgrad(dtype, N, T):
     dy = rs.standard_normal(y.shape)
     dy[m] = 0
     dyr = nchw(rnd(nftc(dy), dtype))
-    _, dw, _ = O.conv2d_bwd(xq, w, dyr, (2, 2), (20, 5), need_dx=False)
+    # the general kernels (geometries other than 161 bins) multiply the fp32 input itself; the matrix-pipe kernel its bf16 rounding
+    xw = xq if F0 == 161 else x.astype(np.float32).astype(np.float64)
+    _, dw, _ = O.conv2d_bwd(xw, w, dyr, (2, 2), (20, 5), need_dx=False)
     got = o.conv1_wgrad(xd, cu(nftc(dy), dtype), Tp)
     assert relerr(np64(got), dw.reshape(32, 451).T) < 1e-4
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("N,Tp", [(2, 19), (3, 75), (2, 300)])
-def test_conv2_fwd_dgrad_wgrad(dtype, N, Tp):
+@pytest.mark.parametrize("N,Tp,F0", [(2, 19, 161), (3, 75, 161), (2, 300, 161),
+                                     (2, 40, 81), (3, 21, 129), (1, 17, 257), (2, 15, 41)])   # F1 = 41 / 65 / 129 / 21 (odd and even)
+def test_conv2_fwd_dgrad_wgrad(dtype, N, Tp, F0):
     rs = np.random.RandomState(8 + Tp)
-    a1 = np.maximum(rs.standard_normal((N, 32, 81, Tp)), 0)
+    a1 = np.maximum(rs.standard_normal((N, 32, ops().conv_rows(F0)[0], Tp)), 0)
     lens = np.array([Tp, max(Tp - 5, 1), max(Tp // 3, 1)][:N], dtype=np.int32)
     a1[O.time_mask(a1.shape, lens)] = 0
     w, b = rs.uniform(-0.02, 0.02, (32, 32, 21, 11)), rs.uniform(-0.1, 0.1, 32)
@@ -269,7 +273,8 @@ def test_conv2_fwd_dgrad_wgrad(dtype, N, Tp):
     lens_d = torch.from_numpy(lens).to(DEV)
     a1d = cu(nftc(a1), dtype)
     w2t = cu(w.transpose(2, 3, 0, 1), dtype)            # [kf][kt][co][ci]
-    y2 = o.conv2_fwd(a1d, w2t, cu(b), lens_d)
+    y2 = o.conv2_fwd(a1d, w2t, cu(b), lens_d, F0)
+    assert tuple(y2.shape) == (N, o.conv_rows(F0)[1], Tp, 32)
     assert relerr(np64(y2), nftc(y)) < TOL[dtype]
     # backward
     dy = rs.standard_normal(y.shape)
@@ -279,10 +284,10 @@ def test_conv2_fwd_dgrad_wgrad(dtype, N, Tp):
     wt = torch.from_numpy(w)
     w2d = [wt[:, :, q::2, :].flip(2, 3).permute(2, 3, 1, 0).contiguous().to(DEV).to(dtype) for q in (0, 1)]
     dyd = cu(nftc(dy), dtype)
-    da1 = o.conv2_dgrad(dyd, w2d[0], w2d[1])
+    da1 = o.conv2_dgrad(dyd, w2d[0], w2d[1], F0)
     assert relerr(np64(da1), nftc(dx)) < TOL[dtype]
     # wgrad contracts bf16-exact products in fp32: compare against the oracle on the rounded operands
-    dw2 = o.conv2_wgrad(dyd, a1d)
+    dw2 = o.conv2_wgrad(dyd, a1d, F0)
     assert relerr(np64(dw2).reshape(21, 11, 32, 32), dw.transpose(2, 3, 0, 1)) < 1e-4
 
 

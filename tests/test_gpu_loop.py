@@ -28,7 +28,7 @@ def build(fx, precision=32, optim="adam"):
         mc = configs.UniDirectionalConfig(rnn_type=rt, hidden_size=c["hidden_size"], hidden_layers=c["hidden_layers"],
                                           lookahead_context=c["lookahead_context"])
     oc = configs.AdamConfig() if optim == "adam" else configs.SGDConfig()
-    m = DeepSpeech(labels=fx.labels, model_cfg=mc, precision=precision, optim_cfg=oc, spect_cfg=configs.SpectConfig())
+    m = DeepSpeech(labels=fx.labels, model_cfg=mc, precision=precision, optim_cfg=oc, spect_cfg=configs.SpectConfig(sample_rate=fx.sample_rate))
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in fx.params().items()}, strict=True)
     return m.to(DEV)
 

@@ -23,7 +23,7 @@ def build(fx, precision=32):
         mc = configs.UniDirectionalConfig(rnn_type=rt, hidden_size=c["hidden_size"], hidden_layers=c["hidden_layers"],
                                           lookahead_context=c["lookahead_context"])
     m = DeepSpeech(labels=fx.labels, model_cfg=mc, precision=precision, optim_cfg=configs.AdamConfig(),
-                   spect_cfg=configs.SpectConfig())
+                   spect_cfg=configs.SpectConfig(sample_rate=fx.sample_rate))
     sd = {k: torch.from_numpy(v.copy()) for k, v in fx.params().items()}
     m.load_state_dict(sd, strict=True)     # reference state_dict keys/shapes load unchanged
     return m.to(DEV)
@@ -114,7 +114,7 @@ def test_fp32_logits_eval_transcripts_and_carry(name):
 
 BF16_CASES = ["gru_bi_tiny", "lstm_bi_tiny", "gru_uni_la", "gru_bi_mid", "gru_bi_1024", "lstm_uni_1024_la", "rnn_bi_1024", "lstm_bi_1024",
               "cfg2_full", "lstm_bi_1280", "lstm_uni_1280_la", "gru_bi_1024_l5_n32", "lstm_bi_1280_l7_n18", "lstm_uni_1280_la_l7_n18",
-              "lstm_bi_h10_n10", "gru_uni_h50_la40_c45", "rnn_bi_h24_c40", "gru_bi_h32_c300"]
+              "lstm_bi_h10_n10", "gru_uni_h50_la40_c45", "rnn_bi_h24_c40", "gru_bi_h32_c300", "gru_bi_8khz", "lstm_uni_12k8"]
 # Stated bf16 bounds.  The comparator is the REFERENCE ITSELF under torch.autocast(bfloat16) (fixture keys loss_ac /
 # logits_ac / grad_ac.* / acnoise.*, tests/golden/make_golden.py leg C) next to the reference in float64:
 #   loss     within 1e-3 relative of the reference's autocast loss AND of its float64 loss

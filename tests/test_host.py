@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert lib.ds2_norm_partials(10) == 2 and lib.ds2_norm_partials(10 ** 7) == 1024
     assert lib.ds2_ctc_ws_floats(751, 32, 29, 180) == 32 * 751 * 32 + 2 * 32 * 751 * 361 + 32
     # conv2 forward (bf16 storage): fp32 partial sums of the even kernel rows, [N][41][T'][32]; none for fp32 storage
-    assert lib.ds2_conv2_fwd_ws_bytes(1, 32, 751) == 32 * 41 * 751 * 32 * 4 and lib.ds2_conv2_fwd_ws_bytes(0, 32, 751) == 0
+    assert lib.ds2_conv2_fwd_ws_bytes(1, 32, 161, 751) == 32 * 41 * 751 * 32 * 4 and lib.ds2_conv2_fwd_ws_bytes(0, 32, 161, 751) == 0 and lib.ds2_conv2_fwd_ws_bytes(1, 32, 81, 751) == 0
 
 
 def build_model(fx):
@@ -51,7 +51,7 @@ def build_model(fx):
         mc = configs.UniDirectionalConfig(rnn_type=rt, hidden_size=c["hidden_size"], hidden_layers=c["hidden_layers"],
                                           lookahead_context=c["lookahead_context"])
     return DeepSpeech(labels=fx.labels, model_cfg=mc, precision=32, optim_cfg=configs.AdamConfig(),
-                      spect_cfg=configs.SpectConfig())
+                      spect_cfg=configs.SpectConfig(sample_rate=fx.sample_rate))
 
 
 @pytest.mark.parametrize("name", fixture_names())
