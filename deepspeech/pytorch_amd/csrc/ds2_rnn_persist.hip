@@ -333,8 +333,8 @@ int ds2_rnn_persist_fwd(int dtype, int cell, int D, int N, int H, int Tp, const 
 // (may be null) = per-sample sums over time of the gate-gradient planes as stored (NB = 4 for GRU: dr, dz, dn, dQ; G otherwise):
 // bias_ih.grad = sum over samples of planes 0..G-1, bias_hh.grad (GRU) = planes 0, 1, 3.
 int ds2_rnn_persist_bwd(int dtype, int cell, int D, int N, int H, int Tp, const int* lens, const void* dOut, const void* WhhT,
-                        const void* Hseq, long hseq_dstride, const void* S, void* dGI, void* dQ, float* dBacc, void* ws, int* err,
-                        ds2_stream_t st_) {
+                        const void* Hseq, long hseq_dstride, const void* S, void* dGI, void* dQ, float* dBacc, int flags, void* ws,
+                        int* err, ds2_stream_t st_) {
   void* dGH = dQ;
   hipStream_t st = (hipStream_t)st_;
   DS2_REQUIRE(Tp > 0 && Tp < (int)TAG_INIT && ws && err, DS2_ERR_ARG);
@@ -368,7 +368,7 @@ int ds2_rnn_persist_bwd(int dtype, int cell, int D, int N, int H, int Tp, const 
     a.xbuf = (char*)ws + AUX_BYTES; a.xgroup_bytes = xb / p3.NG; a.err = err; a.lerr = (int*)((char*)ws + 3072);
     ra.xcc = (u64*)((char*)ws + AUX_BYTES + xb); ra.P = p3.P; ra.xmap = p3.xmap; ra.gx = p3.gx; ra.nset = p3.nset;
     ra.skip = (p3.nset == 2 && !(g_variant & 2u)) ? 1 : 0;
-    if (ra.skip & 1) {
+    if ((ra.skip & 1) && !(flags & 1)) {     // flags bit 0: nobody reads the padding rows (row-list consumers)
       const long GHb = (long)gates(cell) * H * 2;
       zero_pad3(dGI, D * GHb, D * GHb, lens, N, Tp, st);
       if (dGH)

@@ -486,10 +486,14 @@ def _rnn_layer_backward(mod, li, meta, saved, lparams, dout, lens_dev, N, Tp, dt
     if wgrad_done is not None:
         main.wait_event(wgrad_done)
         wgrad_done = None
-    rg = ops.rnn_bwd(kind, dout, WhhT, hext, Sv, lens_dev, D, N, H, Tp)
-    dGI = rg.dGI
     fast = ops.wgrad_tn_ok(dtype, R, D * GH, Xh.shape[1], lda=D * GH, ldb=Xh.stride(0)) and \
         ops.wgrad_tn_ok(dtype, R, GH, H, lda=D * GH, ldb=H)
+    # one launch for the weight gradients + dX (below): every reader of the sweep's dGI / dQ then works from the row list
+    n_probs = 1 + D * (2 if (kind == "gru" and (2 * H) % 256 != 0) else 1)
+    fuse_dx = fast and WGRAD_WITH_DX and not WGRAD_BESIDE_DX and n_probs < 6 and WihT.dim() == 2 and WihT.data_ptr() % 16 == 0 and \
+        ops.gemm8_nt_shape_ok(dtype, R, WihT.shape[0], D * GH, D * GH, WihT.stride(0))
+    rg = ops.rnn_bwd(kind, dout, WhhT, hext, Sv, lens_dev, D, N, H, Tp, pad_rows_unread=bool(fuse_dx and rows is not None))
+    dGI = rg.dGI
     dXh_fused = None
     if fast:
         # ---- weight gradients as ONE grouped launch of TN products (contraction over the T'*N rows, both operands as the
@@ -524,8 +528,8 @@ def _rnn_layer_backward(mod, li, meta, saved, lparams, dout, lens_dev, N, Tp, dt
                     probs.append(dict(At=rg.dGH[d], Bt=hprev, M=GH, N=H, lda=GH, ldb=H, out=dWhh[d]))
                 else:
                     probs.append(dict(At=dGI[:, d * GH:], Bt=hprev, M=GH, N=H, lda=D * GH, ldb=H, out=dWhh[d]))
-            if WGRAD_WITH_DX and wstream is main and len(probs) < 6 and ops.gemm8_nt_ok(dGI, WihT, R, WihT.shape[0], D * GH, D * GH,
-                                                                                        WihT.stride(0)):
+            assert not fuse_dx or ops.gemm8_nt_ok(dGI, WihT, R, WihT.shape[0], D * GH, D * GH, WihT.stride(0))
+            if fuse_dx:
                 # + the layer's dX in the same launch; with a row list the padding frames are neither contracted over nor computed
                 _, dXh_fused = ops.gemm8_tn_grouped(probs, R, dx=(dGI, WihT), rows=rows, zero_pad=(lens_dev, Tp, N))
             else:

@@ -94,10 +94,15 @@ def empty_padded(rows, cols, dtype, device):
 GEMM8_ENABLED = True     # tests flip this to run the 128x128-tile kernels on shapes the 256x256 kernel covers
 
 
+def gemm8_nt_shape_ok(dtype, M, N, K, lda, ldb):
+    """The shape part of gemm8_nt_ok (decidable before the operands exist)."""
+    return (GEMM8_ENABLED and dtype == torch.bfloat16 and K % 64 == 0 and lda % 8 == 0 and ldb % 8 == 0 and
+            M >= 1024 and N >= 256 and rup(M, 256) // 256 * (rup(N, 256) // 256) >= 160 and M * lda < (1 << 31) and N * ldb < (1 << 31))
+
+
 def gemm8_nt_ok(A, B, M, N, K, lda, ldb):
     """Shapes the 256x256 phase-split kernel takes (and wins on): bf16, whole K-tiles, enough tiles to fill the chip."""
-    return (GEMM8_ENABLED and A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and K % 64 == 0 and lda % 8 == 0 and ldb % 8 == 0 and
-            M >= 1024 and N >= 256 and rup(M, 256) // 256 * (rup(N, 256) // 256) >= 160 and M * lda < (1 << 31) and N * ldb < (1 << 31) and
+    return (A.dtype == B.dtype and gemm8_nt_shape_ok(A.dtype, M, N, K, lda, ldb) and
             A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0)
 
 
@@ -480,6 +485,8 @@ class PinnedRing:
         return out
 
 
+POISON_UNWRITTEN = False  # tests: the BPTT outputs start as NaN, so a consumer that reads a row the sweep was allowed to leave
+                          # unwritten (rnn_bwd(pad_rows_unread=True)) shows up as NaN gradients
 PERSIST_ENABLED = True   # tests flip this to run the per-time-step kernels on shapes the persistent kernels cover
 
 
@@ -565,19 +572,25 @@ class RnnGrads:
         return [t for t in (self.dGI, self.dGH, self.dQ, self.bacc) if t is not None]
 
 
-def rnn_bwd(kind, dOut, WhhT, hext, Sv, lens, D, N, H, Tp):
+def rnn_bwd(kind, dOut, WhhT, hext, Sv, lens, D, N, H, Tp, pad_rows_unread=False):
+    """pad_rows_unread: the caller reads dGI / dQ only through a row list of the real frames (and takes the bias gradients from the
+    sweep's per-sample sums): a persistent sweep that leaves the padding rows unwritten then does not zero them."""
     dev, dtype = dOut.device, dOut.dtype
     G = GATES[kind]
     dGI = torch.empty((Tp * N, D * G * H), dtype=dtype, device=dev)
     if use_persistent(kind, dtype, D, N, H):
         dQ = torch.empty((D, Tp, N, H), dtype=dtype, device=dev) if kind == "gru" else None
+        if POISON_UNWRITTEN:
+            dGI.fill_(float("nan"))
+            if dQ is not None:
+                dQ.fill_(float("nan"))
         bacc = torch.empty((D, N, (4 if kind == "gru" else G) * H), dtype=torch.float32, device=dev)
         ws = torch.empty(query("ds2_rnn_persist_ws_bytes", dt(dtype), CELLS[kind], D, N, H), dtype=torch.uint8, device=dev)
         global LAST_PERSIST_WS
         LAST_PERSIST_WS = ws
         with _sweep_timer("rnn_bwd_persistent", Tp):
             call("ds2_rnn_persist_bwd", dt(dtype), CELLS[kind], D, N, H, Tp, P(lens), P(dOut), P(WhhT), P(hext[:, 1]), (Tp + 2) * N * H,
-                 P(Sv), P(dGI), P(dQ), P(bacc), P(ws), P(_persist_err(dev)), S())
+                 P(Sv), P(dGI), P(dQ), P(bacc), 1 if pad_rows_unread else 0, P(ws), P(_persist_err(dev)), S())
         return RnnGrads(dGI, dQ=dQ, bacc=bacc)
     dGH = torch.empty((D, Tp, N, G * H), dtype=dtype, device=dev) if kind == "gru" else None
     state = torch.empty(query("ds2_rnn_state_bytes", D, N, H), dtype=torch.uint8, device=dev)

@@ -191,9 +191,12 @@ int ds2_rnn_persist_fwd(int dtype, int cell, int D, int N, int H, int Tp, const 
 /* BPTT: dGI as ds2_rnn_bwd; GRU: dQ [D][Tp][N][H] = dn*r (the one slot of the hidden-side gate gradient [dr,dz,dQ] that differs
  * from dGI's; null for LSTM / RNN); dBacc [D][N][NB*H] f32 (may be null): per-sample sums over time of the stored gate-gradient
  * planes (NB = 4 for GRU: dr, dz, dn, dQ; G otherwise) -- the bias gradients are their sums over the samples. */
+/* flags bit 0: the caller never reads the padding rows (t >= lens[n]) of dGI / dQ -- its products over the frames run on a row list
+ * (ds2_gemm8_*_rows) and its bias gradients come from dBacc -- so a sweep whose half-steps leave those rows unwritten (two-set groups
+ * of the round-4 general kernels) skips zeroing them. */
 int ds2_rnn_persist_bwd(int dtype, int cell, int D, int N, int H, int Tp, const int* lens, const void* dOut, const void* WhhT,
-                        const void* Hseq, long hseq_dstride, const void* S, void* dGI, void* dQ, float* dBacc, void* ws, int* err,
-                        ds2_stream_t stream);
+                        const void* Hseq, long hseq_dstride, const void* S, void* dGI, void* dQ, float* dBacc, int flags, void* ws,
+                        int* err, ds2_stream_t stream);
 
 /* ---- small sequence ops ---------------------------------------------------------------------------------------------------
  * add2: out = a + b (direction sum, model.py:101).  transpose: dst[C][ldd] = src[R][lds]^T, zero-filling r in [R, ldd).

@@ -602,3 +602,33 @@ def test_hidden_sizes_between_the_instantiated_widths_ride_the_persistent_sweeps
         assert ga[k].shape == gb[k].shape
         den = max(np.sqrt((gb[k] ** 2).sum()), 1e-12)
         assert np.sqrt(((ga[k] - gb[k]) ** 2).sum()) / den <= tol_g, (k, np.sqrt(((ga[k] - gb[k]) ** 2).sum()) / den)
+
+
+def test_nobody_reads_the_padding_rows_a_two_set_sweep_leaves_unwritten(monkeypatch):
+    """Round 5: with a row list in force every reader of a BPTT sweep's dGI works from the real frames (weight gradients + dX in one
+    row-list launch, bias gradients from the sweep's per-sample sums), so the two-set general sweeps no longer zero the padding rows
+    their half-steps leave out (ds2_rnn_persist_bwd flags bit 0).  Here dGI starts as NaN: had anybody read an unwritten row, the
+    step's gradients would be NaN; and they equal the gradients of the same step with the rows zeroed as before."""
+    from deepspeech.pytorch_amd import configs, model as M, ops, synth
+    lengths = np.array(sorted([97] * 6 + [90] * 10 + [71] * 12 + [50] * 12 + [33] * 12 + [21] * 12, reverse=True))     # 64 clips, 40 % padding
+    inputs, targets, pct, tsz = synth.synth_batch(lengths, seed=9)
+    mc = configs.BiDirectionalConfig(rnn_type=configs.RNNType.lstm, hidden_size=1280, hidden_layers=2)
+
+    def step(poison):
+        monkeypatch.setattr(ops, "POISON_UNWRITTEN", poison)
+        torch.manual_seed(4)
+        m = M.DeepSpeech(configs.LABELS, mc, "bf16", configs.AdamConfig(), configs.SpectConfig()).to(DEV).train()
+        loss = m.training_step((torch.from_numpy(inputs).to(DEV), torch.from_numpy(targets), torch.from_numpy(pct.copy()), torch.from_numpy(tsz)), 0)
+        assert m._frame_rows is not None                      # the row list is in force (enough padding)
+        loss.backward()
+        ops.check_persistent_kernels()
+        return float(loss.item()), {k: p.grad.detach().double().cpu().numpy() for k, p in m.named_parameters()}
+
+    from deepspeech.pytorch_amd._lib import query
+    assert query("ds2_rnn_persist_kind", ops.dt(torch.bfloat16), ops.CELLS["lstm"], 2, 64, 1280) == 3      # two-set general sweeps
+    la, ga = step(True)
+    lb, gb = step(False)
+    assert np.isfinite(la) and la == lb
+    for k in ga:
+        assert np.isfinite(ga[k]).all(), k
+        assert np.array_equal(ga[k], gb[k]), k
