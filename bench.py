@@ -183,17 +183,33 @@ def run_native(args, rank, world, device):
             # the same step with the gradient exchange switched off (DDP.no_sync): step time with - without = what the all-reduce
             # costs the step after overlap (exposed tail + contention under the sweeps), measured, not modelled
             k2 = max(3, min(args.steps, 10))
-            with step_mod.no_sync():              # (ops.SWEEP_EVENTS is None again: step() records no events in this leg)
+            ns_marks = []
+
+            def step_marked():
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                ns_marks.append(ev)
+                return step()
+            with step_mod.no_sync():              # (ops.SWEEP_EVENTS is None again: step() itself records no events in this leg)
                 for _ in range(2):
                     step()
-                dt_ns, _ = dsdist.timed_steps(step, k2, device, world)
-            t = torch.tensor([dt / args.steps, dt_ns / k2], dtype=torch.float64, device=device)
+                dt_ns, _ = dsdist.timed_steps(step_marked, k2, device, world)
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            ev.synchronize()
+            ns_marks.append(ev)
+            ns_steps = sorted(ns_marks[i].elapsed_time(ns_marks[i + 1]) for i in range(k2))
+            med_with = step_stats["median_ms"] if step_stats else dt / args.steps * 1e3
+            t = torch.tensor([dt / args.steps * 1e3, dt_ns / k2 * 1e3, med_with, ns_steps[k2 // 2]], dtype=torch.float64, device=device)
             if dist_.is_initialized():
                 dist_.all_reduce(t, op=dist_.ReduceOp.MAX)
-            dp_info.update(ms_per_step_with_allreduce=round(float(t[0]) * 1e3, 3), ms_per_step_no_sync=round(float(t[1]) * 1e3, 3),
-                           comm_exposed_ms=round(float(t[0] - t[1]) * 1e3, 3), no_sync_steps=k2,
-                           comm_exposed_how="max-over-ranks step time of the timed region minus the same step under DDP.no_sync() "
-                                            "(%d steps right after it): exposed all-reduce tail + its contention with the sweeps" % k2)
+            dp_info.update(ms_per_step_with_allreduce=round(float(t[0]), 3), ms_per_step_no_sync=round(float(t[1]), 3),
+                           median_ms_with_allreduce=round(float(t[2]), 3), median_ms_no_sync=round(float(t[3]), 3),
+                           comm_exposed_ms=round(float(t[2] - t[3]), 3), comm_exposed_ms_from_means=round(float(t[0] - t[1]), 3),
+                           no_sync_steps=k2,
+                           comm_exposed_how="max-over-ranks MEDIAN per-step device time of the timed region minus the same step under "
+                                            "DDP.no_sync() (%d steps right after it): exposed all-reduce tail + its contention with the "
+                                            "sweeps; the means are given too (one host-side stall in a 20-step window moves them by ms)" % k2)
         mine = {"rank": rank, "device": torch.cuda.get_device_name(device), "uuid": str(getattr(torch.cuda.get_device_properties(device), "uuid", "?")),
                 "pci_bus_id": getattr(torch.cuda.get_device_properties(device), "pci_bus_id", None),
                 "step_ms_min": step_stats["min_ms"] if step_stats else None, "step_ms_median": step_stats["median_ms"] if step_stats else None,

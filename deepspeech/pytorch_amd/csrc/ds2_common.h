@@ -42,6 +42,10 @@ __device__ __host__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
 // two fp32 -> packed bf16x2 (lo in bits 15:0) in ONE instruction: gfx950's v_cvt_pk_bf16_f32 (round-to-nearest-even,
 // NaN stays NaN).  The portable bit-twiddling version above costs ~10 instructions and an exec-mask branch per value
 // (the NaN test), which dominated the epilogues of latency-bound kernels.
+// (Round 5, measured and not adopted: `__builtin_convertvector(float2 -> bf16x2)` lowers to the same single instruction and lets the
+// compiler schedule and if-convert it, but the sweeps' forward kernels came out 1.5-4 % slower with it (profiles/r05h_ab_sweep_timing.txt).
+// With the asm form, never write `cond ? pack(a, b) : pack(b, a)`: the statement cannot be if-converted and becomes a divergent branch
+// diamond -- select the operands, then pack once.)
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
   uint32_t r;
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));

@@ -1517,10 +1517,13 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd4(PArgs a) {
 #pragma unroll
       for (int g = 0; g < G; ++g) go[g] = dpp_xor1(gx[g]);
       const float gn_o = dpp_xor1(gn);
+      // (selects in front of ONE pack per plane: the pack is an asm statement, which the compiler cannot if-convert -- written as
+      // `e == 0 ? pack(a, b) : pack(b, a)` every plane became a divergent branch diamond in front of the publish)
+      // BPTT 1.63 -> 1.55 us per time step (GRU), 2.12 -> 2.01 (LSTM): profiles/r05h_ab_sweep_timing.txt
       uint32_t pk[G];
 #pragma unroll
-      for (int g = 0; g < G; ++g) pk[g] = e == 0 ? pack_bf16x2(gx[g], go[g]) : pack_bf16x2(go[g], gx[g]);
-      const uint32_t pkn = e == 0 ? pack_bf16x2(gn, gn_o) : pack_bf16x2(gn_o, gn);
+      for (int g = 0; g < G; ++g) pk[g] = pack_bf16x2(e == 0 ? gx[g] : go[g], e == 0 ? go[g] : gx[g]);
+      const uint32_t pkn = pack_bf16x2(e == 0 ? gn : gn_o, e == 0 ? gn_o : gn);
 #ifdef DS2_QUAD_STORES
       u32x4q pubv[G], stv[G];
 #pragma unroll
