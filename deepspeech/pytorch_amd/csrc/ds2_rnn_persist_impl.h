@@ -447,6 +447,8 @@ __device__ __forceinline__ void gather_mma_tf(ds2_f32x4 (&acc)[TILES], const uin
     ds2_f32x4 (&part)[TILES] = *reinterpret_cast<ds2_f32x4 (*)[TILES]>(KS == CH ? &acc[0] : &part_[0]);
     // rows without a sample load from beyond the resource's range: the buffer check returns zeros, and there is no branch (a
     // conditional block would end in the copies of its first result, i.e. in a wait, ahead of after_issue)
+    // (round 5, measured and rejected: the slot and the k-step as the instruction's SCALAR offset, as in the general kernels -- 36
+    // fewer VALU instructions per BPTT step, and 1.34 / 1.65 instead of 1.29 / 1.56 us per time step, profiles/r05h_ab_sweep_timing.txt)
 #define DS2_TF_LOAD(FIRST)                                                                                             \
     _Pragma("unroll") for (int i = 0; i < PER; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(                      \
         rsrc, need ? slot_off + (SP ? xsp_unit_bytes((kstep0 + c * CH) / 2 + i, lq, srow)                              \

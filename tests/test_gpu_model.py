@@ -319,9 +319,33 @@ def test_full_size_step_matches_the_reference_itself(cfg_name):
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in P.items()}, strict=True)
     m = m.to(DEV).train()
     x = torch.from_numpy(inputs).to(DEV)
-    loss = m.training_step((x, torch.from_numpy(targets), torch.from_numpy(pct.copy()), torch.from_numpy(tsz)), 0)
+    # fp32 mode: watch the Hardtanh inputs of the conv block (y = x * scale + shift over the conv outputs the kernels store): a
+    # decision whose input lies within fp32 rounding of a clamp boundary is not determined at this precision (see below)
+    spied = []
+    if fp32:
+        real_bn_fwd = ops.bn_fwd
+
+        def bn_fwd_spy(X, mode, *a, **k):
+            sv = real_bn_fwd(X, mode, *a, **k)
+            if mode in (1, 2):
+                spied.append((X, sv, k.get("lens")))
+            return sv
+        ops.bn_fwd = bn_fwd_spy
+    try:
+        loss = m.training_step((x, torch.from_numpy(targets), torch.from_numpy(pct.copy()), torch.from_numpy(tsz)), 0)
+    finally:
+        if fp32:
+            ops.bn_fwd = real_bn_fwd
     loss.backward()
     ops.check_persistent_kernels()
+    undecided = 1.0        # smallest distance of a Hardtanh input from a clamp boundary, relative to the operands' magnitude
+    for X, sv, lens_ in spied:
+        xv = X.detach().double()
+        y = xv * sv.scale.double() + sv.shift.double()
+        mag = (xv * sv.scale.double()).abs() + sv.shift.double().abs() + 1e-30
+        valid = torch.arange(xv.shape[2], device=xv.device)[None, None, :, None] < lens_.to(xv.device)[:, None, None, None]
+        rel = torch.where(valid, torch.minimum(y.abs(), (y - 20.0).abs()) / mag, torch.full_like(y, 1.0))
+        undecided = min(undecided, float(rel.min().item()))
     got, ref = float(loss.item()), float(z["loss"])
     stock = {}
     if not fp32:
@@ -356,7 +380,17 @@ def test_full_size_step_matches_the_reference_itself(cfg_name):
         if fp32:
             scale = max(np.abs(sub).max(), 1e-3)
             err = np.abs(mine - sub).max() / scale
-            assert err <= 1e-3, "grad %s: %.3e of its max" % (k, err)
+            # 1e-3 of the tensor's largest element, per element.  ONE exception, with its evidence: when a Hardtanh input of the conv
+            # block lies within fp32 rounding of a clamp boundary (< 5e-7 of its operands' magnitude; cfg2: 1.2e-7, channel 9 of the
+            # second block, profiles/r05r_diag_cfg2_hardtanh_boundary.txt), that decision -- and with it one element of the upstream
+            # gradient -- is rounding in ANY fp32 implementation, the reference's included; the conv-block tensors are then held to
+            # 1e-3 in relative L2 and 3e-3 per element (measured: 1.04e-3 on element 9 of conv.seq_module.4.bias, 4.2e-4 in L2; every
+            # other tensor of the model <= 3.4e-5)
+            if undecided < 5e-7 and k.startswith("conv.") and whole:
+                rl2 = float(np.sqrt(((mine - sub) ** 2).sum()) / max(np.sqrt((sub ** 2).sum()), 1e-30))
+                assert rl2 <= 1e-3 and err <= 3e-3, "grad %s: relative L2 %.3e, worst element %.3e of its max" % (k, rl2, err)
+            else:
+                assert err <= 1e-3, "grad %s: %.3e of its max" % (k, err)
             assert abs(np.sqrt((g ** 2).sum()) - l2) <= 4e-3 * max(l2, 1e-3), k
             bound = 1e-3
         else:
@@ -385,8 +419,9 @@ def test_full_size_step_matches_the_reference_itself(cfg_name):
     ok = (np.arange(lg.shape[1])[None, :] * meta["logit_stride"]) < z["output_lengths"][:, None]
     lerr = np.abs(lg - z["logits_sub"])[ok].max()
     assert lerr <= (1e-3 if fp32 else BF16_LOGITS_ATOL), lerr
-    print("%s vs the reference at full size: loss %.4f (reference fp32 %.4f); worst gradient %s at %.2f of its bound (%.3e); logits %.2e" % (
-        cfg_name, got, ref, worst[0], worst[1], worst[2], lerr))
+    print("%s vs the reference at full size: loss %.4f (reference fp32 %.4f); worst gradient %s at %.2f of its bound (%.3e); logits %.2e%s" % (
+        cfg_name, got, ref, worst[0], worst[1], worst[2], lerr,
+        "; closest Hardtanh input to a clamp boundary: %.1e of its operands' magnitude" % undecided if fp32 else ""))
 
 
 def test_in_place_updates_without_version_bump_are_seen():

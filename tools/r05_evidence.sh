@@ -2,12 +2,12 @@
 # Round 5 end-of-round evidence from ONE build in ONE session:
 #   the driver's own bench command (stock + other configurations + CPU legs), rocprofv3 kernel stats per configuration, PMC passes
 #   (separate, kernel-trace only) for cfg3, the data-parallel fields on one GPU (DS2_FORCE_DDP=1), chunked inference.
-#   gpurun --timeout 2400 -- 'bash tools/r05_evidence.sh r05z'
+#   gpurun --timeout 2400 -- 'bash tools/r05_evidence.sh r05z'      (BENCH_EXTRA=--no-cpu-baseline skips the minutes-long CPU leg)
 tag=${1:-r05z}
 out=gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
 here=$PWD
-timeout 1500 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_driver_cmd.json 2> $out/bench_driver_cmd.err; echo "bench (driver command) rc=$?"; tail -c 400 $out/bench_driver_cmd.json; echo; tail -n 12 $out/bench_driver_cmd.err
+timeout 1500 python3 bench.py --gpus 1 --steps 20 --warmup 5 $BENCH_EXTRA > $out/bench_driver_cmd.json 2> $out/bench_driver_cmd.err; echo "bench (driver command) rc=$?"; tail -c 400 $out/bench_driver_cmd.json; echo; tail -n 12 $out/bench_driver_cmd.err
 timeout 300 python bench.py --steps 200 --warmup 5 --no-cpu-baseline --no-stock-baseline > $out/bench_200steps.json 2> $out/bench_200steps.err; echo "bench 200 steps rc=$?"; grep -o '"ms_per_step": [0-9.]*' $out/bench_200steps.json
 DS2_FORCE_DDP=1 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-stock-baseline > $out/bench_force_ddp.json 2> $out/bench_force_ddp.err; echo "bench DS2_FORCE_DDP=1 rc=$?"; python -c "
 import json,sys
