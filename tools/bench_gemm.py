@@ -36,6 +36,17 @@ for name, M, N, K, f32, sk in shapes:
     ref = (A[rows].float() @ B.float().t())
     err = (C[rows].float() - ref).abs().max().item() / ref.abs().max().item()
     assert err < (1e-5 if f32 else 6e-3), (name, err)
+    if not f32:   # yard-stick only (never on the product path): the vendor library (hipBLASLt behind torch.matmul) on the same operands
+        ts = []
+        for it in range(12):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            Cl = torch.matmul(A, B.t())
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        t = sorted(ts[2:])[len(ts[2:]) // 2]
+        print("   vendor library (torch.matmul, bf16):   %.3f ms  %.0f TFLOP/s" % (t, 2.0 * M * N * K / t / 1e9))
     if K % 64 == 0 and N >= 256:
         ts = []
         for it in range(12):
@@ -135,3 +146,27 @@ for rnd in range(6):
 t0, t1 = sorted(res[0][1:])[2], sorted(res[1][1:])[2]
 print("grouped TN wgrad     four pieces in phases 2,3: %.3f ms %.0f TFLOP/s | two pieces per phase: %.3f ms %.0f TFLOP/s" % (t0, fl / t0 / 1e9, t1, fl / t1 / 1e9))
 lib.ds2_gemm8_set_variant(0)
+
+# yard-stick: the vendor library on the TN weight-gradient product and on config 5a's input projection (bf16 results; the kernels of
+# this repository accumulate and store the weight gradients in fp32)
+def _time(fn, n=10):
+    ts = []
+    for it in range(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return sorted(ts[2:])[len(ts[2:]) // 2]
+
+
+t = _time(lambda: torch.matmul(dGI.t(), X))
+print("vendor library, TN dW_ih of one cfg3 layer (M=6144 N=1024 K=%d): %.3f ms  %.0f TFLOP/s" % (R, t, 2.0 * R * 6 * H * H / t / 1e9))
+M5, N5, K5 = 64 * 751, 2 * 4 * 1280, 1280
+A5 = torch.randn(M5, K5, device=dev).to(torch.bfloat16)
+B5 = torch.randn(N5, K5, device=dev).to(torch.bfloat16)
+t = _time(lambda: torch.matmul(A5, B5.t()))
+print("cfg5a i2h M=%d N=%d K=%d vendor library: %.3f ms  %.0f TFLOP/s" % (M5, N5, K5, t, 2.0 * M5 * N5 * K5 / t / 1e9))
+t = _time(lambda: ops.gemm8_nt(A5, B5))
+print("cfg5a i2h M=%d N=%d K=%d gemm8:          %.3f ms  %.0f TFLOP/s" % (M5, N5, K5, t, 2.0 * M5 * N5 * K5 / t / 1e9))
