@@ -630,36 +630,75 @@ __device__ __forceinline__ uint4 cw_window(const uint4& lo, const uint4& hi) {
 // e = wave + 3 + 4 i the dword offset is (1 + 2 i) + ((wave + 1) >> 1) and the parity that of wave + 1 -- wave-uniform values, so
 // the windows are selections + v_alignbyte with a register shift and the code is the same for the four waves (a switch over
 // per-wave instantiations made hipcc keep several copies of the accumulators: spills).
+// Round 5: the tile loop is a software pipeline.  Until then a k-step was "three LDS reads, 28 VALU instructions of window selection,
+// then 12 MFMAs with an LDS read in front of every third one" -- with one wave per SIMD nothing covered the waits, and around it stood
+// ~380 instructions of 64-bit address arithmetic per tile and 48 v_and of edge masks (10 000 cycles per tile for 3 072 cycles of matrix
+// pipe: 22 % of the MFMA rate, profiles/r05zz_roofline_cfg3.md).  Now (a) the staged operands come through buffer loads: the tile's row
+// base is the SCALAR offset, the lane's position offset is computed once per tile, and a position or row that does not exist is an
+// out-of-range offset (zeros, no mask); (b) inside the tile the LDS reads run two k-steps (X) / one k-step (dY^T) ahead and the windows
+// of k-step ks + 1 are selected between the MFMAs of k-step ks (sched_group_barrier pins the interleave: MFMA, LDS read, 3 VALU).
+// The summation order is unchanged: results are bit-identical to the round-2 form.
+typedef uint32_t cw_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int CW_OOB = 0x7ffffff0;
+
+// (operands as VALUES: a conditional expression over array elements is control flow to the front end, and is not always if-converted)
+__device__ __forceinline__ uint32_t cw_sel(bool c, uint32_t a, uint32_t b) { return c ? a : b; }
+__device__ __forceinline__ void cwr_windows(uint4 (&w)[3], const uint4& q0, const uint4& q1, const uint4& q2, int delta, uint32_t sh) {
+  const uint32_t D[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int b = 1 + 2 * i;
+    uint32_t X[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const uint32_t c2 = b + j + 2 < 12 ? D[b + j + 2] : 0u;      // only read for delta = 2, j = 4, i = 2: the non-existent tap
+      X[j] = cw_sel(delta == 0, D[b + j], cw_sel(delta == 1, D[b + j + 1], c2));
+    }
+    w[i] = make_uint4(__builtin_amdgcn_alignbyte(X[1], X[0], sh), __builtin_amdgcn_alignbyte(X[2], X[1], sh),
+                      __builtin_amdgcn_alignbyte(X[3], X[2], sh), __builtin_amdgcn_alignbyte(X[4], X[3], sh));
+  }
+}
+
 template <int R>
 __device__ __forceinline__ void cwr_multiply(ds2_f32x16 (&acc)[R][3], const uint16_t* sdy, const uint16_t* sx, int li, int lq, int wave) {
-  const int delta = (wave + 1) >> 1;
+  int delta = (wave + 1) >> 1;
+  // wave-uniform, but the compiler must not know: it turns selections on a uniform value into a tree of scalar BRANCHES around every
+  // window (one basic block per tap and k-step: no schedule left).  As a per-lane value they are two v_cndmask on loop-invariant masks.
+  asm volatile("" : "+v"(delta));
   const uint32_t sh = (wave & 1) ? 0u : 2u;
+  const uint16_t* xb = sx + li * CWB_X_LD + lq * 8;          // k-step ks: + 16 ks elements
+  const uint16_t* ab = sdy + li * CWB_DY_LD + 8 * lq;        // k-step ks: + 16 ks; kernel row r: + r * CH * CWB_DY_LD
+  uint4 q[2][3], w[2][3], a[2][R];
+  auto load_q = [&](uint4 (&d)[3], int ks) {
+    d[0] = *reinterpret_cast<const uint4*>(xb + 16 * ks);
+    d[1] = *reinterpret_cast<const uint4*>(xb + 16 * ks + 8);
+    d[2] = *reinterpret_cast<const uint4*>(xb + 16 * ks + 16);
+  };
+  auto load_a = [&](uint4 (&d)[R], int ks) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) d[r] = *reinterpret_cast<const uint4*>(ab + r * CH * CWB_DY_LD + 16 * ks);
+  };
+  load_q(q[0], 0);
+  load_q(q[1], 1);
+  load_a(a[0], 0);
+  cwr_windows(w[0], q[0][0], q[0][1], q[0][2], delta, sh);
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) {
-    const uint16_t* xb = sx + li * CWB_X_LD + (2 * ks + lq) * 8;
-    const uint4 q0 = *reinterpret_cast<const uint4*>(xb);
-    const uint4 q1 = *reinterpret_cast<const uint4*>(xb + 8);
-    const uint4 q2 = *reinterpret_cast<const uint4*>(xb + 16);
-    const uint32_t D[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
-    uint4 w[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int b = 1 + 2 * i;
-      uint32_t X[5];
-#pragma unroll
-      for (int j = 0; j < 5; ++j) {
-        const uint32_t c2 = b + j + 2 < 12 ? D[b + j + 2] : 0u;      // only read for delta = 2, j = 4, i = 2: the non-existent tap
-        X[j] = delta == 0 ? D[b + j] : (delta == 1 ? D[b + j + 1] : c2);
-      }
-      w[i] = make_uint4(__builtin_amdgcn_alignbyte(X[1], X[0], sh), __builtin_amdgcn_alignbyte(X[2], X[1], sh),
-                        __builtin_amdgcn_alignbyte(X[3], X[2], sh), __builtin_amdgcn_alignbyte(X[4], X[3], sh));
-    }
+    const int c = ks & 1, n = c ^ 1;
+    if (ks + 1 < 8) load_a(a[n], ks + 1);                    // first: the LDS slots of the pipeline are filled in program order
+    if (ks + 2 < 8) load_q(q[c], ks + 2);                    // q[c] held k-step ks: its windows are in w[c] already
+    if (ks + 1 < 8) cwr_windows(w[n], q[n][0], q[n][1], q[n][2], delta, sh);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const uint4 a = *reinterpret_cast<const uint4*>(sdy + (r * CH + li) * CWB_DY_LD + 16 * ks + 8 * lq);
-      Mma<bf16_t>::mma32(acc[r][0], a, w[0]);
-      Mma<bf16_t>::mma32(acc[r][1], a, w[1]);
-      Mma<bf16_t>::mma32(acc[r][2], a, w[2]);
+      Mma<bf16_t>::mma32(acc[r][0], a[c][r], w[c][0]);
+      Mma<bf16_t>::mma32(acc[r][1], a[c][r], w[c][1]);
+      Mma<bf16_t>::mma32(acc[r][2], a[c][r], w[c][2]);
+    }
+#pragma unroll
+    for (int m = 0; m < 3 * R; ++m) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // at most one LDS read
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);     // at most three VALU instructions in its shadow
     }
   }
 }
@@ -687,14 +726,14 @@ __global__ void __launch_bounds__(256, 1) k_conv2_wgrad_bf16r(const bf16_t* __re
       for (int e = 0; e < 16; ++e) acc[r][i][e] = 0.f;
   const int ntiles = (Tp + CW_TB - 1) / CW_TB;
   constexpr int NJ = F2 + R - 1;             // j = 0 .. 40 + R - 1: kernel row r pairs with output row j - r
-  const long nwork = (long)N * NJ * ntiles;
-  auto decode = [&](long wk, int& n, int& j, int& t0) {
-    const int q = (int)(wk / ntiles);
-    t0 = (int)(wk % ntiles) * CW_TB;
+  const int nwork = N * NJ * ntiles;         // (the host bounds both tensors by 2 GB: far below 2^31 items)
+  auto decode = [&](int wk, int& n, int& j, int& t0) {
+    const int q = wk / ntiles;
+    t0 = (wk - q * ntiles) * CW_TB;
     n = q / NJ;
-    j = q % NJ;
+    j = q - n * NJ;
   };
-  auto next_live = [&](long wk) {            // skip the items whose input row does not exist
+  auto next_live = [&](int wk) {             // skip the items whose input row does not exist
     for (; wk < nwork; wk += gridDim.x) {
       int n, j, t0;
       decode(wk, n, j, t0);
@@ -703,61 +742,60 @@ __global__ void __launch_bounds__(256, 1) k_conv2_wgrad_bf16r(const bf16_t* __re
     }
     return wk;
   };
+  const int row_bytes = Tp * CH * 2;         // one (sample, frequency row) of either tensor
+  const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)dY, 0, N * F2 * row_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)A1, 0, N * F1 * row_bytes, 0x00020000);
   // staging identity: dY item = (position pair tid % 64, channel group tid / 64); X items tid, tid + 256 (< 288)
   const int dy_pp = tid & 63, dy_v = tid >> 6;
   const int x_pp0 = tid % 72, x_v0 = tid / 72;
   const int x_pp1 = (tid + 256) % 72, x_v1 = (tid + 256) / 72;
   const bool x_has1 = tid + 256 < 72 * 4;
-  uint4 g[2 * R + 4];
-  uint32_t gm[2 * R + 4];
-  auto issue = [&](long wk) {
+  cw_u32x4 g[2 * R + 4];
+  auto issue = [&](int wk) {
     int n, j, t0;
     decode(wk, n, j, t0);
     const int fi = 2 * j - 10 + kf0;
-    const bf16_t* xrow = A1 + ((long)n * F1 + fi) * Tp * CH;
+    const int sx_off = __builtin_amdgcn_readfirstlane((n * F1 + fi) * row_bytes);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int t = t0 + 2 * dy_pp + h;
+      const int vdy = t < Tp ? t * (CH * 2) + dy_v * 16 : CW_OOB;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const int fo = j - r;
-        gm[2 * r + h] = (t < Tp && fo >= 0 && fo < F2 && kf0 + 2 * r < K2F) ? 0xffffffffu : 0u;
-        g[2 * r + h] = *reinterpret_cast<const uint4*>(dY + (((long)n * F2 + min(max(fo, 0), F2 - 1)) * Tp + min(t, Tp - 1)) * CH + dy_v * 8);
+        const bool row_ok = fo >= 0 && fo < F2 && kf0 + 2 * r < K2F;                   // workgroup-uniform
+        const int sdy_off = __builtin_amdgcn_readfirstlane(row_ok ? (n * F2 + fo) * row_bytes : 0);
+        g[2 * r + h] = __builtin_amdgcn_raw_buffer_load_b128(rdy, row_ok ? vdy : CW_OOB, sdy_off, 0);
       }
       const int tx = t0 - 8 + 2 * x_pp0 + h;
-      gm[2 * R + h] = (tx >= 0 && tx < Tp) ? 0xffffffffu : 0u;
-      g[2 * R + h] = *reinterpret_cast<const uint4*>(xrow + (long)min(max(tx, 0), Tp - 1) * CH + x_v0 * 8);
+      g[2 * R + h] = __builtin_amdgcn_raw_buffer_load_b128(rx, (unsigned)tx < (unsigned)Tp ? tx * (CH * 2) + x_v0 * 16 : CW_OOB, sx_off, 0);
       const int ty = t0 - 8 + 2 * x_pp1 + h;
-      gm[2 * R + 2 + h] = (x_has1 && ty >= 0 && ty < Tp) ? 0xffffffffu : 0u;
-      g[2 * R + 2 + h] = *reinterpret_cast<const uint4*>(xrow + (long)min(max(ty, 0), Tp - 1) * CH + (x_has1 ? x_v1 : 0) * 8);
+      g[2 * R + 2 + h] = __builtin_amdgcn_raw_buffer_load_b128(rx, (x_has1 && (unsigned)ty < (unsigned)Tp) ? ty * (CH * 2) + x_v1 * 16 : CW_OOB,
+                                                               sx_off, 0);
     }
   };
-  auto put = [&](uint16_t* base, int ld, int v, int pp, const uint4& a, const uint4& b) {   // 8 channels x 2 positions, transposed
+  auto put = [&](uint16_t* base, int ld, int v, int pp, const cw_u32x4& a, const cw_u32x4& b) {   // 8 channels x 2 positions, transposed
     uint32_t* row = reinterpret_cast<uint32_t*>(base + (v * 8) * ld + 2 * pp);
     const int L = ld / 2;
-    row[0 * L] = cw_pair_lo(a.x, b.x); row[1 * L] = cw_pair_hi(a.x, b.x);
-    row[2 * L] = cw_pair_lo(a.y, b.y); row[3 * L] = cw_pair_hi(a.y, b.y);
-    row[4 * L] = cw_pair_lo(a.z, b.z); row[5 * L] = cw_pair_hi(a.z, b.z);
-    row[6 * L] = cw_pair_lo(a.w, b.w); row[7 * L] = cw_pair_hi(a.w, b.w);
+    row[0 * L] = cw_pair_lo(a[0], b[0]); row[1 * L] = cw_pair_hi(a[0], b[0]);
+    row[2 * L] = cw_pair_lo(a[1], b[1]); row[3 * L] = cw_pair_hi(a[1], b[1]);
+    row[4 * L] = cw_pair_lo(a[2], b[2]); row[5 * L] = cw_pair_hi(a[2], b[2]);
+    row[6 * L] = cw_pair_lo(a[3], b[3]); row[7 * L] = cw_pair_hi(a[3], b[3]);
   };
   auto stage = [&]() {
-#pragma unroll
-    for (int i = 0; i < 2 * R + 4; ++i) {
-      g[i].x &= gm[i]; g[i].y &= gm[i]; g[i].z &= gm[i]; g[i].w &= gm[i];
-    }
 #pragma unroll
     for (int r = 0; r < R; ++r) put(sdy + r * CH * CWB_DY_LD, CWB_DY_LD, dy_v, dy_pp, g[2 * r], g[2 * r + 1]);
     put(sx, CWB_X_LD, x_v0, x_pp0, g[2 * R], g[2 * R + 1]);
     if (x_has1) put(sx, CWB_X_LD, x_v1, x_pp1, g[2 * R + 2], g[2 * R + 3]);
   };
 
-  long wk = next_live(split);
+  int wk = next_live(split);
   if (wk < nwork) issue(wk);
   while (wk < nwork) {
     __syncthreads();            // previous tile's fragment reads are done
     stage();
     __syncthreads();
-    const long nxt = next_live(wk + gridDim.x);
+    const int nxt = next_live(wk + gridDim.x);
     if (nxt < nwork) issue(nxt);   // in flight during the MFMAs below
     cwr_multiply<R>(acc, sdy, sx, li, lq, wave);
     wk = nxt;
@@ -1131,7 +1169,9 @@ int ds2_conv2_wgrad(int dtype, const void* dy2, const void* a1, float* dw2t, int
   int f1, f2;
   DS2_REQUIRE(conv_geometry(F0_, f1, f2), DS2_ERR_ARG);
   dim3 grid(K2F, CW_SPLITS);
-  const bool general = dtype == DS2_F32 || F0_ != F0;
+  // (the row-group kernel addresses both tensors through 32-bit buffer offsets: beyond 2 GB -- 64 clips of over two minutes -- the
+  // general kernel takes over)
+  const bool general = dtype == DS2_F32 || F0_ != F0 || (long)N * F1 * Tp * CH * 2 >= (long)CW_OOB;
   if (dtype == DS2_F32) {
     hipLaunchKernelGGL(k_conv2_wgrad<float>, grid, dim3(256), 0, st, (const float*)dy2, (const float*)a1, ws, N, Tp, f1, f2);
   } else if (general) {
