@@ -814,6 +814,245 @@ __global__ void __launch_bounds__(256, 1) k_conv2_wgrad_bf16r(const bf16_t* __re
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The same row-group kernel WITHOUT a transposing stage (round 5).  k_conv2_wgrad_bf16r above moves every operand tile through
+// registers to turn the position-major activations into channel-major LDS images (12 loads, 40 pack instructions and 44 LDS stores
+// per thread and tile, un-overlapped: one wave per SIMD), and then cuts the 11 shifted tap windows out of them on the VALU.  gfx950
+// needs neither:
+//   * `buffer_load_dwordx4 ... lds` copies a tile global -> LDS as it lies in memory ([position][32 channels], 64 B per position:
+//     a wave-instruction = 16 positions = 1 KiB, contiguous on both sides); a position outside the clip or a row that does not exist
+//     is an out-of-range offset and arrives as ZEROS (tools/probe_lds_dma_oob.py, profiles/r05zz_lds_dma_out_of_range.txt).  No
+//     registers, no LDS stores: the next tile lands in the other buffer while this one is multiplied (one barrier per tile), and its
+//     DMA instructions are issued one at a time BETWEEN the MFMAs (ten in one go behind the barrier, from all four waves at once,
+//     wait at the full address queue while the matrix pipe idles: 0.56 -> 0.51 ms);
+//   * `ds_read_b64_tr_b16` hands a lane k = 4 consecutive POSITIONS of one channel out of that layout (16 lanes pass the addresses of
+//     a 4-position x 16-channel block): two reads = one MFMA operand.  A tap shift is a row offset of the read: (wave + 3) * 64 B in
+//     the lane's base register, 4 i * 64 B as an immediate -- no window arithmetic at all.
+// Per k-step and wave: 14 transposing reads (8 for the R dY^T fragments, 6 for the three tap windows), 12 MFMAs, no VALU; the reads
+// of k-step ks + 1 are issued between the MFMAs of k-step ks (inline asm: the compiler would otherwise guard every LDS read against
+// the DMA in flight with a vmcnt(0); every wait is explicit).
+// KSN = k-steps (16 positions) per tile.  KSN = 7: two buffers are 72 KB and the kernel's 256 registers leave room for TWO workgroups
+// per CU -- what one workgroup cannot cover (the barrier, the first fragments of a tile, the scalar bookkeeping) the other one's
+// MFMAs do.  Work map: unit u = (position split, row group), units 64 x .. 64 x + 63 on XCD x (workgroup L runs on XCD L % 8), so
+// that the six row groups of a split are neighbours on ONE XCD, resident together, and walk through the same tiles: a tile comes
+// out of HBM / the Infinity Cache once per XCD and out of that XCD's L2 the other five times.
+// ------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* cw_lds_ptr_t;
+#ifndef CWD_ABL
+#define CWD_ABL 0   // timing-only ablations: 1 no DMA after the first tile, 2 no LDS reads after k-step 0
+#endif
+#ifndef CWD_KSN
+#define CWD_KSN 7
+#endif
+#define CWD_RDTR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+#define CWD_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define CWD_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+constexpr int cwd_dy_bytes(int ksn) { return ksn * 16 * CH * 2; }          // one dY tile [16 KSN positions][32 channels]
+constexpr int cwd_x_bytes(int ksn) { return (ksn + 1) * 16 * CH * 2; }     // X tile: 16 (KSN + 1) positions, position t0 - 8 first
+constexpr int cwd_buf_bytes(int ksn) { return 4 * cwd_dy_bytes(ksn) + cwd_x_bytes(ksn); }
+constexpr int cwd_smem_bytes(int ksn) { return 2 * cwd_buf_bytes(ksn); }
+constexpr int cwd_wgs_per_cu(int ksn) { return 2 * cwd_smem_bytes(ksn) <= 160 * 1024 ? 2 : 1; }
+
+struct CwdFrag {
+  uint2 lo, hi;      // k = 0..3 | 4..7 of the lane's eight positions
+};
+__device__ __forceinline__ uint4 cwd_frag(const CwdFrag& f) { return make_uint4(f.lo.x, f.lo.y, f.hi.x, f.hi.y); }
+
+// the 14 reads of k-step KS into fragment set (FA, FB), numbered 0..13: 2 r + h -> dY^T row r, half h; 8 + 2 i + h -> tap window i
+#define CWD_READ(FA, FB, KS, IDX)                                                                             \
+  do {                                                                                                        \
+    constexpr int idx_ = (IDX);                                                                               \
+    if constexpr ((CWD_ABL & 2) != 0 && (KS) > 0) {                                                           \
+    } else if constexpr (idx_ < 8) {                                                                          \
+      if constexpr (idx_ % 2 == 0) CWD_RDTR(FA[idx_ / 2].lo, aA, (idx_ / 2) * DYB + (KS) * 1024);             \
+      else CWD_RDTR(FA[idx_ / 2].hi, aA, (idx_ / 2) * DYB + (KS) * 1024 + 256);                               \
+    } else if constexpr (idx_ < 14) {                                                                         \
+      if constexpr (idx_ % 2 == 0) CWD_RDTR(FB[(idx_ - 8) / 2].lo, aB, (KS) * 1024 + ((idx_ - 8) / 2) * 256); \
+      else CWD_RDTR(FB[(idx_ - 8) / 2].hi, aB, (KS) * 1024 + ((idx_ - 8) / 2) * 256 + 256);                   \
+    }                                                                                                         \
+  } while (0)
+
+// The NEXT tile's staging, cut into pieces that are issued between the MFMAs of this tile.  Branch-free: without a next tile (or for
+// a row that does not exist) every lane's offset is out of range and the piece writes zeros into the idle buffer.
+struct CwdNext {
+  __amdgpu_buffer_rsrc_t rdy, rx;
+  unsigned char* base;          // the other buffer
+  int soff, sxoff;              // scalar offsets: this wave's dY row, the X row
+  int t0, Tp;
+  bool row_ok, any;             // dY row exists / there is a next tile
+  int wave, lpos, lbyte;
+};
+template <int KSN, int C>
+__device__ __forceinline__ void cwd_dma_dy(const CwdNext& nx) {       // 16 positions of this wave's dY^T tile
+  const int pos = nx.t0 + 16 * C + nx.lpos;
+  const int voff = (nx.row_ok && pos < nx.Tp) ? pos * (CH * 2) + nx.lbyte : CW_OOB;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(nx.rdy, (cw_lds_ptr_t)(nx.base + nx.wave * cwd_dy_bytes(KSN) + C * 1024), 16, voff, nx.soff, 0, 0);
+}
+template <int KSN, int Q>
+__device__ __forceinline__ void cwd_dma_x(const CwdNext& nx) {        // chunk wave + 4 Q of the KSN + 1 X chunks
+  const int c = nx.wave + 4 * Q;
+  if (c < KSN + 1) {                                                  // wave-uniform
+    const int pos = nx.t0 - 8 + 16 * c + nx.lpos;
+    const int voff = (nx.any && (unsigned)pos < (unsigned)nx.Tp) ? pos * (CH * 2) + nx.lbyte : CW_OOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(nx.rx, (cw_lds_ptr_t)(nx.base + 4 * cwd_dy_bytes(KSN) + c * 1024), 16, voff, nx.sxoff, 0, 0);
+  }
+}
+
+template <int KSN, int KS>
+__device__ __forceinline__ void cwd_kstep(ds2_f32x16 (&acc)[4][3], CwdFrag (&fa)[2][4], CwdFrag (&fb)[2][3], uint32_t aA, uint32_t aB,
+                                          const CwdNext& nx) {
+  constexpr int c = KS & 1, n = c ^ 1, DYB = cwd_dy_bytes(KSN);
+  CWD_WAIT_LGKM0();                            // the fragments of this k-step (issued during the previous one) have arrived
+  __builtin_amdgcn_sched_barrier(0);
+#define CWD_SLOT(M)                                                                          \
+  Mma<bf16_t>::mma32(acc[(M) / 3][(M) % 3], cwd_frag(fa[c][(M) / 3]), cwd_frag(fb[c][(M) % 3])); \
+  if constexpr (KS + 1 < KSN) {                                                              \
+    CWD_READ(fa[n], fb[n], KS + 1, 2 * (M));                                                 \
+    CWD_READ(fa[n], fb[n], KS + 1, 2 * (M) + 1);                                             \
+  }                                                                                          \
+  if constexpr (!(CWD_ABL & 1)) {                                                            \
+    if constexpr ((M) == 8) cwd_dma_dy<KSN, KS>(nx);                                         \
+    if constexpr ((M) == 10 && KS < 3) cwd_dma_x<KSN, KS>(nx);                               \
+  }                                                                                          \
+  __builtin_amdgcn_sched_barrier(0);
+  CWD_SLOT(0) CWD_SLOT(1) CWD_SLOT(2) CWD_SLOT(3) CWD_SLOT(4) CWD_SLOT(5)
+  CWD_SLOT(6) CWD_SLOT(7) CWD_SLOT(8) CWD_SLOT(9) CWD_SLOT(10) CWD_SLOT(11)
+#undef CWD_SLOT
+}
+
+constexpr int CWD_UNITS_PER_XCD = 64;     // 85 splits x 6 row groups = 510 units on 8 x 64 workgroup slots
+
+template <int KSN>
+__global__ void __launch_bounds__(256, cwd_wgs_per_cu(KSN)) k_conv2_wgrad_bf16d(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ A1,
+                                                                                float* __restrict__ partial, int N, int Tp, int nsplit) {
+  constexpr int R = 4;        // kernel rows per workgroup = waves: wave r stages dY^T tile r
+  constexpr int TB = 16 * KSN, DYB = cwd_dy_bytes(KSN), BUF = cwd_buf_bytes(KSN);
+  static_assert(KSN >= 3 && KSN <= 8, "X chunks: at most three per wave; DMA pieces: one dY chunk per k-step");
+  const int unit = (blockIdx.x & 7) * CWD_UNITS_PER_XCD + (blockIdx.x >> 3);
+  if (unit >= nsplit * 6) return;
+  const int split = unit / 6, rg = unit - split * 6;
+  const int kf0 = rg < 3 ? 8 * rg : 1 + 8 * (rg - 3);      // row groups {0,2,4,6} {8..14} {16,18,20,-} {1..7} {9..15} {17,19,-,-}
+  extern __shared__ __attribute__((aligned(16))) unsigned char cwd_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31;
+  ds2_f32x16 acc[R][3];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[r][i][e] = 0.f;
+  // work items (sample n, j in [0, 40 + R - 1], tile t) in the order wk = (n * NJ + j) * ntiles + t, every nsplit-th one is ours;
+  // the cursor advances by additions and carries (a division per tile was a tenth of the tile's time in scalar instructions)
+  const int ntiles = (Tp + TB - 1) / TB;
+  constexpr int NJ = F2 + R - 1;
+  struct Cursor {
+    int n, j, t;
+  };
+  const int d_t = nsplit % ntiles, d_q = nsplit / ntiles, d_j = d_q % NJ, d_n = d_q / NJ;
+  auto advance = [&](Cursor& c) {
+    c.t += d_t;
+    if (c.t >= ntiles) { c.t -= ntiles; c.j += 1; }
+    c.j += d_j;
+    if (c.j >= NJ) { c.j -= NJ; c.n += 1; }
+    c.n += d_n;
+  };
+  auto next_live = [&](Cursor c) {              // skip the items whose input row does not exist; c.n >= N: no more work
+    for (; c.n < N; advance(c)) {
+      const int fi = 2 * c.j - 10 + kf0;
+      if (fi >= 0 && fi < F1) break;
+    }
+    return c;
+  };
+  const int row_bytes = Tp * CH * 2;
+  const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)dY, 0, N * F2 * row_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)A1, 0, N * F1 * row_bytes, 0x00020000);
+  const int lpos = lane >> 2, lbyte = (lane & 3) * 16;      // a wave-instruction: 16 positions x 64 B
+  auto plan = [&](const Cursor& c, int b) {    // where a tile comes from and where it goes (scalar work only)
+    CwdNext nx;
+    nx.rdy = rdy;
+    nx.rx = rx;
+    nx.base = cwd_smem + b * BUF;
+    nx.Tp = Tp;
+    nx.wave = wave;
+    nx.lpos = lpos;
+    nx.lbyte = lbyte;
+    nx.any = c.n < N;
+    const int n = nx.any ? c.n : 0;
+    const int fi = min(max(2 * c.j - 10 + kf0, 0), F1 - 1);
+    const int fo = c.j - wave;
+    nx.row_ok = nx.any && fo >= 0 && fo < F2 && kf0 + 2 * wave < K2F;
+    nx.soff = __builtin_amdgcn_readfirstlane(nx.row_ok ? (n * F2 + fo) * row_bytes : 0);
+    nx.sxoff = __builtin_amdgcn_readfirstlane((n * F1 + fi) * row_bytes);
+    nx.t0 = c.t * TB;
+    return nx;
+  };
+  // transposing reads: the 16-lane group gq = lane >> 4 covers channels 16 (gq & 1) .. + 15 and the positions 8 (gq >> 1) + {0..3 | 4..7}
+  // of a k-step; lane i of the group passes the address of (position i / 4, channels 4 (i % 4) .. + 3) and receives its own channel
+  const int l16 = lane & 15, gq = lane >> 4;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)cwd_smem;
+  const uint32_t la = lds0 + (8 * (gq >> 1) + (l16 >> 2)) * (CH * 2) + (16 * (gq & 1) + 4 * (l16 & 3)) * 2;
+  const uint32_t lb = la + R * DYB + (wave + 3) * (CH * 2);      // tap kt = wave + 4 i reads X row p + kt + 3 (the tile starts at t0 - 8)
+  CwdFrag fa[2][R], fb[2][3];
+
+  Cursor cur;
+  {
+    const int q0 = split / ntiles;
+    cur.t = split - q0 * ntiles;
+    cur.n = q0 / NJ;
+    cur.j = q0 - cur.n * NJ;
+  }
+  cur = next_live(cur);
+  int b = 0;
+  if (cur.n < N) {
+    const CwdNext first = plan(cur, 0);
+    cwd_dma_dy<KSN, 0>(first); cwd_dma_dy<KSN, 1>(first); cwd_dma_dy<KSN, 2>(first);
+    if constexpr (KSN > 3) cwd_dma_dy<KSN, 3>(first);
+    if constexpr (KSN > 4) cwd_dma_dy<KSN, 4>(first);
+    if constexpr (KSN > 5) cwd_dma_dy<KSN, 5>(first);
+    if constexpr (KSN > 6) cwd_dma_dy<KSN, 6>(first);
+    if constexpr (KSN > 7) cwd_dma_dy<KSN, 7>(first);
+    cwd_dma_x<KSN, 0>(first); cwd_dma_x<KSN, 1>(first); cwd_dma_x<KSN, 2>(first);
+  }
+  while (cur.n < N) {
+    Cursor nc = cur;
+    advance(nc);
+    nc = next_live(nc);
+    const CwdNext nx = plan(nc, b ^ 1);        // (scalar: before the wait, not behind it)
+    CWD_WAIT_VM0();                            // this wave's share of the tile has landed ...
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();              // ... and everybody's; everybody is done with the other buffer
+    __builtin_amdgcn_sched_barrier(0);
+    const uint32_t aA = la + b * BUF, aB = lb + b * BUF;
+#define CWD_FIRST(IDX) CWD_READ(fa[0], fb[0], 0, IDX);
+    CWD_FIRST(0) CWD_FIRST(1) CWD_FIRST(2) CWD_FIRST(3) CWD_FIRST(4) CWD_FIRST(5) CWD_FIRST(6)
+    CWD_FIRST(7) CWD_FIRST(8) CWD_FIRST(9) CWD_FIRST(10) CWD_FIRST(11) CWD_FIRST(12) CWD_FIRST(13)
+#undef CWD_FIRST
+    cwd_kstep<KSN, 0>(acc, fa, fb, aA, aB, nx);
+    cwd_kstep<KSN, 1>(acc, fa, fb, aA, aB, nx);
+    cwd_kstep<KSN, 2>(acc, fa, fb, aA, aB, nx);
+    if constexpr (KSN > 3) cwd_kstep<KSN, 3>(acc, fa, fb, aA, aB, nx);
+    if constexpr (KSN > 4) cwd_kstep<KSN, 4>(acc, fa, fb, aA, aB, nx);
+    if constexpr (KSN > 5) cwd_kstep<KSN, 5>(acc, fa, fb, aA, aB, nx);
+    if constexpr (KSN > 6) cwd_kstep<KSN, 6>(acc, fa, fb, aA, aB, nx);
+    if constexpr (KSN > 7) cwd_kstep<KSN, 7>(acc, fa, fb, aA, aB, nx);
+    cur = nc;
+    b ^= 1;
+  }
+  // every wave owns its taps: straight to partial[split][kf][kt][co][ci]
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int kt = wave + 4 * i;
+      if (kt < K2T && kf0 + 2 * r < K2F) {
+        float* out = partial + (((long)split * K2F + (kf0 + 2 * r)) * K2T + kt) * (CH * CH);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) out[mma32_row(e, lane) * 32 + li] = acc[r][i][e];
+      }
+    }
+}
+
 // ============================================================================================================
 // conv2 forward / dgrad for bf16 storage with the TAPS RESIDENT IN REGISTERS.
 // k_conv_tap above is LDS-bound: every MFMA reads a fresh weight fragment and a fresh activation fragment (2 KB of LDS per
@@ -1177,7 +1416,12 @@ int ds2_conv2_wgrad(int dtype, const void* dy2, const void* a1, float* dw2t, int
   } else if (general) {
     hipLaunchKernelGGL(k_conv2_wgrad<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dy2, (const bf16_t*)a1, ws, N, Tp, f1, f2);
   } else {
-    hipLaunchKernelGGL(k_conv2_wgrad_bf16r<4>, dim3(CWR_SPLITS, 6), dim3(256), 0, st, (const bf16_t*)dy2, (const bf16_t*)a1, ws, N, Tp);
+    static bool attr[DS2_MAX_DEVICES];
+    constexpr int smem = cwd_smem_bytes(CWD_KSN);
+    if (ds2_first_use_on_device(attr))
+      (void)hipFuncSetAttribute((const void*)k_conv2_wgrad_bf16d<CWD_KSN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipLaunchKernelGGL(k_conv2_wgrad_bf16d<CWD_KSN>, dim3(8 * CWD_UNITS_PER_XCD), dim3(256), smem, st, (const bf16_t*)dy2, (const bf16_t*)a1, ws, N,
+                       Tp, CWR_SPLITS);
   }
   DS2_CHECK_LAUNCH();
   const int C = K2F * K2T * CH * CH;
