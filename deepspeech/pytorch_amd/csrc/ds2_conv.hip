@@ -1080,10 +1080,76 @@ struct RTapArgs {
 };
 constexpr int RT_FB = 4, RT_TB = 32, RT_PC = RT_TB + K2T - 1;        // tile: 4 output rows x 32 frames; 42 patch columns
 constexpr int RT_KFM = 11, RT_PR = RT_FB - 1 + RT_KFM;               // <= 11 kernel rows -> <= 14 patch rows
-constexpr int RT_PATCH = RT_PR * RT_PC * CT_POSB;                    // 47040 bytes (80-byte positions: conflict-free b128 reads)
+// (round 5) the patch travels global -> LDS by DMA (`buffer_load_dwordx4 ... lds`: no registers, no commit phase, out-of-range
+// positions and rows arrive as zeros), one wave-instruction per 16 positions = 1 KiB, so a patch row is staged as 48 positions of
+// 64 B (the last six are never loaded or read).  Without padding between positions a fragment read (32 positions x one 16-byte chunk)
+// would hit every bank four times; the 16-byte chunks of position p are therefore stored in the order c ^ ((p >> 2) & 3) -- which the
+// DMA does on its SOURCE side (lane l of a chunk fetches channel chunk (l & 3) ^ (l >> 4)): with ds_read_b128's lane groups
+// {0-3, 12-15, 20-27}, ... the sixteen lanes of a group then touch sixteen different 16-byte slots of the 256-byte bank row.
+constexpr int RT_PCD = 48, RT_ROWB = RT_PCD * CH * 2;                // staged positions per patch row; 3 072 bytes
+constexpr int RT_PATCH = RT_PR * RT_ROWB;                            // 43 008 bytes
 constexpr int RT_RED = 4 * RT_FB * 4096;                             // partial sums [wave][row][4][64 lanes] x 16 bytes
-constexpr int RT_SMEM = 2 * RT_PATCH + RT_RED;                       // 159616
-constexpr int RT_NLOAD = (RT_PR * RT_PC * 4 + 255) / 256;            // 16-byte patch chunks per thread: 10
+constexpr int RT_SMEM = 2 * RT_PATCH + RT_RED;                       // 151 552
+#define RT_RD128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+
+struct RtNext {                 // the tile whose patch is being staged (into the other buffer) while this one is multiplied
+  __amdgpu_buffer_rsrc_t rx;
+  unsigned char* patch;
+  int n, ub, tb;                // tile coordinates; n < 0: no such tile (every lane out of range)
+  int Fin, Tp, PF, ISF, IQ;
+  int wave, lane;
+};
+// piece I of this wave: chunk I % 3 (16 positions) of patch row wave + 4 (I / 3) -- row offset and chunk are compile-time, what is left
+// per piece is a handful of scalar instructions (a division of the chunk number by 3 and the row test per piece were 35: 385 SALU
+// instructions per tile, issued where only one to four MFMAs are queued behind them)
+template <int PR, int I>
+__device__ __forceinline__ void rt_dma_piece(const RtNext& nx) {
+  constexpr int k = I % 3;
+  const int pr = nx.wave + 4 * (I / 3);
+  if (pr < PR) {                                                     // wave-uniform
+    const int fi = (nx.ub * RT_FB + pr - nx.PF) * nx.ISF + nx.IQ;
+    const bool row_ok = nx.n >= 0 && fi >= 0 && fi < nx.Fin;
+    const int soff = __builtin_amdgcn_readfirstlane(row_ok ? (nx.n * nx.Fin + fi) * (nx.Tp * CH * 2) : 0);
+    const int pc = 16 * k + (nx.lane >> 2), ti = nx.tb * RT_TB - 5 + pc;
+    const int voff = (row_ok && pc < RT_PC && (unsigned)ti < (unsigned)nx.Tp) ? ti * (CH * 2) + (((nx.lane & 3) ^ (nx.lane >> 4)) << 4) : CW_OOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(nx.rx, (cw_lds_ptr_t)(nx.patch + pr * RT_ROWB + k * 1024), 16, voff, soff, 0, 0);
+  }
+}
+template <int PR, int I>
+__device__ __forceinline__ void rt_dma_all(const RtNext& nx) {
+  rt_dma_piece<PR, I>(nx);
+  if constexpr (I + 1 < 12) rt_dma_all<PR, I + 1>(nx);
+}
+constexpr int RT_AH = 4;          // steps a fragment is read ahead of its MFMAs (two: a step of one or two MFMAs is shorter than the LDS)
+template <int ST>
+__device__ __forceinline__ void rt_prefetch(uint4 (&bq)[RT_AH + 1], const uint32_t (&aj)[6]) {
+  RT_RD128(bq[ST], aj[ST % 6], (ST / 6) * RT_ROWB);
+  if constexpr (ST + 1 < RT_AH) rt_prefetch<ST + 1>(bq, aj);
+}
+// step ST = (input row rho, contraction item j) of a tile: the read of step ST + AH, the wait for this step's fragment, its MFMAs
+// (one per output row that uses input row rho), now and then a DMA piece of the next tile.  Compile-time recursion: every LDS offset
+// is an immediate and every branch below folds.
+template <int KF, int ST>
+__device__ __forceinline__ void rt_step(ds2_f32x16 (&acc)[RT_FB], const uint4 (&A)[KF][6], uint4 (&bq)[RT_AH + 1], const uint32_t (&aj)[6],
+                                        const RtNext& nx) {
+  constexpr int PR = RT_FB - 1 + KF, NS = PR * 6, rho = ST / 6, j = ST % 6;
+  if constexpr (ST + RT_AH < NS) RT_RD128(bq[(ST + RT_AH) % (RT_AH + 1)], aj[(ST + RT_AH) % 6], ((ST + RT_AH) / 6) * RT_ROWB);
+  constexpr int left = RT_AH < NS - 1 - ST ? RT_AH : NS - 1 - ST;      // reads that may still be in flight behind this step's fragment
+  if constexpr (left >= 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+  else if constexpr (left == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+  else if constexpr (left == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+  else if constexpr (left == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+  else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int fl = 0; fl < RT_FB; ++fl) {
+    const int m = rho - fl;
+    if (m >= 0 && m < KF) Mma<bf16_t>::mma32(acc[fl], A[m][j], bq[ST % (RT_AH + 1)]);
+  }
+  if constexpr (ST % 6 == 3 && ST >= 9 && (ST - 9) / 6 < 12) rt_dma_piece<PR, (ST - 9) / 6>(nx);   // behind an MFMA group of the middle rows
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (ST + 1 < NS) rt_step<KF, ST + 1>(acc, A, bq, aj, nx);
+}
 
 template <int KF>   // kernel rows of the launch (11 or 10): compile-time, so that the MFMA loop is straight-line code
 __global__ void __launch_bounds__(256, 1) k_conv_rtap(RTapArgs a) {
@@ -1096,11 +1162,13 @@ __global__ void __launch_bounds__(256, 1) k_conv_rtap(RTapArgs a) {
   // every MFMA group)
   const int i0 = wave < 2 ? 6 * wave : 12 + 5 * (wave - 2), icnt = wave < 2 ? 6 : 5;
   uint4 A[KF][6];
-  int boff[6];                                   // byte offset of item j's activation fragment inside a patch row
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)rsm;
+  uint32_t boff[6];                              // LDS byte address of item j's activation fragment in patch row 0 of buffer 0
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
     const int item = i0 + min(j, icnt - 1), kt = item >> 1, half = item & 1;
-    boff[j] = (li + kt) * CT_POSB + half * 32 + lq * 16;
+    const int p = li + kt;
+    boff[j] = lds0 + p * (CH * 2) + (((half * 2 + lq) ^ ((p >> 2) & 3)) << 4);
 #pragma unroll
     for (int m = 0; m < KF; ++m) {
       const uint4 wv = *reinterpret_cast<const uint4*>(a.W + (((long)(m * a.WSF + a.WQ) * K2T + kt) * CH + li) * CH + half * 16 + lq * 8);
@@ -1108,68 +1176,50 @@ __global__ void __launch_bounds__(256, 1) k_conv_rtap(RTapArgs a) {
     }
   }
   constexpr int PR = RT_FB - 1 + KF;
+  constexpr int NPIECE = 12;                     // DMA pieces per wave and tile: up to four patch rows x three chunks
   const int nub = ds2_cdiv_dev(a.U, RT_FB), ntb = ds2_cdiv_dev(a.Tp, RT_TB);
   const int total = a.N * nub * ntb;
-
-  // ---- patch prefetch: chunk i = tid + 256*it -> (position i>>2, 16-byte chunk i&3); the validity bits travel with the data
-  uint4 pf[RT_NLOAD];
-  unsigned pmask = 0;
-  auto issue = [&](int tile) {
-    const int tb = tile % ntb, ub = (tile / ntb) % nub, n = tile / (ntb * nub);
-    const bf16_t* Xn = a.X + (long)n * a.Fin * a.Tp * CH;
-    pmask = 0;
-#pragma unroll
-    for (int it = 0; it < RT_NLOAD; ++it) {
-      const int i = min(tid + it * 256, RT_PR * RT_PC * 4 - 1);
-      const int v = i & 3, pos = i >> 2;
-      const int pr = pos / RT_PC, pc = pos - pr * RT_PC;
-      const int fi = (ub * RT_FB + pr - a.PF) * a.ISF + a.IQ, ti = tb * RT_TB - 5 + pc;
-      const bool ok = fi >= 0 && fi < a.Fin && ti >= 0 && ti < a.Tp;
-      pmask |= ok ? (1u << it) : 0u;
-      pf[it] = *reinterpret_cast<const uint4*>(Xn + ((long)min(max(fi, 0), a.Fin - 1) * a.Tp + min(max(ti, 0), a.Tp - 1)) * CH + v * 8);
-    }
-  };
-  auto commit = [&](unsigned char* patch) {
-#pragma unroll
-    for (int it = 0; it < RT_NLOAD; ++it) {
-      const int i = min(tid + it * 256, RT_PR * RT_PC * 4 - 1);
-      const uint32_t mk = (pmask >> it) & 1u ? 0xffffffffu : 0u;
-      uint4 val = pf[it];
-      val.x &= mk; val.y &= mk; val.z &= mk; val.w &= mk;
-      *reinterpret_cast<uint4*>(patch + (i >> 2) * CT_POSB + (i & 3) * 16) = val;
-    }
+  RtNext nx;
+  nx.rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.X, 0, a.N * a.Fin * a.Tp * CH * 2, 0x00020000);
+  nx.Fin = a.Fin; nx.Tp = a.Tp; nx.PF = a.PF; nx.ISF = a.ISF; nx.IQ = a.IQ;
+  nx.wave = wave; nx.lane = lane;
+  auto aim = [&](int tile, int buf) {            // scalar: which tile, which buffer
+    const bool any = tile < total;
+    const int tt = any ? tile : 0;
+    nx.tb = tt % ntb;
+    nx.ub = (tt / ntb) % nub;
+    nx.n = any ? tt / (ntb * nub) : -1;
+    nx.patch = rsm + buf * RT_PATCH;
   };
 
   int tile = blockIdx.x;
   if (tile < total) {
-    issue(tile);
-    __builtin_amdgcn_sched_barrier(0);
-    commit(rsm);
+    aim(tile, 0);
+    rt_dma_all<PR, 0>(nx);
   }
-  __syncthreads();
+  __syncthreads();                               // (waits for the DMA: vmcnt(0) is part of it)
   int buf = 0;
   for (; tile < total; tile += gridDim.x, buf ^= 1) {
     const int tb = tile % ntb, ub = (tile / ntb) % nub, n = tile / (ntb * nub);
     const int next = tile + gridDim.x;
-    if (next < total) issue(next);                       // global -> registers, in flight under the MFMAs below
-    __builtin_amdgcn_sched_barrier(0);
-    const unsigned char* patch = rsm + buf * RT_PATCH;
+    aim(next, buf ^ 1);                          // its pieces are issued between the MFMAs below
     ds2_f32x16 acc[RT_FB];
 #pragma unroll
     for (int fl = 0; fl < RT_FB; ++fl)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[fl][r] = 0.f;
+    // The activation fragments run TWO steps (input row rho, contraction item j) ahead of their MFMAs through three registers.  Inline
+    // asm with explicit waits: the compiler would guard every LDS read it knows of against the DMA in flight with a vmcnt(0) -- and
+    // left to itself it read every fragment into the same four registers and waited for it in front of its MFMAs (84 exposed LDS
+    // latencies per tile, one wave per SIMD).  Same order of summation as before.
+    {
+      uint4 bq[RT_AH + 1];
+      uint32_t aj[6];
 #pragma unroll
-    for (int rho = 0; rho < PR; ++rho) {
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const uint4 b = *reinterpret_cast<const uint4*>(patch + rho * RT_PC * CT_POSB + boff[j]);
-#pragma unroll
-        for (int fl = 0; fl < RT_FB; ++fl) {
-          const int m = rho - fl;
-          if (m >= 0 && m < KF) Mma<bf16_t>::mma32(acc[fl], A[m][j], b);
-        }
-      }
+      for (int j = 0; j < 6; ++j) aj[j] = boff[j] + buf * RT_PATCH;
+      __builtin_amdgcn_sched_barrier(0);
+      rt_prefetch<0>(bq, aj);
+      rt_step<KF, 0>(acc, A, bq, aj, nx);
     }
     // ---- the four waves' partial sums meet: red[wave][row][g][lane] x 16 bytes
 #pragma unroll
@@ -1219,8 +1269,7 @@ __global__ void __launch_bounds__(256, 1) k_conv_rtap(RTapArgs a) {
         }
       }
     }
-    if (next < total) commit(rsm + (buf ^ 1) * RT_PATCH);   // registers -> the other patch buffer (last read two tiles ago)
-    __syncthreads();
+    __syncthreads();                                         // (also: the next tile's patch has landed -- vmcnt(0) is part of it)
   }
 }
 
@@ -1357,7 +1406,8 @@ int ds2_conv2_fwd(int dtype, const void* a1, const void* w2t, const float* b2, c
   DS2_REQUIRE(dtype == DS2_F32 || dtype == DS2_BF16, DS2_ERR_DTYPE);
   int f1, f2;
   DS2_REQUIRE(N > 0 && Tp > 0 && conv_geometry(F0_, f1, f2), DS2_ERR_ARG);
-  if (dtype == DS2_F32 || F0_ != F0) {
+  // (the register-resident tap kernels address their input through 32-bit buffer offsets: beyond 2 GB the general kernel takes over)
+  if (dtype == DS2_F32 || F0_ != F0 || (long)N * F1 * Tp * CH * 2 >= (long)CW_OOB) {
     ConvTapArgs a{a1, w2t, b2, lens, y2, N, Tp, f1, f2, K2F, 2, 10, f2, 1, 0};
     return dtype == DS2_F32 ? conv_tap_launch<float>(a, st) : conv_tap_launch<bf16_t>(a, st);
   }
@@ -1379,7 +1429,7 @@ int ds2_conv2_dgrad(int dtype, const void* dy2, const void* w2d_even, const void
   DS2_REQUIRE(dtype == DS2_F32 || dtype == DS2_BF16, DS2_ERR_DTYPE);
   int f1, f2;
   DS2_REQUIRE(N > 0 && Tp > 0 && conv_geometry(F0_, f1, f2), DS2_ERR_ARG);
-  if (dtype == DS2_BF16 && F0_ == F0) {
+  if (dtype == DS2_BF16 && F0_ == F0 && (long)N * F1 * Tp * CH * 2 < (long)CW_OOB) {
     RTapArgs e{(const bf16_t*)dy2, (const bf16_t*)w2d_even, nullptr, nullptr, nullptr, nullptr, (bf16_t*)da1, N, Tp, F2, F1, 11, 1, 0, 1, 0, 5, 41, 2, 0};
     RTapArgs o{(const bf16_t*)dy2, (const bf16_t*)w2d_odd, nullptr, nullptr, nullptr, nullptr, (bf16_t*)da1, N, Tp, F2, F1, 10, 1, 0, 1, 0, 4, 40, 2, 1};
     const int rc = conv_rtap_launch(e, st);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Times ds2_conv2_wgrad (bf16, 161 bins) on the cfg3 / cfg5a shapes and, with DS2_AB_LIB=<other build>, runs that build in a child
+"""Times ds2_conv2_wgrad, ds2_conv2_fwd and ds2_conv2_dgrad (bf16, 161 bins) on the cfg3 / cfg5a shapes and, with DS2_AB_LIB=<other build>, runs that build in a child
 process on the same seeded operands and compares the results BIT FOR BIT (the pipelined kernel keeps the summation order).
 
     python tools/bench_conv2_wgrad.py                 # this build
@@ -40,6 +40,23 @@ for name, N, Tp in (("cfg3", 32, 751), ("cfg5a", 64, 751), ("ragged", 3, 77)):
     fl = 2.0 * 32 * 32 * 231 * N * 41 * Tp
     print("%-6s N=%2d T'=%4d: %.3f ms (kernel + reduction)  %.0f TFLOP/s  [%s]" % (name, N, Tp, t, fl / t / 1e9, os.path.basename(_lib.LIB_PATH)))
     out[name] = dw.cpu()
+    w = (torch.randn(32, 32, 21, 11, generator=g) * 0.02)
+    w2t = w.permute(2, 3, 0, 1).contiguous().to(torch.bfloat16).to(dev)
+    w2d = [w[:, :, q::2, :].flip(2, 3).permute(2, 3, 1, 0).contiguous().to(torch.bfloat16).to(dev) for q in (0, 1)]
+    b2 = (torch.randn(32, generator=g) * 0.1).to(dev)
+    lens = torch.tensor([max(Tp - 7 * i, 1) for i in range(N)], dtype=torch.int32, device=dev)
+    for what, fn in (("fwd", lambda: ops.conv2_fwd(a1, w2t, b2, lens, 161)), ("dgrad", lambda: ops.conv2_dgrad(dy, w2d[0], w2d[1], 161))):
+        ts = []
+        for it in range(10):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        t = sorted(ts[2:])[len(ts[2:]) // 2]
+        print("%-6s conv2 %-5s: %.3f ms  %.0f TFLOP/s" % (name, what, t, fl / t / 1e9))
+        out[name + "." + what] = r.float().cpu()
 if a.dump:
     torch.save(out, a.dump)
 if a.compare:
