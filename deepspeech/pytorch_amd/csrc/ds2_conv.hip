@@ -1120,6 +1120,9 @@ __device__ __forceinline__ void rt_dma_all(const RtNext& nx) {
   rt_dma_piece<PR, I>(nx);
   if constexpr (I + 1 < 12) rt_dma_all<PR, I + 1>(nx);
 }
+#ifndef RT_ABL
+#define RT_ABL 0   // timing-only ablations: 1 no DMA pieces in the loop, 2 no partial-sum exchange and no output, 4 no fragment reads
+#endif
 constexpr int RT_AH = 4;          // steps a fragment is read ahead of its MFMAs (two: a step of one or two MFMAs is shorter than the LDS)
 template <int ST>
 __device__ __forceinline__ void rt_prefetch(uint4 (&bq)[RT_AH + 1], const uint32_t (&aj)[6]) {
@@ -1146,7 +1149,7 @@ __device__ __forceinline__ void rt_step(ds2_f32x16 (&acc)[RT_FB], const uint4 (&
     const int m = rho - fl;
     if (m >= 0 && m < KF) Mma<bf16_t>::mma32(acc[fl], A[m][j], bq[ST % (RT_AH + 1)]);
   }
-  if constexpr (ST % 6 == 3 && ST >= 9 && (ST - 9) / 6 < 12) rt_dma_piece<PR, (ST - 9) / 6>(nx);   // behind an MFMA group of the middle rows
+  if constexpr (ST % 6 == 3 && ST >= 9 && (ST - 9) / 6 < 12 && !(RT_ABL & 1)) rt_dma_piece<PR, (ST - 9) / 6>(nx);   // behind an MFMA group of the middle rows
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (ST + 1 < NS) rt_step<KF, ST + 1>(acc, A, bq, aj, nx);
 }
@@ -1203,6 +1206,15 @@ __global__ void __launch_bounds__(256, 1) k_conv_rtap(RTapArgs a) {
     const int tb = tile % ntb, ub = (tile / ntb) % nub, n = tile / (ntb * nub);
     const int next = tile + gridDim.x;
     aim(next, buf ^ 1);                          // its pieces are issued between the MFMAs below
+    // the partial sums of the first pass (second launch of the forward) are needed behind the MFMAs: their loads go out now, not there
+    float4 pin[4];
+    {
+      const int u = ub * RT_FB + wave, t = tb * RT_TB + li;
+      const bool have = a.Pin != nullptr && u < a.U && t < a.Tp;
+      const float* src = a.Pin + (((long)n * a.U + min(u, a.U - 1)) * a.Tp + min(t, a.Tp - 1)) * CH + 4 * lq;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) pin[g] = have ? *reinterpret_cast<const float4*>(src + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     ds2_f32x16 acc[RT_FB];
 #pragma unroll
     for (int fl = 0; fl < RT_FB; ++fl)
@@ -1222,12 +1234,21 @@ __global__ void __launch_bounds__(256, 1) k_conv_rtap(RTapArgs a) {
       rt_step<KF, 0>(acc, A, bq, aj, nx);
     }
     // ---- the four waves' partial sums meet: red[wave][row][g][lane] x 16 bytes
+    if (RT_ABL & 2) {
+      if (acc[0][0] == 123.f && acc[1][1] == 3.f && acc[2][2] == 1.f && acc[3][3] == 7.f) red[0] = 1.f;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      continue;
+    }
 #pragma unroll
     for (int fl = 0; fl < RT_FB; ++fl)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         *reinterpret_cast<float4*>(red + (((wave * RT_FB + fl) * 4 + g) * 64 + lane) * 4) =
             make_float4(acc[fl][4 * g], acc[fl][4 * g + 1], acc[fl][4 * g + 2], acc[fl][4 * g + 3]);
+    // the next tile's patch (this wave's DMA pieces) must have landed before the barrier that publishes it: the compiler does not put
+    // the vmcnt(0) there by itself.  Cheap: the pieces went out during the MFMA loop; the Pin loads are needed right behind anyway
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     {
       const int u = ub * RT_FB + wave, t = tb * RT_TB + li;       // wave w finishes output row w of the tile
@@ -1248,8 +1269,7 @@ __global__ void __launch_bounds__(256, 1) k_conv_rtap(RTapArgs a) {
         if (a.Pin) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const float4 q4 = *reinterpret_cast<const float4*>(a.Pin + pidx + 8 * g);
-            o[4 * g] += q4.x; o[4 * g + 1] += q4.y; o[4 * g + 2] += q4.z; o[4 * g + 3] += q4.w;
+            o[4 * g] += pin[g].x; o[4 * g + 1] += pin[g].y; o[4 * g + 2] += pin[g].z; o[4 * g + 3] += pin[g].w;
           }
         }
         if (a.Pout) {
@@ -1269,7 +1289,13 @@ __global__ void __launch_bounds__(256, 1) k_conv_rtap(RTapArgs a) {
         }
       }
     }
-    __syncthreads();                                         // (also: the next tile's patch has landed -- vmcnt(0) is part of it)
+    // End of the tile: everybody is done with `red`.  NOT __syncthreads(): its vmcnt(0) would wait for the acknowledgement of the output
+    // stores issued a moment ago (a memory round trip per tile with nothing to cover it); the next tile's patch has landed for every
+    // wave since the barrier behind the partial sums (whose __syncthreads did wait for this wave's DMA).
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
