@@ -11,7 +11,7 @@
 //          LDS, 80-byte position stride = conflict-free ds_read_b128); dgrad is the SAME kernel run once per output-row parity
 //          with the flipped, parity-subsampled weights (a stride-2 transposed conv is two stride-1 convs); wgrad contracts over
 //          positions with the exact-fp32 MFMA 32x32x2.
-//          bf16 storage: k_conv_rtap (forward and dgrad: taps resident in registers) and k_conv2_wgrad_bf16r (several kernel
+//          bf16 storage: k_conv_rtap (forward and dgrad: taps resident in registers) and k_conv2_wgrad_bf16d (several kernel
 //          rows per workgroup, taps split over the waves).
 // Layouts: x (N,1,161,T) f32 as given by the loader; activations NFTC [N][F][T'][32] in storage type T.
 #include "ds2_common.h"
@@ -587,237 +587,25 @@ __global__ void __launch_bounds__(256, 1) k_conv2_wgrad(const T* __restrict__ dY
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// bf16 variant on the bf16 MFMA (16x the rate of the exact-fp32 form above; the operands ARE bf16 in this mode, so the
-// products are exact and only the fp32 summation order differs).  The contraction runs over POSITIONS, which are the
-// slow axis of the NFTC activations, so both operand tiles are transposed on their way into LDS: a thread loads the same
-// 8 channels of two neighbouring positions (2 x 16 B), pairs them up in registers and writes 8 dwords into a
-// channel-major image  sdy[co][t] / sx[ci][t]  (row strides 272 B / 304 B: conflict-free ds_read_b128 over 16 rows).
-// A fragment = dY^T (rows co, 8 consecutive positions per lane: one aligned ds_read_b128); B fragment of tap kt = the
-// same 8 positions shifted by kt-5: three aligned 16-byte reads per k-step cover all 11 shifts, v_alignbyte picks the
-// window.  Per 128-position tile: 8 k-steps x 11 taps of v_mfma_f32_32x32x16_bf16, k-steps split over the 4 waves; the
-// next tile's global loads are issued before the MFMAs of the current one.
+// bf16 variant on the bf16 MFMA (16x the rate of the exact-fp32 form above; the operands ARE bf16 in this mode, so the products
+// are exact and only the fp32 summation order differs): SEVERAL kernel rows per workgroup and the TAPS split over the waves.
+// Wave w owns the taps kt = w, w + 4, w + 8 of R = 4 kernel rows kf0, kf0 + 2, ... of one parity -- they read the SAME input row
+// fi = 2 j - 10 + kf0 against the output rows j, j - 1, ... -- and walks over all positions of a tile: 3 R accumulator tiles per wave
+// (no cross-wave reduction at the end; wave 3's third tap does not exist: its products land in an accumulator that is never written
+// out).  Six row groups cover the 21 kernel rows: {0,2,4,6} {8,..,14} {16,18,20,-} {1,..,7} {9,..,15} {17,19,-,-}.  Work item =
+// (sample, j in [0, 40 + R - 1], position tile); an output row that does not exist is staged as zeros (branch-free).
+// History (in the repository's history, not in this file): round 2 staged both operands through registers into channel-major LDS
+// images (a transposing stage) and cut the tap windows out of them with v_alignbyte (`k_conv2_wgrad_bf16r`: 0.91 ms on config 3,
+// 22 % of the MFMA rate); round 5 first pipelined that form (buffer loads without edge masks, window selection between the MFMAs:
+// 0.71 ms) and then replaced it by the kernel below (0.49 ms).
 // ------------------------------------------------------------------------------------------------------------
-constexpr int CWB_DY_LD = 136;          // bf16 per channel row of the dY^T tile (128 positions + pad)
-constexpr int CWB_X_POS = 144;          // staged X positions: t0-8 .. t0+135
-constexpr int CWB_X_LD = 152;
-
-__device__ __forceinline__ uint32_t cw_pair_lo(uint32_t a, uint32_t b) { return (a & 0xffffu) | (b << 16); }      // even channel of (t, t+1)
-__device__ __forceinline__ uint32_t cw_pair_hi(uint32_t a, uint32_t b) { return (a >> 16) | (b & 0xffff0000u); }  // odd channel
-
-template <int S>   // window of 8 bf16 starting at element S (0..7) of the 16-element concatenation lo|hi
-__device__ __forceinline__ uint4 cw_window(const uint4& lo, const uint4& hi) {
-  const uint32_t d[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-  constexpr int o = S / 2;
-  if (S % 2 == 0) return make_uint4(d[o], d[o + 1], d[o + 2], d[o + 3]);
-  return make_uint4(__builtin_amdgcn_alignbyte(d[o + 1], d[o], 2), __builtin_amdgcn_alignbyte(d[o + 2], d[o + 1], 2),
-                    __builtin_amdgcn_alignbyte(d[o + 3], d[o + 2], 2), __builtin_amdgcn_alignbyte(d[o + 4], d[o + 3], 2));
-}
+constexpr int CW_OOB = 0x7ffffff0;       // a buffer offset beyond any resource: the load returns zeros
+constexpr int CWR_SPLITS = 85;           // position splits: 6 row groups x 85 = 510 workgroups on 512 slots (two per CU)
 
 // ------------------------------------------------------------------------------------------------------------
-// conv2 weight gradient, SEVERAL kernel rows per workgroup and the TAPS split over the waves.
-// Until round 2e (k_conv2_wgrad_bf16, in the history) every wave had all 11 taps of one kernel row (176 accumulator registers) and a
-// quarter of the positions: 22 MFMAs per wave between two barriers, and a work item was bound by what surrounds them (the
-// transposing stage, the barriers, the tap windows on the VALU): 0.96 ms, 19 % of the MFMA rate.  Here wave w owns the taps kt = w, w + 4, w + 8 of R kernel rows kf0, kf0 + 2, ... of
-// one parity -- they read the SAME input row fi = 2 j - 10 + kf0 against the output rows j, j - 1, ... -- and walks over all 128
-// positions of the tile: 3 R accumulator tiles per wave (no cross-wave reduction at the end), one staged input tile and one set of
-// tap windows per k-step for 3 R MFMAs.  Six row groups (R = 4) cover the 21 kernel rows: {0,2,4,6} {8,..,14} {16,18,20,-} {1,..,7}
-// {9,..,15} {17,19,-,-}.  Work item = (sample, j in [0, 40 + R - 1], 128-frame tile); an output or kernel row that does not exist
-// is staged as zeros (branch-free).
-// ------------------------------------------------------------------------------------------------------------
-// One tile: wave `wave` multiplies its taps kt = wave + 4 i (i = 0..2; wave 3's third tap does not exist: its products land
-// in an accumulator that is never written out) of the R kernel rows against all 8 k-steps.  The tap window of element offset
-// e = kt + 3 inside the 24 staged positions is dwords (e >> 1) .. +3 of q0|q1|q2, shifted by one element when e is odd: with
-// e = wave + 3 + 4 i the dword offset is (1 + 2 i) + ((wave + 1) >> 1) and the parity that of wave + 1 -- wave-uniform values, so
-// the windows are selections + v_alignbyte with a register shift and the code is the same for the four waves (a switch over
-// per-wave instantiations made hipcc keep several copies of the accumulators: spills).
-// Round 5: the tile loop is a software pipeline.  Until then a k-step was "three LDS reads, 28 VALU instructions of window selection,
-// then 12 MFMAs with an LDS read in front of every third one" -- with one wave per SIMD nothing covered the waits, and around it stood
-// ~380 instructions of 64-bit address arithmetic per tile and 48 v_and of edge masks (10 000 cycles per tile for 3 072 cycles of matrix
-// pipe: 22 % of the MFMA rate, profiles/r05zz_roofline_cfg3.md).  Now (a) the staged operands come through buffer loads: the tile's row
-// base is the SCALAR offset, the lane's position offset is computed once per tile, and a position or row that does not exist is an
-// out-of-range offset (zeros, no mask); (b) inside the tile the LDS reads run two k-steps (X) / one k-step (dY^T) ahead and the windows
-// of k-step ks + 1 are selected between the MFMAs of k-step ks (sched_group_barrier pins the interleave: MFMA, LDS read, 3 VALU).
-// The summation order is unchanged: results are bit-identical to the round-2 form.
-typedef uint32_t cw_u32x4 __attribute__((ext_vector_type(4)));
-constexpr int CW_OOB = 0x7ffffff0;
-
-// (operands as VALUES: a conditional expression over array elements is control flow to the front end, and is not always if-converted)
-__device__ __forceinline__ uint32_t cw_sel(bool c, uint32_t a, uint32_t b) { return c ? a : b; }
-__device__ __forceinline__ void cwr_windows(uint4 (&w)[3], const uint4& q0, const uint4& q1, const uint4& q2, int delta, uint32_t sh) {
-  const uint32_t D[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int b = 1 + 2 * i;
-    uint32_t X[5];
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      const uint32_t c2 = b + j + 2 < 12 ? D[b + j + 2] : 0u;      // only read for delta = 2, j = 4, i = 2: the non-existent tap
-      X[j] = cw_sel(delta == 0, D[b + j], cw_sel(delta == 1, D[b + j + 1], c2));
-    }
-    w[i] = make_uint4(__builtin_amdgcn_alignbyte(X[1], X[0], sh), __builtin_amdgcn_alignbyte(X[2], X[1], sh),
-                      __builtin_amdgcn_alignbyte(X[3], X[2], sh), __builtin_amdgcn_alignbyte(X[4], X[3], sh));
-  }
-}
-
-template <int R>
-__device__ __forceinline__ void cwr_multiply(ds2_f32x16 (&acc)[R][3], const uint16_t* sdy, const uint16_t* sx, int li, int lq, int wave) {
-  int delta = (wave + 1) >> 1;
-  // wave-uniform, but the compiler must not know: it turns selections on a uniform value into a tree of scalar BRANCHES around every
-  // window (one basic block per tap and k-step: no schedule left).  As a per-lane value they are two v_cndmask on loop-invariant masks.
-  asm volatile("" : "+v"(delta));
-  const uint32_t sh = (wave & 1) ? 0u : 2u;
-  const uint16_t* xb = sx + li * CWB_X_LD + lq * 8;          // k-step ks: + 16 ks elements
-  const uint16_t* ab = sdy + li * CWB_DY_LD + 8 * lq;        // k-step ks: + 16 ks; kernel row r: + r * CH * CWB_DY_LD
-  uint4 q[2][3], w[2][3], a[2][R];
-  auto load_q = [&](uint4 (&d)[3], int ks) {
-    d[0] = *reinterpret_cast<const uint4*>(xb + 16 * ks);
-    d[1] = *reinterpret_cast<const uint4*>(xb + 16 * ks + 8);
-    d[2] = *reinterpret_cast<const uint4*>(xb + 16 * ks + 16);
-  };
-  auto load_a = [&](uint4 (&d)[R], int ks) {
-#pragma unroll
-    for (int r = 0; r < R; ++r) d[r] = *reinterpret_cast<const uint4*>(ab + r * CH * CWB_DY_LD + 16 * ks);
-  };
-  load_q(q[0], 0);
-  load_q(q[1], 1);
-  load_a(a[0], 0);
-  cwr_windows(w[0], q[0][0], q[0][1], q[0][2], delta, sh);
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks) {
-    const int c = ks & 1, n = c ^ 1;
-    if (ks + 1 < 8) load_a(a[n], ks + 1);                    // first: the LDS slots of the pipeline are filled in program order
-    if (ks + 2 < 8) load_q(q[c], ks + 2);                    // q[c] held k-step ks: its windows are in w[c] already
-    if (ks + 1 < 8) cwr_windows(w[n], q[n][0], q[n][1], q[n][2], delta, sh);
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      Mma<bf16_t>::mma32(acc[r][0], a[c][r], w[c][0]);
-      Mma<bf16_t>::mma32(acc[r][1], a[c][r], w[c][1]);
-      Mma<bf16_t>::mma32(acc[r][2], a[c][r], w[c][2]);
-    }
-#pragma unroll
-    for (int m = 0; m < 3 * R; ++m) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // at most one LDS read
-      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);     // at most three VALU instructions in its shadow
-    }
-  }
-}
-
-constexpr int CWR_SPLITS = 85;     // 6 row groups x 85 = 510 workgroups: two rounds of 256 CUs
-
-template <int R>
-__global__ void __launch_bounds__(256, 1) k_conv2_wgrad_bf16r(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ A1,
-                                                               float* __restrict__ partial, int N, int Tp) {
-  // row group of this workgroup: kernel rows kf0 + 2 r, r < 4, that exist ({16,18,20} and {17,19} are short: their missing rows
-  // are staged as zeros and not written out)
-  const int kf0 = blockIdx.y < 3 ? 8 * blockIdx.y : 1 + 8 * (blockIdx.y - 3);
-  __shared__ __attribute__((aligned(16))) unsigned char smem[CH * (R * CWB_DY_LD + CWB_X_LD) * 2];   // R dY^T tiles + one X tile
-  uint16_t* sdy = reinterpret_cast<uint16_t*>(smem);
-  uint16_t* sx = sdy + R * CH * CWB_DY_LD;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 31, lq = lane >> 5;
-  const int split = blockIdx.x;
-  ds2_f32x16 acc[R][3];
-#pragma unroll
-  for (int r = 0; r < R; ++r)
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[r][i][e] = 0.f;
-  const int ntiles = (Tp + CW_TB - 1) / CW_TB;
-  constexpr int NJ = F2 + R - 1;             // j = 0 .. 40 + R - 1: kernel row r pairs with output row j - r
-  const int nwork = N * NJ * ntiles;         // (the host bounds both tensors by 2 GB: far below 2^31 items)
-  auto decode = [&](int wk, int& n, int& j, int& t0) {
-    const int q = wk / ntiles;
-    t0 = (wk - q * ntiles) * CW_TB;
-    n = q / NJ;
-    j = q - n * NJ;
-  };
-  auto next_live = [&](int wk) {             // skip the items whose input row does not exist
-    for (; wk < nwork; wk += gridDim.x) {
-      int n, j, t0;
-      decode(wk, n, j, t0);
-      const int fi = 2 * j - 10 + kf0;
-      if (fi >= 0 && fi < F1) break;
-    }
-    return wk;
-  };
-  const int row_bytes = Tp * CH * 2;         // one (sample, frequency row) of either tensor
-  const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)dY, 0, N * F2 * row_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)A1, 0, N * F1 * row_bytes, 0x00020000);
-  // staging identity: dY item = (position pair tid % 64, channel group tid / 64); X items tid, tid + 256 (< 288)
-  const int dy_pp = tid & 63, dy_v = tid >> 6;
-  const int x_pp0 = tid % 72, x_v0 = tid / 72;
-  const int x_pp1 = (tid + 256) % 72, x_v1 = (tid + 256) / 72;
-  const bool x_has1 = tid + 256 < 72 * 4;
-  cw_u32x4 g[2 * R + 4];
-  auto issue = [&](int wk) {
-    int n, j, t0;
-    decode(wk, n, j, t0);
-    const int fi = 2 * j - 10 + kf0;
-    const int sx_off = __builtin_amdgcn_readfirstlane((n * F1 + fi) * row_bytes);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int t = t0 + 2 * dy_pp + h;
-      const int vdy = t < Tp ? t * (CH * 2) + dy_v * 16 : CW_OOB;
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int fo = j - r;
-        const bool row_ok = fo >= 0 && fo < F2 && kf0 + 2 * r < K2F;                   // workgroup-uniform
-        const int sdy_off = __builtin_amdgcn_readfirstlane(row_ok ? (n * F2 + fo) * row_bytes : 0);
-        g[2 * r + h] = __builtin_amdgcn_raw_buffer_load_b128(rdy, row_ok ? vdy : CW_OOB, sdy_off, 0);
-      }
-      const int tx = t0 - 8 + 2 * x_pp0 + h;
-      g[2 * R + h] = __builtin_amdgcn_raw_buffer_load_b128(rx, (unsigned)tx < (unsigned)Tp ? tx * (CH * 2) + x_v0 * 16 : CW_OOB, sx_off, 0);
-      const int ty = t0 - 8 + 2 * x_pp1 + h;
-      g[2 * R + 2 + h] = __builtin_amdgcn_raw_buffer_load_b128(rx, (x_has1 && (unsigned)ty < (unsigned)Tp) ? ty * (CH * 2) + x_v1 * 16 : CW_OOB,
-                                                               sx_off, 0);
-    }
-  };
-  auto put = [&](uint16_t* base, int ld, int v, int pp, const cw_u32x4& a, const cw_u32x4& b) {   // 8 channels x 2 positions, transposed
-    uint32_t* row = reinterpret_cast<uint32_t*>(base + (v * 8) * ld + 2 * pp);
-    const int L = ld / 2;
-    row[0 * L] = cw_pair_lo(a[0], b[0]); row[1 * L] = cw_pair_hi(a[0], b[0]);
-    row[2 * L] = cw_pair_lo(a[1], b[1]); row[3 * L] = cw_pair_hi(a[1], b[1]);
-    row[4 * L] = cw_pair_lo(a[2], b[2]); row[5 * L] = cw_pair_hi(a[2], b[2]);
-    row[6 * L] = cw_pair_lo(a[3], b[3]); row[7 * L] = cw_pair_hi(a[3], b[3]);
-  };
-  auto stage = [&]() {
-#pragma unroll
-    for (int r = 0; r < R; ++r) put(sdy + r * CH * CWB_DY_LD, CWB_DY_LD, dy_v, dy_pp, g[2 * r], g[2 * r + 1]);
-    put(sx, CWB_X_LD, x_v0, x_pp0, g[2 * R], g[2 * R + 1]);
-    if (x_has1) put(sx, CWB_X_LD, x_v1, x_pp1, g[2 * R + 2], g[2 * R + 3]);
-  };
-
-  int wk = next_live(split);
-  if (wk < nwork) issue(wk);
-  while (wk < nwork) {
-    __syncthreads();            // previous tile's fragment reads are done
-    stage();
-    __syncthreads();
-    const int nxt = next_live(wk + gridDim.x);
-    if (nxt < nwork) issue(nxt);   // in flight during the MFMAs below
-    cwr_multiply<R>(acc, sdy, sx, li, lq, wave);
-    wk = nxt;
-  }
-  // every wave owns its taps: straight to partial[split][kf][kt][co][ci]
-#pragma unroll
-  for (int r = 0; r < R; ++r)
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int kt = wave + 4 * i;
-      if (kt < K2T && kf0 + 2 * r < K2F) {
-        float* out = partial + (((long)split * K2F + (kf0 + 2 * r)) * K2T + kt) * (CH * CH);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) out[mma32_row(e, lane) * 32 + li] = acc[r][i][e];
-      }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// The same row-group kernel WITHOUT a transposing stage (round 5).  k_conv2_wgrad_bf16r above moves every operand tile through
+// The row-group kernel WITHOUT a transposing stage (round 5).  Its predecessor moved every operand tile through
 // registers to turn the position-major activations into channel-major LDS images (12 loads, 40 pack instructions and 44 LDS stores
-// per thread and tile, un-overlapped: one wave per SIMD), and then cuts the 11 shifted tap windows out of them on the VALU.  gfx950
+// per thread and tile, un-overlapped: one wave per SIMD), and then cut the 11 shifted tap windows out of them on the VALU.  gfx950
 // needs neither:
 //   * `buffer_load_dwordx4 ... lds` copies a tile global -> LDS as it lies in memory ([position][32 channels], 64 B per position:
 //     a wave-instruction = 16 positions = 1 KiB, contiguous on both sides); a position outside the clip or a row that does not exist
@@ -1063,7 +851,10 @@ __global__ void __launch_bounds__(256, cwd_wgs_per_cu(KSN)) k_conv2_wgrad_bf16d(
 // walks over its tiles (4 output rows x 32 frames).  Per tile a wave reads each activation fragment of its items once per INPUT
 // row and multiplies it into every output row that uses that input row (fl = rho - m): 84 LDS fragment reads for 264 MFMAs.
 // The waves' partial sums over their items meet in LDS once per tile (fixed order), wave w finishing output row w; the next
-// tile's input patch travels global -> registers during the MFMAs and registers -> LDS after them (two patch buffers).
+// tile's input patch travels global -> LDS by DMA during the MFMAs (two patch buffers; round 5 -- until then it went through 40
+// registers per lane and a commit phase behind the MFMAs).  Where a tile's time goes (config 3, forward = two launches, timing-only
+// ablations RT_ABL): 0.51 ms as shipped, 0.46 without the DMA pieces, 0.40 without the partial-sum exchange and the output, 0.37
+// without both; 0.28 would be the matrix pipe alone.
 // ============================================================================================================
 struct RTapArgs {
   const bf16_t* X;    // [N][Fin][Tp][32]
@@ -1343,7 +1134,7 @@ int conv_tap_launch(const ConvTapArgs& a, hipStream_t st) {
 }  // namespace
 
 // Frequency geometry (reference model.py:166-169): F0 = sample_rate * window_size / 2 + 1 input bins (161 at 16 kHz / 20 ms), F1 and
-// F2 the rows after the two convolutions.  The matrix-pipe kernels of the bf16 path (k_conv1_*_mfma, k_conv_rtap, k_conv2_wgrad_bf16r)
+// F2 the rows after the two convolutions.  The matrix-pipe kernels of the bf16 path (k_conv1_*_mfma, k_conv_rtap, k_conv2_wgrad_bf16d)
 // are specialised for 161 / 81 / 41; any other geometry runs the general kernels (k_conv1_fwd / _wgrad, k_conv_tap, k_conv2_wgrad)
 // in the same storage type: same results, 2-3x the time of the layer.
 static bool conv_geometry(int f0, int& f1, int& f2) {
