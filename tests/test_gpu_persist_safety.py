@@ -136,7 +136,9 @@ def test_sweep_that_cannot_get_its_cus_times_out_loudly_and_recovers():
         assert rc == 0
         hext = ops.rnn_fwd(p["kind"], p["GI"], p["Whh"], p["bhh"], p["lens"], p["D"], p["N"], p["H"], p["Tp"])[0]
         ops.poll_persistent_error(torch.device(DEV, 0))        # enqueues the asynchronous look at the error word
-        time.sleep(0.3)                                        # the resident half of the sweep has spent its 20 k polls by now
+        time.sleep(1.0)                                        # the resident half of the sweep has spent its start-up budget by now (1e6
+                                                               # polls = ~0.3 s, measured by the next test: 0.3 s of sleep was a coin toss;
+                                                               # the squatters stay for up to 3 s)
         with torch.cuda.stream(torch.cuda.Stream()):
             release.fill_(1)                                   # the squatters leave; the rest of the sweep's workgroups start, see the
         torch.cuda.synchronize()                               # launch's error word and end at once
