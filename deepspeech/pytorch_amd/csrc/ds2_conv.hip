@@ -709,6 +709,7 @@ __device__ __forceinline__ void cwd_kstep(ds2_f32x16 (&acc)[4][3], CwdFrag (&fa)
 }
 
 constexpr int CWD_UNITS_PER_XCD = 64;     // 85 splits x 6 row groups = 510 units on 8 x 64 workgroup slots
+static_assert(CWR_SPLITS * 6 <= 8 * CWD_UNITS_PER_XCD, "every (split, row group) needs a workgroup slot");
 
 template <int KSN>
 __global__ void __launch_bounds__(256, cwd_wgs_per_cu(KSN)) k_conv2_wgrad_bf16d(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ A1,
