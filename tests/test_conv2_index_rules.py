@@ -147,3 +147,52 @@ def test_rtap_swizzle_reader_finds_the_dma_writers_bytes_and_is_conflict_free():
                 for grp in B128_GROUPS:                              # lanes 32-63 (lq = 1) form the same groups shifted by 32
                     slots = {(addr[li] % 256) // 16 for li in grp}
                     assert len(slots) == 16, (kt, half, lq, sorted(slots))
+
+
+def test_wgrad_decomposition_in_numpy_equals_the_oracle():
+    """The kernel's decomposition restated in numpy on a small batch (full 81 -> 41 frequency geometry, short clips): tiles of 16 KSN
+    positions staged as they lie in memory with ZEROS outside the clip / for rows that do not exist (what the LDS-DMA delivers), the X
+    tile starting at position t0 - 8, work items (n, j, tile) with input row 2 j - 10 + kf0 against the output rows j - r, tap kt of
+    wave w and slot i read at row offset p + kt + 3 -- summed over every split -- is the weight gradient of the oracle
+    (oracle/ds2_oracle.py:conv2d_bwd = autograd of model.py:161)."""
+    import numpy as np
+    from oracle import ds2_oracle as O
+
+    rs = np.random.RandomState(5)
+    N, Tp, KSN = 2, 37, 7
+    TB = 16 * KSN
+    a1 = rs.standard_normal((N, 32, F1, Tp))
+    dy = rs.standard_normal((N, 32, F2, Tp))
+    _, dw_ref, _ = O.conv2d_bwd(a1, np.zeros((32, 32, K2F, K2T)), dy, (2, 1), (10, 5), need_dx=False)      # [co][ci][kf][kt]
+    X = a1.transpose(0, 2, 3, 1)          # NFTC [n][f][t][ci]
+    DY = dy.transpose(0, 2, 3, 1)         # [n][fo][t][co]
+    ntiles = -(-Tp // TB)
+    dw = np.zeros((K2F, K2T, 32, 32))     # [kf][kt][co][ci]
+    for rg in range(6):
+        kf0 = kf0_of(rg)
+        for n, j, t in itertools.product(range(N), range(NJ), range(ntiles)):
+            fi = 2 * j - 10 + kf0
+            if not 0 <= fi < F1:
+                continue
+            t0 = t * TB
+            xt = np.zeros((16 * (KSN + 1), 32))                       # staged X tile: positions t0 - 8 ...
+            for q in range(xt.shape[0]):
+                pos = t0 - 8 + q
+                if 0 <= pos < Tp:
+                    xt[q] = X[n, fi, pos]
+            for r in range(R):
+                fo, kf = j - r, kf0 + 2 * r
+                dyt = np.zeros((TB, 32))                              # staged dY^T tile of wave r
+                if 0 <= fo < F2 and kf < K2F:
+                    m = min(TB, Tp - t0)
+                    dyt[:m] = DY[n, fo, t0:t0 + m]
+                if kf >= K2F:
+                    continue                                          # (the kernel multiplies, and never writes the result out)
+                for wave, i in itertools.product(range(4), range(3)):
+                    kt = wave + 4 * i
+                    if kt >= K2T:
+                        continue
+                    win = xt[kt + 3:kt + 3 + TB]                      # row p + kt + 3 for p = 0 .. TB - 1
+                    dw[kf, kt] += dyt.T @ win
+    got = dw.transpose(2, 3, 0, 1)        # [co][ci][kf][kt]
+    assert np.abs(got - dw_ref).max() <= 1e-9 * np.abs(dw_ref).max()
