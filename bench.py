@@ -247,7 +247,7 @@ def run_native(args, rank, world, device):
     dom = max(kernels, key=lambda k: kernels[k]["ms_per_train_step"]) if kernels else None
     # the kernel symbols behind the tags (what rocprofv3 lists), from the library's own dispatch decision
     from deepspeech.pytorch_amd._lib import query
-    fam = query("ds2_rnn_persist_kind", ops.dt(torch.bfloat16 if dtype == "bf16" else torch.float32), ops.CELLS[kind], D, N, H)
+    fam = ops.persist_kind(torch.bfloat16 if dtype == "bf16" else torch.float32, kind, D, N, H)
     stem = {1: ("k_rnn_persist_fwd4", "k_rnn_persist_bwd4"), 2: ("k_rnn_persist_fwd", "k_rnn_persist_bwd"),
             3: ("k_rnn_persist3_fwd", "k_rnn_persist3_bwd"), 4: ("k_rnn_persist2_fwd", "k_rnn_persist2_bwd")}.get(fam, ("?", "?"))
     names = {"rnn_fwd_persistent": stem[0], "rnn_bwd_persistent": stem[1], "rnn_fwd": "k_rnn_step_fwd", "rnn_bwd": "k_rnn_step_bwd"}

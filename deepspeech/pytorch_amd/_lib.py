@@ -23,7 +23,6 @@ SIGNATURES = {
     "ds2_gemm_nt_rows2": (_i, [_i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _l, _l, _l, _i, _i, _i, _vp]),
     "ds2_gemm8_nt": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _l, _l, _l, _i, _vp]),
     "ds2_gemm8_tn_grouped": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
-    "ds2_gemm8_set_variant": (_i, [_i]),
     "ds2_gemm8_nt_rows": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _l, _l, _l, _i, _vp, _i, _vp]),
     "ds2_gemm8_tn_grouped_rows": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     "ds2_gemm8_wgrad_dx_rows": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _l, _l, _l, _vp, _i, _vp]),
@@ -48,14 +47,12 @@ SIGNATURES = {
     "ds2_rnn_state_bytes": (_l, [_i, _i, _i]),
     "ds2_rnn_fwd": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp]),
     "ds2_rnn_bwd": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp]),
-    "ds2_rnn_persist_set_spin_limit": (C.c_uint, [C.c_uint]),
-    "ds2_rnn_persist_set_variant": (C.c_uint, [C.c_uint]),
-    "ds2_rnn_persist_supported": (_i, [_i, _i, _i, _i, _i]),
+    "ds2_rnn_persist_supported": (_i, [_i, _i, _i, _i, _i, C.c_uint]),
     "ds2_rnn_persist_shape_covered": (_i, [_i, _i, _i, _i, _i]),
-    "ds2_rnn_persist_kind": (_i, [_i, _i, _i, _i, _i]),
-    "ds2_rnn_persist_ws_bytes": (_l, [_i, _i, _i, _i, _i]),
-    "ds2_rnn_persist_fwd": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "ds2_rnn_persist_bwd": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "ds2_rnn_persist_kind": (_i, [_i, _i, _i, _i, _i, C.c_uint]),
+    "ds2_rnn_persist_ws_bytes": (_l, [_i, _i, _i, _i, _i, C.c_uint]),
+    "ds2_rnn_persist_fwd": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ds2_rnn_persist_bwd": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "ds2_add2": (_i, [_i, _vp, _vp, _vp, _l, _vp]),
     "ds2_transpose": (_i, [_i, _vp, _vp, _l, _i, _l, _l, _vp]),
     "ds2_split3_bf16": (_i, [_vp, _l, _l, _i, _i, _i, _vp, _l, _vp]),
@@ -67,7 +64,6 @@ SIGNATURES = {
     "ds2_lookahead_ws_floats": (_l, [_i, _i, _i, _i]),
     "ds2_lookahead_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "ds2_rnn_bias_grads": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
-    "ds2_ctc_set_variant": (_i, [_i]),
     "ds2_softmax_rows": (_i, [_vp, _vp, _l, _i, _l, _l, _vp]),
     "ds2_opt_max_tensors": (_i, []),
     "ds2_clip_ws_floats": (_l, [_i, _vp]),
@@ -79,8 +75,15 @@ SIGNATURES = {
     "ds2_spectrogram": (_i, [_vp, _l, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "ds2_greedy_decode": (_i, [_vp, _l, _l, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "ds2_ctc_ws_floats": (_l, [_i, _i, _i, _i]),
-    "ds2_ctc_loss_grad": (_i, [_vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _l, _vp, _vp]),
+    "ds2_ctc_loss_grad": (_i, [_vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _l, _vp, _i, _vp]),
 }
+
+
+
+class PersistOpts(C.Structure):
+    """ds2_persist_opts (include/ds2hip.h): per-launch options of the persistent sweeps."""
+    _fields_ = [("variant", C.c_uint), ("spin_limit", C.c_uint), ("startup_ms", C.c_uint)]
+
 
 _lib = None
 

@@ -604,17 +604,11 @@ __global__ void k_sum_small(const float* __restrict__ v, int n, float* __restric
 
 extern "C" {
 
-// 1 (default): the one-wave-per-recursion kernel where it wins -- <= 32 classes and targets of <= 63 labels (2 states per lane:
+// `recursion` argument of ds2_ctc_loss_grad (kernel selection for A/B runs and tests; identical results in every setting):
+// 0 (default): the one-wave-per-recursion kernel where it wins -- <= 32 classes and targets of <= 63 labels (2 states per lane:
 //    253 vs 330 us on 32 clips of 751 frames; with 6 states per lane -- cfg3's 180 labels -- the single SIMD's VALU throughput loses
-//    to the four-wave kernel, 555 vs 414 us; profiles/r03g_ctc_ab.txt);  0: always the four-wave kernel;  2: the one-wave kernel up
-//    to 255 labels (tests).  Results are identical in every setting.
-static int g_ctc_wave = 1;
-int ds2_ctc_set_variant(int mode) {
-  const int old = g_ctc_wave;
-  g_ctc_wave = mode < 0 ? 0 : mode > 2 ? 2 : mode;
-  return old;
-}
-
+//    to the four-wave kernel, 555 vs 414 us; profiles/r03g_ctc_ab.txt);  1: always the four-wave kernel;  2: the one-wave kernel up
+//    to 255 labels.  (Rounds 3-5: a process-wide ds2_ctc_set_variant.)
 constexpr int CTC_MAX_CLASSES = 8192;     // the gradient pass keeps one row of per-class sums per wave in LDS (4 x 32 KB at 8192)
 static int ctc_class_stride(int C) { return C <= 32 ? 32 : C <= 64 ? 64 : C <= 128 ? 128 : C <= 256 ? 256 : (C + 63) / 64 * 64; }
 
@@ -625,8 +619,9 @@ long ds2_ctc_ws_floats(int Tp, int N, int C, int max_target_len) {
 
 int ds2_ctc_loss_grad(const float* logits, long ldl, const int* targets, const int* target_offsets, const int* input_lengths,
                       const int* target_lengths, int Tp, int N, int C, int blank, int max_target_len, float grad_scale,
-                      float* nll, float* loss_sum, float* dlogits, long ldg, float* ws, ds2_stream_t st_) {
+                      float* nll, float* loss_sum, float* dlogits, long ldg, float* ws, int recursion, ds2_stream_t st_) {
   hipStream_t st = (hipStream_t)st_;
+  const int g_ctc_wave = recursion == 1 ? 0 : recursion == 2 ? 2 : 1;
   DS2_REQUIRE(Tp > 0 && N > 0 && C > 0 && C <= CTC_MAX_CLASSES && blank >= 0 && blank < C && max_target_len >= 0, DS2_ERR_ARG);
   DS2_REQUIRE(ldg >= C && ldl >= C, DS2_ERR_ARG);
   const int CP = ctc_class_stride(C);

@@ -473,29 +473,16 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(G8Args g) {
     g8_tile<false, SPREAD>(P, t_id, lds);
 }
 
-int g_variant = 0;   // 0: four DMA pieces in phases 2 and 3 (default); 1: two per phase (SPREAD) -- measured: no gain on the NT
-                     // shapes of the step (0.289 vs 0.290 ms), slower on the grouped TN launch (0.555 vs 0.589 ms), profiles/r03d_gemm8_ab.txt
+// The SPREAD staging schedule (two DMA pieces per phase) stays in the source as a measured-and-rejected experiment: no gain on the NT
+// shapes of the step (0.289 vs 0.290 ms), slower on the grouped TN launch (0.555 vs 0.589 ms), profiles/r03d_gemm8_ab.txt.  It is not
+// instantiated (round 6: the process-wide ds2_gemm8_set_variant hook that selected it is gone from the ABI).
 template <int MODE>
 void g8_launch(int total, const G8Args& g, hipStream_t st) {
-  if (g_variant && g.p[0].rows == nullptr)
-    hipLaunchKernelGGL((k_gemm8<MODE, true>), dim3(total), dim3(512), 0, st, g);
-  else
-    hipLaunchKernelGGL((k_gemm8<MODE, false>), dim3(total), dim3(512), 0, st, g);
+  hipLaunchKernelGGL((k_gemm8<MODE, false>), dim3(total), dim3(512), 0, st, g);
 }
 
 }  // namespace
 
-extern "C" {
-
-// Staging schedule of the 256x256 kernels (for A/B measurements): 0 = four DMA pieces in the last two phases of a K-tile (default),
-// 1 = two per phase.  Returns the previous value.  Results are identical either way.
-int ds2_gemm8_set_variant(int v) {
-  const int old = g_variant;
-  g_variant = v != 0;
-  return old;
-}
-
-}  // extern "C"
 
 // The `_rows` entries take a row list (device, int32, strictly inside [0, n_phys)) and visit only the listed rows of the row dimension
 // shared by the activations of a padded [T' x batch] sequence matrix -- the frames t < length of every clip (model.py:96,100: the

@@ -46,11 +46,12 @@ int cu_count() {   // of the CURRENT device (cached per device)
   return n[dev];
 }
 
-// ds2_rnn_persist_set_variant (A/B runs on one box): bit 0 = do not use the round-4 general kernels; 1 = two-set groups execute every
-// half-step; 2 = unused; 3 = the general kernels take H = 1024 too; 4 = the tuned kernels keep 9-16 clips per group;
-// 5 = the 8-clip tuned kernels use dense products (round 4's form) instead of the structured-sparse ones
-unsigned g_variant = 0;
-int dispatch(bool bwd, int cell, int H, const PArgs& a, hipStream_t st) {
+// Routing A/B bits (ds2_persist_opts.variant / the `variant` argument of the queries; 0 = the shipping routing): bit 0 = do not use
+// the round-4 general kernels; 1 = two-set groups execute every half-step; 2 = unused; 3 = the general kernels take H = 1024 too;
+// 4 = the tuned kernels keep 9-16 clips per group; 5 = the 8-clip tuned kernels use dense products (round 4's form) instead of the
+// structured-sparse ones.  Rounds 2-5 kept these bits -- and the spin budget -- in process-wide variables behind setter entries;
+// they travel with every call now, so the entries are re-entrant and a test that dies cannot re-route the launches after it.
+int dispatch(bool bwd, int cell, int H, const PArgs& a, hipStream_t st, unsigned g_variant) {
   const bool dense = (g_variant & 32u) != 0;    // A/B: the 8-clip kernels without the structured-sparse products (round 4's form)
   switch (cell) {
     case CELL_GRU: return launch_gru(bwd, H, a, st, dense);
@@ -61,17 +62,20 @@ int dispatch(bool bwd, int cell, int H, const PArgs& a, hipStream_t st) {
 }
 
 // scratch head: [0,1024) cycle counters (-DDS2_PROBE builds only), [1024,3072) XCC-id handshake slots, [3072] the per-launch
-// error word; the exchange buffer follows.  All of it is reset to 0xFF bytes before every launch: the payload-only exchanges use
+// error word, [3076] the launch's spin budget, [3080] the arrival word of the kernels without a handshake; the exchange buffer follows.  All of it is reset to 0xFF bytes before every launch: the payload-only exchanges use
 // the all-ones dword as "not published yet"; an all-ones tag never equals a step index, an all-ones handshake slot is not a
 // signature, and the error word counts as raised only when it is 1.
 constexpr long AUX_BYTES = 4096;
 
-unsigned g_spin_limit = 0;   // 0 = the kernels' own SPIN_LIMIT; tests lower it (ds2_rnn_persist_set_spin_limit)
 // [3076] of the scratch head: the launch's spin budget (all-ones after the reset = none beyond SPIN_LIMIT)
-int set_spin_budget(void* ws, hipStream_t st) {
-  if (g_spin_limit == 0) return 0;
-  return (int)hipMemsetD32Async((hipDeviceptr_t)((char*)ws + 3076), (int)g_spin_limit, 1, st);
+int set_spin_budget(void* ws, const ds2_persist_opts* o, hipStream_t st) {
+  if (!o || o->spin_limit == 0) return 0;
+  return (int)hipMemsetD32Async((hipDeviceptr_t)((char*)ws + 3076), (int)o->spin_limit, 1, st);
 }
+// How long the workgroups of a launch wait for ALL of them to become resident (csrc/ds2_rnn_persist_impl.h, raise_err_startup).
+constexpr unsigned STARTUP_MS_DEFAULT = 300;
+unsigned startup_ms(const ds2_persist_opts* o) { return o && o->startup_ms ? o->startup_ms : STARTUP_MS_DEFAULT; }
+unsigned variant_of(const ds2_persist_opts* o) { return o ? o->variant : 0u; }
 
 int gates(int cell) { return cell == CELL_GRU ? 3 : cell == CELL_LSTM ? 4 : 1; }
 
@@ -81,7 +85,7 @@ long xbuf_bytes(int cell, int H, bool bwd) {
 }
 
 
-bool tuned_ok(int dtype, int cell, int D, int N, int H) {
+bool tuned_ok(int dtype, int cell, int D, int N, int H, unsigned g_variant) {
   if (dtype != DS2_BF16 || H != 1024 || (D != 1 && D != 2)) return false;
   const int gpd = NGROUPS / D;
   if (g_variant & 8u) return false;                     // A/B: the general kernels take H = 1024 too
@@ -138,7 +142,7 @@ int launch3_any(bool probe, bool bwd, int cell, int H, const ds2r::RArgs& a, hip
   return DS2_ERR_ARG;
 }
 // cus = compute units to plan for (the device's, or 256 for the "would a full device take this shape" question)
-bool plan3h(int dtype, int cell, int D, int N, int H, int cus, Plan3H& pl) {
+bool plan3h(int dtype, int cell, int D, int N, int H, int cus, Plan3H& pl, unsigned g_variant) {
   if ((g_variant & 1u) || dtype != DS2_BF16 || (D != 1 && D != 2) || N < 1 || H % 32 != 0) return false;
   if (cell != CELL_GRU && cell != CELL_LSTM) return false;
   if (cus < 256) return false;
@@ -199,11 +203,11 @@ long xbuf2_bytes(int dtype, int cell, int H, const Plan2& pl, bool bwd) {
 extern "C" {
 
 // 1 if a persistent kernel covers this problem on the current device (>= 256 CUs: one workgroup per CU, all co-resident).
-int ds2_rnn_persist_supported(int dtype, int cell, int D, int N, int H) {
+int ds2_rnn_persist_supported(int dtype, int cell, int D, int N, int H, unsigned variant) {
   if (cell != CELL_GRU && cell != CELL_LSTM && cell != CELL_RNN) return 0;
-  if (tuned_ok(dtype, cell, D, N, H)) return 1;
+  if (tuned_ok(dtype, cell, D, N, H, variant)) return 1;
   Plan3H p3;
-  if (plan3h(dtype, cell, D, N, H, cu_count(), p3)) return 1;
+  if (plan3h(dtype, cell, D, N, H, cu_count(), p3, variant)) return 1;
   Plan2 pl;
   return plan2(dtype, cell, D, N, H, pl) ? 1 : 0;
 }
@@ -211,11 +215,11 @@ int ds2_rnn_persist_supported(int dtype, int cell, int D, int N, int H) {
 // Which kernel family ds2_rnn_persist_fwd / _bwd run for the problem on the current device: 0 none, 1 tuned (H = 1024, <= 8 samples
 // per group: k_rnn_persist_fwd4 / bwd4), 2 tuned (9-16 samples: k_rnn_persist_fwd / bwd), 3 round-4 general (k_rnn_persist3_*),
 // 4 round-2 general (k_rnn_persist2_*).  For measurement tools (bench.py names the rocprofv3 kernel from it).
-int ds2_rnn_persist_kind(int dtype, int cell, int D, int N, int H) {
+int ds2_rnn_persist_kind(int dtype, int cell, int D, int N, int H, unsigned variant) {
   if (cell != CELL_GRU && cell != CELL_LSTM && cell != CELL_RNN) return 0;
-  if (tuned_ok(dtype, cell, D, N, H)) return (N + NGROUPS / D - 1) / (NGROUPS / D) <= 8 ? 1 : 2;
+  if (tuned_ok(dtype, cell, D, N, H, variant)) return (N + NGROUPS / D - 1) / (NGROUPS / D) <= 8 ? 1 : 2;
   Plan3H p3;
-  if (plan3h(dtype, cell, D, N, H, cu_count(), p3)) return 3;
+  if (plan3h(dtype, cell, D, N, H, cu_count(), p3, variant)) return 3;
   Plan2 pl;
   return plan2(dtype, cell, D, N, H, pl) ? 4 : 0;
 }
@@ -226,7 +230,7 @@ int ds2_rnn_persist_shape_covered(int dtype, int cell, int D, int N, int H) {
   if (cell != CELL_GRU && cell != CELL_LSTM && cell != CELL_RNN) return 0;
   if (dtype == DS2_BF16 && H == 1024 && (D == 1 || D == 2) && N >= 1 && (N + NGROUPS / D - 1) / (NGROUPS / D) <= MAXS) return 1;
   Plan3H p3;
-  if (plan3h(dtype, cell, D, N, H, 256, p3)) return 1;
+  if (plan3h(dtype, cell, D, N, H, 256, p3, 0u)) return 1;
   if ((dtype != DS2_BF16 && dtype != DS2_F32) || (D != 1 && D != 2) || N < 1 || H % 16 != 0) return 0;
   const int P = H / 16;
   if (P * D > 256) return 0;
@@ -239,32 +243,14 @@ int ds2_rnn_persist_shape_covered(int dtype, int cell, int D, int N, int H) {
   return launch2_any(true, false, dtype, cell, H, MT, dummy, nullptr) == 0 ? 1 : 0;
 }
 
-// A/B hook: bit 0 = route the shapes of the round-4 general kernels to the round-2 general kernels (or launch-per-step) instead;
-// bit 1 = two-set groups execute every half-step (no set schedules); bit 2 unused; bit 3 = the round-4 general kernels also take H = 1024 (instead of the tuned kernels); bit 4 = the tuned kernels
-// keep groups of 9-16 clips (round 3's routing).
-// Returns the previous value.  Process-wide.
-unsigned ds2_rnn_persist_set_variant(unsigned bits) {
-  const unsigned old = g_variant;
-  g_variant = bits;
-  return old;
-}
-
-// Fault-injection hook for tests: polls a waiting workgroup may spend on one exchange before it gives up (raises *err, poisons its
-// outputs with NaN and ends); 0 restores the built-in budget (~seconds).  Returns the previous value.  Process-wide.
-unsigned ds2_rnn_persist_set_spin_limit(unsigned polls) {
-  const unsigned old = g_spin_limit;
-  g_spin_limit = polls;
-  return old;
-}
-
 // scratch bytes of one sweep (exchange buffer for the larger of the forward / BPTT needs + the head described above)
-long ds2_rnn_persist_ws_bytes(int dtype, int cell, int D, int N, int H) {
+long ds2_rnn_persist_ws_bytes(int dtype, int cell, int D, int N, int H, unsigned variant) {
 #ifdef DS2_PROBE
-  if (tuned_ok(dtype, cell, D, N, H)) return AUX_BYTES + xbuf_bytes(cell, H, true) + 32 * ds2p::TL_N * ds2p::TL_K * 8;   // + timeline
+  if (tuned_ok(dtype, cell, D, N, H, variant)) return AUX_BYTES + xbuf_bytes(cell, H, true) + 32 * ds2p::TL_N * ds2p::TL_K * 8;   // + timeline
 #endif
-  if (tuned_ok(dtype, cell, D, N, H)) return AUX_BYTES + xbuf_bytes(cell, H, true);
+  if (tuned_ok(dtype, cell, D, N, H, variant)) return AUX_BYTES + xbuf_bytes(cell, H, true);
   Plan3H p3;
-  if (plan3h(dtype, cell, D, N, H, cu_count(), p3)) return AUX_BYTES + xbuf3_bytes(cell, H, p3, true) + xcc3_bytes(p3);
+  if (plan3h(dtype, cell, D, N, H, cu_count(), p3, variant)) return AUX_BYTES + xbuf3_bytes(cell, H, p3, true) + xcc3_bytes(p3);
   Plan2 pl;
   if (!plan2(dtype, cell, D, N, H, pl)) return 0;
   return AUX_BYTES + xbuf2_bytes(dtype, cell, H, pl, true);
@@ -274,36 +260,37 @@ long ds2_rnn_persist_ws_bytes(int dtype, int cell, int D, int N, int H) {
 // err: one device int, set to 1 if a workgroup gave up waiting (outputs are then NaN-poisoned).
 int ds2_rnn_persist_fwd(int dtype, int cell, int D, int N, int H, int Tp, const int* lens, const void* GI, const void* Whh,
                         const float* bhh, const float* h0, const float* c0, void* Hseq, long hseq_dstride, void* S, float* hn,
-                        float* cn, void* ws, int* err, ds2_stream_t st_) {
+                        float* cn, void* ws, int* err, const ds2_persist_opts* opts, ds2_stream_t st_) {
   hipStream_t st = (hipStream_t)st_;
+  const unsigned g_variant = variant_of(opts);
   DS2_REQUIRE(Tp > 0 && Tp < (int)TAG_INIT && ws && err, DS2_ERR_ARG);
-  if (tuned_ok(dtype, cell, D, N, H)) {
+  if (tuned_ok(dtype, cell, D, N, H, g_variant)) {
     hipError_t e = hipMemsetAsync(ws, 0xff, AUX_BYTES + xbuf_bytes(cell, H, false), st);   // 0xFF: see gather_mma_tf
     if (e != hipSuccess) return (int)e;
-    if (int r = set_spin_budget(ws, st)) return r;
+    if (int r = set_spin_budget(ws, opts, st)) return r;
     PArgs a{};
     a.N = N; a.Tp = Tp; a.D = D; a.gpd = NGROUPS / D; a.lens = lens; a.W = (const bf16_t*)Whh; a.bhh = bhh;
     a.GI = (const bf16_t*)GI; a.Hseq = (bf16_t*)Hseq; a.hseq_dstride = hseq_dstride; a.S = (bf16_t*)S; a.h0 = h0; a.c0 = c0;
     a.hn = hn; a.cn = cn; a.xbuf = (u64*)((char*)ws + AUX_BYTES); a.err = err;
-    a.xcc = (u64*)((char*)ws + 1024); a.lerr = (int*)((char*)ws + 3072);
+    a.xcc = (u64*)((char*)ws + 1024); a.lerr = (int*)((char*)ws + 3072); a.startup_ms = startup_ms(opts);
 #ifdef DS2_PROBE
     a.dbg = (unsigned long long*)ws;
     a.tl = (unsigned long long*)((char*)ws + AUX_BYTES + xbuf_bytes(cell, H, true));
     { const char* e_ = getenv("DS2_PERSIST_DBG"); a.dbgmask = e_ ? atoi(e_) : 0; }
 #endif
-    return dispatch(false, cell, H, a, st);
+    return dispatch(false, cell, H, a, st, g_variant);
   }
   Plan3H p3;
-  if (plan3h(dtype, cell, D, N, H, cu_count(), p3)) {
+  if (plan3h(dtype, cell, D, N, H, cu_count(), p3, g_variant)) {
     const long xb = xbuf3_bytes(cell, H, p3, false);
     hipError_t e = hipMemsetAsync(ws, 0xff, AUX_BYTES + xb + xcc3_bytes(p3), st);
     if (e != hipSuccess) return (int)e;
-    if (int r = set_spin_budget(ws, st)) return r;
+    if (int r = set_spin_budget(ws, opts, st)) return r;
     ds2r::RArgs ra{};
     ds2q::QArgs& a = ra.q;
     a.N = N; a.Tp = Tp; a.D = D; a.gpd = p3.gpd; a.NG = p3.NG; a.lens = lens; a.W = Whh; a.bhh = bhh; a.GI = GI; a.Hseq = Hseq;
     a.hseq_dstride = hseq_dstride; a.S = S; a.h0 = h0; a.c0 = c0; a.hn = hn; a.cn = cn;
-    a.xbuf = (char*)ws + AUX_BYTES; a.xgroup_bytes = xb / p3.NG; a.err = err; a.lerr = (int*)((char*)ws + 3072);
+    a.xbuf = (char*)ws + AUX_BYTES; a.xgroup_bytes = xb / p3.NG; a.err = err; a.lerr = (int*)((char*)ws + 3072); a.startup_ms = startup_ms(opts);
     ra.xcc = (u64*)((char*)ws + AUX_BYTES + xb); ra.P = p3.P; ra.xmap = p3.xmap; ra.gx = p3.gx; ra.nset = p3.nset;
     ra.skip = (p3.nset == 2 && !(g_variant & 2u)) ? 1 : 0;
     if (ra.skip & 1)
@@ -320,11 +307,11 @@ int ds2_rnn_persist_fwd(int dtype, int cell, int D, int N, int H, int Tp, const 
   const long xb = xbuf2_bytes(dtype, cell, H, pl, false);
   hipError_t e = hipMemsetAsync(ws, 0xff, AUX_BYTES + xb, st);
   if (e != hipSuccess) return (int)e;
-  if (int r = set_spin_budget(ws, st)) return r;
+  if (int r = set_spin_budget(ws, opts, st)) return r;
   ds2q::QArgs a{};
   a.N = N; a.Tp = Tp; a.D = D; a.gpd = pl.gpd; a.NG = pl.NG; a.lens = lens; a.W = Whh; a.bhh = bhh; a.GI = GI; a.Hseq = Hseq;
   a.hseq_dstride = hseq_dstride; a.S = S; a.h0 = h0; a.c0 = c0; a.hn = hn; a.cn = cn;
-  a.xbuf = (char*)ws + AUX_BYTES; a.xgroup_bytes = xb / pl.NG; a.err = err; a.lerr = (int*)((char*)ws + 3072);
+  a.xbuf = (char*)ws + AUX_BYTES; a.xgroup_bytes = xb / pl.NG; a.err = err; a.lerr = (int*)((char*)ws + 3072); a.startup_ms = startup_ms(opts);
   return launch2_any(false, false, dtype, cell, H, pl.MT, a, st);
 }
 
@@ -334,38 +321,39 @@ int ds2_rnn_persist_fwd(int dtype, int cell, int D, int N, int H, int Tp, const 
 // bias_ih.grad = sum over samples of planes 0..G-1, bias_hh.grad (GRU) = planes 0, 1, 3.
 int ds2_rnn_persist_bwd(int dtype, int cell, int D, int N, int H, int Tp, const int* lens, const void* dOut, const void* WhhT,
                         const void* Hseq, long hseq_dstride, const void* S, void* dGI, void* dQ, float* dBacc, int flags, void* ws,
-                        int* err, ds2_stream_t st_) {
+                        int* err, const ds2_persist_opts* opts, ds2_stream_t st_) {
   void* dGH = dQ;
   hipStream_t st = (hipStream_t)st_;
+  const unsigned g_variant = variant_of(opts);
   DS2_REQUIRE(Tp > 0 && Tp < (int)TAG_INIT && ws && err, DS2_ERR_ARG);
   DS2_REQUIRE(cell != CELL_GRU || dGH != nullptr, DS2_ERR_ARG);
-  if (tuned_ok(dtype, cell, D, N, H)) {
+  if (tuned_ok(dtype, cell, D, N, H, g_variant)) {
     hipError_t e = hipMemsetAsync(ws, 0xff, AUX_BYTES + xbuf_bytes(cell, H, true), st);
     if (e != hipSuccess) return (int)e;
-    if (int r = set_spin_budget(ws, st)) return r;
+    if (int r = set_spin_budget(ws, opts, st)) return r;
     PArgs a{};
     a.N = N; a.Tp = Tp; a.D = D; a.gpd = NGROUPS / D; a.lens = lens; a.W = (const bf16_t*)WhhT;
     a.Hseq = (bf16_t*)Hseq; a.hseq_dstride = hseq_dstride; a.S = (bf16_t*)S; a.dOut = (const bf16_t*)dOut;
     a.dGI = (bf16_t*)dGI; a.dGH = (bf16_t*)dGH; a.dBacc = dBacc; a.xbuf = (u64*)((char*)ws + AUX_BYTES); a.err = err;
-    a.xcc = (u64*)((char*)ws + 1024); a.lerr = (int*)((char*)ws + 3072);
+    a.xcc = (u64*)((char*)ws + 1024); a.lerr = (int*)((char*)ws + 3072); a.startup_ms = startup_ms(opts);
 #ifdef DS2_PROBE
     a.dbg = (unsigned long long*)ws;
     a.tl = (unsigned long long*)((char*)ws + AUX_BYTES + xbuf_bytes(cell, H, true));
     { const char* e_ = getenv("DS2_PERSIST_DBG"); a.dbgmask = e_ ? atoi(e_) : 0; }
 #endif
-    return dispatch(true, cell, H, a, st);
+    return dispatch(true, cell, H, a, st, g_variant);
   }
   Plan3H p3;
-  if (plan3h(dtype, cell, D, N, H, cu_count(), p3)) {
+  if (plan3h(dtype, cell, D, N, H, cu_count(), p3, g_variant)) {
     const long xb = xbuf3_bytes(cell, H, p3, true);
     hipError_t e = hipMemsetAsync(ws, 0xff, AUX_BYTES + xb + xcc3_bytes(p3), st);
     if (e != hipSuccess) return (int)e;
-    if (int r = set_spin_budget(ws, st)) return r;
+    if (int r = set_spin_budget(ws, opts, st)) return r;
     ds2r::RArgs ra{};
     ds2q::QArgs& a = ra.q;
     a.N = N; a.Tp = Tp; a.D = D; a.gpd = p3.gpd; a.NG = p3.NG; a.lens = lens; a.W = WhhT; a.Hseq = (void*)Hseq;
     a.hseq_dstride = hseq_dstride; a.S = (void*)S; a.dOut = dOut; a.dGI = dGI; a.dGH = dGH; a.dBacc = dBacc;
-    a.xbuf = (char*)ws + AUX_BYTES; a.xgroup_bytes = xb / p3.NG; a.err = err; a.lerr = (int*)((char*)ws + 3072);
+    a.xbuf = (char*)ws + AUX_BYTES; a.xgroup_bytes = xb / p3.NG; a.err = err; a.lerr = (int*)((char*)ws + 3072); a.startup_ms = startup_ms(opts);
     ra.xcc = (u64*)((char*)ws + AUX_BYTES + xb); ra.P = p3.P; ra.xmap = p3.xmap; ra.gx = p3.gx; ra.nset = p3.nset;
     ra.skip = (p3.nset == 2 && !(g_variant & 2u)) ? 1 : 0;
     if ((ra.skip & 1) && !(flags & 1)) {     // flags bit 0: nobody reads the padding rows (row-list consumers)
@@ -385,11 +373,11 @@ int ds2_rnn_persist_bwd(int dtype, int cell, int D, int N, int H, int Tp, const 
   const long xb = xbuf2_bytes(dtype, cell, H, pl, true);
   hipError_t e = hipMemsetAsync(ws, 0xff, AUX_BYTES + xb, st);
   if (e != hipSuccess) return (int)e;
-  if (int r = set_spin_budget(ws, st)) return r;
+  if (int r = set_spin_budget(ws, opts, st)) return r;
   ds2q::QArgs a{};
   a.N = N; a.Tp = Tp; a.D = D; a.gpd = pl.gpd; a.NG = pl.NG; a.lens = lens; a.W = WhhT; a.Hseq = (void*)Hseq;
   a.hseq_dstride = hseq_dstride; a.S = (void*)S; a.dOut = dOut; a.dGI = dGI; a.dGH = dGH; a.dBacc = dBacc;
-  a.xbuf = (char*)ws + AUX_BYTES; a.xgroup_bytes = xb / pl.NG; a.err = err; a.lerr = (int*)((char*)ws + 3072);
+  a.xbuf = (char*)ws + AUX_BYTES; a.xgroup_bytes = xb / pl.NG; a.err = err; a.lerr = (int*)((char*)ws + 3072); a.startup_ms = startup_ms(opts);
   return launch2_any(false, true, dtype, cell, H, pl.MT, a, st);
 }
 

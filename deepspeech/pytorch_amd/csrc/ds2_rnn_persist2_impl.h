@@ -44,6 +44,7 @@ struct QArgs {
   long xgroup_bytes;        // 2 * PAR_BYTES
   int* err;                 // sticky device word (the host reads it)
   int* lerr;                // per-launch word in the scratch (reset before the launch; raised == 1)
+  unsigned startup_ms;      // per-launch budget of the start-up wait (ds2_persist_opts.startup_ms, never 0 here)
 };
 
 // ---- storage-type traits: pair access, granule packing, gate math --------------------------------------------------
@@ -460,6 +461,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_fwd(QArgs a) {
   }
   const long gi_stride = dstep * N * ldgi, sv_stride = dstep * N * NSH_, hs_stride = dstep * N * H;
   bool dead = false;
+  wait_all_resident(a.lerr, tid, a.err, a.startup_ms, dead);   // no wait of the sweep before all of the launch's workgroups are resident
 #pragma unroll
   for (int it = 0; it < IT; ++it)
     if (on[it]) {   // zero guard slots of the state sequence at t = -1 and t = T' ("previous h" reads are unconditional)
@@ -670,6 +672,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_bwd(QArgs a) {
     dgh_ptr[it] = a.dGH ? (T*)a.dGH + (((long)d * Tp + t_first) * N + n) * H + j : nullptr;     // dQ
   }
   bool dead = false;
+  wait_all_resident(a.lerr, tid, a.err, a.startup_ms, dead);   // no wait of the sweep before all of the launch's workgroups are resident
 
   for (int s = 0; s < Tp; ++s) {
     const int t = d == 0 ? Tp - 1 - s : s;

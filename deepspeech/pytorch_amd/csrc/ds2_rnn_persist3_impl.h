@@ -116,13 +116,14 @@ constexpr int lds_bytes3(int RT, int KSW) {
 }
 
 // XCC-id handshake of ds2_rnn_persist_impl.h for groups of P <= 32 workgroups
-__device__ __forceinline__ bool group_is_xcd_local3(u64* slots, int p, int P, int tid, int* err, int* lerr, bool& dead) {
+__device__ __forceinline__ bool group_is_xcd_local3(u64* slots, int p, int P, int tid, int* err, int* lerr, unsigned startup_ms, bool& dead) {
   __shared__ int s_local3;
   if (tid < 64) {
     const unsigned my = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf;   // HW_REG_XCC_ID[3:0]
     if (tid == 0) g_store(slots + p, (0x5ca1ab1eull << 32) | my);
     bool same = true;
     unsigned spins = 0;
+    const u64 t0 = wall_clock64();
     for (;;) {
       u64 v = 0;
       if (tid < P) v = g_load(slots + tid);
@@ -131,7 +132,7 @@ __device__ __forceinline__ bool group_is_xcd_local3(u64* slots, int p, int P, in
         same = !(tid < P) || ((unsigned)v == my);
         break;
       }
-      if (++spins > STARTUP_SPIN_LIMIT || ((spins & 1023u) == 0 && spin_check(lerr, spins))) {
+      if (((++spins) & 1023u) == 0 && startup_expired(lerr, t0, startup_ms)) {
         dead = true;
         raise_err_startup(err, lerr);
         same = false;
@@ -576,7 +577,11 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_fwd(RArgs ra) {
   }
   const long gi_stride = dstep * N * ldgi, sv_stride = dstep * N * NSH_, hs_stride = dstep * N * H;
   bool dead = false;
-  const bool local = ra.xmap ? group_is_xcd_local3(ra.xcc + grp * 32, p, ra.P, tid, a.err, a.lerr, dead) : false;
+  bool local = false;
+  if (ra.xmap)
+    local = group_is_xcd_local3(ra.xcc + grp * 32, p, ra.P, tid, a.err, a.lerr, a.startup_ms, dead);
+  else
+    wait_all_resident(a.lerr, tid, a.err, a.startup_ms, dead);    // groups that span XCDs: no XCC-id handshake, one arrival word
 #pragma unroll
   for (int q = 0; q < NSET; ++q)
     if (on[q]) {   // zero guard slots of the state sequence at t = -1 and t = T' ("previous h" reads are unconditional)
@@ -866,7 +871,11 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_bwd(RArgs ra) {
     dgh_ptr[q] = a.dGH ? (bf16_t*)a.dGH + (((long)d * Tp + t_first) * N + n) * H + j : nullptr;     // dQ
   }
   bool dead = false;
-  const bool local = ra.xmap ? group_is_xcd_local3(ra.xcc + grp * 32, p, ra.P, tid, a.err, a.lerr, dead) : false;
+  bool local = false;
+  if (ra.xmap)
+    local = group_is_xcd_local3(ra.xcc + grp * 32, p, ra.P, tid, a.err, a.lerr, a.startup_ms, dead);
+  else
+    wait_all_resident(a.lerr, tid, a.err, a.startup_ms, dead);    // groups that span XCDs: no XCC-id handshake, one arrival word
   __syncthreads();
 
   DS2_PROBE_ONLY(const int dbgmask = ra.dbgmask;)

@@ -79,6 +79,7 @@ struct PArgs {
   int* err;                 // device word, set to 1 on a spin time-out (sticky: the host reads it)
   int* lerr;                // per-LAUNCH word in the scratch (reset before the launch, raised == 1): lets the peers of a timed-out workgroup stop early
   u64* xcc;                 // [NGROUPS][32] start-up exchange of the workgroups' XCC ids, reset (0xFF bytes) before the launch
+  unsigned startup_ms;      // per-launch budget of the start-up handshake (wall clock; ds2_persist_opts.startup_ms, never 0 here)
 #ifdef DS2_PROBE            // tools/probe_rnn_persist.py builds its own library with -DDS2_PROBE; the shipping kernels carry none of it
   unsigned long long* dbg;  // [NGROUPS][8] cycle counters of workgroup 0 of each group
   unsigned long long* tl;   // [32 workgroups of group 0][TL_N steps][TL_K stamps]: s_memtime of wave 0 (see DS2_TL)
@@ -111,9 +112,9 @@ __device__ __forceinline__ void publish(u64* p, u64 v, bool local) {
 
 // Start-up handshake (placement-independent sc1 protocol): every workgroup publishes its XCC id, waits for the 31 peers of
 // its group and returns true iff all 32 ids are equal.  Every member evaluates the same 32 words, so the group agrees.
-// Every 1024 polls of a wait: has a peer already given up (lerr[0] == 1), or has this wait outlived the launch's own spin budget
-// (lerr[1]: all-ones from the scratch reset = none beyond SPIN_LIMIT; ds2_rnn_persist_set_spin_limit lowers it for fault-injection
-// tests)?
+// Every 1024 polls of a mid-sweep wait: has a peer already given up (lerr[0] == 1), or has this wait outlived the launch's own spin
+// budget (lerr[1]: all-ones from the scratch reset = none beyond SPIN_LIMIT; ds2_persist_opts.spin_limit lowers it per launch for
+// fault-injection tests)?
 __device__ __forceinline__ bool spin_check(int* lerr, unsigned spins) {
   return __hip_atomic_load(lerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1 ||
          spins > (unsigned)__hip_atomic_load(lerr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -123,23 +124,31 @@ __device__ __forceinline__ void raise_err(int* err, int* lerr) {
   __hip_atomic_store(lerr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // groups of the same launch stop with code 1 when they see lerr
 }
 // The start-up handshake is where a sweep finds out that its workgroups are NOT all resident: every workgroup needs a whole CU (512
-// registers per lane), so a kernel of another process on this GPU -- or a long kernel on another stream -- that holds CUs keeps some
-// of the 256 from starting while the others wait here.  That wait gets its own, much shorter budget (~0.3 s: an RCCL collective
-// beside the sweep ends within milliseconds) and its own code in the sticky error word, so that the host can NAME the cause
-// (ops.check_persistent_kernels) instead of reporting a generic time-out after seconds.  max: a later mid-sweep time-out of the
-// same launch must not hide it.
-constexpr unsigned STARTUP_SPIN_LIMIT = 1000000;   // measured: 1e5 polls = 0.03 s (tests/test_gpu_persist_safety.py)
+// registers per lane), so a kernel of another process on this GPU -- or a long kernel on another stream, e.g. an RCCL collective
+// that waits for a late peer rank -- that holds CUs keeps some of the 256 from starting while the others wait here.  That wait has
+// its own budget, a property of the LAUNCH (PArgs::startup_ms, measured on the 100 MHz wall clock, so it does not depend on the
+// shader clock or on how long a poll takes): the host passes ~0.3 s for a single-process run (nothing legitimate holds CUs that
+// long: fail fast and name the cause) and the process group's time-out under data parallelism (a sweep behind a collective must
+// WAIT, as any stock kernel would queue) -- ops.persist_startup_ms().  Its own code in the sticky error word lets the host NAME the
+// cause (ops.check_persistent_kernels) instead of reporting a generic time-out.  max: a later mid-sweep time-out of the same
+// launch must not hide it.
 __device__ __forceinline__ void raise_err_startup(int* err, int* lerr) {
   __hip_atomic_fetch_max(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_store(lerr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ bool group_is_xcd_local(u64* slots /* this group's [32] */, int p, int tid, int* err, int* lerr, bool& dead) {
+// every 1024 polls of a start-up wait: has a peer given up, or is the launch's start-up budget spent?
+__device__ __forceinline__ bool startup_expired(int* lerr, u64 t0, unsigned startup_ms) {
+  return __hip_atomic_load(lerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1 || wall_clock64() - t0 > (u64)startup_ms * 100000ull;
+}
+__device__ __forceinline__ bool group_is_xcd_local(u64* slots /* this group's [32] */, int p, int tid, int* err, int* lerr, unsigned startup_ms,
+                                                   bool& dead) {
   __shared__ int s_local;
   if (tid < 64) {
     const unsigned my = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf;   // HW_REG_XCC_ID[3:0]
     if (tid == 0) g_store(slots + p, (0x5ca1ab1eull << 32) | my);
     bool same = true;
     unsigned spins = 0;
+    const u64 t0 = wall_clock64();
     for (;;) {
       u64 v = 0;
       if (tid < 32) v = g_load(slots + tid);
@@ -148,7 +157,7 @@ __device__ __forceinline__ bool group_is_xcd_local(u64* slots /* this group's [3
         same = !(tid < 32) || ((unsigned)v == my);
         break;
       }
-      if (++spins > STARTUP_SPIN_LIMIT || ((spins & 1023u) == 0 && spin_check(lerr, spins))) {
+      if (((++spins) & 1023u) == 0 && startup_expired(lerr, t0, startup_ms)) {
         dead = true;
         raise_err_startup(err, lerr);
         same = false;
@@ -161,6 +170,31 @@ __device__ __forceinline__ bool group_is_xcd_local(u64* slots /* this group's [3
   }
   __syncthreads();
   return s_local != 0;
+}
+// Kernels without an XCC-id handshake (groups that span XCDs, the round-2 general kernels): ONE arrival word per launch in the
+// scratch head (lerr[2], all-ones after the reset): every workgroup adds 1 and waits until all gridDim.x have, under the same
+// start-up budget and with the same error code.  After it every wait of the sweep is between RESIDENT workgroups.
+__device__ __forceinline__ void wait_all_resident(int* lerr, int tid, int* err, unsigned startup_ms, bool& dead) {
+  __shared__ int s_dead;
+  if (tid == 0) {
+    int gone = 0;
+    unsigned* arrive = reinterpret_cast<unsigned*>(lerr + 2);
+    __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned want = gridDim.x - 1u;          // 0xFFFFFFFF + gridDim.x
+    unsigned spins = 0;
+    const u64 t0 = wall_clock64();
+    while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+      if (((++spins) & 1023u) == 0 && startup_expired(lerr, t0, startup_ms)) {
+        raise_err_startup(err, lerr);
+        gone = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    s_dead = gone;
+  }
+  __syncthreads();
+  if (s_dead) dead = true;
 }
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) { return cvt_pk_bf16(lo, hi); }
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
@@ -637,7 +671,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd(PArgs a) {
   bf16_t* hs_ptr = a.Hseq + (long)d * a.hseq_dstride + ((long)t_first * N + nn_) * H + j;
   const long hs_stride = dstep * N * H;
   bool dead = false;
-  const bool local = group_is_xcd_local(a.xcc + grp * 32, p, tid, a.err, a.lerr, dead);
+  const bool local = group_is_xcd_local(a.xcc + grp * 32, p, tid, a.err, a.lerr, a.startup_ms, dead);
   if (gate_thread) {         // zero guard slots of the state sequence at t = -1 and t = T' ("previous h" reads are unconditional)
     bf16_t* hb = a.Hseq + (long)d * a.hseq_dstride + (long)n * H + j;
     *reinterpret_cast<uint32_t*>(hb - (long)N * H) = 0u;
@@ -860,7 +894,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd4(PArgs a) {
   bf16_t* hs_ptr = a.Hseq + (long)d * a.hseq_dstride + ((long)t_first * N + nn_) * H + j;
   const long hs_stride = dstep * N * H;
   bool dead = false;
-  const bool local = group_is_xcd_local(a.xcc + grp * 32, p, tid, a.err, a.lerr, dead);
+  const bool local = group_is_xcd_local(a.xcc + grp * 32, p, tid, a.err, a.lerr, a.startup_ms, dead);
   if (gate_thread && e == 0) {   // zero guard slots of the state sequence at t = -1 and t = T'
     bf16_t* hb = a.Hseq + (long)d * a.hseq_dstride + (long)n * H + j;
     *reinterpret_cast<uint32_t*>(hb - (long)N * H) = 0u;
@@ -1129,7 +1163,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd(PArgs a) {
   for (int g = 0; g < NB; ++g) bsum[g][0] = bsum[g][1] = 0.f;
   const long prev_off = d == 0 ? -1 : 1;                    // previous step in FORWARD order of this direction
   bool dead = false;
-  const bool local = group_is_xcd_local(a.xcc + grp * 32, p, tid, a.err, a.lerr, dead);
+  const bool local = group_is_xcd_local(a.xcc + grp * 32, p, tid, a.err, a.lerr, a.startup_ms, dead);
   unsigned rounds = 0;
   DS2_PROBE_ONLY(unsigned long long c_gather = 0, c_bar = 0, c_gate = 0;)
 
@@ -1358,7 +1392,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd4(PArgs a) {
   for (int g = 0; g < NB; ++g) bsum[g] = 0.f;
   const long prev_off = d == 0 ? -1 : 1;
   bool dead = false;
-  const bool local = group_is_xcd_local(a.xcc + grp * 32, p, tid, a.err, a.lerr, dead);
+  const bool local = group_is_xcd_local(a.xcc + grp * 32, p, tid, a.err, a.lerr, a.startup_ms, dead);
   unsigned rounds = 0;
   const int pidx = partial_t_index((2 * up + e) / 16, gi_i, (2 * up + e) % 16);
   const int xoff = SP ? xsp_pair_bytes(j, gi_i) : xtf_pair_bytes(j, gi_i);     // this pair's dword of gate 0 inside a slot

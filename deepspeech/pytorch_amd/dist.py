@@ -217,6 +217,8 @@ def wrap_data_parallel(step_module, device, world, bucket_cap_mb=64, overlap=Non
     try:      # the drop-in class then builds one autograd node per layer for every shape (the reducer sees gradients progressively)
         from . import model as _model
         _model.PER_LAYER_NODES_FOR_DDP[0] = True
+        from . import ops as _ops
+        _ops.FORCE_DATA_PARALLEL_BUDGET[0] = True      # sweeps wait for their CUs behind a collective (ops.persist_startup_ms)
     except Exception:  # noqa: BLE001  (stand-in modules in the CPU tests)
         pass
     if overlap_allreduce() if overlap is None else overlap:

@@ -378,6 +378,86 @@ def conv2_wgrad(dy2, a1, F0=161):
 _PERSIST_ERR = {}
 LAST_PERSIST_WS = None   # the most recent persistent sweep's scratch (its tail holds the kernel's cycle counters)
 
+# ---- per-launch options of the persistent sweeps (ds2_persist_opts) -----------------------------------------------------------
+# What the host decides per launch: the routing A/B bits and the fault-injection spin budget (tests / tools only, through the
+# persist_options() context, which restores them on exit whatever happens inside), and the START-UP budget -- how long the sweep's
+# workgroups wait for all of them to become resident (a sweep needs every CU at once):
+#   * single process: 300 ms.  Nothing legitimate holds compute units that long; fail fast, error code 2 names the cause.
+#   * data parallel (torch.distributed initialised with > 1 rank, or dist.wrap_data_parallel told model.py): the process group's
+#     time-out (torch's default for "nccl": 10 min).  An RCCL all-reduce on DDP's stream stays resident until its SLOWEST peer
+#     arrives -- the reference's sampler hands ranks unequal batches (loader/data_loader.py:320-360), rank 0 saves checkpoints,
+#     loaders stall -- and a sweep launched behind it must WAIT, exactly as a stock kernel would queue; if a peer is really gone
+#     the collective's own watchdog ends the job, not the sweep.
+#   * DS2_PERSIST_STARTUP_MS overrides both.
+STARTUP_MS_SINGLE = 300
+STARTUP_MS_DP_MIN, STARTUP_MS_DP_MAX = 30_000, 3_600_000
+_OPTS = {"variant": 0, "spin_limit": 0, "startup_ms": None}
+FORCE_DATA_PARALLEL_BUDGET = [False]      # model.PER_LAYER_NODES_FOR_DDP's twin: dist.wrap_data_parallel sets it for DS2_FORCE_DDP runs
+
+
+class persist_options:
+    """with ops.persist_options(variant=..., spin_limit=..., startup_ms=...): every persistent sweep launched inside (forward on this
+    thread, backward on autograd's) carries these ds2_persist_opts; the previous values come back on exit."""
+
+    def __init__(self, **kw):
+        assert set(kw) <= set(_OPTS), kw
+        self.kw = kw
+
+    def __enter__(self):
+        self.old = dict(_OPTS)
+        _OPTS.update(self.kw)
+        return self
+
+    def __exit__(self, *exc):
+        _OPTS.clear()
+        _OPTS.update(self.old)
+        return False
+
+
+def data_parallel_ranks():
+    """World size of the initialised default process group (1 if none)."""
+    try:
+        import torch.distributed as _dist
+        if _dist.is_available() and _dist.is_initialized():
+            return int(_dist.get_world_size())
+    except Exception:  # noqa: BLE001
+        pass
+    return 1
+
+
+def persist_startup_ms():
+    """The start-up budget the next sweep is launched with (see above)."""
+    if _OPTS["startup_ms"] is not None:
+        return int(_OPTS["startup_ms"])
+    env = _os.environ.get("DS2_PERSIST_STARTUP_MS", "")
+    if env:
+        return max(1, int(env))
+    if data_parallel_ranks() > 1 or FORCE_DATA_PARALLEL_BUDGET[0]:
+        ms = 600_000
+        try:
+            import torch.distributed as _dist
+            from torch.distributed.distributed_c10d import _get_default_group
+            if _dist.is_initialized():
+                to = getattr(_get_default_group(), "_timeout", None) or getattr(_dist, "default_pg_timeout", None)
+                if to is not None:
+                    ms = int(to.total_seconds() * 1000)
+        except Exception:  # noqa: BLE001
+            pass
+        return min(max(ms, STARTUP_MS_DP_MIN), STARTUP_MS_DP_MAX)
+    return STARTUP_MS_SINGLE
+
+
+def _persist_opts():
+    """(ctypes struct, byref) for one launch; the struct must stay alive until the call returns."""
+    o = _lib.PersistOpts(int(_OPTS["variant"]), int(_OPTS["spin_limit"]), persist_startup_ms())
+    return o
+
+
+def persist_kind(dtype, kind, D, N, H):
+    """Kernel family the persistent entries run for the problem on the current device under the current routing (0 none, 1 / 2 tuned
+    H = 1024, 3 round-4 general, 4 round-2 general)."""
+    return query("ds2_rnn_persist_kind", dt(dtype), CELLS[kind], D, N, H, int(_OPTS["variant"]))
+
 
 def _persist_err(dev):
     """One int32 word per device that the persistent recurrent kernels raise when a workgroup times out."""
@@ -390,11 +470,13 @@ def _persist_err(dev):
 
 def _persist_error_message(code, key):
     """The sticky error word of the persistent sweeps: 1 = a workgroup gave up waiting for a peer's data in the middle of a sweep,
-    2 = the start-up handshake never completed, i.e. the sweep's 256 workgroups (one whole CU each) were not all resident."""
+    2 = the start-up wait never completed, i.e. the sweep's workgroups (one whole CU each) were not all resident."""
     if code == 2:
-        return ("a persistent recurrent sweep on device %d could not start: its 256 workgroups never became co-resident within ~0.3 s -- "
-                "another kernel holds compute units (a second process on this GPU, e.g. a validation job or two ranks with the same "
-                "LOCAL_RANK; or a long-running kernel on another stream).  The sweep gave up, its outputs were NaN-poisoned" % key)
+        return ("a persistent recurrent sweep on device %d could not start: its workgroups never became co-resident within its start-up "
+                "budget (%.1f s now; 0.3 s single-process, the process group's time-out under data parallelism, DS2_PERSIST_STARTUP_MS "
+                "overrides) -- another kernel holds compute units (a second process on this GPU, e.g. a validation job or two ranks with "
+                "the same LOCAL_RANK; or a long-running kernel on another stream).  The sweep gave up, its outputs were NaN-poisoned"
+                % (key, persist_startup_ms() / 1000.0))
     return ("a persistent recurrent kernel timed out on device %d waiting for its peer workgroups in the middle of a sweep "
             "(are other kernels occupying CUs?); its outputs were NaN-poisoned" % key)
 
@@ -503,7 +585,7 @@ def use_persistent(kind, dtype, D, N, H):
     train_config.py:49) the launch-per-time-step kernels run, 5-8x slower per step, and a warning says so once per shape."""
     if not PERSIST_ENABLED:
         return False
-    ok = bool(query("ds2_rnn_persist_supported", dt(dtype), CELLS[kind], D, N, H))
+    ok = bool(query("ds2_rnn_persist_supported", dt(dtype), CELLS[kind], D, N, H, int(_OPTS["variant"])))
     if ok:
         return True
     import os
@@ -526,8 +608,10 @@ def use_persistent(kind, dtype, D, N, H):
             _WARNED_SHAPES.add(key)
             warnings.warn("ds2hip: no persistent recurrent kernel is instantiated for %s %s hidden=%d, %d direction(s), batch %d: the "
                           "sweeps run one launch per time step (5-8x slower per step).  Persistent kernels exist for bf16 GRU / LSTM "
-                          "with hidden in {512, 768, 800, 1024, 1280, 1536} (LSTM: not 1536) up to 32 clips per group, bf16 hidden 1024 "
-                          "(any cell), and fp32 hidden in {800, 1024}." % (str(dtype).replace("torch.", ""), kind, H, D, N))
+                          "with hidden in {384, 512, 640, 768, 800, 896, 1024, 1152, 1280, 1408, 1536} (LSTM: not 1408 / 1536) up to 32 "
+                          "clips per group, bf16 hidden 1024 (any cell), and fp32 GRU / LSTM with hidden in {800, 1024}; the model class "
+                          "zero-pads other hidden sizes up to the nearest of these when that is at most 1.5x as wide (DS2_PAD_HIDDEN)."
+                          % (str(dtype).replace("torch.", ""), kind, H, D, N))
     return False
 
 
@@ -544,12 +628,13 @@ def rnn_fwd(kind, GI, Whh, bhh, lens, D, N, H, Tp, h0=None, c0=None, save=True):
     hn = torch.empty((D, N, H), dtype=torch.float32, device=dev)
     cn = torch.empty((D, N, H), dtype=torch.float32, device=dev) if kind == "lstm" else None
     if persistent:
-        ws = torch.empty(query("ds2_rnn_persist_ws_bytes", dt(dtype), CELLS[kind], D, N, H), dtype=torch.uint8, device=dev)
+        ws = torch.empty(query("ds2_rnn_persist_ws_bytes", dt(dtype), CELLS[kind], D, N, H, int(_OPTS["variant"])), dtype=torch.uint8, device=dev)
         global LAST_PERSIST_WS
         LAST_PERSIST_WS = ws
+        po = _persist_opts()
         with _sweep_timer("rnn_fwd_persistent", Tp):
             call("ds2_rnn_persist_fwd", dt(dtype), CELLS[kind], D, N, H, Tp, P(lens), P(GI), P(Whh), PF(bhh), PF(h0), PF(c0),
-                 P(hext[:, 1]), (Tp + 2) * N * H, P(Sv), P(hn), P(cn), P(ws), P(_persist_err(dev)), S())
+                 P(hext[:, 1]), (Tp + 2) * N * H, P(Sv), P(hn), P(cn), P(ws), P(_persist_err(dev)), C.byref(po), S())
         return hext, Sv, hn, cn
     state = torch.empty(query("ds2_rnn_state_bytes", D, N, H), dtype=torch.uint8, device=dev)
     with _sweep_timer("rnn_fwd", Tp):
@@ -585,12 +670,13 @@ def rnn_bwd(kind, dOut, WhhT, hext, Sv, lens, D, N, H, Tp, pad_rows_unread=False
             if dQ is not None:
                 dQ.fill_(float("nan"))
         bacc = torch.empty((D, N, (4 if kind == "gru" else G) * H), dtype=torch.float32, device=dev)
-        ws = torch.empty(query("ds2_rnn_persist_ws_bytes", dt(dtype), CELLS[kind], D, N, H), dtype=torch.uint8, device=dev)
+        ws = torch.empty(query("ds2_rnn_persist_ws_bytes", dt(dtype), CELLS[kind], D, N, H, int(_OPTS["variant"])), dtype=torch.uint8, device=dev)
         global LAST_PERSIST_WS
         LAST_PERSIST_WS = ws
+        po = _persist_opts()
         with _sweep_timer("rnn_bwd_persistent", Tp):
             call("ds2_rnn_persist_bwd", dt(dtype), CELLS[kind], D, N, H, Tp, P(lens), P(dOut), P(WhhT), P(hext[:, 1]), (Tp + 2) * N * H,
-                 P(Sv), P(dGI), P(dQ), P(bacc), 1 if pad_rows_unread else 0, P(ws), P(_persist_err(dev)), S())
+                 P(Sv), P(dGI), P(dQ), P(bacc), 1 if pad_rows_unread else 0, P(ws), P(_persist_err(dev)), C.byref(po), S())
         return RnnGrads(dGI, dQ=dQ, bacc=bacc)
     dGH = torch.empty((D, Tp, N, G * H), dtype=dtype, device=dev) if kind == "gru" else None
     state = torch.empty(query("ds2_rnn_state_bytes", D, N, H), dtype=torch.uint8, device=dev)
@@ -655,8 +741,11 @@ def greedy_decode(scores, sizes, blank):
     return toks, offs
 
 
+CTC_RECURSION = 0    # tests / A-B tools: 1 = always the four-wave recursion kernel, 2 = the one-wave kernel up to 255 labels
+
+
 def ctc_loss_grad(logits, targets_i32, target_offsets, input_lengths, target_lengths, Tp, N, Cc, blank, max_target_len,
-                  ldg=None):
+                  ldg=None, recursion=None):
     """logits [Tp*N][ld] f32.  Returns (loss_sum [1], nll [N], dlogits [Tp*N][ldg] f32 with unit upstream gradient)."""
     dev = logits.device
     ldg = logits.shape[1] if ldg is None else ldg
@@ -665,5 +754,6 @@ def ctc_loss_grad(logits, targets_i32, target_offsets, input_lengths, target_len
     dlogits = torch.empty((Tp * N, ldg), dtype=torch.float32, device=dev)
     ws = torch.empty(query("ds2_ctc_ws_floats", Tp, N, Cc, max_target_len), dtype=torch.float32, device=dev)
     call("ds2_ctc_loss_grad", P(logits), logits.stride(0), P(targets_i32), P(target_offsets), P(input_lengths),
-         P(target_lengths), Tp, N, Cc, blank, max_target_len, 1.0, P(nll), P(loss), P(dlogits), ldg, P(ws), S())
+         P(target_lengths), Tp, N, Cc, blank, max_target_len, 1.0, P(nll), P(loss), P(dlogits), ldg, P(ws),
+         int(CTC_RECURSION if recursion is None else recursion), S())
     return loss, nll, dlogits

@@ -71,8 +71,6 @@ int ds2_gemm_nt_coresident(int dtype, const void* A, const void* B, void* C, con
  * gate gradient [dr, dz | dQ] lives in two buffers.  Any K (no row past K - 1 is read); M_i, N_i, lda, ldb % 8 == 0. */
 int ds2_gemm8_nt(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long lda, long ldb, long ldc, int out_f32,
                  ds2_stream_t stream);
-/* staging schedule of the 256x256 kernels, for A/B measurements (0 = default); returns the previous value */
-int ds2_gemm8_set_variant(int v);
 int ds2_gemm8_tn_grouped(int n_problems, const void* const* At, const void* const* At2, const int* m_split, const void* const* Bt, void* const* C,
                          const int* M, const int* N, const long* lda, const long* lda2, const long* ldb, const long* ldc, int K, ds2_stream_t stream);
 
@@ -168,26 +166,41 @@ int ds2_rnn_bwd(int dtype, int cell, int D, int N, int H, int Tp, const int* len
  * samples per group (round-4 general kernels: 32 units per workgroup, groups inside one XCD for H <= 1024 -- config 5); GRU /
  * LSTM with fp32 H in {800, 1024} or bf16 H in {800, 1280} and <= 64 samples per group (round-2 general kernels: config 2, the 1e-3
  * parity mode); everything else runs ds2_rnn_fwd / _bwd.
- * ws: ds2_rnn_persist_ws_bytes() bytes of scratch (reset by every call on `stream`); err: one device int that the kernel sets to 1 if a workgroup gave up
- * waiting for its peers (its outputs are then NaN). */
-/* Test hook (fault injection): the number of polls a workgroup of a persistent sweep may spend waiting for its peers on one
- * exchange before it gives up -- raises *err, NaN-poisons its outputs, ends.  0 = the built-in budget (seconds).  Returns the
- * previous value. */
-unsigned ds2_rnn_persist_set_spin_limit(unsigned polls);
-/* A/B hook: bit 0 = the shapes of the round-4 general kernels (csrc/ds2_rnn_persist3_impl.h) run on the round-2 general kernels
- * (or one launch per time step) instead.  Process-wide; returns the previous value. */
-unsigned ds2_rnn_persist_set_variant(unsigned bits);
-int ds2_rnn_persist_supported(int dtype, int cell, int D, int N, int H);
+ * ws: ds2_rnn_persist_ws_bytes() bytes of scratch (reset by every call on `stream`); err: one device int, sticky (maximum): 1 = a
+ * workgroup gave up waiting for its peers in the middle of a sweep, 2 = the launch's workgroups never became co-resident within
+ * opts->startup_ms; the outputs are then NaN-poisoned. */
+/* Per-launch options of the persistent sweeps; pass NULL for the defaults.  (Rounds 2-5 had process-wide setters here --
+ * ds2_rnn_persist_set_variant / _set_spin_limit; options travel with the call now: the entries are re-entrant, backward may run on
+ * autograd's worker thread beside a forward, and nothing a caller sets outlives its call.)
+ *   variant     routing A/B bits for measurements, 0 = the shipping routing: bit 0 the shapes of the round-4 general kernels
+ *               (csrc/ds2_rnn_persist3_impl.h) run on the round-2 general kernels (or one launch per time step) instead, 1 two-set
+ *               groups execute every half-step, 3 the round-4 kernels also take H = 1024 with <= 8 clips per group, 4 the tuned kernels
+ *               keep 9-16 clips per group, 5 the 8-clip tuned kernels use dense products instead of the structured-sparse ones.
+ *               The queries below take the same bits, so that a caller sizes the scratch for the routing it will launch.
+ *   spin_limit  fault injection: polls a workgroup may spend on ONE mid-sweep exchange wait before it gives up (raises *err = 1,
+ *               NaN-poisons its outputs, ends); 0 = the built-in budget (~seconds).
+ *   startup_ms  how long (wall clock) the workgroups of a launch wait for ALL of them to become resident before the first exchange;
+ *               a sweep needs every workgroup on a CU of its own at the same time, so a kernel of another process -- or an RCCL
+ *               collective on another stream that waits for a late peer rank -- keeps it from starting.  0 = 300 ms: right for a
+ *               single process (nothing legitimate holds CUs that long; *err = 2 names the cause).  Under data parallelism pass
+ *               the process group's time-out: a sweep behind a collective must wait, as any stock kernel would simply queue
+ *               (configs/librispeech.yaml:14 `strategy: ddp`; loader/data_loader.py:320-360 hands ranks unequal batches). */
+typedef struct ds2_persist_opts {
+  unsigned variant;
+  unsigned spin_limit;
+  unsigned startup_ms;
+} ds2_persist_opts;
+int ds2_rnn_persist_supported(int dtype, int cell, int D, int N, int H, unsigned variant);
 /* 1 if a persistent kernel exists for the problem on a FULL device (256 CUs), whatever the current device exposes: tells "this
  * device is too small for the persistent sweeps" (the caller raises) from "no persistent kernel for this shape" (it warns). */
 int ds2_rnn_persist_shape_covered(int dtype, int cell, int D, int N, int H);
 /* Kernel family the persistent entries run for the problem on the current device: 0 none (ds2_rnn_fwd / _bwd), 1 / 2 tuned H = 1024
  * (<= 8 / 9-16 samples per group), 3 round-4 general (k_rnn_persist3_*), 4 round-2 general (k_rnn_persist2_*). */
-int ds2_rnn_persist_kind(int dtype, int cell, int D, int N, int H);
-long ds2_rnn_persist_ws_bytes(int dtype, int cell, int D, int N, int H);
+int ds2_rnn_persist_kind(int dtype, int cell, int D, int N, int H, unsigned variant);
+long ds2_rnn_persist_ws_bytes(int dtype, int cell, int D, int N, int H, unsigned variant);
 int ds2_rnn_persist_fwd(int dtype, int cell, int D, int N, int H, int Tp, const int* lens, const void* GI, const void* Whh,
                         const float* bhh, const float* h0, const float* c0, void* Hseq, long hseq_dstride, void* S, float* hn,
-                        float* cn, void* ws, int* err, ds2_stream_t stream);
+                        float* cn, void* ws, int* err, const ds2_persist_opts* opts, ds2_stream_t stream);
 /* BPTT: dGI as ds2_rnn_bwd; GRU: dQ [D][Tp][N][H] = dn*r (the one slot of the hidden-side gate gradient [dr,dz,dQ] that differs
  * from dGI's; null for LSTM / RNN); dBacc [D][N][NB*H] f32 (may be null): per-sample sums over time of the stored gate-gradient
  * planes (NB = 4 for GRU: dr, dz, dn, dQ; G otherwise) -- the bias gradients are their sums over the samples. */
@@ -196,7 +209,7 @@ int ds2_rnn_persist_fwd(int dtype, int cell, int D, int N, int H, int Tp, const 
  * of the round-4 general kernels) skips zeroing them. */
 int ds2_rnn_persist_bwd(int dtype, int cell, int D, int N, int H, int Tp, const int* lens, const void* dOut, const void* WhhT,
                         const void* Hseq, long hseq_dstride, const void* S, void* dGI, void* dQ, float* dBacc, int flags, void* ws,
-                        int* err, ds2_stream_t stream);
+                        int* err, const ds2_persist_opts* opts, ds2_stream_t stream);
 
 /* ---- small sequence ops ---------------------------------------------------------------------------------------------------
  * add2: out = a + b (direction sum, model.py:101).  transpose: dst[C][ldd] = src[R][lds]^T, zero-filling r in [R, ldd).
@@ -244,20 +257,19 @@ int ds2_rnn_bias_grads(int cell, int D, int N, int H, const float* dBacc, float*
 /* probs = softmax(logits) row-wise (InferenceBatchSoftmax, model.py:72-77), f32 [rows][C] */
 int ds2_softmax_rows(const float* logits, float* probs, long rows, int C, long ld_in, long ld_out, ds2_stream_t stream);
 
-/* recursion kernel of ds2_ctc_loss_grad: 1 (default) = one wave per (sample, direction) for <= 32 classes and targets of <= 63
- * labels, the four-wave kernel otherwise; 0 = always the four-wave kernel; 2 = the one-wave kernel up to 255 labels.  A/B and test
- * hook; identical results.  Returns the previous value. */
-int ds2_ctc_set_variant(int mode);
 /* ---- log_softmax + CTC loss + gradient (model.py:246,203,248) -----------------------------------------------------------
  * logits [Tp*N][ldl] f32 (row = t*N+n, C classes), targets int32 concatenated with target_offsets[N] (start of each
  * sample's labels), input_lengths/target_lengths int32 [N].  blank index `blank`; reduction 'sum'; zero_infinity: an
  * infeasible sample contributes loss 0 and gradient 0.  Outputs: nll [N] f32 (per-sample), loss_sum [1] f32,
  * dlogits [Tp*N][ldg] f32 = grad_scale * d(loss_sum)/d(logits) (log_softmax backward fused; zero rows for t >= length;
- * columns >= C are zero-filled up to ldg).  ws: ds2_ctc_ws_floats(...) floats.  max_target_len: max over target_lengths. */
+ * columns >= C are zero-filled up to ldg).  ws: ds2_ctc_ws_floats(...) floats.  max_target_len: max over target_lengths.
+ * recursion: which recursion kernel runs (identical results; for A/B runs and tests): 0 = the default choice (one wave per (sample,
+ * direction) for <= 32 classes and targets of <= 63 labels, the four-wave kernel otherwise), 1 = always the four-wave kernel, 2 = the
+ * one-wave kernel up to 255 labels. */
 long ds2_ctc_ws_floats(int Tp, int N, int C, int max_target_len);
 int ds2_ctc_loss_grad(const float* logits, long ldl, const int* targets, const int* target_offsets, const int* input_lengths,
                       const int* target_lengths, int Tp, int N, int C, int blank, int max_target_len, float grad_scale,
-                      float* nll, float* loss_sum, float* dlogits, long ldg, float* ws, ds2_stream_t stream);
+                      float* nll, float* loss_sum, float* dlogits, long ldg, float* ws, int recursion, ds2_stream_t stream);
 
 /* ---- optimizer step (configure_optimizers, model.py:273-297; Lightning's gradient_clip_val, configs/an4.yaml:12) -----------
  * ds2_clip_coef: out[0] = global L2 norm of `count` fp32 gradient tensors, out[1] = min(1, max_norm / (norm + 1e-6)) -- the

@@ -364,12 +364,9 @@ def test_rnn_persistent_sparse_and_dense_forms_agree(kind, D, N, H, Tp):
     assert o.use_persistent(kind, torch.bfloat16, D, N, H)
     res_sp = _rnn_sweep_case(torch.bfloat16, kind, D, N, H, Tp, 1.0 / np.sqrt(H))
     o.check_persistent_kernels()
-    old = query("ds2_rnn_persist_set_variant", 32)         # bit 5: dense products (round 4's form)
-    try:
+    with o.persist_options(variant=32):                    # bit 5: dense products (round 4's form)
         res_de = _rnn_sweep_case(torch.bfloat16, kind, D, N, H, Tp, 1.0 / np.sqrt(H))
         o.check_persistent_kernels()
-    finally:
-        query("ds2_rnn_persist_set_variant", old)
     for a, b in zip(res_sp, res_de):
         assert np.abs(a - b).max() <= 2e-2 * max(1.0, np.abs(b).max()), np.abs(a - b).max()
 
@@ -410,13 +407,10 @@ def test_rnn_persist3_sweeps(kind, D, N, H, Tp):
     res_p = _rnn_sweep_case(dtype, kind, D, N, H, Tp, 1.0 / np.sqrt(H))
     o.check_persistent_kernels()
     others = []
-    old = query("ds2_rnn_persist_set_variant", 1)          # round-2 general kernels, if they take the shape
-    try:
-        if query("ds2_rnn_persist_supported", o.dt(dtype), o.CELLS[kind], D, N, H):
+    with o.persist_options(variant=1):                     # round-2 general kernels, if they take the shape
+        if query("ds2_rnn_persist_supported", o.dt(dtype), o.CELLS[kind], D, N, H, 1):
             others.append(_rnn_sweep_case(dtype, kind, D, N, H, Tp, 1.0 / np.sqrt(H)))
             o.check_persistent_kernels()
-    finally:
-        query("ds2_rnn_persist_set_variant", old)
     o.PERSIST_ENABLED = False
     try:
         others.append(_rnn_sweep_case(dtype, kind, D, N, H, Tp, 1.0 / np.sqrt(H)))
@@ -705,14 +699,10 @@ def _ctc_case(N, Tp, lens, tlens, seed, Cc=29, scale=2.0):
     (2, 530, [530, 530], [256, 3]),                 # 2S+1 = 513: beyond the one-wave kernel -> the four-wave kernel
     (5, 70, [70, 64, 33, 2, 1], [30, 31, 16, 1, 1]),  # lengths around the 8-step staging chunks; one- and two-frame clips
 ])
-@pytest.mark.parametrize("wave", [2, 0])
-def test_ctc_loss_and_grad(N, Tp, lens, tlens, wave):
-    from deepspeech.pytorch_amd import _lib
-    old = _lib.load().ds2_ctc_set_variant(wave)     # 2: one wave per (sample, direction) up to 255 labels; 0: the four-wave kernel
-    try:
-        _ctc_check(N, Tp, lens, tlens)
-    finally:
-        _lib.load().ds2_ctc_set_variant(old)
+@pytest.mark.parametrize("recursion", [2, 1])
+def test_ctc_loss_and_grad(N, Tp, lens, tlens, recursion, monkeypatch):
+    monkeypatch.setattr(ops(), "CTC_RECURSION", recursion)   # 2: one wave per (sample, direction) up to 255 labels; 1: the four-wave kernel
+    _ctc_check(N, Tp, lens, tlens)
 
 
 def test_ctc_recursion_kernels_agree_bit_for_bit():
@@ -725,14 +715,10 @@ def test_ctc_recursion_kernels_agree_bit_for_bit():
     lg[:, :29] = cu(logits.reshape(Tp * N, 29))
     offs = np.concatenate([[0], np.cumsum(tlens)[:-1]]).astype(np.int32)
     outs = []
-    for wave in (2, 0):
-        old = _lib.load().ds2_ctc_set_variant(wave)
-        try:
-            outs.append(o.ctc_loss_grad(lg, torch.from_numpy(targets.astype(np.int32)).to(DEV), torch.from_numpy(offs).to(DEV),
-                                        torch.from_numpy(np.asarray(lens, np.int32)).to(DEV),
-                                        torch.from_numpy(np.asarray(tlens, np.int32)).to(DEV), Tp, N, 29, 0, int(max(tlens))))
-        finally:
-            _lib.load().ds2_ctc_set_variant(old)
+    for recursion in (2, 1):
+        outs.append(o.ctc_loss_grad(lg, torch.from_numpy(targets.astype(np.int32)).to(DEV), torch.from_numpy(offs).to(DEV),
+                                    torch.from_numpy(np.asarray(lens, np.int32)).to(DEV),
+                                    torch.from_numpy(np.asarray(tlens, np.int32)).to(DEV), Tp, N, 29, 0, int(max(tlens)), recursion=recursion))
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
 

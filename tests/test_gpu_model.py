@@ -660,7 +660,7 @@ def test_nobody_reads_the_padding_rows_a_two_set_sweep_leaves_unwritten(monkeypa
         return float(loss.item()), {k: p.grad.detach().double().cpu().numpy() for k, p in m.named_parameters()}
 
     from deepspeech.pytorch_amd._lib import query
-    assert query("ds2_rnn_persist_kind", ops.dt(torch.bfloat16), ops.CELLS["lstm"], 2, 64, 1280) == 3      # two-set general sweeps
+    assert ops.persist_kind(torch.bfloat16, "lstm", 2, 64, 1280) == 3      # two-set general sweeps
     la, ga = step(True)
     lb, gb = step(False)
     assert np.isfinite(la) and la == lb

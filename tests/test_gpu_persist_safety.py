@@ -3,16 +3,19 @@ on their own stream while the sweeps own the CUs).
 
 * a >= 64 MB all-reduce on a 1-rank RCCL group, enqueued on a side stream, runs concurrently with a full cfg3 BPTT sweep: the sweep
   finishes without a time-out, bit-identical to the sweep alone; the slow-down is printed;
-* FAULT INJECTION: a squatter kernel that holds half of the chip's CUs (all of their LDS) while a sweep starts, with the spin
-  budget lowered through the C ABI's test hook (ds2_rnn_persist_set_spin_limit): the resident half of the sweep gives up, the
-  launch ENDS (bounded spins), the device error word is raised, the outputs are NaN-poisoned, and
-  ops.poll_persistent_error -- what DeepSpeech.training_step calls once per step -- raises at the latest one call later;
-  afterwards a clean sweep works again."""
-import ctypes
+* FAULT INJECTION (tests/squat.py): squatter workgroups hold half of the chip's CUs (all of their LDS) while a sweep starts.
+  The pre-condition is OBSERVED, not assumed: the squatters count themselves in, the sweep is launched only when all of them run,
+  and the test reads how many of the sweep's workgroups have signed the start-up handshake WHILE the squatters are still there --
+  0 means the squatters' stream shares a hardware queue with the sweep's (the two were serialised: round 5's red gate), all of them
+  means the squatters did not hold their CUs; either fails with that message instead of a misleading one.
+    - single-process budget: the resident half of the sweep gives up after its start-up budget by itself, the launch ENDS, the
+      device error word says 2 ("never co-resident"), the outputs are NaN-poisoned, ops.poll_persistent_error -- what
+      DeepSpeech.training_step calls once per step -- raises at the latest one call later; afterwards a clean sweep works again;
+    - the same with the squatters in a SECOND PROCESS (the scenario the error message names);
+    - DATA-PARALLEL budget: the squatters hold the CUs for a second -- an RCCL collective waiting for a late peer rank -- and the
+      sweep WAITS, then completes bit-identical with no error."""
 import os
 import socket
-import subprocess
-import tempfile
 import time
 
 import numpy as np
@@ -21,34 +24,6 @@ import torch
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-
-SQUAT_SRC = r"""
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-// occupies a CU's whole LDS (so that no persistent-sweep workgroup fits beside it) until `until` (wall-clock ticks, 100 MHz) or
-// until *release becomes non-zero
-__global__ void __launch_bounds__(64) k_squat(unsigned long long ticks, int* release, int* sink) {
-  extern __shared__ unsigned char lds[];
-  lds[threadIdx.x] = (unsigned char)threadIdx.x;
-  const unsigned long long t0 = wall_clock64();
-  while (wall_clock64() - t0 < ticks && __hip_atomic_load(release, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(32);
-  if (sink && threadIdx.x == 0) sink[blockIdx.x] = lds[1];
-}
-extern "C" int run_squat(int blocks, unsigned long long ticks, int* release, int* sink, void* st) {
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)k_squat, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-  hipLaunchKernelGGL(k_squat, dim3(blocks), dim3(64), 160 * 1024, (hipStream_t)st, ticks, release, sink);
-  return (int)hipGetLastError();
-}
-"""
-
-
-def _compile(src, name):
-    d = tempfile.mkdtemp()
-    f, lib = os.path.join(d, name + ".hip"), os.path.join(d, "lib" + name + ".so")
-    open(f, "w").write(src)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", f, "-o", lib])
-    return ctypes.CDLL(lib)
 
 
 def _problem(Tp=751, N=32, H=1024, D=2, kind="gru"):
@@ -114,100 +89,163 @@ def test_allreduce_on_a_side_stream_beside_a_full_bptt_sweep(one_rank_group):
     assert min(times) < 3.0 * alone
 
 
-def test_sweep_that_cannot_get_its_cus_times_out_loudly_and_recovers():
-    from deepspeech.pytorch_amd import _lib, ops
-    if not ops.use_persistent("gru", torch.bfloat16, 2, 32, 1024):
-        pytest.skip("persistent sweeps need all 256 CUs")
-    L = _compile(SQUAT_SRC, "squat")
-    L.run_squat.argtypes = [ctypes.c_int, ctypes.c_ulonglong, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
-    p = _problem(Tp=64)
-    ref = ops.rnn_fwd(p["kind"], p["GI"], p["Whh"], p["bhh"], p["lens"], p["D"], p["N"], p["H"], p["Tp"])[0].clone()
-    ops.check_persistent_kernels()
-    side = torch.cuda.Stream()
-    release = torch.zeros(1, dtype=torch.int32, device=DEV)
-    sink = torch.zeros(256, dtype=torch.int32, device=DEV)
-    lib = _lib.load()
-    old = lib.ds2_rnn_persist_set_spin_limit(20000)            # ~20 k polls instead of seconds
-    try:
-        torch.cuda.synchronize()
-        # 128 squatters, one per CU they land on (160 KB of LDS each), for at most 3 s of wall clock (100 MHz ticks)
-        rc = L.run_squat(128, ctypes.c_ulonglong(300_000_000), ctypes.c_void_p(release.data_ptr()), ctypes.c_void_p(sink.data_ptr()),
-                         ctypes.c_void_p(side.cuda_stream))
-        assert rc == 0
-        hext = ops.rnn_fwd(p["kind"], p["GI"], p["Whh"], p["bhh"], p["lens"], p["D"], p["N"], p["H"], p["Tp"])[0]
-        ops.poll_persistent_error(torch.device(DEV, 0))        # enqueues the asynchronous look at the error word
-        time.sleep(1.0)                                        # the resident half of the sweep has spent its start-up budget by now (1e6
-                                                               # polls = ~0.3 s, measured by the next test: 0.3 s of sleep was a coin toss;
-                                                               # the squatters stay for up to 3 s)
-        with torch.cuda.stream(torch.cuda.Stream()):
-            release.fill_(1)                                   # the squatters leave; the rest of the sweep's workgroups start, see the
-        torch.cuda.synchronize()                               # launch's error word and end at once
-        with pytest.raises(_lib.Ds2HipError, match="co-resident"):   # the message names the cause: the start-up handshake never completed
-            ops.poll_persistent_error(torch.device(DEV, 0))    # the copy has landed: raises now, without a host synchronisation
-            ops.poll_persistent_error(torch.device(DEV, 0))
-        assert not torch.isfinite(hext.float()).all()          # poisoned, never silently wrong
-        with pytest.raises(_lib.Ds2HipError, match="another kernel holds compute units"):
-            ops.check_persistent_kernels()
-    finally:
-        lib.ds2_rnn_persist_set_spin_limit(old)
-        release.fill_(1)
-        torch.cuda.synchronize()
-    # the error word is sticky by design; a fresh word + a clean sweep: same result as before
+def _sweep(p):
+    from deepspeech.pytorch_amd import ops
+    return ops.rnn_fwd(p["kind"], p["GI"], p["Whh"], p["bhh"], p["lens"], p["D"], p["N"], p["H"], p["Tp"])[0]
+
+
+def _fresh_error_word():
+    from deepspeech.pytorch_amd import ops
     ops._PERSIST_ERR.clear()
     ops._ERR_MIRROR.clear()
-    again = ops.rnn_fwd(p["kind"], p["GI"], p["Whh"], p["bhh"], p["lens"], p["D"], p["N"], p["H"], p["Tp"])[0]
+
+
+def _need_full_chip():
+    from deepspeech.pytorch_amd import ops
+    if not ops.use_persistent("gru", torch.bfloat16, 2, 32, 1024):
+        pytest.skip("persistent sweeps need all 256 CUs")
+
+
+def _launch_beside_squatters(sq, p, copy_stream, **opts):
+    """Launches a sweep once all squatters run; returns (outputs, scratch, handshake slots signed while the squatters were there)."""
+    from deepspeech.pytorch_amd import ops
+    import squat
+    n = sq.wait_started()
+    assert n == sq.blocks, "only %d of %d squatter workgroups started: the fault was not injected" % (n, sq.blocks)
+    with ops.persist_options(**opts):
+        hext = _sweep(p)
+    ws = ops.LAST_PERSIST_WS
+    time.sleep(0.05)
+    slots = squat.sweep_handshake_slots(ws, copy_stream)
+    assert sq.running(), "the squatters left before the sweep was observed"
+    assert slots != 0, ("none of the sweep's workgroups became resident while the squatters ran: the two were SERIALISED (the squatters' "
+                        "stream shares a hardware queue with the sweep's) -- the test did not create the condition it is about")
+    assert 0 < slots < 256, "%d of 256 sweep workgroups resident beside %d squatters: the squatters do not hold their CUs" % (slots, n)
+    return hext, ws, slots
+
+
+@pytest.mark.parametrize("where", ["side_stream", "second_process"])
+def test_sweep_that_cannot_get_its_cus_times_out_loudly_and_recovers(where):
+    from deepspeech.pytorch_amd import _lib, ops
+    import squat
+    _need_full_chip()
+    p = _problem(Tp=64)
+    ref = _sweep(p).clone()
+    ops.check_persistent_kernels()
+    _fresh_error_word()
+    (side, copy_s), tried = squat.independent_streams(2)
+    sq = squat.Squatter.in_process(side) if where == "side_stream" else squat.Squatter.second_process()
+    try:
+        t0 = time.perf_counter()
+        hext, ws, slots = _launch_beside_squatters(sq, p, copy_s)           # the default single-process budget: 0.3 s
+        ops.poll_persistent_error(torch.device(DEV, 0))                    # enqueues the asynchronous look at the error word
+        # the resident workgroups raise the word by themselves although the launch cannot end before the squatters leave
+        err = ops._persist_err(torch.device(DEV, 0))
+        probe = torch.zeros(1, dtype=torch.int32).pin_memory()
+        gave_up_after = None
+        while time.perf_counter() - t0 < 3.0:
+            with torch.cuda.stream(copy_s):
+                probe.copy_(err[:1], non_blocking=True)
+            copy_s.synchronize()
+            if int(probe[0]) != 0:
+                gave_up_after = time.perf_counter() - t0
+                break
+            time.sleep(0.02)
+        assert sq.running()
+        assert gave_up_after is not None and gave_up_after < 1.5, gave_up_after
+        assert int(probe[0]) == 2
+    finally:
+        sq.release()                                   # the squatters leave; the rest of the sweep's workgroups start, see the
+        torch.cuda.synchronize()                       # launch's error word and end at once
+    with pytest.raises(_lib.Ds2HipError, match="co-resident"):   # the message names the cause: the start-up wait never completed
+        ops.poll_persistent_error(torch.device(DEV, 0))    # the copy has landed: raises now, without a host synchronisation
+        ops.poll_persistent_error(torch.device(DEV, 0))
+    assert not torch.isfinite(hext.float()).all()          # poisoned, never silently wrong
+    with pytest.raises(_lib.Ds2HipError, match="another kernel holds compute units"):
+        ops.check_persistent_kernels()
+    print("%s: %d of 256 sweep workgroups resident beside 128 squatters (side stream found after %d draws); gave up by itself after %.2f s"
+          % (where, slots, tried, gave_up_after))
+    # the error word is sticky by design; a fresh word + a clean sweep: same result as before
+    _fresh_error_word()
+    again = _sweep(p)
     ops.check_persistent_kernels()
     assert torch.equal(again, ref)
 
 
-def test_sweep_without_its_cus_gives_up_within_a_fraction_of_a_second_by_itself():
-    """Round 5: the start-up handshake has its own budget (~0.1 s instead of the seconds a mid-sweep wait may take) -- with NO test hook
-    lowering the spin limit, a sweep whose workgroups cannot all become resident ends by itself while the squatters are still there,
-    and the error names the cause."""
+@pytest.mark.parametrize("shape", [("gru", 2, 32, 1024), ("lstm", 2, 64, 1280), ("gru", 2, 8, 800)])
+def test_every_kernel_family_gives_up_at_start_up_with_code_2(shape):
+    """The tuned kernels and the XCD-local general kernels find out in their XCC-id handshake; the general kernels whose groups span
+    XCDs (H = 1280) and the round-2 general kernels (fp32 / H = 800 ...) have no handshake: one arrival word per launch.  A short
+    per-launch budget (startup_ms = 30) keeps this quick; the squatters are released by the test."""
     from deepspeech.pytorch_amd import _lib, ops
-    if not ops.use_persistent("gru", torch.bfloat16, 2, 32, 1024):
+    import squat
+    kind, D, N, H = shape
+    dtype = torch.float32 if H == 800 else torch.bfloat16
+    if not ops.use_persistent(kind, dtype, D, N, H):
         pytest.skip("persistent sweeps need all 256 CUs")
-    L = _compile(SQUAT_SRC, "squat")
-    L.run_squat.argtypes = [ctypes.c_int, ctypes.c_ulonglong, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
-    p = _problem(Tp=64)
+    p = _problem(Tp=16, N=N, H=H, D=D, kind=kind)
+    if dtype == torch.float32:
+        for k in ("GI", "Whh", "WhhT", "dout"):
+            p[k] = p[k].float()
+    ref = _sweep(p).clone()
     ops.check_persistent_kernels()
-    ops._PERSIST_ERR.clear()
-    ops._ERR_MIRROR.clear()
-    side = torch.cuda.Stream()
-    release = torch.zeros(1, dtype=torch.int32, device=DEV)
-    sink = torch.zeros(256, dtype=torch.int32, device=DEV)
+    _fresh_error_word()
+    (side, copy_s), _ = squat.independent_streams(2)
+    sq = squat.Squatter.in_process(side, blocks=160)
     try:
-        torch.cuda.synchronize()
-        rc = L.run_squat(128, ctypes.c_ulonglong(300_000_000), ctypes.c_void_p(release.data_ptr()), ctypes.c_void_p(sink.data_ptr()),
-                         ctypes.c_void_p(side.cuda_stream))                     # squatters stay for up to 3 s unless released
-        assert rc == 0
-        t0 = time.perf_counter()
-        hext = ops.rnn_fwd(p["kind"], p["GI"], p["Whh"], p["bhh"], p["lens"], p["D"], p["N"], p["H"], p["Tp"])[0]
-        err = ops._persist_err(torch.device(DEV, 0))
-        done = torch.cuda.Event()
-        done.record()                                                           # behind the sweep on the caller's stream
-        gave_up_after = None
-        while time.perf_counter() - t0 < 2.0:
-            time.sleep(0.02)
-            # the resident workgroups have raised the word although the launch cannot end before the squatters leave
-            with torch.cuda.stream(side):
-                pass
-            probe = torch.empty(1, dtype=torch.int32).pin_memory()
-            with torch.cuda.stream(torch.cuda.Stream()):
-                probe.copy_(err[:1], non_blocking=True)
-                torch.cuda.current_stream().synchronize()
-            if int(probe[0]) != 0:
-                gave_up_after = time.perf_counter() - t0
-                break
-        assert gave_up_after is not None and gave_up_after < 1.0, gave_up_after
-        assert int(probe[0]) == 2
+        n = sq.wait_started()
+        assert n == 160, n
+        with ops.persist_options(startup_ms=30):
+            hext = _sweep(p)
+        time.sleep(0.3)
+        assert sq.running()
     finally:
-        with torch.cuda.stream(torch.cuda.Stream()):
-            release.fill_(1)
+        sq.release()
         torch.cuda.synchronize()
-    with pytest.raises(_lib.Ds2HipError, match="co-resident"):
-        ops.check_persistent_kernels()
+    code = int(ops._persist_err(torch.device(DEV, 0))[0].item())
+    assert code == 2, "family %d: error word %d" % (ops.persist_kind(dtype, kind, D, N, H), code)
     assert not torch.isfinite(hext.float()).all()
-    print("a sweep with half of the CUs taken gave up by itself after %.2f s" % gave_up_after)
-    ops._PERSIST_ERR.clear()
-    ops._ERR_MIRROR.clear()
+    _fresh_error_word()
+    assert torch.equal(_sweep(p), ref)
+    ops.check_persistent_kernels()
+
+
+@pytest.mark.parametrize("shape", [("gru", 2, 32, 1024), ("lstm", 2, 64, 1280)])
+def test_data_parallel_budget_sweep_waits_for_its_cus_and_completes(shape):
+    """Under data parallelism (ops.persist_startup_ms: the process group's time-out) a sweep that finds half of the chip taken --
+    an RCCL collective waiting for a late peer rank (loader/data_loader.py:320-360 hands ranks unequal batches) -- WAITS for its
+    CUs as a stock kernel would queue, then runs: bit-identical, no error."""
+    from deepspeech.pytorch_amd import ops
+    import squat
+    kind, D, N, H = shape
+    if not ops.use_persistent(kind, torch.bfloat16, D, N, H):
+        pytest.skip("persistent sweeps need all 256 CUs")
+    p = _problem(Tp=64, N=N, H=H, D=D, kind=kind)
+    ref = _sweep(p).clone()
+    ops.check_persistent_kernels()
+    _fresh_error_word()
+    (side, copy_s), _ = squat.independent_streams(2)
+    sq = squat.Squatter.in_process(side, max_s=10.0)
+    try:
+        n = sq.wait_started()
+        assert n == sq.blocks, n
+        t0 = time.perf_counter()
+        ops.FORCE_DATA_PARALLEL_BUDGET[0] = True           # what dist.wrap_data_parallel does
+        try:
+            assert ops.persist_startup_ms() >= 30_000
+            hext = _sweep(p)
+        finally:
+            ops.FORCE_DATA_PARALLEL_BUDGET[0] = False
+        done = torch.cuda.Event()
+        done.record()
+        time.sleep(1.0)                                     # the "late peer": three start-up budgets of a single-process run
+        assert sq.running() and not done.query(), "the sweep did not have to wait: the squatters were not in its way"
+        sq.release()
+        torch.cuda.synchronize()
+        waited = time.perf_counter() - t0
+    finally:
+        sq.release()
+        torch.cuda.synchronize()
+    ops.check_persistent_kernels()                          # no error word
+    assert torch.equal(hext, ref)
+    print("%s: the sweep waited %.2f s for its CUs under the data-parallel budget and completed bit-identical" % (shape, waited))

@@ -256,3 +256,28 @@ def test_frame_rows_lists_the_frames_pack_padded_sequence_keeps():
         assert M._frame_rows(lens, Tp, N, "cpu")[1] is None
     finally:
         M.ROW_LISTS = old
+
+
+def test_persistent_sweep_start_up_budget_policy(monkeypatch):
+    """ops.persist_startup_ms: 300 ms for a single process (fail fast, name the cause), the process group's time-out under data
+    parallelism (a sweep behind an RCCL collective that waits for a late peer must WAIT, as a stock kernel would queue;
+    loader/data_loader.py:320-360 hands ranks unequal batches), explicit overrides; persist_options restores what it changed."""
+    from deepspeech.pytorch_amd import ops
+    monkeypatch.delenv("DS2_PERSIST_STARTUP_MS", raising=False)
+    assert ops.data_parallel_ranks() == 1
+    assert ops.persist_startup_ms() == ops.STARTUP_MS_SINGLE == 300
+    with ops.persist_options(startup_ms=1234, variant=32, spin_limit=7):
+        assert ops.persist_startup_ms() == 1234
+        o = ops._persist_opts()
+        assert (o.variant, o.spin_limit, o.startup_ms) == (32, 7, 1234)
+        with pytest.raises(ZeroDivisionError):
+            with ops.persist_options(variant=1):
+                1 / 0
+        assert ops._OPTS["variant"] == 32                    # restored although the body raised
+    o = ops._persist_opts()
+    assert (o.variant, o.spin_limit, o.startup_ms) == (0, 0, 300)
+    monkeypatch.setattr(ops, "data_parallel_ranks", lambda: 8)
+    assert ops.STARTUP_MS_DP_MIN <= ops.persist_startup_ms() <= ops.STARTUP_MS_DP_MAX     # no group here: torch's 10-minute default
+    assert ops.persist_startup_ms() == 600_000
+    monkeypatch.setenv("DS2_PERSIST_STARTUP_MS", "45000")
+    assert ops.persist_startup_ms() == 45000

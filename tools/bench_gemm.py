@@ -111,42 +111,8 @@ for Kx in (1024, 2048, 4096):
     t = sorted(ts[2:])[len(ts[2:]) // 2]
     print("M=24032 N=6144 K=%d (ld K+64): %.3f ms  %.0f TFLOP/s" % (Kx, t, 2.0 * M * N * Kx / t / 1e9))
 
-# staging-schedule A/B of the 256x256 kernels (ds2_gemm8_set_variant): step shapes, interleaved rounds
-from deepspeech.pytorch_amd import _lib  # noqa: E402
-lib = _lib.load()
-cases = [("i2h K=1024 ld 1088", 24032, 6144, 1024, 1088), ("i2h l0 K=1344", 24032, 6144, 1344, 1344), ("dX K=6144", 24032, 1024, 6144, 6144)]
-for name, M, N, K, ld in cases:
-    Aw = torch.randn(M, ld, device=dev).to(torch.bfloat16)
-    Bw = torch.randn(N, ld, device=dev).to(torch.bfloat16)
-    res = {0: [], 1: []}
-    for rnd in range(6):
-        for v in (0, 1):
-            lib.ds2_gemm8_set_variant(v)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(3):
-                ops.gemm8_nt(Aw, Bw, M=M, N=N, K=K, lda=ld, ldb=ld)
-            e1.record()
-            torch.cuda.synchronize()
-            res[v].append(e0.elapsed_time(e1) / 3)
-    t0, t1 = sorted(res[0][1:])[2], sorted(res[1][1:])[2]
-    print("%-20s four pieces in phases 2,3: %.3f ms %.0f TFLOP/s | two pieces per phase: %.3f ms %.0f TFLOP/s" % (
-        name, t0, 2.0 * M * N * K / t0 / 1e9, t1, 2.0 * M * N * K / t1 / 1e9))
-res = {0: [], 1: []}
-for rnd in range(6):
-    for v in (0, 1):
-        lib.ds2_gemm8_set_variant(v)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(3):
-            ops.gemm8_tn_grouped(probs, R)
-        e1.record()
-        torch.cuda.synchronize()
-        res[v].append(e0.elapsed_time(e1) / 3)
-t0, t1 = sorted(res[0][1:])[2], sorted(res[1][1:])[2]
-print("grouped TN wgrad     four pieces in phases 2,3: %.3f ms %.0f TFLOP/s | two pieces per phase: %.3f ms %.0f TFLOP/s" % (t0, fl / t0 / 1e9, t1, fl / t1 / 1e9))
-lib.ds2_gemm8_set_variant(0)
-
+# (the staging-schedule A/B of rounds 3-5 -- ds2_gemm8_set_variant -- is gone with the hook: profiles/r03d_gemm8_ab.txt keeps its result)
+from deepspeech.pytorch_amd import _lib  # noqa: E402,F401
 # yard-stick: the vendor library on the TN weight-gradient product and on config 5a's input projection (bf16 results; the kernels of
 # this repository accumulate and store the weight gradients in fp32)
 def _time(fn, n=10):

@@ -4,9 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from deepspeech.pytorch_amd import ops, synth
 
-if os.environ.get("DS2_CTC_VARIANT"):           # A/B: 0 = four-wave recursion kernel, 2 = one-wave kernel wherever it applies
-    from deepspeech.pytorch_amd import _lib
-    _lib.load().ds2_ctc_set_variant(int(os.environ["DS2_CTC_VARIANT"]))
+if os.environ.get("DS2_CTC_RECURSION"):         # A/B: 1 = four-wave recursion kernel, 2 = one-wave kernel wherever it applies
+    ops.CTC_RECURSION = int(os.environ["DS2_CTC_RECURSION"])
 lengths = synth.synth_lengths(32, 1201, 1501, seed=3000)
 inputs, targets, pct, tsz = synth.synth_batch(lengths, seed=3000)
 N = 32

@@ -49,7 +49,7 @@ for kind, D, N, H, Tp, label in CASES:
     lens = torch.from_numpy(np.sort(np.random.RandomState(0).randint(Tp // 3, Tp + 1, N))[::-1].copy().astype(np.int32)).to(dev)
     lens[0] = Tp
     dout = torch.randn(Tp, N, H, device=dev).to(torch.bfloat16)
-    fam = _lib.query("ds2_rnn_persist_kind", ops.dt(torch.bfloat16), ops.CELLS[kind], D, N, H)
+    fam = ops.persist_kind(torch.bfloat16, kind, D, N, H)
     slots = (8 * (32 // (H // 32))) if H // 32 <= 32 else 256 // (H // 32)
     gpd = min(slots // D, N)
     ns = -(-N // gpd)

@@ -25,7 +25,7 @@ for kind, D, N, H, Tp in CASES:
     lens_np[0] = Tp
     lens = torch.from_numpy(lens_np).to(dev)
     dout = torch.randn(Tp, N, H, device=dev).to(torch.bfloat16)
-    fam = _lib.query("ds2_rnn_persist_kind", ops.dt(torch.bfloat16), ops.CELLS[kind], D, N, H)
+    fam = ops.persist_kind(torch.bfloat16, kind, D, N, H)
     print("====", kind, D, N, H, Tp, "family", fam, flush=True)
     ops.PERSIST_ENABLED = False
     hext_r, Sv_r, hn_r, cn_r = ops.rnn_fwd(kind, GI, Whh, bhh, lens, D, N, H, Tp)

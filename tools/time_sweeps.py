@@ -20,8 +20,8 @@ if os.environ.get("DS2_AB_LIB"):          # tools/ab_sweeps.py: another build of
 dev = "cuda"
 shapes = sys.argv[1:] or ["lstm,1,88,1024,401", "lstm,1,66,1280,401", "lstm,2,128,1024,401", "lstm,2,64,1280,401", "lstm,2,64,1280,401,ragged"]
 for spec in shapes:
-    if spec.startswith("variant="):        # ds2_rnn_persist_set_variant bits for the shapes that follow
-        _lib.query("ds2_rnn_persist_set_variant", int(spec.split("=")[1]))
+    if spec.startswith("variant="):        # ds2_persist_opts.variant bits for the shapes that follow (this tool's process only)
+        ops._OPTS["variant"] = int(spec.split("=")[1])
         print("-- variant bits", spec.split("=")[1], flush=True)
         continue
     f = spec.split(",")
@@ -40,7 +40,7 @@ for spec in shapes:
         lens_np = np.full(N, Tp, dtype=np.int32)
     lens = torch.from_numpy(lens_np).to(dev)
     dout = torch.randn(Tp, N, H, device=dev).to(torch.bfloat16)
-    fam = _lib.query("ds2_rnn_persist_kind", ops.dt(torch.bfloat16), ops.CELLS[kind], D, N, H)
+    fam = ops.persist_kind(torch.bfloat16, kind, D, N, H)
     best = {"fwd": 1e9, "bwd": 1e9}
     for it in range(4):
         for which in ("fwd", "bwd"):
