@@ -49,7 +49,7 @@ int cu_count() {   // of the CURRENT device (cached per device)
 // Routing A/B bits (ds2_persist_opts.variant / the `variant` argument of the queries; 0 = the shipping routing): bit 0 = do not use
 // the round-4 general kernels; 1 = two-set groups execute every half-step; 2 = unused; 3 = the general kernels take H = 1024 too;
 // 4 = the tuned kernels keep 9-16 clips per group; 5 = the 8-clip tuned kernels use dense products (round 4's form) instead of the
-// structured-sparse ones.  Rounds 2-5 kept these bits -- and the spin budget -- in process-wide variables behind setter entries;
+// structured-sparse ones; 6 = the general kernels keep dense 16-row tiles for groups of <= 16 clips (round 5's form).  Rounds 2-5 kept these bits -- and the spin budget -- in process-wide variables behind setter entries;
 // they travel with every call now, so the entries are re-entrant and a test that dies cannot re-route the launches after it.
 int dispatch(bool bwd, int cell, int H, const PArgs& a, hipStream_t st, unsigned g_variant) {
   const bool dense = (g_variant & 32u) != 0;    // A/B: the 8-clip kernels without the structured-sparse products (round 4's form)
@@ -123,7 +123,7 @@ bool plan2(int dtype, int cell, int D, int N, int H, Plan2& pl) {
 }
 // ---- round-4 general kernels (bf16, 32 units per workgroup) -----------------------------------------------------------------
 struct Plan3H {
-  int gpd, NG, P, xmap, gx, nset;
+  int gpd, NG, P, xmap, gx, nset, sparse;
 };
 int launch3_any(bool probe, bool bwd, int cell, int H, const ds2r::RArgs& a, hipStream_t st) {
   switch (H) {
@@ -162,9 +162,13 @@ bool plan3h(int dtype, int cell, int D, int N, int H, int cus, Plan3H& pl, unsig
   if (pl.gpd > N) pl.gpd = N;
   pl.NG = pl.gpd * D;
   const int ns = (N + pl.gpd - 1) / pl.gpd;
-  pl.nset = ns <= 16 ? 1 : ns <= 32 ? 2 : 0;
-  if (pl.nset == 0) return false;
   ds2r::RArgs dummy{};
+  // groups of <= 16 clips: sets of <= 8 on the structured-sparse products where the width has them (H % 256 == 0; variant bit 6: never)
+  dummy.sparse = 1;
+  pl.sparse = (!(g_variant & 64u) && ns <= 16 && launch3_any(true, false, cell, H, dummy, nullptr) == 0) ? 1 : 0;
+  pl.nset = pl.sparse ? (ns <= 8 ? 1 : 2) : (ns <= 16 ? 1 : ns <= 32 ? 2 : 0);
+  if (pl.nset == 0) return false;
+  dummy.sparse = 0;
   return launch3_any(true, false, cell, H, dummy, nullptr) == 0;
 }
 long xbuf3_bytes(int cell, int H, const Plan3H& pl, bool bwd) {
@@ -291,7 +295,7 @@ int ds2_rnn_persist_fwd(int dtype, int cell, int D, int N, int H, int Tp, const 
     a.N = N; a.Tp = Tp; a.D = D; a.gpd = p3.gpd; a.NG = p3.NG; a.lens = lens; a.W = Whh; a.bhh = bhh; a.GI = GI; a.Hseq = Hseq;
     a.hseq_dstride = hseq_dstride; a.S = S; a.h0 = h0; a.c0 = c0; a.hn = hn; a.cn = cn;
     a.xbuf = (char*)ws + AUX_BYTES; a.xgroup_bytes = xb / p3.NG; a.err = err; a.lerr = (int*)((char*)ws + 3072); a.startup_ms = startup_ms(opts);
-    ra.xcc = (u64*)((char*)ws + AUX_BYTES + xb); ra.P = p3.P; ra.xmap = p3.xmap; ra.gx = p3.gx; ra.nset = p3.nset;
+    ra.xcc = (u64*)((char*)ws + AUX_BYTES + xb); ra.P = p3.P; ra.xmap = p3.xmap; ra.gx = p3.gx; ra.nset = p3.nset; ra.sparse = p3.sparse;
     ra.skip = (p3.nset == 2 && !(g_variant & 2u)) ? 1 : 0;
     if (ra.skip & 1)
       for (int d = 0; d < D; ++d)       // h_t of the padding frames (Hseq points at t = 0)
@@ -354,7 +358,7 @@ int ds2_rnn_persist_bwd(int dtype, int cell, int D, int N, int H, int Tp, const 
     a.N = N; a.Tp = Tp; a.D = D; a.gpd = p3.gpd; a.NG = p3.NG; a.lens = lens; a.W = WhhT; a.Hseq = (void*)Hseq;
     a.hseq_dstride = hseq_dstride; a.S = (void*)S; a.dOut = dOut; a.dGI = dGI; a.dGH = dGH; a.dBacc = dBacc;
     a.xbuf = (char*)ws + AUX_BYTES; a.xgroup_bytes = xb / p3.NG; a.err = err; a.lerr = (int*)((char*)ws + 3072); a.startup_ms = startup_ms(opts);
-    ra.xcc = (u64*)((char*)ws + AUX_BYTES + xb); ra.P = p3.P; ra.xmap = p3.xmap; ra.gx = p3.gx; ra.nset = p3.nset;
+    ra.xcc = (u64*)((char*)ws + AUX_BYTES + xb); ra.P = p3.P; ra.xmap = p3.xmap; ra.gx = p3.gx; ra.nset = p3.nset; ra.sparse = p3.sparse;
     ra.skip = (p3.nset == 2 && !(g_variant & 2u)) ? 1 : 0;
     if ((ra.skip & 1) && !(flags & 1)) {     // flags bit 0: nobody reads the padding rows (row-list consumers)
       const long GHb = (long)gates(cell) * H * 2;

@@ -38,6 +38,7 @@ struct RArgs {
   int nset;      // sample sets per group (the kernel's NSET)
   int skip;      // 1: a set executes only the time steps at which one of its clips is inside its sequence (the caller zeroes the
                  // padding rows of the outputs: they are no longer written for the steps left out)
+  int sparse;    // 1: sets of <= 8 clips on the structured-sparse products (Gather3S); 0: dense 16-row tiles
 #ifdef DS2_PROBE   // tools/probe_persist3.py builds its own library with -DDS2_PROBE; the shipping kernels carry none of it
   unsigned long long* dbg;  // [NG][8] cycle counters of workgroup 0 of each group (thread 0 and thread 255)
   int dbgmask;              // 1 skip GI / dOut / S prefetch loads, 2 skip output stores, 8 skip the gather + products (no exchange),
@@ -65,24 +66,29 @@ struct Plan3 {
   bool ok;
 };
 // (scalar arguments: device code must not odr-use a constexpr Plan3 object)
-constexpr bool in_lds3(int TR, unsigned kmask, int t, int k) { return t >= TR || ((kmask >> (k % 10)) & 1u); }
-constexpr int count_lds3(int TR, unsigned kmask, int RT, int KSW) {
+// PS = pair shift: 0 for the dense kernels (k-steps of 32); 1 for the structured-sparse ones (round 6), whose matrix instruction
+// takes the fragments of k-steps (2u, 2u + 1) as ONE operand: whole k-BLOCKS of 64 are LDS-resident or not (bit (u % 10) of kmask).
+constexpr bool in_lds3(int TR, unsigned kmask, int t, int k, int PS = 0) { return t >= TR || ((kmask >> ((k >> PS) % 10)) & 1u); }
+constexpr int count_lds3(int TR, unsigned kmask, int RT, int KSW, int PS = 0) {
   int n = 0;
   for (int k = 0; k < KSW; ++k)
-    for (int t = 0; t < RT; ++t) n += in_lds3(TR, kmask, t, k) ? 1 : 0;
+    for (int t = 0; t < RT; ++t) n += in_lds3(TR, kmask, t, k, PS) ? 1 : 0;
   return n;
 }
-// index of fragment (t, k) among the LDS-resident ones, k-major: closed form (LDS k-steps before k, LDS tiles per other k-step)
-constexpr int lds_index3(int TR, unsigned kmask, int RT, int t, int k) {
-  int kl = 0;                                   // whole-LDS k-steps before k
-  for (int kk = 0; kk < k; ++kk) kl += ((kmask >> (kk % 10)) & 1u) ? 1 : 0;
-  const int before = kl * RT + (k - kl) * (RT - TR);
-  return before + (((kmask >> (k % 10)) & 1u) ? t : t - TR);
+// index of fragment (t, k) among the LDS-resident ones, k-major
+constexpr int lds_index3(int TR, unsigned kmask, int RT, int t, int k, int PS = 0) {
+  int n = 0;
+  for (int kk = 0; kk <= k; ++kk)
+    for (int tt = 0; tt < RT; ++tt)
+      if ((kk < k || tt < t) && in_lds3(TR, kmask, tt, kk, PS)) ++n;
+  return n;
 }
+// position of tile t among the LDS-resident tiles of k-step k (the staging ring's second index)
+constexpr int lds_tile3(int TR, unsigned kmask, int t, int k, int PS = 0) { return ((kmask >> ((k >> PS) % 10)) & 1u) ? t : t - TR; }
 constexpr int PT3_COL = 20, PT3_TILE = 16 * PT3_COL;     // partial-sum tiles stored [col][row], column stride 20 floats (conflict-free)
 constexpr int part_bytes3(int RT, int PB) { return PB * 4 * RT * PT3_TILE * 4; }
 constexpr int FR_MAX3 = 56, FR_CAP3 = 64, LDS_MAX3 = 156 * 1024;
-constexpr Plan3 plan3(int RT, int KSW) {
+constexpr Plan3 plan3(int RT, int KSW, int PS = 0) {
   const int F = RT * KSW;
   if (F <= FR_MAX3) {
     Plan3 pl{RT, 0u, 2, 0, part_bytes3(RT, 2) <= LDS_MAX3};
@@ -97,11 +103,11 @@ constexpr Plan3 plan3(int RT, int KSW) {
       }
     return Plan3{0, 0u, 0, 0, false};
   }
-  for (int n10 = 1; n10 <= 9; ++n10) {          // n10 of every 10 k-steps in LDS, evenly spread
+  for (int n10 = 1; n10 <= 9; ++n10) {          // n10 of every 10 k-steps (k-blocks) in LDS, evenly spread
     unsigned m = 0;
     for (int i = 0; i < n10; ++i) m |= 1u << ((i * 10 + 5) / n10);
     Plan3 pl{RT, m, 2, 0, true};
-    pl.nlds = count_lds3(RT, m, RT, KSW);
+    pl.nlds = count_lds3(RT, m, RT, KSW, PS);
     if (F - pl.nlds > FR_CAP3 - 4) continue;
     for (int pb = 2; pb >= 1; --pb) {
       pl.PB = pb;
@@ -110,8 +116,8 @@ constexpr Plan3 plan3(int RT, int KSW) {
   }
   return Plan3{0, 0u, 0, 0, false};
 }
-constexpr int lds_bytes3(int RT, int KSW) {
-  const Plan3 pl = plan3(RT, KSW);
+constexpr int lds_bytes3(int RT, int KSW, int PS = 0) {
+  const Plan3 pl = plan3(RT, KSW, PS);
   return pl.nlds * 4096 + part_bytes3(RT, pl.PB);
 }
 
@@ -234,6 +240,36 @@ __device__ __forceinline__ void mfma_results_ready(ds2_f32x4 (&acc)[NA]) {
                  "+v"(acc[7]));
 }
 
+// Resident weight fragments beyond what the vector registers hold: these kernels keep 56-60 B fragments (224-240 registers) per lane
+// beside gather buffers and gate state, so the register allocator SPILLS about a third of them into accumulation registers and copies
+// each one back in front of its MFMA (4 x v_accvgpr_read_b32 per fragment: 120-310 VALU instructions per half-step on one wave per
+// SIMD, round 4's PMC pass: a third of a half-step's issue cycles are VALU).  gfx950's MFMA reads srcB from the accumulation file
+// directly, and the compiler does so by itself for a value whose register class IS an accumulation register: an empty asm with an
+// "a" constraint pins the fragment there once, at load time; the builtin MFMA (which the compiler knows as one: hazards handled)
+// then takes it in place.  (Round 4 tried the same through an asm MFMA, which the compiler could not schedule safely.)
+// Which fragments: the register-resident ones from ordinal VKEEP on, in (k, t) order.
+#ifndef DS2R_VKEEP_FWD
+#define DS2R_VKEEP_FWD 20
+#endif
+#ifndef DS2R_VKEEP_BWD
+#define DS2R_VKEEP_BWD 20
+#endif
+__device__ __forceinline__ void pin_agpr(uint4& f) {
+  u32x4_t v = __builtin_bit_cast(u32x4_t, f);
+  asm volatile("" : "+a"(v));
+  f = __builtin_bit_cast(uint4, v);
+}
+// ordinal of fragment (t, k) among the register-resident ones, k-major
+constexpr int reg_index3(int TR, unsigned kmask, int RT, int t, int k, int PS = 0) {
+  int n = 0;
+  for (int kk = 0; kk <= k; ++kk)
+    for (int tt = 0; tt < RT; ++tt)
+      if ((kk < k || tt < t) && !in_lds3(TR, kmask, tt, kk, PS)) ++n;
+  return n;
+}
+typedef __attribute__((ext_vector_type(8))) unsigned int u32x8_t;
+__device__ __forceinline__ void pin_agpr8(u32x8_t& v) { asm volatile("" : "+a"(v)); }
+
 // k-steps per gather chunk: two chunks per K-quarter up to 16 k-steps (the products of the first overlap the arrival of the
 // second), chunks of 8 beyond (BPTT: K = G*H)
 constexpr int chunk3(int KSW, int SP) { return KSW <= 16 ? ((KSW + 1) / 2 + SP - 1) / SP * SP : 8; }
@@ -254,7 +290,19 @@ template <int RT, int KSW, int SP, bool RAGGED, bool BWD>
 struct Gather3 {
   static constexpr int TR = plan3(RT, KSW).TR, NLDS = plan3(RT, KSW).nlds;
   static constexpr unsigned KM = plan3(RT, KSW).kmask;
+  static constexpr int PS = 0;
   static constexpr int CH = chunk3(KSW, SP), PER = CH / SP, NCH = (KSW + CH - 1) / CH;
+  typedef uint4 WArr[RT][KSW];       // the register-resident B fragments (only those are ever touched)
+  int spidx;                         // (unused by the dense form)
+  static __device__ __forceinline__ void set_frag(WArr& w, int t, int k, const uint4& f) { w[t][k] = f; }
+  template <int VKEEP>
+  static __device__ __forceinline__ void pin(WArr& w) {      // see pin_agpr
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int k = 0; k < KSW; ++k)
+        if (!in_lds3(TR, KM, t, k) && reg_index3(TR, KM, RT, t, k) >= VKEEP) pin_agpr(w[t][k]);
+  }
   static constexpr int LA = BWD ? 3 : 1;
   static constexpr int TL = NLDS == 0 ? 1 : (BWD ? RT : (RT - TR > 0 ? RT - TR : 1));   // LDS fragments of one k-step, at most
   static_assert(CH % SP == 0 && NCH >= 2, "two chunks at least, tiling into lane parts");
@@ -294,7 +342,7 @@ struct Gather3 {
     if (NLDS > 0 && k_ < KSW) {
 #pragma unroll
       for (int t = 0; t < RT; ++t)
-        if (in_lds3(TR, KM, t, k_)) st[slot][((KM >> (k_ % 10)) & 1u) ? t : t - TR] = wl_lane[lds_index3(TR, KM, RT, t, k_) * 256];
+        if (in_lds3(TR, KM, t, k_)) st[slot][lds_tile3(TR, KM, t, k_)] = wl_lane[lds_index3(TR, KM, RT, t, k_) * 256];
     }
   }
   __device__ __forceinline__ void lds_prefetch(int c, const uint4* wl_lane) {
@@ -304,7 +352,7 @@ struct Gather3 {
   }
   static constexpr int NACC = BWD ? 2 * RT : RT;     // BPTT (two tiles): even and odd k-steps accumulate apart, so that an accumulator is
                                                      // reused every 4th MFMA at the earliest (see mfma_breg)
-  __device__ __forceinline__ void mma(int b, int c, ds2_f32x4 (&acc)[NACC], const uint4 (&w)[RT][KSW], const uint4* wl_lane, int dbgmask) {
+  __device__ __forceinline__ void mma(int b, int c, ds2_f32x4 (&acc)[NACC], const WArr& w, const uint4* wl_lane, int dbgmask) {
     u32x4_t rot[SP == 2 ? PER : 1];     // SP == 2: the rotated fragments of the odd k-steps
 #pragma unroll
     for (int kk = 0; kk < CH; ++kk) {
@@ -322,7 +370,7 @@ struct Gather3 {
         for (int t = 0; t < RT; ++t) {
           ds2_f32x4& ac = acc[BWD ? t + RT * (k_ & 1) : t];
           if (in_lds3(TR, KM, t, k_)) {
-            const uint4 wv = st[kk % (LA + 1)][((KM >> (k_ % 10)) & 1u) ? t : t - TR];
+            const uint4 wv = st[kk % (LA + 1)][lds_tile3(TR, KM, t, k_)];
             if (!(dbgmask & 32)) mfma_bvgpr(ac, a_, wv);
           } else {
             mfma_breg(ac, a_, w[t][k_]);
@@ -347,6 +395,99 @@ struct Gather3 {
   }
 };
 
+// ---- Structured-sparse form (round 6): sets of <= 8 clips on all 16 tile rows ---------------------------------------------------
+// What ds2_rnn_persist_impl.h does for config 3 (see smma16 there), in the general kernels: tile rows s and s + 8 both belong to clip
+// s -- row s carries its k = 0, 1 (mod 4) elements, row s + 8 its k = 2, 3 (mod 4) ones, so every row is 2:4-sparse by construction --
+// and v_smfmac_f32_16x16x64_bf16 multiplies a k-BLOCK of 64 at the cost of a dense k-step of 32: half the matrix instructions for a
+// set, and D[s] + D[s + 8] is the full dot product.  Exchange slot: [k-block][lq][tile row (16)] x 16 bytes (ds2p::xsp_unit_bytes /
+// xsp_pair_bytes); a lane loads ONE 16-byte unit per k-block = its compressed A fragment; the B operand of k-block u is the pair of
+// dense fragments of k-steps (2u, 2u + 1), kept as one 256-bit value (registers: pinned pairs; LDS: two reads into one tuple).
+// Needs whole k-blocks per wave: K-quarters of an even number of k-steps (H % 256 == 0).
+__device__ __forceinline__ void smma16v(ds2_f32x4& acc, const u32x4_t& a, const u32x8_t& b, int idx) {
+  acc = __builtin_amdgcn_smfmac_f32_16x16x64_bf16(__builtin_bit_cast(ds2_bf16x8, a), __builtin_bit_cast(ds2_bf16x16, b), acc, idx, 0, 0);
+}
+template <int RT, int KSW, bool BWD>
+struct Gather3S {
+  static_assert(KSW % 2 == 0, "whole k-blocks of 64 per wave");
+  static constexpr int PS = 1, KB = KSW / 2;
+  static constexpr int TR = plan3(RT, KSW, 1).TR, NLDS = plan3(RT, KSW, 1).nlds;
+  static constexpr unsigned KM = plan3(RT, KSW, 1).kmask;
+  static constexpr int CH = chunk3(KB, 1), PER = CH, NCH = (KB + CH - 1) / CH;
+  static constexpr int LA = BWD ? 3 : 1;             // k-blocks the LDS reads run ahead of their products
+  static constexpr int TL = NLDS == 0 ? 1 : (BWD ? RT : (RT - TR > 0 ? RT - TR : 1));
+  static_assert(NCH >= 2, "two chunks at least");
+  typedef u32x8_t WArr[RT][KB];
+  u32x4_t v[2][PER];
+  u32x8_t st[LA + 1][TL];
+  int spidx;                                         // this lane's index word: 0x4444 (tile rows 0-7) / 0xEEEE (rows 8-15)
+  static __device__ __forceinline__ void set_frag(WArr& w, int t, int k, const uint4& f) {
+    const int o = (k & 1) * 4;
+    w[t][k >> 1][o] = f.x; w[t][k >> 1][o + 1] = f.y; w[t][k >> 1][o + 2] = f.z; w[t][k >> 1][o + 3] = f.w;
+  }
+  template <int VKEEP>
+  static __device__ __forceinline__ void pin(WArr& w) {
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int u = 0; u < KB; ++u)
+        if (!in_lds3(TR, KM, t, 2 * u, 1) && reg_index3(TR, KM, RT, t, 2 * u, 1) >= VKEEP) pin_agpr8(w[t][u]);
+  }
+  __device__ __forceinline__ void issue(int b, int c, __amdgpu_buffer_rsrc_t rsrc, int base, bool need, int ks0, int /*cnt*/, int /*part*/) {
+    const int lane_off = need ? base : XOOB;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int u = c * CH + i;                                        // k-block of the wave's K-quarter (compile-time after unrolling)
+      const bool ok = u < KB;
+      const int soff = __builtin_amdgcn_readfirstlane(ok ? (ks0 / 2 + u) * 1024 : 0);
+      const int voff = ok ? lane_off : XOOB;
+      if (DS2R_VAR & 512)
+        v[b][i] = u32x4_t{0u, 0u, 0u, 0u};
+      else
+        v[b][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 16 /* sc1 */);
+    }
+  }
+  __device__ __forceinline__ bool bad(int b) const {
+    uint32_t mx = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) mx = max(max(mx, max(v[b][i][0], v[b][i][1])), max(v[b][i][2], v[b][i][3]));
+    return mx == XSENT2;
+  }
+  __device__ __forceinline__ void lds_unit(int slot, int u, const uint4* wl_lane) {
+    if (NLDS > 0 && u < KB) {
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+        if (in_lds3(TR, KM, t, 2 * u, 1)) {
+          const uint4 f0 = wl_lane[lds_index3(TR, KM, RT, t, 2 * u, 1) * 256], f1 = wl_lane[lds_index3(TR, KM, RT, t, 2 * u + 1, 1) * 256];
+          st[slot][lds_tile3(TR, KM, t, 2 * u, 1)] = u32x8_t{f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+        }
+    }
+  }
+  __device__ __forceinline__ void lds_prefetch(int c, const uint4* wl_lane) {
+#pragma unroll
+    for (int kk = 0; kk < LA; ++kk)
+      if (kk < CH) lds_unit(kk % (LA + 1), c * CH + kk, wl_lane);
+  }
+  static constexpr int NACC = BWD ? 2 * RT : RT;
+  __device__ __forceinline__ void mma(int b, int c, ds2_f32x4 (&acc)[NACC], const WArr& w, const uint4* wl_lane, int dbgmask) {
+#pragma unroll
+    for (int kk = 0; kk < CH; ++kk) {
+      const int u = c * CH + kk;                     // compile-time after unrolling
+      if (kk + LA < CH) lds_unit((kk + LA) % (LA + 1), u + LA, wl_lane);
+      if (u < KB && !(dbgmask & 128)) {
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+          ds2_f32x4& ac = acc[BWD ? t + RT * (u & 1) : t];
+          if (in_lds3(TR, KM, t, 2 * u, 1)) {
+            if (!(dbgmask & 32)) smma16v(ac, v[b][kk], st[kk % (LA + 1)][lds_tile3(TR, KM, t, 2 * u, 1)], spidx);
+          } else {
+            smma16v(ac, v[b][kk], w[t][u], spidx);
+          }
+        }
+      }
+    }
+  }
+};
+
 // partial sums of the 4 K-quarters: tile t of wave w at part + (w*RT + t)*PT3_TILE, stored [col][row] with a 20-float column
 // stride: the four rows a lane holds of an accumulator are ONE conflict-free 16-byte store
 template <int RT>
@@ -355,13 +496,19 @@ __device__ __forceinline__ void store_partials3(float* part, const ds2_f32x4 (&a
   for (int t = 0; t < RT; ++t)
     *reinterpret_cast<ds2_f32x4*>(part + (wave * RT + t) * PT3_TILE + (lane & 15) * PT3_COL + 4 * (lane >> 4)) = acc[t];
 }
-// sum over the 4 waves of the columns (col, col + 1) of row `row` of tile t
-template <int RT>
+// sum over the 4 waves of the columns (col, col + 1) of row `row` of tile t; SS (structured-sparse sets): of rows `row` and `row + 8`,
+// the two halves of clip `row`'s dot product
+template <int RT, bool SS = false>
 __device__ __forceinline__ float2 load_partials3(const float* part, int t, int row, int col) {
   const float* p0 = part + t * PT3_TILE + col * PT3_COL + row;
   float2 s;
   s.x = (p0[0] + p0[RT * PT3_TILE]) + (p0[2 * RT * PT3_TILE] + p0[3 * RT * PT3_TILE]);
   s.y = (p0[PT3_COL] + p0[RT * PT3_TILE + PT3_COL]) + (p0[2 * RT * PT3_TILE + PT3_COL] + p0[3 * RT * PT3_TILE + PT3_COL]);
+  if (SS) {
+    const float* p8 = p0 + 8;
+    s.x += (p8[0] + p8[RT * PT3_TILE]) + (p8[2 * RT * PT3_TILE] + p8[3 * RT * PT3_TILE]);
+    s.y += (p8[PT3_COL] + p8[RT * PT3_TILE + PT3_COL]) + (p8[2 * RT * PT3_TILE + PT3_COL] + p8[3 * RT * PT3_TILE + PT3_COL]);
+  }
   return s;
 }
 
@@ -441,10 +588,10 @@ __device__ __forceinline__ float2 load_partials3(const float* part, int t, int r
 // same for 6 rows as for 16: it is a latency chain).  sched3: the step range [lo, hi) of the sweep's step counter s in which set q has a clip inside its
 // sequence, for a sweep that visits t = s (ascending = true) or t = T' - 1 - s (false): outside it the set's half-steps are not
 // executed at all -- no gather, no products, no publish (the carried state of every clip is its initial one there).
-template <int NSET>
+template <int NSET, int CAP = 16>
 __device__ __forceinline__ void sched3(const int* lens, int slice, int gpd, int Ns, int Tp, bool ascending, bool skip, int (&lo)[NSET],
                                        int (&hi)[NSET], int& RPS) {
-  RPS = NSET == 1 ? Ns : min(16, Ns);
+  RPS = NSET == 1 ? Ns : min(CAP, Ns);
 #pragma unroll
   for (int q = 0; q < NSET; ++q) {
     int mx = 0;
@@ -471,7 +618,7 @@ __device__ __forceinline__ void block_map3(const RArgs& ra, int& grp, int& p) {
 // ------------------------------------------------------------------------------------------------------------------
 // forward sweep
 // ------------------------------------------------------------------------------------------------------------------
-template <int CELL, int H, int NSET, int SP>
+template <int CELL, int H, int NSET, int SP, bool SS = false>
 __global__ void __launch_bounds__(256, 1) k_rnn_persist3_fwd(RArgs ra) {
   typedef XT<bf16_t> X;
   const QArgs& a = ra.q;
@@ -479,12 +626,15 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_fwd(RArgs ra) {
   constexpr int RT = 2 * G;                              // tile 2g + ut = gate g, units 16 ut .. 16 ut + 15 of this workgroup's 32
   constexpr int KT = H / 32, KSW = (KT + 3) / 4;
   constexpr bool RAGGED = KT % 4 != 0;
-  constexpr Plan3 PL = plan3(RT, KSW);
+  constexpr int PS = SS ? 1 : 0;
+  constexpr Plan3 PL = plan3(RT, KSW, PS);
   constexpr int PB = PL.PB, P_TR = PL.TR, P_NLDS = PL.nlds;
   constexpr unsigned P_KM = PL.kmask;
-  constexpr int SLOT = KT * 1024, SETB = 4 * SLOT;       // bytes of one slot / of one set's four slots
+  constexpr int SLOT = KT * 1024, SETB = 4 * SLOT;       // bytes of one slot / of one set's four slots (SS uses the first half of a slot)
   static_assert(H % 32 == 0 && PL.ok, "unsupported hidden size");
   static_assert(SP == 1 || NSET == 1, "lane sharing is instantiated for single-set groups only");
+  static_assert(!SS || (SP == 1 && KT % 8 == 0), "structured-sparse sets: whole k-blocks per wave, no lane sharing");
+  typedef typename std::conditional<SS, Gather3S<RT, KSW, false>, Gather3<RT, KSW, SP, RAGGED, false>>::type GX;
   extern __shared__ __attribute__((aligned(16))) uint4 smem3[];
   uint4* wl = smem3;                                                   // [LDS-resident fragment][4 waves][64 lanes]
   float* part = reinterpret_cast<float*>(smem3 + P_NLDS * 256);       // [PB][4 waves][RT tiles][PT3_TILE]
@@ -503,7 +653,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_fwd(RArgs ra) {
   const int ks0 = wave * KSW;
   const int cnt = RAGGED ? max(0, min(KSW, KT - ks0)) : KSW;
 
-  uint4 w[RT][KSW];            // only the register-resident fragments are ever touched (the others never become registers)
+  typename GX::WArr w;         // only the register-resident fragments are ever touched (the others never become registers)
   {
     const bf16_t* Wd = (const bf16_t*)a.W + (long)d * GH * H;
 #pragma unroll
@@ -512,31 +662,34 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_fwd(RArgs ra) {
 #pragma unroll
       for (int k = 0; k < KSW; ++k) {
         const uint4 f = (!RAGGED || k < cnt) ? *reinterpret_cast<const uint4*>(row + (long)(ks0 + k) * 32) : make_uint4(0, 0, 0, 0);
-        if (in_lds3(P_TR, P_KM, t, k))
-          wl[lds_index3(P_TR, P_KM, RT, t, k) * 256 + tid] = f;
+        if (in_lds3(P_TR, P_KM, t, k, PS))
+          wl[lds_index3(P_TR, P_KM, RT, t, k, PS) * 256 + tid] = f;
         else
-          w[t][k] = f;
+          GX::set_frag(w, t, k, f);
       }
     }
+    GX::template pin<DS2R_VKEEP_FWD>(w);
   }
   const uint4* wl_lane = wl + tid;
   char* xg = a.xbuf + (long)grp * a.xgroup_bytes;
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, NSET * SETB, 0x00020000);
-  // gather identity of this lane
-  const int srow = SP == 2 ? (li & 7) : li, gpart = SP == 2 ? (li >> 3) : 0;
+  // gather identity of this lane (SS: tile row li carries one half of clip li & 7)
+  const int srow = SS ? li : (SP == 2 ? (li & 7) : li), gpart = SP == 2 ? (li >> 3) : 0;
+  const int crow = SS ? (li & 7) : srow;                // the clip (row of the set) this lane gathers
   const int gbase = lq * 256 + srow * 16;
   int lo[NSET], hi[NSET], RPS;
   const bool asc = d == 0;                              // the sweep's step s visits t = s (else t = T' - 1 - s)
-  sched3<NSET>(a.lens, slice, a.gpd, Ns, Tp, asc, (ra.skip & 1) != 0, lo, hi, RPS);
+  sched3<NSET, SS ? 8 : 16>(a.lens, slice, a.gpd, Ns, Tp, asc, (ra.skip & 1) != 0, lo, hi, RPS);
   int glen[NSET];
 #pragma unroll
   for (int q = 0; q < NSET; ++q)
-    glen[q] = (srow < RPS && q * RPS + srow < Ns) ? Tp : 0;
+    glen[q] = (crow < RPS && q * RPS + crow < Ns) ? Tp : 0;
 
   // ---- gate identity: thread bits (dw: unit pair of the 16-byte unit (2), sample row (4), lq (2)) = the exchange layout's order
   const int lqw = tid >> 6, grow = (tid >> 2) & 15, dw = tid & 3;
   const int jl = lqw * 8 + dw * 2, j = p * 32 + jl;                   // units (j, j + 1)
-  const int xoff = ((p * 4 + lqw) * 16 + grow) * 16 + dw * 4;         // this pair's dword inside a slot (k-step p)
+  const int xoff = SS ? xsp_pair_bytes(j, grow & 7)                   // this pair's dword inside a slot: sparse layout,
+                      : ((p * 4 + lqw) * 16 + grow) * 16 + dw * 4;    // dense: k-step p
   bool on[NSET];
   int len[NSET];
   float hprev[NSET][2], cprev[NSET][2], bh[G][2];
@@ -550,7 +703,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_fwd(RArgs ra) {
   for (int q = 0; q < NSET; ++q) {
     const int t_first = d == 0 ? lo[q] : Tp - 1 - lo[q];      // the set's first executed step
     const int i = q * RPS + grow;
-    on[q] = grow < RPS && i < Ns && grow < 16 / SP;
+    on[q] = grow < RPS && i < Ns && grow < (SS ? 8 : 16 / SP);
     const int n = on[q] ? slice + a.gpd * i : 0;
     nsmp[q] = n;
     len[q] = on[q] ? a.lens[n] : 0;
@@ -613,8 +766,8 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_fwd(RArgs ra) {
   constexpr int dbgmask = DS2R_VAR;
 #endif
   const bool plain = local || (dbgmask & 64);
-  typedef Gather3<RT, KSW, SP, RAGGED, false> GX;
   GX gx;
+  gx.spidx = (li & 8) ? 0xEEEE : 0x4444;
   bool pre = false;             // the first two chunks of the half-step about to run are in flight (NSET == 2)
   int s_lo = lo[0], s_hi = hi[0];
 #pragma unroll
@@ -660,7 +813,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_fwd(RArgs ra) {
         const bool act = t < len[q] && !(dbgmask & 256);
         float2 gh[G];
 #pragma unroll
-        for (int g = 0; g < G; ++g) gh[g] = load_partials3<RT>(pp, 2 * g + (jl >> 4), grow, jl & 15);
+        for (int g = 0; g < G; ++g) gh[g] = load_partials3<RT, SS>(pp, 2 * g + (jl >> 4), grow, jl & 15);
         if (CELL == CELL_GRU) {
           if (act) {
             const float q0 = gh[2 % G].x + bh[2 % G][0], q1 = gh[2 % G].y + bh[2 % G][1];
@@ -775,7 +928,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_fwd(RArgs ra) {
 // BPTT sweep.  dh_t = dOut[t] + carry (elementwise part of dh from the step processed before) + dgates_{t'} * W_hh.
 // The workgroup owns the W_hh^T rows of its 32 units (two 16-row tiles), K = G*H: gate g's element j is k = g*H + j.
 // ------------------------------------------------------------------------------------------------------------------
-template <int CELL, int H, int NSET, int SP>
+template <int CELL, int H, int NSET, int SP, bool SS = false>
 __global__ void __launch_bounds__(256, 1) k_rnn_persist3_bwd(RArgs ra) {
   typedef XT<bf16_t> X;
   const QArgs& a = ra.q;
@@ -783,12 +936,15 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_bwd(RArgs ra) {
   constexpr int RT = 2;
   constexpr int KTH = H / 32, KT = G * KTH, KSW = (KT + 3) / 4;
   constexpr bool RAGGED = KT % 4 != 0;
-  constexpr Plan3 PL = plan3(RT, KSW);
+  constexpr int PS = SS ? 1 : 0;
+  constexpr Plan3 PL = plan3(RT, KSW, PS);
   constexpr int PB = PL.PB, P_TR = PL.TR, P_NLDS = PL.nlds;
   constexpr unsigned P_KM = PL.kmask;
-  constexpr int SLOT = KT * 1024, SETB = 4 * SLOT, GATEB = KTH * 1024;
+  constexpr int SLOT = KT * 1024, SETB = 4 * SLOT, GATEB = SS ? KTH * 512 : KTH * 1024;   // gate g's k = g * H + j
   static_assert(H % 32 == 0 && PL.ok, "unsupported hidden size");
   static_assert(SP == 1 || NSET == 1, "lane sharing is instantiated for single-set groups only");
+  static_assert(!SS || (SP == 1 && KT % 8 == 0 && H % 64 == 0), "structured-sparse sets: whole k-blocks per wave and gate");
+  typedef typename std::conditional<SS, Gather3S<RT, KSW, true>, Gather3<RT, KSW, SP, RAGGED, true>>::type GX;
   extern __shared__ __attribute__((aligned(16))) uint4 smem3[];
   uint4* wl = smem3;
   float* part = reinterpret_cast<float*>(smem3 + P_NLDS * 256);
@@ -807,7 +963,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_bwd(RArgs ra) {
   const int ks0 = wave * KSW;
   const int cnt = RAGGED ? max(0, min(KSW, KT - ks0)) : KSW;
 
-  uint4 w[RT][KSW];            // only the register-resident fragments are ever touched (the others never become registers)
+  typename GX::WArr w;         // only the register-resident fragments are ever touched (the others never become registers)
   {
     const bf16_t* WT = (const bf16_t*)a.W + (long)d * H * GH;
 #pragma unroll
@@ -816,29 +972,32 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_bwd(RArgs ra) {
 #pragma unroll
       for (int k = 0; k < KSW; ++k) {
         const uint4 f = (!RAGGED || k < cnt) ? *reinterpret_cast<const uint4*>(row + (long)(ks0 + k) * 32) : make_uint4(0, 0, 0, 0);
-        if (in_lds3(P_TR, P_KM, t, k))
-          wl[lds_index3(P_TR, P_KM, RT, t, k) * 256 + tid] = f;
+        if (in_lds3(P_TR, P_KM, t, k, PS))
+          wl[lds_index3(P_TR, P_KM, RT, t, k, PS) * 256 + tid] = f;
         else
-          w[t][k] = f;
+          GX::set_frag(w, t, k, f);
       }
     }
+    GX::template pin<DS2R_VKEEP_BWD>(w);
   }
   const uint4* wl_lane = wl + tid;
   char* xg = a.xbuf + (long)grp * a.xgroup_bytes;
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, NSET * SETB, 0x00020000);
-  const int srow = SP == 2 ? (li & 7) : li, gpart = SP == 2 ? (li >> 3) : 0;
+  const int srow = SS ? li : (SP == 2 ? (li & 7) : li), gpart = SP == 2 ? (li >> 3) : 0;
+  const int crow = SS ? (li & 7) : srow;                // the clip (row of the set) this lane gathers
   const int gbase = lq * 256 + srow * 16;
   int lo[NSET], hi[NSET], RPS;
   const bool asc = d != 0;                              // BPTT visits t = T' - 1 - s for direction 0
-  sched3<NSET>(a.lens, slice, a.gpd, Ns, Tp, asc, (ra.skip & 1) != 0, lo, hi, RPS);
+  sched3<NSET, SS ? 8 : 16>(a.lens, slice, a.gpd, Ns, Tp, asc, (ra.skip & 1) != 0, lo, hi, RPS);
   int glen[NSET];
 #pragma unroll
   for (int q = 0; q < NSET; ++q)
-    glen[q] = (srow < RPS && q * RPS + srow < Ns) ? Tp : 0;
+    glen[q] = (crow < RPS && q * RPS + crow < Ns) ? Tp : 0;
 
   const int lqw = tid >> 6, grow = (tid >> 2) & 15, dw = tid & 3;
   const int jl = lqw * 8 + dw * 2, j = p * 32 + jl;
-  const int xoff = ((p * 4 + lqw) * 16 + grow) * 16 + dw * 4;         // gate 0's dword of this pair inside a slot; gate g: + g * GATEB
+  const int xoff = SS ? xsp_pair_bytes(j, grow & 7)                   // gate 0's dword of this pair inside a slot; gate g: + g * GATEB
+                      : ((p * 4 + lqw) * 16 + grow) * 16 + dw * 4;
   constexpr int NB = CELL == CELL_GRU ? 4 : G;
   bool on[NSET];
   int len[NSET], nsmp[NSET];
@@ -856,7 +1015,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_bwd(RArgs ra) {
   for (int q = 0; q < NSET; ++q) {
     const int t_first = d == 0 ? Tp - 1 - lo[q] : lo[q];      // the set's first executed step
     const int i = q * RPS + grow;
-    on[q] = grow < RPS && i < Ns && grow < 16 / SP;
+    on[q] = grow < RPS && i < Ns && grow < (SS ? 8 : 16 / SP);
     const int n = on[q] ? slice + a.gpd * i : 0;
     nsmp[q] = n;
     len[q] = on[q] ? a.lens[n] : 0;
@@ -913,8 +1072,8 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_bwd(RArgs ra) {
   unsigned rounds = 0;
   DS2_PROBE_ONLY(unsigned long long c_gather = 0, c_bar = 0, c_gate = 0;)
   const bool plain = local || (dbgmask & 64);
-  typedef Gather3<RT, KSW, SP, RAGGED, true> GX;
   GX gx;
+  gx.spidx = (li & 8) ? 0xEEEE : 0x4444;
 #pragma unroll
   for (int q = 0; q < NSET; ++q)
 #pragma unroll
@@ -959,7 +1118,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist3_bwd(RArgs ra) {
       for (int g = 0; g < G; ++g) gx[g][0] = gx[g][1] = 0.f;
       if (on[q]) {
         const bool act = t < len[q] && !(dbgmask & 256);
-        const float2 mp = load_partials3<RT>(pp, jl >> 4, grow, jl & 15);
+        const float2 mp = load_partials3<RT, SS>(pp, jl >> 4, grow, jl & 15);
         const float din0 = car[q][0] + mp.x, din1 = car[q][1] + mp.y;
         car[q][0] = din0;
         car[q][1] = din1;
@@ -1117,32 +1276,45 @@ constexpr bool covered3() {
   return H % 32 == 0 && plan3(2 * G, (H / 32 + 3) / 4).ok && plan3(2, (G * H / 32 + 3) / 4).ok;
 }
 
-template <int CELL, int H, int NSET, int SP>
+// Structured-sparse sets (Gather3S): every wave's K-quarter is a whole number of k-blocks of 64, forward (K = H) and BPTT (K = G * H)
+template <int CELL, int H>
+constexpr bool sparse3() {
+  constexpr int G = CellInfo<CELL>::G;
+  return H % 256 == 0 && covered3<CELL, H>() && plan3(2 * G, H / 128, 1).ok && plan3(2, G * H / 128, 1).ok;
+}
+
+template <int CELL, int H, int NSET, int SP, bool SS = false>
 int launch3_one(bool bwd, const RArgs& ra, hipStream_t st) {
   constexpr int G = CellInfo<CELL>::G;
-  if constexpr (!covered3<CELL, H>()) {
+  if constexpr (!covered3<CELL, H>() || (SS && !sparse3<CELL, H>())) {
     return DS2_ERR_ARG;
   } else {
-    const size_t shm = bwd ? (size_t)lds_bytes3(2, (G * H / 32 + 3) / 4) : (size_t)lds_bytes3(2 * G, (H / 32 + 3) / 4);
+    const size_t shm = bwd ? (size_t)lds_bytes3(2, (G * H / 32 + 3) / 4, SS ? 1 : 0) : (size_t)lds_bytes3(2 * G, (H / 32 + 3) / 4, SS ? 1 : 0);
     static bool attr[2][DS2_MAX_DEVICES];
-    const void* fn = bwd ? (const void*)k_rnn_persist3_bwd<CELL, H, NSET, SP> : (const void*)k_rnn_persist3_fwd<CELL, H, NSET, SP>;
+    const void* fn = bwd ? (const void*)k_rnn_persist3_bwd<CELL, H, NSET, SP, SS> : (const void*)k_rnn_persist3_fwd<CELL, H, NSET, SP, SS>;
     if (ds2_first_use_on_device(attr[bwd ? 1 : 0])) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     const int grid = ra.xmap ? 8 * ra.gx * ra.P : ra.q.NG * ra.P;
     if (bwd)
-      hipLaunchKernelGGL((k_rnn_persist3_bwd<CELL, H, NSET, SP>), dim3(grid), dim3(256), shm, st, ra);
+      hipLaunchKernelGGL((k_rnn_persist3_bwd<CELL, H, NSET, SP, SS>), dim3(grid), dim3(256), shm, st, ra);
     else
-      hipLaunchKernelGGL((k_rnn_persist3_fwd<CELL, H, NSET, SP>), dim3(grid), dim3(256), shm, st, ra);
+      hipLaunchKernelGGL((k_rnn_persist3_fwd<CELL, H, NSET, SP, SS>), dim3(grid), dim3(256), shm, st, ra);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
   }
 }
 
-// nset = sample sets (1 or 2); single-set groups of <= 8 samples share the gather loads between lane pairs (SP = 2)
+// nset = sample sets (1 or 2).  ra.sparse (the host's choice for groups of <= 16 clips at the widths sparse3 covers): sets of <= 8 clips
+// on the structured-sparse products; otherwise single-set groups of <= 8 samples share the gather loads between lane pairs (SP = 2).
+// probe: is the combination instantiated?
 template <int CELL, int H>
 int launch3(bool probe, bool bwd, const RArgs& ra, hipStream_t st) {
   if (!covered3<CELL, H>()) return DS2_ERR_ARG;
-  if (probe) return 0;
+  if (probe) return (!ra.sparse || sparse3<CELL, H>()) ? 0 : DS2_ERR_ARG;
   const int ns = (ra.q.N + ra.q.gpd - 1) / ra.q.gpd;
+  if (ra.sparse) {
+    if (ra.nset == 2) return launch3_one<CELL, H, 2, 1, true>(bwd, ra, st);
+    return launch3_one<CELL, H, 1, 1, true>(bwd, ra, st);
+  }
   if (ra.nset == 2) return launch3_one<CELL, H, 2, 1>(bwd, ra, st);
   if (ns <= 8) return launch3_one<CELL, H, 1, 2>(bwd, ra, st);
   return launch3_one<CELL, H, 1, 1>(bwd, ra, st);

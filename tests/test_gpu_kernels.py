@@ -393,7 +393,31 @@ PERSIST3_CASES = [
     # round 5: the widths in between (every bf16 hidden size up to 1536 is at most 128 zero units away from a persistent kernel)
     ("gru", 2, 9, 384, 6), ("lstm", 1, 40, 384, 5), ("gru", 2, 33, 640, 5), ("lstm", 2, 8, 640, 6), ("gru", 1, 7, 896, 6),
     ("lstm", 2, 64, 896, 4), ("gru", 2, 64, 1152, 4), ("lstm", 2, 11, 1152, 5), ("gru", 2, 16, 1408, 5), ("gru", 1, 40, 1408, 4),
+    # round 6: sets of <= 8 clips on the structured-sparse products (H % 256 == 0, <= 16 clips per group): one set (<= 8 clips) and
+    # two sets (8 + the rest), XCD-local groups and groups across XCDs, LDS-resident k-blocks in BPTT (LSTM-1280: 6 of 20 per wave)
+    ("lstm", 1, 64, 1280, 6), ("lstm", 2, 64, 1024, 5), ("gru", 2, 48, 512, 6), ("gru", 1, 100, 768, 5), ("lstm", 1, 90, 1536 // 2, 4),
+    ("gru", 2, 27, 1280, 7), ("lstm", 2, 32, 1280, 5),
 ]
+SPARSE3_CASES = [("lstm", 1, 64, 1280, 9), ("lstm", 1, 3, 1280, 6), ("gru", 2, 30, 1536, 4), ("gru", 2, 64, 1024, 6), ("lstm", 2, 48, 512, 7),
+                 ("gru", 1, 100, 768, 5), ("gru", 2, 7, 1280, 8)]
+
+
+@pytest.mark.parametrize("kind,D,N,H,Tp", SPARSE3_CASES)
+def test_rnn_persist3_sparse_and_dense_sets_agree(kind, D, N, H, Tp):
+    """Round 6: groups of <= 16 clips run as one or two sets of <= 8 on the structured-sparse instruction in the general kernels too
+    (tile row s = a clip's k = 0, 1 (mod 4) elements, row s + 8 its k = 2, 3 (mod 4) ones).  Same bf16 operands as the dense
+    16-row tiles (routing bit 6 keeps those); both are held to the oracle by _rnn_sweep_case; against each other only the fp32
+    summation order differs."""
+    o = ops()
+    assert o.use_persistent(kind, torch.bfloat16, D, N, H) and o.persist_kind(torch.bfloat16, kind, D, N, H) == 3
+    res_sp = _rnn_sweep_case(torch.bfloat16, kind, D, N, H, Tp, 1.0 / np.sqrt(H))
+    o.check_persistent_kernels()
+    with o.persist_options(variant=64):
+        assert o.persist_kind(torch.bfloat16, kind, D, N, H) == 3
+        res_de = _rnn_sweep_case(torch.bfloat16, kind, D, N, H, Tp, 1.0 / np.sqrt(H))
+        o.check_persistent_kernels()
+    for a, b in zip(res_sp, res_de):
+        assert np.abs(a - b).max() <= 2e-2 * max(1.0, np.abs(b).max()), np.abs(a - b).max()
 
 
 @pytest.mark.parametrize("kind,D,N,H,Tp", PERSIST3_CASES)
