@@ -49,7 +49,8 @@ int cu_count() {   // of the CURRENT device (cached per device)
 // Routing A/B bits (ds2_persist_opts.variant / the `variant` argument of the queries; 0 = the shipping routing): bit 0 = do not use
 // the round-4 general kernels; 1 = two-set groups execute every half-step; 2 = unused; 3 = the general kernels take H = 1024 too;
 // 4 = the tuned kernels keep 9-16 clips per group; 5 = the 8-clip tuned kernels use dense products (round 4's form) instead of the
-// structured-sparse ones; 6 = the general kernels keep dense 16-row tiles for groups of <= 16 clips (round 5's form).  Rounds 2-5 kept these bits -- and the spin budget -- in process-wide variables behind setter entries;
+// structured-sparse ones; 6 = the general kernels keep dense 16-row tiles for groups of <= 8 clips too (round 5's form); 7 = groups
+// of 9-16 clips run as two structured-sparse sets (measured and rejected, kept for A/B).  Rounds 2-5 kept these bits -- and the spin budget -- in process-wide variables behind setter entries;
 // they travel with every call now, so the entries are re-entrant and a test that dies cannot re-route the launches after it.
 int dispatch(bool bwd, int cell, int H, const PArgs& a, hipStream_t st, unsigned g_variant) {
   const bool dense = (g_variant & 32u) != 0;    // A/B: the 8-clip kernels without the structured-sparse products (round 4's form)
@@ -163,9 +164,14 @@ bool plan3h(int dtype, int cell, int D, int N, int H, int cus, Plan3H& pl, unsig
   pl.NG = pl.gpd * D;
   const int ns = (N + pl.gpd - 1) / pl.gpd;
   ds2r::RArgs dummy{};
-  // groups of <= 16 clips: sets of <= 8 on the structured-sparse products where the width has them (H % 256 == 0; variant bit 6: never)
+  // groups of <= 8 clips: ONE set on the structured-sparse products where the width has them (H % 256 == 0; variant bit 6: never).
+  // 9-16 clips as two sparse sets of <= 8 (variant bit 7, A/B only) LOSE to one dense 16-row set: a half-step is a latency chain
+  // whatever its matrix work -- config 5b's groups of 11: 4.07 / 4.54 us per time step against 2.71 / 3.38 (profiles/r06c_time_sweeps.txt)
   dummy.sparse = 1;
-  pl.sparse = (!(g_variant & 64u) && ns <= 16 && launch3_any(true, false, cell, H, dummy, nullptr) == 0) ? 1 : 0;
+  const int sparse_max = (g_variant & 128u) ? 16 : 8;
+  // measured (profiles/r06e_sparse_single_set.txt): LSTM-1280, 8 clips per group 2.62 / 2.88 against 2.70 / 3.01 us per time step
+  // dense; GRU-768 equal; LSTM-512 forward 1.93 against 1.69 (two k-blocks per wave leave nothing to overlap) -> from H = 1024 on
+  pl.sparse = (!(g_variant & 64u) && ns <= sparse_max && (H >= 1024 || (g_variant & 128u)) && launch3_any(true, false, cell, H, dummy, nullptr) == 0) ? 1 : 0;
   pl.nset = pl.sparse ? (ns <= 8 ? 1 : 2) : (ns <= 16 ? 1 : ns <= 32 ? 2 : 0);
   if (pl.nset == 0) return false;
   dummy.sparse = 0;

@@ -252,7 +252,7 @@ __device__ __forceinline__ void mfma_results_ready(ds2_f32x4 (&acc)[NA]) {
 #define DS2R_VKEEP_FWD 20
 #endif
 #ifndef DS2R_VKEEP_BWD
-#define DS2R_VKEEP_BWD 20
+#define DS2R_VKEEP_BWD 0
 #endif
 __device__ __forceinline__ void pin_agpr(uint4& f) {
   u32x4_t v = __builtin_bit_cast(u32x4_t, f);
@@ -272,7 +272,10 @@ __device__ __forceinline__ void pin_agpr8(u32x8_t& v) { asm volatile("" : "+a"(v
 
 // k-steps per gather chunk: two chunks per K-quarter up to 16 k-steps (the products of the first overlap the arrival of the
 // second), chunks of 8 beyond (BPTT: K = G*H)
-constexpr int chunk3(int KSW, int SP) { return KSW <= 16 ? ((KSW + 1) / 2 + SP - 1) / SP * SP : 8; }
+#ifndef DS2R_CHUNK_MAX
+#define DS2R_CHUNK_MAX 16
+#endif
+constexpr int chunk3(int KSW, int SP) { return KSW <= 2 * DS2R_CHUNK_MAX ? ((KSW + 1) / 2 + SP - 1) / SP * SP : 8; }
 
 // The gather of one wave: a stream of chunks (CH k-steps = CH / SP 16-byte loads per lane) through TWO register buffers.  The kernel
 // keeps two chunks in flight: after the products of a chunk its buffer is refilled with the chunk two ahead -- of the same

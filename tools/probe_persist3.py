@@ -19,6 +19,8 @@ from deepspeech.pytorch_amd import _lib, build  # noqa: E402
 _lib.LIB_PATH = build.build(probe=True, verbose=False)
 from deepspeech.pytorch_amd import ops  # noqa: E402
 
+ops._OPTS["variant"] = int(os.environ.get("DS2_PROBE_VARIANT", "64"))     # 64: dense 16-row tiles for <= 16 clips (the counters' nset assumes it)
+
 CASES = [("lstm", 2, 64, 1280, 751, "cfg5a"), ("lstm", 1, 64, 1280, 751, "cfg5b"), ("gru", 2, 8, 800, 401, "bf16 GRU-800 bi (XCD-local)"),
          ("lstm", 2, 128, 1024, 301, "LSTM-1024 bi, 128 clips (XCD-local, 2 sets)")]
 MASKS = [0, 3, 8, 32, 128]     # (64: plain-store publishes -- only meaningful for XCD-local groups, stale forever otherwise)
