@@ -461,7 +461,8 @@ def cpu_baseline(args):
     dt = time.perf_counter() - t0
     secs = synth.audio_seconds(lengths)
     out.update(value=round(secs / dt, 4), short_sample=short, seconds_per_step=round(dt, 2), ctc_loss_first_step=float(loss.detach().item()),
-               sample="%s, the bench's own rank-0 batch: %d clips of %.2f-%.2f s (%.1f s of audio, the metric's configuration %s), ONE timed "
+               timed_steps=1, same_shape_warmup_steps=0,     # "n = 1, cold": SURVEY 8(d) asks >= 1 warm-up + >= 3 timed; a step is ~6 min here
+               sample="n = 1, cold (1 timed step, 0 same-shape warm-ups): %s, the bench's own rank-0 batch: %d clips of %.2f-%.2f s (%.1f s of audio, the metric's configuration %s), ONE timed "
                       "training step (forward + CTC + backward + clip_grad_norm(400) + AdamW) of %.1f s with 0 same-shape warm-up steps "
                       "(thread pool / allocator warm from the short sample), torch %s, %d threads on this box's host cores" % (
                           what, len(lengths), lengths.min() * 0.01, lengths.max() * 0.01, secs, args.config, dt, torch.__version__, cores))

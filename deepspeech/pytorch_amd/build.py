@@ -17,7 +17,7 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libds2hip.so")
 SOURCES = ["ds2_norm.hip", "ds2_gemm.hip", "ds2_gemm8.hip", "ds2_rnn.hip", "ds2_rnn_persist.hip", "ds2_rnn_persist_gru.hip", "ds2_rnn_persist_lstm.hip",
            "ds2_rnn_persist_rnn.hip", "ds2_rnn_persist2_bf16_800.hip", "ds2_rnn_persist2_bf16_1280.hip", "ds2_rnn_persist2_f32_800.hip",
-           "ds2_rnn_persist2_f32_1024.hip", "ds2_rnn_persist3_384.hip", "ds2_rnn_persist3_640.hip", "ds2_rnn_persist3_896.hip", "ds2_rnn_persist3_1152.hip", "ds2_rnn_persist3_1408.hip", "ds2_rnn_persist3_512.hip", "ds2_rnn_persist3_768.hip", "ds2_rnn_persist3_800.hip",
+           "ds2_rnn_persist2_f32_1024.hip", "ds2_rnn_persist2_f32_1280.hip", "ds2_rnn_persist3_384.hip", "ds2_rnn_persist3_640.hip", "ds2_rnn_persist3_896.hip", "ds2_rnn_persist3_1152.hip", "ds2_rnn_persist3_1408.hip", "ds2_rnn_persist3_512.hip", "ds2_rnn_persist3_768.hip", "ds2_rnn_persist3_800.hip",
            "ds2_rnn_persist3_1024.hip", "ds2_rnn_persist3_1280.hip", "ds2_rnn_persist3_1536.hip", "ds2_conv.hip", "ds2_ctc.hip", "ds2_seqops.hip", "ds2_decode.hip", "ds2_optim.hip", "ds2_spect.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-pass-failed"] + \

@@ -19,6 +19,7 @@ int launch_bf16_800(bool probe, bool bwd, int cell, int MT, const QArgs& a, hipS
 int launch_bf16_1280(bool probe, bool bwd, int cell, int MT, const QArgs& a, hipStream_t st);
 int launch_f32_800(bool probe, bool bwd, int cell, int MT, const QArgs& a, hipStream_t st);
 int launch_f32_1024(bool probe, bool bwd, int cell, int MT, const QArgs& a, hipStream_t st);
+int launch_f32_1280(bool probe, bool bwd, int cell, int MT, const QArgs& a, hipStream_t st);
 }  // namespace ds2q
 
 namespace ds2r {
@@ -106,6 +107,7 @@ int launch2_any(bool probe, bool bwd, int dtype, int cell, int H, int MT, const 
   if (dtype == DS2_BF16 && H == 1280) return ds2q::launch_bf16_1280(probe, bwd, cell, MT, a, st);
   if (dtype == DS2_F32 && H == 800) return ds2q::launch_f32_800(probe, bwd, cell, MT, a, st);
   if (dtype == DS2_F32 && H == 1024) return ds2q::launch_f32_1024(probe, bwd, cell, MT, a, st);
+  if (dtype == DS2_F32 && H == 1280) return ds2q::launch_f32_1280(probe, bwd, cell, MT, a, st);
   return DS2_ERR_ARG;
 }
 bool plan2(int dtype, int cell, int D, int N, int H, Plan2& pl) {

@@ -6,7 +6,7 @@
 namespace ds2q {
 int launch_f32_1024(bool probe, bool bwd, int cell, int MT, const QArgs& a, hipStream_t st) {
 #define DS2Q_CASE(CELL, M) if (cell == CELL && MT == M) return probe ? 0 : launch2<CELL, float, 1024, M>(bwd, a, st);
-  DS2Q_CASE(CELL_GRU, 1) DS2Q_CASE(CELL_LSTM, 1)
+  DS2Q_CASE(CELL_GRU, 1) DS2Q_CASE(CELL_LSTM, 1) DS2Q_CASE(CELL_RNN, 1)   // tanh cells: round 6 (fp32 mode had them on one launch per time step)
 #undef DS2Q_CASE
   return DS2_ERR_ARG;
 }

@@ -432,6 +432,22 @@ __device__ __forceinline__ ds2_f32x4 zero_in_vgprs() {
   asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0" : "=v"(z[0]), "=v"(z[1]), "=v"(z[2]), "=v"(z[3]));
   return z;
 }
+// A/B VARIANT (-DDS2_PREADD, round 6; measured and not kept, profiles/r06g_ab_preadd.txt): the two tile rows of a clip (lanes l and
+// l + 32 of an accumulator register) are added BEFORE the partial sums go to LDS -- one v_permlane32_swap + one add per register, 24
+// of each per wave and forward step -- so that a gate thread reads 4 instead of 8 partial sums per gate.
+#ifndef DS2_PREADD
+#define DS2_PREADD 0
+#endif
+template <int TILES>
+__device__ __forceinline__ void preadd_rows(ds2_f32x4 (&acc)[TILES]) {
+#pragma unroll
+  for (int t = 0; t < TILES; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[t][r]), __float_as_uint(acc[t][r]), false, false);
+      acc[t][r] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+}
 __device__ __forceinline__ void smma16(ds2_f32x4& acc, const uint4& a, const uint4& b0, const uint4& b1, int idx) {
   struct {
     uint4 lo, hi;
@@ -988,6 +1004,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd4(PArgs a) {
 #endif
     DS2_PROBE_ONLY(const unsigned long long t1 = __builtin_readcyclecounter();)
     DS2_TL(2);
+    if (SP && DS2_PREADD) preadd_rows<TILES>(acc);
     store_partials_t<TILES>(part[par], acc, wave, lane);
     __syncthreads();
     DS2_PROBE_ONLY(const unsigned long long t2 = __builtin_readcyclecounter();)
@@ -1003,7 +1020,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_fwd4(PArgs a) {
       for (int g = 0; g < G; ++g) {
         const float* pp = part[par] + pidx[g];
         gh[g] = (pp[0] + pp[TILES * PT_TILE]) + (pp[2 * TILES * PT_TILE] + pp[3 * TILES * PT_TILE]);
-        if (SP)      // the clip's second tile row (k = 2, 3 mod 4), 8 floats on in the [col][row] tile
+        if (SP && !DS2_PREADD)      // the clip's second tile row (k = 2, 3 mod 4), 8 floats on in the [col][row] tile
           gh[g] += (pp[8] + pp[TILES * PT_TILE + 8]) + (pp[2 * TILES * PT_TILE + 8] + pp[3 * TILES * PT_TILE + 8]);
       }
       if (act) {
@@ -1498,6 +1515,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd4(PArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     DS2_PROBE_ONLY(const unsigned long long t1 = __builtin_readcyclecounter();)
     DS2_TL(2);
+    if (SP && DS2_PREADD) preadd_rows<TILES>(acc);
     store_partials_t<TILES>(part[par], acc, wave, lane);
     __syncthreads();
     DS2_PROBE_ONLY(const unsigned long long t2 = __builtin_readcyclecounter();)
@@ -1510,7 +1528,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist_bwd4(PArgs a) {
       const bool act = t < len;
       const float* pp = part[par] + pidx;
       float psum = (pp[0] + pp[TILES * PT_TILE]) + (pp[2 * TILES * PT_TILE] + pp[3 * TILES * PT_TILE]);
-      if (SP) psum += (pp[8] + pp[TILES * PT_TILE + 8]) + (pp[2 * TILES * PT_TILE + 8] + pp[3 * TILES * PT_TILE + 8]);   // tile row s + 8
+      if (SP && !DS2_PREADD) psum += (pp[8] + pp[TILES * PT_TILE + 8]) + (pp[2 * TILES * PT_TILE + 8] + pp[3 * TILES * PT_TILE + 8]);   // tile row s + 8
       const float din = car + psum;
       car = din;
       if (CELL == CELL_GRU) {

@@ -100,7 +100,7 @@ PER_LAYER_NODES_FOR_DDP = [False]
 PAD_HIDDEN = os.environ.get("DS2_PAD_HIDDEN", "1") != "0"
 
 
-def _padded_hidden(H, kind, precision):
+def _padded_hidden(H, kind, precision, bidirectional=None):
     """Internal width of the recurrent stack: `hidden_size` rounded up to the 16-unit MFMA tile -- and, from 200 units on, further up to
     the nearest width the persistent sweeps are instantiated for (bf16: every 128 from 384 to 1280 / 1536, plus 800; fp32: 800 and
     1024), if that is at most 1.5x as wide.  The extra units carry zero weights and biases and stay exactly 0 (GRU, LSTM and tanh
@@ -108,15 +108,18 @@ def _padded_hidden(H, kind, precision):
     one notch off the instantiated set used to fall to the launch-per-time-step kernels at 5-8x the time per step (the reference
     leaves hidden_size free, train_config.py:49); zero units in a latency-bound sweep cost next to nothing."""
     base = (int(H) + 15) // 16 * 16
-    if not PAD_HIDDEN or base < 200 or kind not in ("gru", "lstm"):
+    if not PAD_HIDDEN or base < 200 or kind not in ("gru", "lstm", "rnn"):
         return base
     try:
         from ._lib import query
         # compute_dtype()'s rule; a model built for fp32 and run under autocast lands on 800 / 1024, which the bf16 kernels cover too
         dt_ = ops.dt(torch.bfloat16 if str(precision) in ("16", "bf16", "16-mixed", "bf16-mixed") else torch.float32)
         cell = ops.CELLS[kind]
+        # the model's own direction count (both when the caller does not say): a width covered only for the other one would pad
+        # the units by up to 1.5x and still run one launch per time step
+        dirs = (2, 1) if bidirectional is None else ((2,) if bidirectional else (1,))
         for w in range(base, int(base * 1.5) + 1, 16):
-            if query("ds2_rnn_persist_shape_covered", dt_, cell, 2, 1, w) or query("ds2_rnn_persist_shape_covered", dt_, cell, 1, 1, w):
+            if any(query("ds2_rnn_persist_shape_covered", dt_, cell, D_, 1, w) for D_ in dirs):
                 return w
     except Exception:  # noqa: BLE001  (library not built: the constructor must still work on a CPU-only box)
         pass
@@ -985,7 +988,7 @@ class DeepSpeech(_Base):
         # Internal, tile-aligned sizes (never visible in the state_dict): the recurrent kernels tile the hidden units by 16 and
         # the head / CTC kernels the classes by 32.  Extra hidden units carry zero weights and biases (they stay exactly 0 in
         # GRU, LSTM and tanh cells), extra classes zero weight rows that nothing reads.
-        self._Hp = _padded_hidden(H, kind, precision)
+        self._Hp = _padded_hidden(H, kind, precision, self.bidirectional)
         self._Cp = (num_classes + 31) // 32 * 32
 
         self.conv = MaskConv(nn.Sequential(

@@ -529,42 +529,79 @@ class PinnedRing:
     profiles/r05c_step_jitter.txt, r05d_step_jitter_env.txt).  The slot is therefore copied by an in-stream kernel (ds2_copy_words)."""
 
     def __init__(self, depth=32):
-        self.depth, self.cap, self.buf, self.events, self.i = depth, 0, None, None, 0
+        self.depth = depth
+        self._per_device = {}          # device index -> _RingState: slots, events and the copy kernel's stream belong to ONE device
+        self._lock = __import__("threading").Lock()
+
+    class _RingState:
+        def __init__(self):
+            self.cap, self.buf, self.events, self.i = 0, None, None, 0
 
     def stage(self, dev, parts):
-        """parts: 1-D int32 numpy arrays -> their concatenation as ONE int32 device tensor (asynchronous copy)."""
+        """parts: 1-D int32 numpy arrays -> their concatenation as ONE int32 device tensor (asynchronous copy on `dev`'s current
+        stream; `dev` need not be the current device)."""
         n = int(sum(p.size for p in parts))
         dev = torch.device(dev)
         if dev.type != "cuda":
             return torch.from_numpy(np.concatenate([np.asarray(p, dtype=np.int32).reshape(-1) for p in parts]) if parts else np.zeros(0, np.int32))
-        if self.buf is None or n > self.cap:
-            if self.events is not None:
-                for e in self.events:               # the old buffer must outlive the copies that still read it
-                    if e is not None:
-                        e.synchronize()
-            self.cap = max(1024, 1 << (max(n, 1) - 1).bit_length())
-            self.buf = torch.empty(self.depth * self.cap, dtype=torch.int32, pin_memory=True)
-            self.events = [None] * self.depth
-            self.i = 0
-        k = self.i
-        self.i = (k + 1) % self.depth
-        if self.events[k] is not None and not self.events[k].query():
-            self.events[k].synchronize()            # the host is a whole ring ahead of the device: wait for the slot's last copy
-        slot = self.buf[k * self.cap:k * self.cap + n]
-        hv = slot.numpy()
-        o = 0
-        for p in parts:
-            hv[o:o + p.size] = np.asarray(p).reshape(-1)
-            o += p.size
-        out = torch.empty(n, dtype=torch.int32, device=dev)
-        if n:
-            # a kernel that reads the (device-mapped) pinned slot, not hipMemcpyAsync: see ds2_copy_words for what SDMA transfers of
-            # later steps cost the sweeps of earlier ones
-            call("ds2_copy_words", C.c_void_p(slot.data_ptr()), P(out), n, S())
-        if self.events[k] is None:
-            self.events[k] = torch.cuda.Event()
-        self.events[k].record()
-        return out
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        with self._lock, torch.cuda.device(key):
+            st = self._per_device.setdefault(key, PinnedRing._RingState())
+            if st.buf is None or n > st.cap:
+                if st.events is not None:
+                    for e in st.events:               # the old buffer must outlive the copies that still read it
+                        if e is not None:
+                            e.synchronize()
+                st.cap = max(1024, 1 << (max(n, 1) - 1).bit_length())
+                st.buf = torch.empty(self.depth * st.cap, dtype=torch.int32, pin_memory=True)
+                st.events = [None] * self.depth
+                st.i = 0
+            k = st.i
+            st.i = (k + 1) % self.depth
+            if st.events[k] is not None and not st.events[k].query():
+                st.events[k].synchronize()            # the host is a whole ring ahead of the device: wait for the slot's last copy
+            slot = st.buf[k * st.cap:k * st.cap + n]
+            hv = slot.numpy()
+            o = 0
+            for p in parts:
+                hv[o:o + p.size] = np.asarray(p).reshape(-1)
+                o += p.size
+            out = torch.empty(n, dtype=torch.int32, device=torch.device("cuda", key))
+            if n:
+                # a kernel that reads the (device-mapped) pinned slot, not hipMemcpyAsync: see ds2_copy_words for what SDMA transfers
+                # of later steps cost the sweeps of earlier ones.  The kernel needs the slot's DEVICE address: equal to the host
+                # address for torch's default pinned allocator (hipHostMalloc, unified addressing); with
+                # PYTORCH_CUDA_ALLOC_CONF=pinned_use_cuda_host_register the two can differ, and the copy goes through torch instead
+                dptr = _pinned_device_ptr(slot)
+                if dptr is not None:
+                    call("ds2_copy_words", C.c_void_p(dptr), P(out), n, S())
+                else:
+                    out.copy_(slot, non_blocking=True)
+            if st.events[k] is None:
+                st.events[k] = torch.cuda.Event()
+            st.events[k].record()
+            return out
+
+
+_HIPRT = []
+
+
+def _pinned_device_ptr(t):
+    """Device address of a pinned host tensor (hipHostGetDevicePointer), or None if the runtime cannot give one."""
+    if not _HIPRT:
+        try:
+            lib = C.CDLL("libamdhip64.so")
+            lib.hipHostGetDevicePointer.restype = C.c_int
+            lib.hipHostGetDevicePointer.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_uint]
+            _HIPRT.append(lib)
+        except OSError:
+            _HIPRT.append(None)
+    lib = _HIPRT[0]
+    if lib is None:
+        return t.data_ptr()                           # no runtime library to ask: unified addressing is the default
+    dp = C.c_void_p(0)
+    rc = lib.hipHostGetDevicePointer(C.byref(dp), C.c_void_p(t.data_ptr()), 0)
+    return dp.value if rc == 0 and dp.value else None
 
 
 POISON_UNWRITTEN = False  # tests: the BPTT outputs start as NaN, so a consumer that reads a row the sweep was allowed to leave
@@ -609,7 +646,7 @@ def use_persistent(kind, dtype, D, N, H):
             warnings.warn("ds2hip: no persistent recurrent kernel is instantiated for %s %s hidden=%d, %d direction(s), batch %d: the "
                           "sweeps run one launch per time step (5-8x slower per step).  Persistent kernels exist for bf16 GRU / LSTM "
                           "with hidden in {384, 512, 640, 768, 800, 896, 1024, 1152, 1280, 1408, 1536} (LSTM: not 1408 / 1536) up to 32 "
-                          "clips per group, bf16 hidden 1024 (any cell), and fp32 GRU / LSTM with hidden in {800, 1024}; the model class "
+                          "clips per group, bf16 hidden 1024 (any cell), and fp32 GRU / LSTM / RNN with hidden in {800, 1024, 1280}; the model class "
                           "zero-pads other hidden sizes up to the nearest of these when that is at most 1.5x as wide (DS2_PAD_HIDDEN)."
                           % (str(dtype).replace("torch.", ""), kind, H, D, N))
     return False

@@ -375,6 +375,10 @@ GENERAL_PERSISTENT_CASES = [
     # fp32 storage (the 1e-3 parity mode): BASELINE config 2's width (H = 800; 25 / 150 k-steps: ragged K split) and 1024
     (torch.float32, "gru", 2, 8, 800, 9), (torch.float32, "lstm", 1, 5, 800, 7), (torch.float32, "gru", 2, 32, 1024, 6),
     (torch.float32, "lstm", 2, 3, 1024, 5), (torch.float32, "gru", 1, 1, 800, 4),
+    # round 6: fp32 tanh cells and the fp32 width 1280 (LSTM: 80 KB of weights per wave) -- no fp32 shape of the test suite is left on
+    # the launch-per-time-step kernels
+    (torch.float32, "rnn", 2, 5, 1024, 7), (torch.float32, "rnn", 1, 9, 800, 6), (torch.float32, "lstm", 1, 18, 1280, 5),
+    (torch.float32, "lstm", 2, 3, 1280, 4), (torch.float32, "gru", 2, 8, 1280, 5), (torch.float32, "rnn", 2, 12, 1280, 4),
     # bf16 storage: H = 800 and config 5's LSTM-1280 with 1, 2 and 4 m-tiles (up to 64 samples per group)
     (torch.bfloat16, "gru", 2, 8, 800, 9), (torch.bfloat16, "lstm", 2, 13, 800, 6), (torch.bfloat16, "gru", 2, 7, 1280, 8),
     (torch.bfloat16, "lstm", 1, 64, 1280, 5), (torch.bfloat16, "lstm", 2, 64, 1280, 5), (torch.bfloat16, "lstm", 2, 40, 1280, 4),
