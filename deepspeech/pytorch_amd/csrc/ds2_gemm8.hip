@@ -66,7 +66,22 @@ __device__ __forceinline__ void g8_tile(const G8Problem& P, int t_id, unsigned c
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  const int m0 = (t_id / P.tiles_n) * 256, n0 = (t_id % P.tiles_n) * 256;
+  // Tile order inside an XCD's run of ids.  Row-major (n fastest) puts the 32 tiles that an XCD's CUs work on at one time on
+  // 32 / tiles_n rows: with the input projection's 24 column tiles that is 1.3 rows -- 2 A panels + 24 B panels through a 4 MB L2
+  // per 32 tiles.  DS2_G8_SWZ = GM > 1 walks stripes of GM tile rows column by column: 32 consecutive ids = GM x (32 / GM) tiles
+  // (4 x 8: 12 panels), and the stripe's A panels stay in L2 for its later columns (round 6 A/B: profiles/r06h_gemm8_swizzle.txt).
+#ifndef DS2_G8_SWZ
+#define DS2_G8_SWZ 1
+#endif
+  int tm_ = t_id / P.tiles_n, tn_ = t_id % P.tiles_n;
+  if (DS2_G8_SWZ > 1 && P.tiles_n > 32 / DS2_G8_SWZ) {
+    const int tiles_m = ((TN ? P.M : P.M) + 255) / 256;
+    const int per = DS2_G8_SWZ * P.tiles_n, st = t_id / per, wi = t_id - st * per;
+    const int rows = min(DS2_G8_SWZ, tiles_m - st * DS2_G8_SWZ);
+    tm_ = st * DS2_G8_SWZ + wi % rows;
+    tn_ = wi / rows;
+  }
+  const int m0 = tm_ * 256, n0 = tn_ * 256;
   const int K_ = P.K;
   const int nkt = (K_ + 63) / 64;                       // NT: K % 64 == 0 (host check); TN: a ragged last K-tile is zero-filled in LDS
   const int krem = K_ - (nkt - 1) * 64;                 // valid k-rows of the last K-tile (1..64)

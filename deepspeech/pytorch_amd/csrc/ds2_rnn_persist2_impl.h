@@ -227,6 +227,137 @@ __device__ __forceinline__ void gather_mma2(ds2_f32x4 (&acc)[MT][RT], const uint
 #undef DS2Q_CHECK
 }
 
+// ---- fp32 storage, <= 4 samples per group (config 2: the 1e-3 parity mode): 4x4x1 MFMA with A-block broadcast (round 6) ----------
+// The fp32 matrix pipe is the floor of these sweeps, and with 4 clips a 16x16x4 instruction spends 12 of its 16 rows on padding
+// (156 instructions x 32 cycles per wave and forward step at GRU-800).  v_mfma_f32_4x4x1_16b_f32 computes SIXTEEN independent 4x4
+// blocks of K = 1: lane l = (block l / 4, index l % 4), A = row l % 4, B = column l % 4, D = the four rows of column l % 4.  With
+// CBSZ = c, ABID = a the A rows of block (g * 2^c + a) are broadcast to the 2^c blocks of group g (tools/probe_mfma4x4.py checks
+// this model against the hardware for every (c, a) and times it: 10 cycles per instruction against 32.5 -- with 4 clips 25.5
+// instead of 7.9 useful MACs per cycle and SIMD, profiles/r06i_probe_mfma4x4_broadcast.txt).  The SP = 4 gather already holds the
+// operand in exactly that shape: lane (lq, li = part * 4 + srow) = block 4 lq + part, row srow carries sample srow's values of
+// k-step (chunk + part + 4 i), k = 4 lq + e -- no DPP rotation any more, the broadcast selects the block.
+//   forward (Q4F): CBSZ 4 -- one instruction = 4 clips x 64 unit slots (gate g = slot / 16, unit slot % 16 of the workgroup) x ONE k;
+//                  the weights are one float per lane and k: wq[k-step][16] (GRU: 48 of the 64 slots used);
+//   BPTT (Q4B):    CBSZ 2 -- the four block groups (= lq) take four different k (their own lq), a group's four blocks the
+//                  workgroup's 16 units: one instruction = 4 clips x 16 units x FOUR k; the weights stay the uint4 fragments of the
+//                  16x16x4 form (element e of w[0][k-step]); the four groups' partial sums are added with the waves' in the gate phase.
+// Exact fp32 products as before: only the summation order changes.
+template <int KSW, int SP, bool RAGGED, bool BWD, typename WQ, typename WF>
+__device__ __forceinline__ void gather_mma2_q4(ds2_f32x4& out, const WQ& wq /* forward: float [KSW][16] */, const WF& w /* BPTT: uint4 [1][KSW] */,
+                                               __amdgpu_buffer_rsrc_t rsrc, int par_off, int ks0, int cnt, int lq, int li, int Ns,
+                                               unsigned epoch, int* err, int* lerr, bool& dead) {
+  static_assert(SP == 4, "4x4x1 blocks: four samples per group");
+  constexpr int MT = 1, RT = BWD ? 1 : 4;        // (RT only sizes the gather chunk: resident weight registers / (4 KSW))
+  constexpr int CH = chunk2(KSW, MT, RT, SP);
+  constexpr int PER = CH / SP;
+  constexpr int NCH = (KSW + CH - 1) / CH;
+  constexpr int NB = NCH > 1 ? 2 : 1;
+  u32x4_t v[NB][PER][MT][2];
+  const int srow = li & 3, part = li >> 2;
+  bool need[MT];
+  need[0] = srow < Ns;
+  ds2_f32x4 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
+#define DS2Q_LOAD(c, b)                                                                                                  \
+  _Pragma("unroll") for (int i = 0; i < PER; ++i) {                                                                     \
+    const int k_ = (c) * CH + part + SP * i;                                                                             \
+    const bool kok = k_ < KSW && (!RAGGED || k_ < cnt);                                                                  \
+    _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int q = 0; q < 2; ++q)                        \
+        v[b][i][m][q] = (kok && need[m]) ? __builtin_amdgcn_raw_buffer_load_b128(rsrc, par_off + xunit2<MT>(ks0 + k_, m, q, lq, srow), 0, 16 /* sc1 */) \
+                                         : u32x4_t{0u, epoch, 0u, epoch};                                                \
+  }
+#define DS2Q_CHECK(b, bad)                                                                                               \
+  bool bad = false;                                                                                                      \
+  _Pragma("unroll") for (int i = 0; i < PER; ++i) _Pragma("unroll") for (int m = 0; m < MT; ++m)                        \
+      _Pragma("unroll") for (int q = 0; q < 2; ++q) bad |= (v[b][i][m][q][1] != epoch) | (v[b][i][m][q][3] != epoch);
+  DS2Q_LOAD(0, 0)
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int b = NB > 1 ? (c & 1) : 0;
+    DS2Q_CHECK(b, bad0)
+    if (__any(bad0) && !dead) {        // not all there yet: poll this chunk (bounded)
+      unsigned spins = 0;
+      for (;;) {
+        __builtin_amdgcn_s_sleep(1);
+        DS2Q_LOAD(c, b)
+        DS2Q_CHECK(b, bad1)
+        if (!__any(bad1)) break;
+        if (++spins > SPIN_LIMIT || ((spins & 1023u) == 0 && spin_check(lerr, spins))) {
+          dead = true;
+          raise_err(err, lerr);
+          break;
+        }
+      }
+    }
+    if (c + 1 < NCH) { DS2Q_LOAD(c + 1, b ^ 1) }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int kb = c * CH + SP * i;                              // k-steps kb .. kb + 3 (lane part p holds kb + p)
+      const float ae[4] = {__uint_as_float(v[b][i][0][0][0]), __uint_as_float(v[b][i][0][0][2]), __uint_as_float(v[b][i][0][1][0]),
+                           __uint_as_float(v[b][i][0][1][2])};
+      if constexpr (!BWD) {
+        // block beta = 4 lq' + part' broadcasts h[sample][16 (kb + part') + 4 lq' + e] to all 16 blocks
+#define DS2Q_M4(E, B_)                                                                                                   \
+        if (kb + ((B_) & 3) < KSW)                                                                                       \
+          acc[(B_) & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(ae[E], wq[kb + ((B_) & 3) < KSW ? kb + ((B_) & 3) : 0][4 * ((B_) >> 2) + (E)], acc[(B_) & 3], 4, B_, 0);
+#define DS2Q_M4E(E) DS2Q_M4(E, 0) DS2Q_M4(E, 1) DS2Q_M4(E, 2) DS2Q_M4(E, 3) DS2Q_M4(E, 4) DS2Q_M4(E, 5) DS2Q_M4(E, 6) DS2Q_M4(E, 7) \
+                    DS2Q_M4(E, 8) DS2Q_M4(E, 9) DS2Q_M4(E, 10) DS2Q_M4(E, 11) DS2Q_M4(E, 12) DS2Q_M4(E, 13) DS2Q_M4(E, 14) DS2Q_M4(E, 15)
+        DS2Q_M4E(0) DS2Q_M4E(1) DS2Q_M4E(2) DS2Q_M4E(3)
+#undef DS2Q_M4E
+#undef DS2Q_M4
+      } else {
+        // group lq' takes block 4 lq' + alpha: dG[sample][16 (kb + alpha) + 4 lq' + e]; this lane's weight = its own fragment's element e
+#define DS2Q_M2(E, A_)                                                                                                   \
+        if (kb + (A_) < KSW) {                                                                                           \
+          const uint4& wf = w[0][kb + (A_) < KSW ? kb + (A_) : 0];                                                       \
+          const uint32_t wb = (E) == 0 ? wf.x : (E) == 1 ? wf.y : (E) == 2 ? wf.z : wf.w;                                \
+          acc[A_] = __builtin_amdgcn_mfma_f32_4x4x1f32(ae[E], __uint_as_float(wb), acc[A_], 2, A_, 0);                   \
+        }
+#define DS2Q_M2E(E) DS2Q_M2(E, 0) DS2Q_M2(E, 1) DS2Q_M2(E, 2) DS2Q_M2(E, 3)
+        DS2Q_M2E(0) DS2Q_M2E(1) DS2Q_M2E(2) DS2Q_M2E(3)
+#undef DS2Q_M2E
+#undef DS2Q_M2
+      }
+    }
+  }
+#undef DS2Q_LOAD
+#undef DS2Q_CHECK
+  out = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+// partial sums of the Q4 forms.  Forward: part[wave][sample (4)][unit slot (64)]; BPTT: part[wave * 4 + lq][sample (4)][unit (16)]
+__device__ __forceinline__ void store_partials_q4f(float* part, const ds2_f32x4& acc, int wave, int lane) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) part[(wave * 4 + r) * 64 + lane] = acc[r];
+}
+__device__ __forceinline__ float2 load_partials_q4f(const float* part, int g, int row, int col) {
+  float2 s = make_float2(0.f, 0.f);
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const float2 v = *reinterpret_cast<const float2*>(part + (w * 4 + row) * 64 + g * 16 + col);
+    s.x += v.x;
+    s.y += v.y;
+  }
+  return s;
+}
+__device__ __forceinline__ void store_partials_q4b(float* part, const ds2_f32x4& acc, int wave, int lane) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) part[((wave * 4 + (lane >> 4)) * 4 + r) * 16 + (lane & 15)] = acc[r];
+}
+__device__ __forceinline__ float2 load_partials_q4b(const float* part, int row, int col) {
+  float2 s = make_float2(0.f, 0.f);
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    const float2 v = *reinterpret_cast<const float2*>(part + (w * 4 + row) * 16 + col);
+    s.x += v.x;
+    s.y += v.y;
+  }
+  return s;
+}
+#ifndef DS2Q_Q4
+#define DS2Q_Q4 1        // 0: the 16x16x4 form everywhere (round 5), for A/B runs
+#endif
+
 // ---- payload-only exchange (MT >= 2, bf16): the large-batch regime is bound by the gathered BYTES (a workgroup reads N_s x K
 // values per step through one CU's vector-memory path), so the granule tags are dropped: payload = plain bf16 in A-fragment order
 // [k-step][m-tile][lq (4)][row (16)] x 16 bytes (ONE 16-byte load = one complete MFMA A fragment: half the bytes and half the load
@@ -383,6 +514,8 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_fwd(QArgs a) {
   constexpr bool FLAGS = sizeof(T) == 2 && MT >= 2;        // > 16 samples per group, bf16: payload-only exchange in four slots
   constexpr int PAR_BYTES = KT * MT * (FLAGS ? 1024 : 2048);   // one slot (payload-only) / one parity (tagged granules)
   static_assert(H % KSZ == 0 && H % 16 == 0, "unsupported hidden size");
+  // fp32, <= 4 samples per group, GRU / LSTM: the 4x4x1 broadcast form (gather_mma2_q4); tanh cells would use 16 of its 64 unit slots
+  constexpr bool Q4 = DS2Q_Q4 && std::is_same<T, float>::value && MT == 1 && SP == 4 && G >= 3;
   extern __shared__ __attribute__((aligned(16))) float part[];       // [2][4][MT][RT][256]
   constexpr int PART_FLOATS = 4 * MT * RT * 256;
   __builtin_amdgcn_s_setprio(3);
@@ -397,8 +530,21 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_fwd(QArgs a) {
   const int ks0 = wave * KSW;
   const int cnt = RAGGED ? max(0, min(KSW, KT - ks0)) : KSW;
 
-  uint4 w[RT][KSW];
-  {
+  uint4 w[Q4 ? 1 : RT][Q4 ? 1 : KSW];
+  float wq[Q4 ? KSW : 1][16];          // Q4: lane = unit slot (gate lane / 16, unit lane % 16), one float per k of the wave's K-quarter
+  if constexpr (Q4) {
+    const int g_ = lane >> 4;
+    const float* row = (const float*)a.W + (long)d * GH * H + ((long)min(g_, G - 1) * H + p * 16 + (lane & 15)) * H;
+#pragma unroll
+    for (int k = 0; k < KSW; ++k) {
+      const bool ok = g_ < G && (!RAGGED || k < cnt);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 f = ok ? *reinterpret_cast<const float4*>(row + (long)(ks0 + k) * 16 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        wq[k][4 * q] = f.x; wq[k][4 * q + 1] = f.y; wq[k][4 * q + 2] = f.z; wq[k][4 * q + 3] = f.w;
+      }
+    }
+  } else {
     const T* Wd = (const T*)a.W + (long)d * GH * H;
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
@@ -491,15 +637,23 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_fwd(QArgs a) {
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int tt = 0; tt < RT; ++tt) acc[m][tt] = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
-    if (s > 0 || a.h0) {
-      if constexpr (FLAGS)
-        gather_mma2f<T, MT, RT, KSW, RAGGED>(acc, w, rsrc, ((s + 3) & 3) * PAR_BYTES, ks0, cnt, lq, li, Ns, a.err, a.lerr, dead);
-      else
-        gather_mma2<T, MT, RT, KSW, SP, RAGGED>(acc, w, rsrc, (par ^ 1) * PAR_BYTES, ks0, cnt, lq, li, Ns, s > 0 ? (unsigned)s : TAG_INIT,
-                                                a.err, a.lerr, dead);
-    }
     float* pp = part + par * PART_FLOATS;
-    store_partials2<MT, RT>(pp, acc, wave, lane);
+    if constexpr (Q4) {
+      ds2_f32x4 accq = ds2_f32x4{0.f, 0.f, 0.f, 0.f};
+      if (s > 0 || a.h0)
+        gather_mma2_q4<KSW, SP, RAGGED, false>(accq, wq, w, rsrc, (par ^ 1) * PAR_BYTES, ks0, cnt, lq, li, Ns, s > 0 ? (unsigned)s : TAG_INIT,
+                                               a.err, a.lerr, dead);
+      store_partials_q4f(pp, accq, wave, lane);
+    } else {
+      if (s > 0 || a.h0) {
+        if constexpr (FLAGS)
+          gather_mma2f<T, MT, RT, KSW, RAGGED>(acc, w, rsrc, ((s + 3) & 3) * PAR_BYTES, ks0, cnt, lq, li, Ns, a.err, a.lerr, dead);
+        else
+          gather_mma2<T, MT, RT, KSW, SP, RAGGED>(acc, w, rsrc, (par ^ 1) * PAR_BYTES, ks0, cnt, lq, li, Ns, s > 0 ? (unsigned)s : TAG_INIT,
+                                                  a.err, a.lerr, dead);
+      }
+      store_partials2<MT, RT>(pp, acc, wave, lane);
+    }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
@@ -509,7 +663,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_fwd(QArgs a) {
         float hn0 = 0.f, hn1 = 0.f;     // emitted h_t (0 when inactive)
         float2 gh[G];
 #pragma unroll
-        for (int g = 0; g < G; ++g) gh[g] = load_partials2<MT, RT>(pp, it_mt[it], g, it_row[it], jo);
+        for (int g = 0; g < G; ++g) gh[g] = Q4 ? load_partials_q4f(pp, g, it_row[it], jo) : load_partials2<MT, RT>(pp, it_mt[it], g, it_row[it], jo);
         float pl[NS ? NS : 1][2];
 #pragma unroll
         for (int q = 0; q < (NS ? NS : 1); ++q) pl[q][0] = pl[q][1] = 0.f;
@@ -611,6 +765,7 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_bwd(QArgs a) {
   static_assert(H % KSZ == 0 && H % 16 == 0, "unsupported hidden size");
   extern __shared__ __attribute__((aligned(16))) float part[];       // [2][4][MT][1][256]
   constexpr int PART_FLOATS = 4 * MT * RT * 256;
+  constexpr bool Q4 = DS2Q_Q4 && std::is_same<T, float>::value && MT == 1 && SP == 4 && G >= 3;   // see gather_mma2_q4
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: wave-uniform predicates
   const int grp = blockIdx.x % a.NG, p = blockIdx.x / a.NG;
@@ -703,18 +858,23 @@ __global__ void __launch_bounds__(256, 1) k_rnn_persist2_bwd(QArgs a) {
     if (s > 0) {
       if constexpr (FLAGS)
         gather_mma2f<T, MT, RT, KSW, RAGGED>(acc, w, rsrc, ((s + 3) & 3) * PAR_BYTES, ks0, cnt, lq, li, Ns, a.err, a.lerr, dead);
+      else if constexpr (Q4)
+        gather_mma2_q4<KSW, SP, RAGGED, true>(acc[0][0], w, w, rsrc, (par ^ 1) * PAR_BYTES, ks0, cnt, lq, li, Ns, (unsigned)s, a.err, a.lerr, dead);
       else
         gather_mma2<T, MT, RT, KSW, SP, RAGGED>(acc, w, rsrc, (par ^ 1) * PAR_BYTES, ks0, cnt, lq, li, Ns, (unsigned)s, a.err, a.lerr, dead);
     }
     float* pp = part + par * PART_FLOATS;
-    store_partials2<MT, RT>(pp, acc, wave, lane);
+    if constexpr (Q4)
+      store_partials_q4b(pp, acc[0][0], wave, lane);
+    else
+      store_partials2<MT, RT>(pp, acc, wave, lane);
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
       if (on[it]) {
         const bool act = t < it_len[it];
         const int jo = it_j[it] - p * 16;
-        const float2 mp = load_partials2<MT, RT>(pp, it_mt[it], 0, it_row[it], jo);
+        const float2 mp = Q4 ? load_partials_q4b(pp, it_row[it], jo) : load_partials2<MT, RT>(pp, it_mt[it], 0, it_row[it], jo);
         const float din0 = car[it][0] + mp.x, din1 = car[it][1] + mp.y;
         char* xo = xg + (FLAGS ? (s & 3) : par) * PAR_BYTES;
         char* xr = xg + ((s + 2) & 3) * PAR_BYTES;      // payload-only form: the slot re-armed for step s + 2
