@@ -54,6 +54,7 @@ SIGNATURES = {
     "ds2_rnn_persist_fwd": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ds2_rnn_persist_bwd": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "ds2_add2": (_i, [_i, _vp, _vp, _vp, _l, _vp]),
+    "ds2_sum_slices": (_i, [_vp, _vp, _l, _i, _vp]),
     "ds2_transpose": (_i, [_i, _vp, _vp, _l, _i, _l, _l, _vp]),
     "ds2_split3_bf16": (_i, [_vp, _l, _l, _i, _i, _i, _vp, _l, _vp]),
     "ds2_cast_transpose_bf16": (_i, [_vp, _l, _i, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp]),

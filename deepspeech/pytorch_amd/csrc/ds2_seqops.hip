@@ -17,6 +17,18 @@ __global__ void __launch_bounds__(256) k_add2(const T* __restrict__ a, const T* 
   }
 }
 
+// out[i] = sum_{s < slices} src[s * n + i], slices added in index order (fixed summation order: the K-slices of a split product)
+__global__ void __launch_bounds__(256) k_sum_slices(const float* __restrict__ src, float* __restrict__ o, long nvec, int slices) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    float4 acc = reinterpret_cast<const float4*>(src)[i];
+    for (int s = 1; s < slices; ++s) {
+      const float4 v = reinterpret_cast<const float4*>(src)[(long)s * nvec + i];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    reinterpret_cast<float4*>(o)[i] = acc;
+  }
+}
+
 // dst[c][r] = src[r][c]; tile 64x64 through LDS (row stride padded by one 4-byte word -> conflict-free column reads)
 template <typename E>   // E = storage element (uint16_t or float)
 __global__ void __launch_bounds__(256) k_transpose(const E* __restrict__ src, E* __restrict__ dst, long R, int C, long lds_,
@@ -604,6 +616,17 @@ int ds2_add2(int dtype, const void* a, const void* b, void* out, long n, ds2_str
     hipLaunchKernelGGL(k_add2<float>, dim3(ew_grid(n / V)), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)out, n / V);
   else
     hipLaunchKernelGGL(k_add2<bf16_t>, dim3(ew_grid(n / V)), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n / V);
+  DS2_CHECK_LAUNCH();
+  return 0;
+}
+
+// out[n] f32 = sum over `slices` consecutive [n] blocks of src, added in index order (n % 4 == 0, 16-byte aligned).  The reduction of a
+// product whose contraction was cut into K-slices (ds2_gemm_nt with the slices as its batch): deterministic, unlike atomic split-K.
+int ds2_sum_slices(const float* src, float* out, long n, int slices, ds2_stream_t st_) {
+  hipStream_t st = (hipStream_t)st_;
+  DS2_REQUIRE(src != nullptr && out != nullptr && slices >= 1 && n > 0, DS2_ERR_ARG);
+  DS2_REQUIRE(n % 4 == 0 && ((((uintptr_t)src) | ((uintptr_t)out)) & 15) == 0, DS2_ERR_ALIGN);
+  hipLaunchKernelGGL(k_sum_slices, dim3(ew_grid(n / 4)), dim3(256), 0, st, src, out, n / 4, slices);
   DS2_CHECK_LAUNCH();
   return 0;
 }

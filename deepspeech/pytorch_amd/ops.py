@@ -139,6 +139,20 @@ def gemm_nt(A, B, bias=None, out_dtype=None, M=None, N=None, K=None, lda=None, l
         if rows is not None and zero_pad is not None:
             zero_pad_rows(res, *zero_pad)
         return res
+    ks = fp32_ksplit(A.dtype, M, N, K) if (out is None and splitk == 1 and batch == 1 and not coresident and bias is None and
+                                            out_dtype == torch.float32 and A.dtype == torch.float32) else 1
+    if ks > 1:
+        # fp32 mode, few output tiles and a long contraction (a layer's dX at config 2: 49 tiles of K = 4 800 on 256 CUs): the
+        # K-slices run as the kernel's BATCH into a [slices][M][N] scratch and are added in index order (ds2_sum_slices) -- split-K
+        # without atomics, i.e. with a fixed summation order
+        Ks = K // ks
+        ws = torch.empty((ks, M, N), dtype=torch.float32, device=A.device)
+        call("ds2_gemm_nt", dt(A), P(A), P(B), P(ws), None, M, N, Ks, lda, ldb, N, 1, ks, Ks, Ks, M * N, 0, 1, S())
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+        call("ds2_sum_slices", P(ws), P(out), M * N, ks, S())
+        if rows is not None and zero_pad is not None:
+            zero_pad_rows(out, *zero_pad)
+        return out
     if out is None:
         shape = (batch, M, N) if batch > 1 else (M, N)
         out = torch.empty(shape, dtype=out_dtype, device=A.device)       # split-K: the entry zeroes C itself
@@ -150,6 +164,25 @@ def gemm_nt(A, B, bias=None, out_dtype=None, M=None, N=None, K=None, lda=None, l
     if rows is not None and zero_pad is not None and batch == 1:
         zero_pad_rows(out, *zero_pad)          # same contract whichever kernel ran: unlisted rows are zero
     return out
+
+
+FP32_KSPLIT = __import__("os").environ.get("DS2_FP32_KSPLIT", "1") != "0"    # 0: every exact-fp32 product in one pass (round 5)
+
+
+def fp32_ksplit(dtype, M, N, K):
+    """K-slices of an exact-fp32 product (ops.gemm_nt): > 1 when its 128x128 tiles fill less than half of the chip and the
+    contraction is long; a divisor of the K-tile count (32 elements) so that every slice is whole tiles of the same length."""
+    if not FP32_KSPLIT or dtype != torch.float32 or K % 32 != 0 or (M * N) % 4 != 0:
+        return 1
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    nkt = K // 32
+    if tiles >= 128 or nkt < 32:
+        return 1
+    want = min(8, max(1, 256 // tiles))
+    for s_ in range(want, 1, -1):
+        if nkt % s_ == 0 and nkt // s_ >= 8:
+            return s_
+    return 1
 
 
 def gemm_nt_rows2(A, A2, m_split, B, M, N, K, lda, ldb, splitk=1, coresident=False):

@@ -218,6 +218,10 @@ int ds2_rnn_persist_bwd(int dtype, int cell, int D, int N, int H, int Tp, const 
  * `pre` keeps the pre-Hardtanh value for backward (may be null in eval).
  * bwd: dx and dw (dw via ws of ds2_lookahead_ws_floats). */
 int ds2_add2(int dtype, const void* a, const void* b, void* out, long n, ds2_stream_t stream);
+/* out[n] f32 = the sum of `slices` consecutive [n] blocks of src, added in index order: the fixed-order reduction of a product whose
+ * contraction was cut into K-slices (ds2_gemm_nt with the slices as its batch) -- the fp32-mode dX of nn.GRU / nn.LSTM (model.py:97-99
+ * backward: few output tiles, long K) without the run-to-run summation order of atomic split-K.  n % 4 == 0. */
+int ds2_sum_slices(const float* src, float* out, long n, int slices, ds2_stream_t stream);
 int ds2_transpose(int dtype, const void* src, void* dst, long R, int C, long lds, long ldd, ds2_stream_t stream);
 /* fp32 operand [rows][K] (row stride lds) -> bf16 [rows][3 * Kp] (row stride ldd; Kp = K rounded up to 64, zero beyond K): the K
  * segments [hi | hi | lo] (mode 0, the A operand of a product) or [hi | lo | hi] (mode 1, the B operand) with hi = bf16(x),

@@ -56,6 +56,32 @@ def test_gemm_nt(dtype, M, N, K):
     assert relerr(np64(got_c), ref) < TOL[dtype]
 
 
+@pytest.mark.parametrize("M,N,K", [(808, 800, 4800), (300, 1024, 6144), (128, 128, 2048)])
+def test_gemm_nt_fp32_k_slices_are_exact_and_repeatable(M, N, K):
+    """Round 6: an exact-fp32 product with few output tiles and a long contraction (a layer's dX in the 1e-3 parity mode: 49 tiles
+    of K = 4 800 on 256 CUs) runs its K-slices as the kernel's batch and adds them in index order (ds2_sum_slices) -- split-K
+    without atomics: fp32-exact against float64, and bit-identical from launch to launch."""
+    rs = np.random.RandomState(M + N + K)
+    A, B = rs.standard_normal((M, K)), rs.standard_normal((N, K))
+    o = ops()
+    ks = o.fp32_ksplit(torch.float32, M, N, K)
+    assert ks > 1
+    Ad, Bd = cu(A, torch.float32), cu(B, torch.float32)
+    got = o.gemm_nt(Ad, Bd)
+    ref = rnd(A, torch.float32) @ rnd(B, torch.float32).T
+    assert relerr(np64(got), ref) < 1e-5
+    for _ in range(3):
+        assert torch.equal(o.gemm_nt(Ad, Bd), got)
+    # against the single-pass kernel: the same products, another (fixed) summation order
+    old = o.FP32_KSPLIT
+    o.FP32_KSPLIT = False
+    try:
+        one = o.gemm_nt(Ad, Bd)
+    finally:
+        o.FP32_KSPLIT = old
+    assert relerr(np64(one), np64(got)) < 1e-5
+
+
 @pytest.mark.parametrize("coresident", [False, True])
 @pytest.mark.parametrize("M,ms,N,K,sk", [(3072, 2048, 1024, 1536, 1), (192, 128, 96, 640, 1), (160, 96, 64, 4096, 4)])
 def test_gemm_nt_rows2(coresident, M, ms, N, K, sk):
