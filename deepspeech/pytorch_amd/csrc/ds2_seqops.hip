@@ -557,10 +557,15 @@ __global__ void __launch_bounds__(256) k_split3(const float* __restrict__ src, l
       lo[i] = cvt_pk_bf16(x[2 * i] - h0, x[2 * i + 1] - h1);
     }
     const uint4 H = make_uint4(hi[0], hi[1], hi[2], hi[3]), L = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    // modes 0 / 1: the three segments side by side in a row (K' = 3 Kp: operands of an NT product); modes 2 / 3 (round 6): stacked by
+    // ROWS ([3 rows][ldd]: operands of a TN product, whose contraction index is the row -- the weight gradients over the activations
+    // as stored, no transposes)
+    const long seg = (mode & 2) ? rows * ldd : (long)Kp;
+    const bool a_pat = (mode & 1) == 0;
     uint16_t* d = dst + r * ldd + c0;
     *reinterpret_cast<uint4*>(d) = H;
-    *reinterpret_cast<uint4*>(d + Kp) = mode == 0 ? H : L;
-    *reinterpret_cast<uint4*>(d + 2 * Kp) = mode == 0 ? L : H;
+    *reinterpret_cast<uint4*>(d + seg) = a_pat ? H : L;
+    *reinterpret_cast<uint4*>(d + 2 * seg) = a_pat ? L : H;
   }
 }
 
@@ -645,8 +650,9 @@ int ds2_zero_pad_rows(int dtype, void* X, long ld, int cols, const int* lens, in
 
 int ds2_split3_bf16(const float* src, long lds_, long rows, int K, int Kp, int mode, void* dst, long ldd, ds2_stream_t st_) {
   hipStream_t st = (hipStream_t)st_;
-  DS2_REQUIRE(src != nullptr && dst != nullptr && rows > 0 && K > 0 && Kp >= K && Kp % 64 == 0 && (mode == 0 || mode == 1), DS2_ERR_ARG);
-  DS2_REQUIRE(lds_ % 4 == 0 && ldd >= 3L * Kp && ldd % 8 == 0 && (((uintptr_t)src) & 15) == 0 && (((uintptr_t)dst) & 15) == 0, DS2_ERR_ALIGN);
+  DS2_REQUIRE(src != nullptr && dst != nullptr && rows > 0 && K > 0 && Kp >= K && (mode >= 0 && mode <= 3), DS2_ERR_ARG);
+  DS2_REQUIRE((mode & 2) ? Kp % 8 == 0 : Kp % 64 == 0, DS2_ERR_ARG);
+  DS2_REQUIRE(lds_ % 4 == 0 && ldd >= ((mode & 2) ? (long)Kp : 3L * Kp) && ldd % 8 == 0 && (((uintptr_t)src) & 15) == 0 && (((uintptr_t)dst) & 15) == 0, DS2_ERR_ALIGN);
   const long total = rows * (Kp / 8);
   const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(k_split3, dim3(grid), dim3(256), 0, st, src, lds_, rows, K, Kp, mode, (uint16_t*)dst, ldd);

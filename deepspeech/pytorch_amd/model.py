@@ -136,6 +136,9 @@ def _data_parallel_active():
         return False
 
 
+# fp32 mode: weight gradients as grouped TN products on row-stacked split operands (DS2_FP32_WGRAD_TN=0: round 4's transposes + NT)
+FP32_WGRAD_TN = os.environ.get("DS2_FP32_WGRAD_TN", "1") != "0"
+
 # Row lists (_frame_rows): the GEMMs over the [T' x N] frames skip the padding when less than this fraction of the frames is real
 # (DS2_ROW_LISTS=0: never; the products then run over every row, padding included, as in rounds 1-3).
 ROW_LISTS = os.environ.get("DS2_ROW_LISTS", "1") != "0"
@@ -587,6 +590,49 @@ def _rnn_layer_backward(mod, li, meta, saved, lparams, dout, lens_dev, N, Tp, dt
         side.wait_event(ready)
         for t in rg.tensors() + [Xh, hext]:
             t.record_stream(side)
+        if s3 and FP32_WGRAD_TN and Xh.shape[1] % 8 == 0 and ops.wgrad_tn_ok(torch.bfloat16, 3 * R, D * GH, Xh.shape[1]) and \
+                ops.wgrad_tn_ok(torch.bfloat16, 3 * R, GH, H) and (kind != "gru" or rg.dQ is not None or rg.dGH is not None):
+            # Round 6: the fp32-mode weight gradients as ONE grouped launch of TN products over the activations as stored, on
+            # row-stacked split operands ([hi; hi; lo] x [hi; lo; hi]: ops.split3_rows) -- no operand transposes, no K-segment
+            # copies, no concatenations (they were 6 transposes + 6 splits + 3 torch cat / copy kernels per layer)
+            Iw = Xh.shape[1]
+            A3 = ops.split3_rows(dGI, 0)                        # [3R][D*G*H]
+            dWih = torch.empty((D * GH, Iw), dtype=torch.float32, device=dGI.device)
+            dWhh_all = torch.empty((D, GH, H), dtype=torch.float32, device=dGI.device)
+            X3 = ops.split3_rows(Xh, 1)                         # [3R][I]
+            probs = [dict(At=A3, Bt=X3, M=D * GH, N=Iw, lda=A3.stride(0), ldb=X3.stride(0), out=dWih)]
+            for d in range(D):
+                hprev = (hext[d, 0:Tp] if d == 0 else hext[d, 2:Tp + 2]).reshape(R, H)
+                H3 = ops.split3_rows(hprev, 1)
+                if kind == "gru" and rg.dQ is not None:         # hidden-side gate gradient = [dr, dz (columns of dGI) | dQ]
+                    probs.append(dict(At=A3[:, d * GH:], Bt=H3, M=2 * H, N=H, lda=A3.stride(0), ldb=H3.stride(0), out=dWhh_all[d, :2 * H]))
+                    Q3 = ops.split3_rows(rg.dQ[d].reshape(R, H), 0)
+                    probs.append(dict(At=Q3, Bt=H3, M=H, N=H, lda=Q3.stride(0), ldb=H3.stride(0), out=dWhh_all[d, 2 * H:]))
+                elif kind == "gru":
+                    G3 = ops.split3_rows(rg.dGH[d].reshape(R, GH), 0)
+                    probs.append(dict(At=G3, Bt=H3, M=GH, N=H, lda=G3.stride(0), ldb=H3.stride(0), out=dWhh_all[d]))
+                else:
+                    probs.append(dict(At=A3[:, d * GH:], Bt=H3, M=GH, N=H, lda=A3.stride(0), ldb=H3.stride(0), out=dWhh_all[d]))
+            ops.gemm8_tn_grouped(probs, 3 * R)
+            if first:
+                dWih = torch.cat([_perm_cols_to_reference(dWih[d * GH:(d + 1) * GH], mod._rnn_in) for d in range(D)], 0)
+            if rg.bacc is not None:
+                dBih, dBhh_all = ops.rnn_bias_grads(kind, rg.bacc, D, N, H)
+                dBhh_l = [dBhh_all[d] for d in range(D)]
+            else:
+                dBih = ops.colsum(dGI)
+                dBhh_all = None
+                dBhh_l = [ops.colsum(rg.dGH[d].reshape(R, GH)) for d in range(D)] if kind == "gru" else \
+                    [dBih[d * GH:(d + 1) * GH] for d in range(D)]
+            for d in range(D):
+                grads[po + 4 * d:po + 4 * d + 4] = [dWih[d * GH:(d + 1) * GH], dWhh_all[d], dBih[d * GH:(d + 1) * GH], dBhh_l[d]]
+            sync = getattr(mod, "_grad_sync", None)
+            if sync is not None and H == Ht:
+                own = [dWih, dWhh_all, dBih] + ([dBhh_all] if dBhh_all is not None else
+                                                [dBhh_l[d] for d in range(D)] if kind == "gru" else [])
+                sync.layer_ready(own, lparams[po:po + 4 * D])
+            _unpad_layer_grads(grads, po, D, G, Ht, H, It, first)
+            return dX, grads, None
         dGI_T = ops.transpose(dGI)                              # [D*G*H][ldT]
         Xh_T = ops.transpose(Xh)                                # [I][ldT]
         ldT = dGI_T.shape[1]

@@ -287,6 +287,18 @@ def split3(X, mode, out=None):
     return out
 
 
+def split3_rows(X, mode):
+    """fp32 [rows][K] (any row stride) -> bf16 [3 * rows][K8] (K8 = K rounded up to 8, zero beyond K): the split segments stacked by
+    rows, [hi; hi; lo] (mode 0: the At operand of a TN product) or [hi; lo; hi] (mode 1: the Bt operand).  The contraction of
+    ds2_gemm8_tn_grouped over the 3 * rows rows of two such operands = a_hi b_hi + a_hi b_lo + a_lo b_hi."""
+    rows, K = X.shape
+    K8 = rup(K, 8)
+    out = torch.empty((3 * rows, K8), dtype=torch.bfloat16, device=X.device)
+    assert X.dtype == torch.float32 and X.stride(1) == 1
+    call("ds2_split3_bf16", P(X), X.stride(0), rows, K, K8, 2 + mode, P(out), K8, S())
+    return out
+
+
 def transpose(X, R=None, Cc=None, lds=None):
     """dst[C][ldd] = X[R][C]^T with ldd = roundup(R, 64) (the K-tile of the MFMA GEMM) and zero fill of the pad columns."""
     R = X.shape[0] if R is None else R

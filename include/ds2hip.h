@@ -226,7 +226,10 @@ int ds2_transpose(int dtype, const void* src, void* dst, long R, int C, long lds
 /* fp32 operand [rows][K] (row stride lds) -> bf16 [rows][3 * Kp] (row stride ldd; Kp = K rounded up to 64, zero beyond K): the K
  * segments [hi | hi | lo] (mode 0, the A operand of a product) or [hi | lo | hi] (mode 1, the B operand) with hi = bf16(x),
  * lo = bf16(x - hi).  One bf16 GEMM over K' = 3 Kp of two such operands = a_hi b_hi + a_hi b_lo + a_lo b_hi: the fp32-mode (1e-3
- * parity) input projections / dX / weight gradients of nn.GRU / nn.LSTM (model.py:97-99) on the bf16 matrix pipe. */
+ * parity) input projections / dX / weight gradients of nn.GRU / nn.LSTM (model.py:97-99) on the bf16 matrix pipe.
+ * Modes 2 / 3 (round 6): the same three segments stacked by ROWS -- dst [3 * rows][ldd], segment s at row s * rows, Kp = K rounded up
+ * to 8 -- i.e. the operands of a TN product (ds2_gemm8_tn_grouped: the contraction index is the row), so that the fp32-mode weight
+ * gradients run over the activations as stored, without operand transposes. */
 int ds2_split3_bf16(const float* src, long lds, long rows, int K, int Kp, int mode, void* dst, long ldd, ds2_stream_t stream);
 /* Weight re-layout of the recurrent layers (what nn.GRU/LSTM/RNN.flatten_parameters + the autocast weight casts do in the
  * reference, model.py:97-99): fp32 src[R][C] -> bf16 dst[R][ldd] and/or bf16 transpose dstT[Cout][lddT] in one pass.
