@@ -970,6 +970,22 @@ __global__ void __launch_bounds__(256, 1) k_conv_rtap(RTapArgs a) {
       A[m][j] = j < icnt ? wv : make_uint4(0u, 0u, 0u, 0u);
     }
   }
+  // Round 6: 66 resident tap fragments do not fit the vector registers beside the accumulators; the allocator spilled ~30 of them into
+  // accumulation registers and copied each back in front of its MFMA (127 v_accvgpr_read per tile row).  Pinned there with an "a"
+  // constraint the MFMA takes them in place (srcA may be an accumulation register on gfx950) -- see pin_agpr in ds2_rnn_persist3_impl.h.
+#ifndef DS2_RTAP_VKEEP
+#define DS2_RTAP_VKEEP 24
+#endif
+#pragma unroll
+  for (int m = 0; m < KF; ++m)
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      if (m * 6 + j >= DS2_RTAP_VKEEP) {
+        typedef __attribute__((ext_vector_type(4))) unsigned int u4v;
+        u4v v = __builtin_bit_cast(u4v, A[m][j]);
+        asm volatile("" : "+a"(v));
+        A[m][j] = __builtin_bit_cast(uint4, v);
+      }
   constexpr int PR = RT_FB - 1 + KF;
   constexpr int NPIECE = 12;                     // DMA pieces per wave and tile: up to four patch rows x three chunks
   const int nub = ds2_cdiv_dev(a.U, RT_FB), ntb = ds2_cdiv_dev(a.Tp, RT_TB);
