@@ -75,8 +75,11 @@ def _worker(rank, world, port, out, use_ddp=False):
         refs.append(torch.cat([p.grad.reshape(-1) for p in m2.parameters()]))
     ref = torch.stack(refs).mean(0)
     tmax, total = dsdist.aggregate(float(rank + 1), 10.0 * (rank + 1), dev, world)
+    # the start-up budget a persistent sweep of THIS rank would be launched with (round 6): the process group's time-out, not 300 ms
+    from deepspeech.pytorch_amd import ops
     out[rank] = dict(grad_err=float((grad - ref).abs().max()), grad_norm=float(ref.abs().max()), tmax=tmax, total=total,
-                     bn_mean=model.bn.running_mean.clone().numpy(), secs=secs, loss=float(last.detach()))
+                     bn_mean=model.bn.running_mean.clone().numpy(), secs=secs, loss=float(last.detach()),
+                     ranks=ops.data_parallel_ranks(), startup_ms=ops.persist_startup_ms())
     dsdist.shutdown(world)
 
 
@@ -93,6 +96,8 @@ def test_two_rank_gloo_data_parallel_step(use_ddp):
         assert o["grad_err"] <= 1e-5 * max(1.0, o["grad_norm"]), o       # DDP: every rank holds the MEAN gradient
         assert o["tmax"] == 2.0 and o["total"] == 30.0                     # max over ranks / sum over ranks
         assert o["secs"] > 0
+        # a sweep behind an RCCL collective that waits for a late peer must WAIT (ops.persist_startup_ms): >= 30 s under 2 ranks
+        assert o["ranks"] == 2 and o["startup_ms"] >= 30_000, o
     # BatchNorm statistics are rank-local (sync_batchnorm=False in the reference): different minibatches -> different buffers
     assert not np.allclose(out[0]["bn_mean"], out[1]["bn_mean"])
 
