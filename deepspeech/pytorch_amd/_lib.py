@@ -46,7 +46,7 @@ SIGNATURES = {
     "ds2_rnn_saved_planes": (_i, [_i]),
     "ds2_rnn_state_bytes": (_l, [_i, _i, _i]),
     "ds2_rnn_fwd": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp]),
-    "ds2_rnn_bwd": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp]),
+    "ds2_rnn_bwd": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ds2_rnn_persist_supported": (_i, [_i, _i, _i, _i, _i, C.c_uint]),
     "ds2_rnn_persist_shape_covered": (_i, [_i, _i, _i, _i, _i]),
     "ds2_rnn_persist_kind": (_i, [_i, _i, _i, _i, _i, C.c_uint]),

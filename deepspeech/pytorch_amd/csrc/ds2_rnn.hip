@@ -53,6 +53,10 @@ struct StepArgs {
   float* h32_out;
   const float* c32_in;   // LSTM cell state (bwd: dc)
   float* c32_out;
+  const float* h0;       // bwd: initial state of the forward [D][N][H] or null (= zeros): h_{t-1} / c_{t-1} of a sample's FIRST step
+  const float* c0;
+  int fold;              // bwd: 1 = the launch behind the last step: only dh += dgates(last step) * W_hh (no stores): the state
+                         // buffers then hold d loss / d h0 (and d c0)
 };
 
 // K-split skinny GEMM: acc[mt][nt] (16x16 tiles) += A[rows][k] * Bmat[cols][k] over this wave's chunks.
@@ -257,6 +261,11 @@ __global__ void __launch_bounds__(256) k_rnn_step_bwd(StepArgs a) {
     const bool act = t < len;
     const long st_off = ((long)d * N + n) * H + j;
     const float dh_in = a.h32_in[st_off] + reduce_load<MT, 1>(red, m, 0, idx);
+    if (a.fold) {           // behind the sweep: the recurrent term of the last processed step completes d loss / d h0
+      a.h32_out[st_off] = dh_in;
+      if (CELL == CELL_LSTM) a.c32_out[st_off] = a.c32_in[st_off];
+      continue;
+    }
     const long row = (long)t * N + n;
     T* dgi = (T*)a.dGI + row * ldgi + (long)d * GH + j;
     // previous step IN FORWARD ORDER (source of h_{t-1}); exists iff it was an active step of this sample
@@ -270,7 +279,8 @@ __global__ void __launch_bounds__(256) k_rnn_step_bwd(StepArgs a) {
       if (act) {
         const T* sv = (const T*)a.S + seq_off * (long)(NS ? NS : 1) * H + j;
         const float r = ldf(sv), z = ldf(sv + H), nn = ldf(sv + 2 * H), hn = ldf(sv + 3 * H);
-        const float hprev = has_prev ? ldf((const T*)a.Hseq + (long)d * a.hseq_dstride + ((long)tprev * N + n) * H + j) : 0.f;
+        const float hprev = has_prev ? ldf((const T*)a.Hseq + (long)d * a.hseq_dstride + ((long)tprev * N + n) * H + j)
+                                     : (a.h0 ? a.h0[st_off] : 0.f);      // the sample's first step: its initial state
         const float dh = ldf((const T*)a.dOut + row * H + j) + dh_in;
         dn = dh * (1.f - z) * (1.f - nn * nn);
         dz = dh * (hprev - nn) * z * (1.f - z);
@@ -291,7 +301,7 @@ __global__ void __launch_bounds__(256) k_rnn_step_bwd(StepArgs a) {
       if (act) {
         const T* sv = (const T*)a.S + seq_off * (long)(NS ? NS : 1) * H + j;
         const float ig = ldf(sv), fg = ldf(sv + H), gg = ldf(sv + 2 * H), og = ldf(sv + 3 * H), cn = ldf(sv + 4 * H);
-        const float cprev = has_prev ? ldf((const T*)a.S + seq_prev * (long)(NS ? NS : 1) * H + 4 * H + j) : 0.f;
+        const float cprev = has_prev ? ldf((const T*)a.S + seq_prev * (long)(NS ? NS : 1) * H + 4 * H + j) : (a.c0 ? a.c0[st_off] : 0.f);
         const float tc = tanhf_(cn);
         const float dh = ldf((const T*)a.dOut + row * H + j) + dh_in;
         const float dcn = dc_in + dh * og * (1.f - tc * tc);
@@ -347,6 +357,8 @@ int sweep(bool bwd, StepArgs a, float* st32[2], void* stT[2], float* c32[2], hip
   const int N = a.N, Tp = a.Tp;
   const int MT = N <= 16 ? 1 : 2;   // batch groups of 32 rows (blockIdx.z); each group re-streams its W slice from L2
   dim3 grid(a.H / 16, a.D, ds2_cdiv(N, MT * 16));
+  const int want_fold = a.fold;
+  a.fold = 0;
   for (int s = 0; s < Tp; ++s) {
     const int cur = s & 1, nxt = cur ^ 1;
     if (!bwd) {
@@ -365,6 +377,16 @@ int sweep(bool bwd, StepArgs a, float* st32[2], void* stT[2], float* c32[2], hip
     a.hT_out = stT[nxt];
     a.c32_in = c32[cur];
     a.c32_out = c32[nxt];
+    if (MT == 1)
+      launch_step<T, CELL, 1>(bwd, a, grid, st);
+    else
+      launch_step<T, CELL, 2>(bwd, a, grid, st);
+  }
+  a.fold = want_fold;
+  if (bwd && a.fold) {     // one launch behind the last step, see StepArgs::fold
+    const int cur = Tp & 1, nxt = cur ^ 1;
+    a.t0 = 0; a.t1 = Tp - 1; a.tp0 = 0; a.tp1 = Tp - 1; a.first = 0;
+    a.h32_in = st32[cur]; a.h32_out = st32[nxt]; a.hT_in = stT[cur]; a.hT_out = stT[nxt]; a.c32_in = c32[cur]; a.c32_out = c32[nxt];
     if (MT == 1)
       launch_step<T, CELL, 1>(bwd, a, grid, st);
     else
@@ -430,9 +452,13 @@ int ds2_rnn_fwd(int dtype, int cell, int D, int N, int H, int Tp, const int* len
 }
 
 // BPTT sweep.  dOut [Tp][N][H] (T) grad of the (direction-summed) layer output;  WhhT [D][H][G*H] (T);
-// writes dGI [Tp*N][D*G*H] (T) and, GRU only, dGH [D][Tp][N][3H] (T).  Assumes zero initial state (training).
+// writes dGI [Tp*N][D*G*H] (T) and, GRU only, dGH [D][Tp][N][3H] (T).
+// h0 / c0 [D][N][H] f32 (may be null = zeros): the initial state the forward was given (reference model.py:224-230: `hs`); a
+// sample's first step then uses them as h_{t-1} / c_{t-1}.  dh0 / dc0 (may be null): d loss / d h0, d c0 -- one extra launch behind
+// the sweep adds the recurrent term of the last processed step.
 int ds2_rnn_bwd(int dtype, int cell, int D, int N, int H, int Tp, const int* lens, const void* dOut, const void* WhhT,
-                const void* Hseq, long hseq_dstride, const void* S, void* dGI, void* dGH, void* state, ds2_stream_t st_) {
+                const void* Hseq, long hseq_dstride, const void* S, void* dGI, void* dGH, const float* h0, const float* c0,
+                float* dh0, float* dc0, void* state, ds2_stream_t st_) {
   hipStream_t st = (hipStream_t)st_;
   DS2_REQUIRE(dtype == DS2_F32 || dtype == DS2_BF16, DS2_ERR_DTYPE);
   DS2_REQUIRE(ds2_rnn_gates(cell) > 0, DS2_ERR_ARG);
@@ -448,9 +474,14 @@ int ds2_rnn_bwd(int dtype, int cell, int D, int N, int H, int Tp, const int* len
   DS2_CHECK_LAUNCH();
   StepArgs a{};
   a.H = H; a.N = N; a.D = D; a.Tp = Tp; a.lens = lens; a.W = WhhT; a.dOut = dOut; a.Hseq = (void*)Hseq; a.hseq_dstride = hseq_dstride; a.S = (void*)S;
-  a.dGI = dGI; a.dGH = dGH;
-  return dtype == DS2_F32 ? sweep_cell<float>(cell, true, a, st32, stT, c32, st)
-                          : sweep_cell<bf16_t>(cell, true, a, st32, stT, c32, st);
+  a.dGI = dGI; a.dGH = dGH; a.h0 = h0; a.c0 = c0; a.fold = (dh0 || dc0) ? 1 : 0;
+  const int rc = dtype == DS2_F32 ? sweep_cell<float>(cell, true, a, st32, stT, c32, st)
+                                  : sweep_cell<bf16_t>(cell, true, a, st32, stT, c32, st);
+  if (rc != 0) return rc;
+  const int fin = (Tp + (a.fold ? 1 : 0)) & 1;      // the buffer the last launch wrote
+  if (dh0) (void)hipMemcpyAsync(dh0, st32[fin], n * 4, hipMemcpyDeviceToDevice, st);
+  if (dc0 && cell == CELL_LSTM) (void)hipMemcpyAsync(dc0, c32[fin], n * 4, hipMemcpyDeviceToDevice, st);
+  return 0;
 }
 
 }  // extern "C"

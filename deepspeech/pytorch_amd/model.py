@@ -460,7 +460,43 @@ def _rnn_layer_forward(mod, li, X, lens_dev, N, Tp, dtype, training, h0, c0, lpa
     return out, hn, cn, [X, Xh if has_bn else None, hext, Sv], (kind, H, D, G, I, has_bn, sv, Ht, layer.input_size)
 
 
-def _rnn_layer_backward(mod, li, meta, saved, lparams, dout, lens_dev, N, Tp, dtype, main, side, wgrad_done, rows=None):
+def _rnn_layer_backward(mod, li, meta, saved, lparams, dout, lens_dev, N, Tp, dtype, main, side, wgrad_done, rows=None, state=None):
+    """state = (h0, c0, want_dstate) when the forward was given an initial state (`hs`, reference model.py:224-230) -- the rare path:
+    the BPTT then runs on the launch-per-time-step kernels (ds2_rnn_bwd takes h0 / c0 and returns d h0 / d c0), and the first steps'
+    share of dW_hh -- h_{t-1} = h0 is not a row of the stored state sequence -- is added here.  Returns (dX, grads, wgrad_done[, dstate])."""
+    if state is None:
+        return _rnn_layer_backward_impl(mod, li, meta, saved, lparams, dout, lens_dev, N, Tp, dtype, main, side, wgrad_done, rows)
+    kind, H, D, G, I, has_bn, sv, Ht, It = meta
+    h0, c0, want = state
+    h0p = _pad_cols(h0, H) if (h0 is not None and H != Ht) else h0
+    c0p = _pad_cols(c0, H) if (c0 is not None and H != Ht) else c0
+    cap = {"h0": h0p, "c0": c0p, "want": bool(want)}
+    dX, grads, wgrad_done = _rnn_layer_backward_impl(mod, li, meta, saved, lparams, dout, lens_dev, N, Tp, dtype, main, side, wgrad_done,
+                                                     rows, cap)
+    if wgrad_done is not None:
+        main.wait_event(wgrad_done)
+    main.wait_stream(side)
+    rg, GH, po = cap["rg"], G * H, (2 if has_bn else 0)
+    if h0p is not None:
+        n4 = (N + 3) // 4 * 4
+        ar = torch.arange(N, device=lens_dev.device)
+        for d in range(D):
+            t_first = torch.zeros_like(ar) if d == 0 else (lens_dev.long().clamp(1, Tp) - 1)
+            src = rg.dGH[d].reshape(Tp * N, GH) if (kind == "gru" and rg.dGH is not None) else rg.dGI[:, d * GH:(d + 1) * GH]
+            g_first = src.index_select(0, t_first * N + ar).float()                     # [N][G*H]: the hidden-side gate gradient
+            A = torch.zeros((GH, n4), dtype=torch.float32, device=g_first.device)         # of every clip's first step
+            A[:, :N] = g_first.t()
+            B = torch.zeros((H, n4), dtype=torch.float32, device=g_first.device)
+            B[:, :N] = h0p[d].t()
+            corr = ops.gemm_nt(A, B, out_dtype=torch.float32)                             # [G*H][H] = sum_n g_first[n]^T (x) h0[n]
+            grads[po + 4 * d + 1] = grads[po + 4 * d + 1] + _unpad_gate_rows(corr, G, Ht, H)[:, :Ht]
+    dstate = None
+    if want:
+        dstate = (rg.dh0[..., :Ht].contiguous(), rg.dc0[..., :Ht].contiguous() if rg.dc0 is not None else None)
+    return dX, grads, None, dstate
+
+
+def _rnn_layer_backward_impl(mod, li, meta, saved, lparams, dout, lens_dev, N, Tp, dtype, main, side, wgrad_done, rows=None, cap=None):
     """Backward of one BatchRNN layer.  bf16 (the performance mode): the BPTT sweep, then ONE launch with the layer's weight
     gradients (grouped TN products over the activations as stored) and its dX, then the BatchNorm backward -- all on the caller's
     stream; nothing runs beside a sweep (a co-runner costs the latency-bound sweep the chip's clock).  fp32 /
@@ -498,7 +534,11 @@ def _rnn_layer_backward(mod, li, meta, saved, lparams, dout, lens_dev, N, Tp, dt
     n_probs = 1 + D * (2 if (kind == "gru" and (2 * H) % 256 != 0) else 1)
     fuse_dx = fast and WGRAD_WITH_DX and not WGRAD_BESIDE_DX and n_probs < 6 and WihT.dim() == 2 and WihT.data_ptr() % 16 == 0 and \
         ops.gemm8_nt_shape_ok(dtype, R, WihT.shape[0], D * GH, D * GH, WihT.stride(0))
-    rg = ops.rnn_bwd(kind, dout, WhhT, hext, Sv, lens_dev, D, N, H, Tp, pad_rows_unread=bool(fuse_dx and rows is not None))
+    if cap is None:
+        rg = ops.rnn_bwd(kind, dout, WhhT, hext, Sv, lens_dev, D, N, H, Tp, pad_rows_unread=bool(fuse_dx and rows is not None))
+    else:
+        rg = ops.rnn_bwd(kind, dout, WhhT, hext, Sv, lens_dev, D, N, H, Tp, h0=cap["h0"], c0=cap["c0"], want_dstate=cap["want"])
+        cap["rg"] = rg
     dGI = rg.dGI
     dXh_fused = None
     if fast:
@@ -711,7 +751,8 @@ class _RnnLayerFn(torch.autograd.Function):
         ctx.rows = mod._frame_rows                   # the row list of the batch in flight (set by _logits)
         out, hn, cn, saved, meta = _rnn_layer_forward(mod, li, X, lens_dev, N, Tp, dtype, training, h0, c0, lparams, rows=ctx.rows)
         ctx.mod, ctx.dims, ctx.meta, ctx.li = mod, (N, Tp, dtype), meta, li
-        ctx.had_state = h0 is not None
+        ctx.had_state = h0 is not None or c0 is not None
+        ctx.h0, ctx.c0 = h0, c0                      # (small [D][N][H] tensors; None in every ordinary training step)
         ctx.none_mask = [t is None for t in saved]
         ctx.save_for_backward(lens_dev, *[t for t in saved if t is not None], *lparams)
         ctx.n_saved = sum(1 for t in saved if t is not None)
@@ -722,8 +763,6 @@ class _RnnLayerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout, *unused):
-        if ctx.had_state:
-            raise Ds2HipError("backward through a forward that was given initial hidden states (hs) is not supported")
         N, Tp, dtype = ctx.dims
         mod = ctx.mod
         st = ctx.saved_tensors
@@ -732,8 +771,17 @@ class _RnnLayerFn(torch.autograd.Function):
         lparams = st[1 + ctx.n_saved:]
         main = torch.cuda.current_stream()
         side = mod._wgrad_stream(dout.device)
-        dX, grads, wgrad_done = _rnn_layer_backward(mod, ctx.li, ctx.meta, saved, lparams, dout.contiguous().to(dtype), st[0], N, Tp,
-                                                    dtype, main, side, None, rows=ctx.rows)
+        dstate = None
+        if ctx.had_state:
+            # round 6: backward through a forward that was given `hs` (reference model.py:224-230; the reference itself only passes
+            # hs in inference) -- launch-per-time-step BPTT with the initial state, d h0 / d c0 returned to autograd
+            want = bool(ctx.needs_input_grad[8] or (len(ctx.needs_input_grad) > 9 and ctx.needs_input_grad[9]))
+            dX, grads, wgrad_done, dstate = _rnn_layer_backward(mod, ctx.li, ctx.meta, saved, lparams, dout.contiguous().to(dtype), st[0],
+                                                                N, Tp, dtype, main, side, None, rows=ctx.rows,
+                                                                state=(ctx.h0, ctx.c0, want))
+        else:
+            dX, grads, wgrad_done = _rnn_layer_backward(mod, ctx.li, ctx.meta, saved, lparams, dout.contiguous().to(dtype), st[0], N, Tp,
+                                                        dtype, main, side, None, rows=ctx.rows)
         # the gradients leave this node now (AccumulateGrad, DDP's reducer): whatever the second stream produced must be complete.
         # The early all-reduces of the opt-in OverlappedGradSync are NOT waited for here -- that is their point -- but at the end
         # of backward (its finish callback)
@@ -746,7 +794,9 @@ class _RnnLayerFn(torch.autograd.Function):
         sync = getattr(mod, "_grad_sync", None)
         if sync is not None:
             grads = sync.defer_early(lparams, grads)      # in flight on RCCL's stream: they become .grad at the end of backward
-        return (dX, None, None, None, None, None, None, None, None, None, *grads)
+        dh0 = dstate[0] if (dstate is not None and ctx.needs_input_grad[8]) else None
+        dc0 = dstate[1] if (dstate is not None and ctx.c0 is not None and ctx.needs_input_grad[9]) else None
+        return (dX, None, None, None, None, None, None, None, dh0, dc0, *grads)
 
 
 class _RnnStackFn(torch.autograd.Function):
@@ -1262,6 +1312,8 @@ class DeepSpeech(_Base):
             fast_bwd = (ops.wgrad_tn_ok(dtype, Tp * N, Dd * GH, Hh, lda=Dd * GH, ldb=ops.pad_ld(Hh, dtype)) and
                         ops.wgrad_tn_ok(dtype, Tp * N, GH, Hh, lda=Dd * GH, ldb=Hh))
             composite = COMPOSITE_NODE if COMPOSITE_NODE is not None else (not fast_bwd and not _data_parallel_active())
+            if any(h is not None for h in h0s) and torch.is_grad_enabled():
+                composite = False                  # backward through a given `hs` lives in the per-layer nodes (_RnnLayerFn)
             if composite:
                 res = _FrontFn.apply(x, self, lens_dev, N, Tp, dtype, training, L, sm[0].weight, sm[0].bias, sm[1].weight, sm[1].bias,
                                      sm[3].weight, sm[3].bias, sm[4].weight, sm[4].bias, *h0s, *c0s, *params)

@@ -730,22 +730,27 @@ class RnnGrads:
     hidden-side pre-activations too, except the GRU's n slot).  GRU only: either dGH [D][Tp][N][3H] (per-time-step kernels: the
     full hidden-side gradient [dr, dz, dQ]) or dQ [D][Tp][N][H] (persistent kernels: only the slot that differs from dGI).
     bacc [D][N][NB*H] f32 or None: per-sample sums over time of the gate-gradient planes (persistent kernels)."""
-    __slots__ = ("dGI", "dGH", "dQ", "bacc")
+    __slots__ = ("dGI", "dGH", "dQ", "bacc", "dh0", "dc0")
 
     def __init__(self, dGI, dGH=None, dQ=None, bacc=None):
         self.dGI, self.dGH, self.dQ, self.bacc = dGI, dGH, dQ, bacc
+        self.dh0 = self.dc0 = None          # d loss / d initial state (rnn_bwd(want_dstate=True))
 
     def tensors(self):
         return [t for t in (self.dGI, self.dGH, self.dQ, self.bacc) if t is not None]
 
 
-def rnn_bwd(kind, dOut, WhhT, hext, Sv, lens, D, N, H, Tp, pad_rows_unread=False):
+def rnn_bwd(kind, dOut, WhhT, hext, Sv, lens, D, N, H, Tp, pad_rows_unread=False, h0=None, c0=None, want_dstate=False):
     """pad_rows_unread: the caller reads dGI / dQ only through a row list of the real frames (and takes the bias gradients from the
-    sweep's per-sample sums): a persistent sweep that leaves the padding rows unwritten then does not zero them."""
+    sweep's per-sample sums): a persistent sweep that leaves the padding rows unwritten then does not zero them.
+    h0 / c0 [D][N][H] f32: the initial state the forward was given (reference model.py:224-230); want_dstate: also return d loss /
+    d h0 (and d c0) as RnnGrads.dh0 / .dc0.  Either routes the sweep to the launch-per-time-step BPTT (the persistent sweeps assume a
+    zero initial state in backward; training through a given `hs` is the rare path)."""
     dev, dtype = dOut.device, dOut.dtype
     G = GATES[kind]
     dGI = torch.empty((Tp * N, D * G * H), dtype=dtype, device=dev)
-    if use_persistent(kind, dtype, D, N, H):
+    with_state = h0 is not None or c0 is not None or want_dstate
+    if not with_state and use_persistent(kind, dtype, D, N, H):
         dQ = torch.empty((D, Tp, N, H), dtype=dtype, device=dev) if kind == "gru" else None
         if POISON_UNWRITTEN:
             dGI.fill_(float("nan"))
@@ -762,10 +767,14 @@ def rnn_bwd(kind, dOut, WhhT, hext, Sv, lens, D, N, H, Tp, pad_rows_unread=False
         return RnnGrads(dGI, dQ=dQ, bacc=bacc)
     dGH = torch.empty((D, Tp, N, G * H), dtype=dtype, device=dev) if kind == "gru" else None
     state = torch.empty(query("ds2_rnn_state_bytes", D, N, H), dtype=torch.uint8, device=dev)
+    dh0 = torch.empty((D, N, H), dtype=torch.float32, device=dev) if want_dstate else None
+    dc0 = torch.empty((D, N, H), dtype=torch.float32, device=dev) if (want_dstate and kind == "lstm") else None
     with _sweep_timer("rnn_bwd", Tp):
         call("ds2_rnn_bwd", dt(dtype), CELLS[kind], D, N, H, Tp, P(lens), P(dOut), P(WhhT), P(hext[:, 1]), (Tp + 2) * N * H,
-             P(Sv), P(dGI), P(dGH), P(state), S())
-    return RnnGrads(dGI, dGH=dGH)
+             P(Sv), P(dGI), P(dGH), PF(h0), PF(c0), P(dh0), P(dc0), P(state), S())
+    rg = RnnGrads(dGI, dGH=dGH)
+    rg.dh0, rg.dc0 = dh0, dc0
+    return rg
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -155,8 +155,12 @@ long ds2_rnn_state_bytes(int D, int N, int H);
 int ds2_rnn_fwd(int dtype, int cell, int D, int N, int H, int Tp, const int* lens, const void* GI, const void* Whh,
                 const float* bhh, const float* h0, const float* c0, void* Hseq, long hseq_dstride, void* S, float* hn, float* cn,
                 void* state, ds2_stream_t stream);
+/* h0 / c0 [D][N][H] f32 (may be NULL = zeros): the initial state the forward was given (`hs`, model.py:224-230); dh0 / dc0 (may be
+ * NULL): d loss / d h0, d c0.  Only the launch-per-time-step BPTT takes them (training through a given `hs` is the rare path; the
+ * persistent sweeps assume a zero initial state in backward). */
 int ds2_rnn_bwd(int dtype, int cell, int D, int N, int H, int Tp, const int* lens, const void* dOut, const void* WhhT,
-                const void* Hseq, long hseq_dstride, const void* S, void* dGI, void* dGH, void* state, ds2_stream_t stream);
+                const void* Hseq, long hseq_dstride, const void* S, void* dGI, void* dGH, const float* h0, const float* c0,
+                float* dh0, float* dc0, void* state, ds2_stream_t stream);
 
 /* Persistent variant (csrc/ds2_rnn_persist.hip): one launch per sweep, all time steps inside the kernel, W_hh resident in
  * registers, h exchanged between the workgroups of a group through a polled exchange buffer inside ws (pure payload in four

@@ -296,8 +296,9 @@ def rnn_dir_fwd(kind, x, lens, w_ih, w_hh, b_ih, b_hh, reverse, h0=None, c0=None
     return out, h, cst, dict(kind=kind, steps=steps, x=x, H=H)
 
 
-def rnn_dir_bwd(cache, dout, w_ih, w_hh):
-    """BPTT for one direction. Returns dx, dw_ih, dw_hh, db_ih, db_hh."""
+def rnn_dir_bwd(cache, dout, w_ih, w_hh, return_dstate=False):
+    """BPTT for one direction. Returns dx, dw_ih, dw_hh, db_ih, db_hh (+ dh0, dc0 with return_dstate: the gradients with respect to
+    the initial state rnn_dir_fwd was given -- `hs` of reference model.py:224-230, i.e. hx of torch's nn.GRU / nn.LSTM / nn.RNN)."""
     kind, steps, x, H = cache["kind"], cache["steps"], cache["x"], cache["H"]
     T, N, I = x.shape
     dt = x.dtype
@@ -343,6 +344,8 @@ def rnn_dir_bwd(cache, dout, w_ih, w_hh):
     dw_ih = flat.T @ x.reshape(T * N, I)
     db_ih = flat.sum(0)
     dx = (flat @ w_ih).reshape(T, N, I)
+    if return_dstate:
+        return dx, dw_ih, dw_hh, db_ih, db_hh, dh, dc
     return dx, dw_ih, dw_hh, db_ih, db_hh
 
 

@@ -571,6 +571,46 @@ def test_rnn_persistent_general_sweeps(dtype, kind, D, N, H, Tp):
         assert np.abs(a_ - b_).max() <= bar * max(1.0, np.abs(b_).max()), np.abs(a_ - b_).max()
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("kind,D,N,H,Tp", [("gru", 2, 5, 32, 9), ("lstm", 2, 4, 48, 7), ("rnn", 1, 6, 32, 8), ("lstm", 1, 20, 64, 6),
+                                           ("gru", 2, 8, 1024, 5)])
+def test_rnn_bptt_with_an_initial_state(dtype, kind, D, N, H, Tp):
+    """Round 6: backward through a forward that was given `hs` (reference model.py:224-230).  The launch-per-time-step BPTT takes
+    h0 / c0 -- h_{t-1} / c_{t-1} of every clip's FIRST step (for the reverse direction that is step length - 1) -- and returns
+    d loss / d h0, d c0 (one launch behind the sweep folds the last step's recurrent term in).  Against the oracle (held to torch's
+    nn.GRU / nn.LSTM / nn.RNN with hx by tests/test_oracle_ops_vs_torch.py): gate gradients and the state gradients."""
+    rs = np.random.RandomState(7 + D + N + H)
+    G = O.GATES[kind]
+    lens = np.sort(rs.randint(1, Tp + 1, size=N))[::-1].copy()
+    lens[0] = Tp
+    Whh = rs.uniform(-1, 1, (D, G * H, H)) / np.sqrt(H)
+    bhh = rs.uniform(-0.2, 0.2, (D, G * H))
+    GI = rs.standard_normal((Tp * N, D * G * H)) * 0.5
+    h0 = rs.standard_normal((D, N, H)) * 0.5
+    c0 = rs.standard_normal((D, N, H)) * 0.5
+    dout = rs.standard_normal((Tp, N, H))
+    GI_r, Whh_r, dout_r = rnd(GI, dtype), rnd(Whh, dtype), rnd(dout, dtype)
+    o = ops()
+    lens_d = torch.from_numpy(lens.astype(np.int32)).to(DEV)
+    h0d, c0d = cu(h0), (cu(c0) if kind == "lstm" else None)
+    hext, Sv, hn, cn = o.rnn_fwd(kind, cu(GI, dtype), cu(Whh, dtype), cu(bhh), lens_d, D, N, H, Tp, h0=h0d, c0=c0d)
+    rg = o.rnn_bwd(kind, cu(dout, dtype), cu(Whh.transpose(0, 2, 1), dtype), hext, Sv, lens_d, D, N, H, Tp, h0=h0d, c0=c0d,
+                   want_dstate=True)
+    o.check_persistent_kernels()
+    dgi = np64(rg.dGI).reshape(Tp, N, D, G * H)
+    tol = TOL[dtype] * (1 if dtype == torch.float32 else 4)
+    for d in range(D):
+        out, hnr, cnr, cache = O.rnn_dir_fwd(kind, GI_r.reshape(Tp, N, D, G * H)[:, :, d], lens, np.eye(G * H), Whh_r[d], np.zeros(G * H),
+                                             bhh[d], reverse=(d == 1), h0=h0[d], c0=c0[d] if kind == "lstm" else None)
+        assert np.abs(np64(hext[d, 1:Tp + 1]) - out).max() < tol
+        dx, _, _, _, _, dh0, dc0 = O.rnn_dir_bwd(cache, dout_r, np.eye(G * H), Whh_r[d], return_dstate=True)
+        sc = max(np.abs(dx).max(), 1e-6)
+        assert np.abs(dgi[:, :, d] - dx).max() / sc < tol * (1 if dtype == torch.float32 else 3), (kind, d)
+        assert np.abs(np64(rg.dh0[d]) - dh0).max() / max(np.abs(dh0).max(), 1e-6) < tol * (1 if dtype == torch.float32 else 3), (kind, d, "dh0")
+        if kind == "lstm":
+            assert np.abs(np64(rg.dc0[d]) - dc0).max() / max(np.abs(dc0).max(), 1e-6) < tol * (1 if dtype == torch.float32 else 3), (kind, d, "dc0")
+
+
 def test_rnn_persistent_general_initial_state():
     """h0/c0 carry (reference inference.py:86-96) through the general persistent forward kernels (fp32 and bf16)."""
     rs = np.random.RandomState(13)

@@ -667,3 +667,54 @@ def test_nobody_reads_the_padding_rows_a_two_set_sweep_leaves_unwritten(monkeypa
     for k in ga:
         assert np.isfinite(ga[k]).all(), k
         assert np.array_equal(ga[k], gb[k]), k
+
+
+@pytest.mark.parametrize("name", ["gru_bi_tiny", "lstm_bi_tiny", "rnn_bi_tiny", "gru_uni_h50_la40_c45", "lstm_bi_h10_n10", "gru_bi_1024"])
+def test_fp32_backward_through_a_given_initial_state(name):
+    """Round 6: `forward(x, lengths, hs)` in training mode followed by backward (reference model.py:224-230 passes hs[i] to every
+    BatchRNN layer as hx; the reference's own callers only do so in inference).  Checked against the torch port of the reference's
+    forward (oracle/ds2_torch_port.py: the same torch calls, nn.GRU / nn.LSTM / nn.RNN with hx on a packed sequence) in float64 on
+    the CPU: logits, EVERY parameter gradient and the gradients with respect to the initial states themselves."""
+    from oracle import ds2_torch_port as TP
+    fx = Fixture(name)
+    m = build(fx, 32).train()
+    c = fx.cfg
+    kind, H, L, D = c["rnn_type"], c["hidden_size"], c["hidden_layers"], (2 if c["bidirectional"] else 1)
+    inputs, targets, pct, tsz = fx.batch()
+    N, T = inputs.shape[0], inputs.shape[3]
+    sizes = torch.from_numpy(pct.copy()).mul_(int(T)).int()
+    g = torch.Generator().manual_seed(11)
+    mk = lambda: (torch.randn((D, N, H), generator=g, dtype=torch.float64) * 0.3)
+    hs_ref = [(mk().requires_grad_(), mk().requires_grad_()) if kind == "lstm" else mk().requires_grad_() for _ in range(L)]
+    port = TP.Port(dict(c), {k: (np.asarray(v, np.float64) if np.asarray(v).dtype.kind == "f" else v) for k, v in fx.params().items()}, "cpu")
+    for k in list(port.P):
+        port.P[k] = port.P[k].detach().double().requires_grad_(True)
+    for l, r in enumerate(port.rnns):
+        r.double()
+        for n_, p_ in r.named_parameters():
+            port.P["rnns.%d.rnn.%s" % (l, n_)] = p_
+    for k in port.buf:
+        if port.buf[k].dtype.is_floating_point:
+            port.buf[k] = port.buf[k].double()
+    logits_ref, _ = port.forward(torch.from_numpy(inputs).double(), sizes, train=True, hs=hs_ref)          # (T', N, C)
+    w = torch.randn(logits_ref.shape, generator=g, dtype=torch.float64)
+    (logits_ref * w).sum().backward()
+    # ---- ours
+    to_dev = lambda t: t.detach().float().to(DEV).requires_grad_()
+    hs = [(to_dev(h[0]), to_dev(h[1])) if kind == "lstm" else to_dev(h) for h in hs_ref]
+    m.zero_grad()
+    out, _, _ = m(torch.from_numpy(inputs).to(DEV), sizes, hs)                                             # (N, T', C)
+    assert np.abs(out.detach().cpu().double().numpy() - logits_ref.detach().transpose(0, 1).numpy()).max() < 1e-3
+    (out * w.transpose(0, 1).float().to(DEV)).sum().backward()
+    ref_g = {k: v.grad.numpy() for k, v in port.P.items()}
+    for k, p in m.named_parameters():
+        got, want = p.grad.detach().cpu().double().numpy(), ref_g[k].reshape(p.shape)
+        # conv-block gradients are sums of ~1e5-1e6 cancelling terms per entry and this loss (random weights on every logit) has
+        # none of CTC's structure: fp32 accumulation noise reaches 3e-3 of the tensor's maximum on the H = 1024 fixture
+        bar = 5e-3 if k.startswith("conv.") else 1e-3
+        assert np.abs(got - want).max() <= bar * max(np.abs(want).max(), 1e-6), (k, np.abs(got - want).max(), np.abs(want).max())
+    for l in range(L):
+        pairs = zip(hs[l], hs_ref[l]) if kind == "lstm" else [(hs[l], hs_ref[l])]
+        for a, b in pairs:
+            got, want = a.grad.detach().cpu().double().numpy(), b.grad.numpy()
+            assert np.abs(got - want).max() <= 1e-3 * max(np.abs(want).max(), 1e-6), ("hs", l, np.abs(got - want).max())

@@ -114,6 +114,47 @@ def test_packed_recurrent_layer_forward_state_and_gradients(kind, bidirectional)
     assert np.abs(dx - xt.grad.numpy()).max() < 1e-10
 
 
+@pytest.mark.parametrize("kind", ["gru", "lstm", "rnn"])
+@pytest.mark.parametrize("bidirectional", [False, True])
+def test_packed_recurrent_layer_with_an_initial_state_and_its_gradients(kind, bidirectional):
+    """`hs` of reference model.py:224-230 = hx of torch's recurrent layers on a packed sequence: forward, every parameter gradient
+    (the first steps' share of dW_hh comes from h0) and the gradients with respect to h0 / c0 themselves."""
+    rs = np.random.RandomState(5)
+    T, N, I, H = 6, 4, 5, 6
+    lens = np.array([6, 6, 4, 1])
+    D = 2 if bidirectional else 1
+    x = rs.standard_normal((T, N, I))
+    for i, ln in enumerate(lens):
+        x[ln:, i] = 0
+    cls = {"gru": torch.nn.GRU, "lstm": torch.nn.LSTM, "rnn": torch.nn.RNN}[kind]
+    m = cls(I, H, bidirectional=bidirectional, bias=True).double()
+    h0 = T64(rs.standard_normal((D, N, H))).requires_grad_()
+    c0 = T64(rs.standard_normal((D, N, H))).requires_grad_()
+    xt = T64(x).requires_grad_()
+    packed = torch.nn.utils.rnn.pack_padded_sequence(xt, torch.from_numpy(lens))
+    out_p, hn = m(packed, (h0, c0) if kind == "lstm" else h0)
+    out_t, _ = torch.nn.utils.rnn.pad_packed_sequence(out_p, total_length=T)
+    dsum = rs.standard_normal((T, N, H))
+    y = out_t[:, :, :H] + (out_t[:, :, H:] if bidirectional else 0)
+    y.backward(T64(dsum))
+    dx = 0
+    for d, suf in enumerate([""] + (["_reverse"] if bidirectional else [])):
+        p = {k: getattr(m, k + "_l0" + suf).detach().numpy() for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")}
+        o, h, c, cache = O.rnn_dir_fwd(kind, x, lens, p["weight_ih"], p["weight_hh"], p["bias_ih"], p["bias_hh"], reverse=(d == 1),
+                                       h0=h0[d].detach().numpy(), c0=c0[d].detach().numpy() if kind == "lstm" else None)
+        assert np.abs(o - out_t.detach().numpy()[:, :, d * H:(d + 1) * H]).max() < 1e-12
+        assert np.abs(h - (hn[0] if kind == "lstm" else hn)[d].detach().numpy()).max() < 1e-12
+        dxd, dwi, dwh, dbi, dbh, dh0, dc0 = O.rnn_dir_bwd(cache, dsum, p["weight_ih"], p["weight_hh"], return_dstate=True)
+        dx = dx + dxd
+        for got, name in ((dwi, "weight_ih"), (dwh, "weight_hh"), (dbi, "bias_ih"), (dbh, "bias_hh")):
+            want = getattr(m, name + "_l0" + suf).grad.numpy()
+            assert np.abs(got - want).max() < 1e-10 * max(1.0, np.abs(want).max()), (name, suf)
+        assert np.abs(dh0 - h0.grad[d].numpy()).max() < 1e-10
+        if kind == "lstm":
+            assert np.abs(dc0 - c0.grad[d].numpy()).max() < 1e-10
+    assert np.abs(dx - xt.grad.numpy()).max() < 1e-10
+
+
 @pytest.mark.parametrize("ctx", [20, 3])
 def test_lookahead_is_the_right_padded_depthwise_conv(ctx):
     rs = np.random.RandomState(3)
