@@ -35,12 +35,23 @@ constexpr int GRAD_FRAMES = 16;   // frames per workgroup of the gradient pass
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // log(exp a + exp b + exp c), branch-free.  v_exp_f32 / v_log_f32 (1 ulp in the base-2 domain) instead of the full-precision
-// libm sequences: the argument of the log is in [1, 3], where the absolute error of the fast form is < 2e-7 -- far below
-// the fp32 resolution of the alpha/beta values themselves (magnitude ~3 T').  All three -inf: exp(-inf) = 0, log(0) = -inf.
+// libm sequences: the argument of the log is in [1, 3] (or 0), where the absolute error of the bare instruction times ln 2 is
+// < 2e-7 -- far below the fp32 resolution of the alpha/beta values themselves (magnitude ~3 T').  Round 6: `__logf` still expanded
+// to a 12-instruction sequence (denormal pre-scaling the argument never needs + a compensated product with ln 2); the bare
+// v_log_f32 is what the comment always promised.  All three -inf: exp(-inf) = 0, log2(0) = -inf.
+// ms + ln(x), the product with ln 2 fused into the sum in EVERY kernel (an explicit fma: no context-dependent contraction)
+__device__ __forceinline__ float add_ln_1to3(float ms, float x) { return __builtin_fmaf(__builtin_amdgcn_logf(x), 0.69314718056f, ms); }
+// The shift ms is the largest term, held above -FLT_MAX so that "all -inf" needs no select: -inf - ms = -inf, sum 0, result -inf.
 __device__ __forceinline__ float lse3(float a, float b, float c) {
-  const float m = fmaxf(fmaxf(a, b), c);
-  const float ms = m == -INFINITY ? 0.f : m;
-  return ms + __logf(__expf(a - ms) + __expf(b - ms) + __expf(c - ms));
+  float m;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(a), "v"(b), "v"(c));      // (the builtin pair canonicalises each operand first)
+  const float ms = __builtin_fmaxf(m, -3.4028234e38f);
+  return add_ln_1to3(ms, __expf(a - ms) + __expf(b - ms) + __expf(c - ms));
+}
+// the same with c = -inf (exp(-inf) = 0 and x + 0 = x: bit-identical to lse3(a, b, -inf), one exponential less)
+__device__ __forceinline__ float lse2(float a, float b) {
+  const float ms = __builtin_fmaxf(__builtin_fmaxf(a, b), -3.4028234e38f);
+  return add_ln_1to3(ms, __expf(a - ms) + __expf(b - ms));
 }
 
 template <int CP>
@@ -379,6 +390,159 @@ __global__ void __launch_bounds__(64) k_ctc_recursion_wave(const int* __restrict
   }
 }
 
+// Round 6: the recursion as overlapping tiles of state PAIRS, the default for targets of up to 783 labels and any class count.
+//
+// Pair P of a sample = the blank state 2P and the label state 2P + 1 of the extended sequence, in TRAVERSAL order: alpha walks the
+// targets forwards and time forwards, beta walks both backwards -- in that order beta's rule (s, s+1, s+2) is alpha's (s, s-1, s-2),
+// so one body serves both.  A lane keeps its pair in two registers; all it needs from outside is the label state of pair P - 1:
+//     blank'  = lse(blank, label[P-1])                                  + lp[t][blank]
+//     label'  = lse(label, blank, label[P-1] + (same label ? -inf : 0)) + lp[t][label]
+// which is one wave shift.  No LDS round trip of the rows and no workgroup barrier per step (the four-wave kernel above spends most
+// of its 0.5 us per step there); and, unlike the one-wave kernel, no limit of one SIMD: wave w holds pairs w (64 - K) ... + 63, i.e.
+// its lowest K lanes repeat the top K pairs of the wave below (the halo).  A step without exchange invalidates one more halo lane
+// from the bottom (lane j after j + 1 steps), so after K steps exactly the halo is stale: every K steps the waves swap the K
+// boundary pairs through LDS (one barrier per K steps).  Only owned, existing states are stored.  The emission terms do not depend
+// on the recursion: each lane gathers its two log-probs of a whole chunk of K steps from global memory one chunk ahead (the
+// sample's log-prob rows are L2-resident), so there is no class-row staging and no class-count limit.  Same lse3 / lse2 terms in the
+// same order as the kernels above: bit-identical rows.
+template <int K, bool is_beta>
+__device__ __forceinline__ void ctc_recursion_pairs(const int* __restrict__ targets, const int* __restrict__ toff,
+                                                    const int* __restrict__ in_len, const int* __restrict__ tg_len, int Tp, int blank,
+                                                    int LS, int CP, float* __restrict__ nll_out, const float* __restrict__ ws_lp,
+                                                    float* __restrict__ ws_alpha, float* __restrict__ ws_beta,
+                                                    float* __restrict__ ws_ll, float (*xch)[16][K][2], float* fin) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, W = blockDim.x >> 6;
+  const int n = blockIdx.x;
+  int Ti = in_len[n];
+  if (Ti > Tp) Ti = Tp;
+  const int S = tg_len[n];
+  const int L = 2 * S + 1;
+  if (Ti <= 0) {
+    if (!is_beta && threadIdx.x == 0) {
+      nll_out[n] = 0.f;
+      ws_ll[n] = INFINITY;
+    }
+    return;
+  }
+  const int* tg = targets + toff[n];
+  const int P = w * (64 - K) + lane;                 // pair index in traversal order
+  const bool own = w == 0 || lane >= K;
+  const int lab = P < S ? tg[is_beta ? S - 1 - P : P] : blank;
+  const int labp = (P >= 1 && P - 1 < S) ? tg[is_beta ? S - P : P - 1] : -1;
+  const float m_lo = P >= 1 ? 0.f : -INFINITY;                           // pair -1 does not exist
+  const float m_skip = (P >= 1 && P < S && lab != labp) ? 0.f : -INFINITY;
+  // A pair is ONE 8-byte store: rows have an even stride LS = 2 S_max + 2 and the beta rows start one float late (the host passes
+  // ws_beta + 1), so alpha's {2P, 2P + 1} and beta's {L - 2 - 2P, L - 1 - 2P} are both 8-byte aligned; the label half of pair S (it
+  // does not exist) lands in the row's pad slot.
+  const bool st = own && 2 * P < L;
+  const int sp = is_beta ? L - 2 - 2 * P : 2 * P;
+  const float* lp = ws_lp + (long)n * Tp * CP;
+  float* dst = (is_beta ? ws_beta : ws_alpha) + (long)n * Tp * LS;
+  const long tstep = is_beta ? -1 : 1;
+  const int t0 = is_beta ? Ti - 1 : 0;
+  // step 0: the first blank and the first label
+  float a0, a1;
+  {
+    const float* row = lp + (long)t0 * CP;
+    a0 = (P == 0 ? 0.f : -INFINITY) + row[blank];
+    a1 = (P == 0 ? 0.f : -INFINITY) + row[lab];
+  }
+  float2* drow = reinterpret_cast<float2*>(dst + (long)t0 * LS + sp);
+  const long dstep = tstep * (LS / 2);
+  if (st) *drow = is_beta ? float2{a1, a0} : float2{a0, a1};
+  drow += dstep;
+  auto step = [&](float pe0, float pe1) {
+    const float below = wave_from_below(a1);
+    const float v0 = lse2(a0, below + m_lo) + pe0;
+    const float v1 = lse3(a1, a0, below + m_skip) + pe1;
+    a0 = v0;
+    a1 = v1;
+    if (st) *drow = is_beta ? float2{v1, v0} : float2{v0, v1};
+    drow += dstep;
+  };
+  // steps 1 .. Ti - 1 in chunks of K; the emission terms of a chunk are gathered one chunk ahead
+  float pe0[K], pe1[K], nx0[K], nx1[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int i = 1 + k < Ti ? 1 + k : Ti - 1;
+    const float* row = lp + (t0 + tstep * i) * CP;
+    pe0[k] = row[blank];
+    pe1[k] = row[lab];
+  }
+  for (int c0 = 1; c0 < Ti; c0 += K) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      int i = c0 + K + k;
+      if (i > Ti - 1) i = Ti - 1;
+      const float* row = lp + (t0 + tstep * i) * CP;
+      nx0[k] = row[blank];
+      nx1[k] = row[lab];
+    }
+    if (c0 > 1 && W > 1) {                           // halo exchange: the top K pairs of wave w are the bottom K of wave w + 1
+      const int par = ((c0 - 1) / K) & 1;
+      if (lane >= 64 - K) {
+        xch[par][w][lane - (64 - K)][0] = a0;
+        xch[par][w][lane - (64 - K)][1] = a1;
+      }
+      lds_barrier();
+      if (w > 0 && lane < K) {
+        a0 = xch[par][w - 1][lane][0];
+        a1 = xch[par][w - 1][lane][1];
+      }
+    }
+    if (c0 + K <= Ti) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) step(pe0[k], pe1[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        if (c0 + k < Ti) step(pe0[k], pe1[k]);       // uniform
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      pe0[k] = nx0[k];
+      pe1[k] = nx1[k];
+    }
+  }
+  if (!is_beta) {
+    if (own && 2 * P == L - 1) fin[0] = a0;
+    if (own && 2 * P + 1 == L - 2) fin[1] = a1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float l1 = fin[0];
+      const float l2 = L > 1 ? fin[1] : -INFINITY;
+      const float ll = lse3(l1, l2, -INFINITY);
+      const bool feasible = L <= 2 * Ti + 1 && ll != -INFINITY;      // zero_infinity: only an infinite loss is zeroed (see above)
+      nll_out[n] = feasible ? -ll : 0.f;
+      ws_ll[n] = feasible ? ll : INFINITY;
+    }
+  }
+}
+#ifndef DS2_PAIRS_K
+#define DS2_PAIRS_K 16    // steps between halo exchanges = halo lanes (cfg3's call: 217 / 187 / 172 us with 4 / 8 / 16, r06s)
+#endif
+constexpr int PAIRS_K = DS2_PAIRS_K;
+// blockIdx.x = sample, blockIdx.y = 0: alpha, 1: beta (the direction is a template parameter of the body: no per-step selects)
+template <int K>
+__global__ void __launch_bounds__(1024) k_ctc_recursion_pairs(const int* __restrict__ targets, const int* __restrict__ toff,
+                                                              const int* __restrict__ in_len, const int* __restrict__ tg_len,
+                                                              int Tp, int blank, int LS, int CP, float* __restrict__ nll_out,
+                                                              const float* __restrict__ ws_lp, float* __restrict__ ws_alpha,
+                                                              float* __restrict__ ws_beta, float* __restrict__ ws_ll) {
+  __shared__ float xch[2][16][K][2];                 // [chunk parity][wave][halo lane]{blank, label}
+  __shared__ float fin[2];
+  if (blockIdx.y == 0)
+    ctc_recursion_pairs<K, false>(targets, toff, in_len, tg_len, Tp, blank, LS, CP, nll_out, ws_lp, ws_alpha, ws_beta, ws_ll, xch, fin);
+  else
+    ctc_recursion_pairs<K, true>(targets, toff, in_len, tg_len, Tp, blank, LS, CP, nll_out, ws_lp, ws_alpha, ws_beta, ws_ll, xch, fin);
+}
+constexpr int PAIRS_MAX_WAVES = 16;
+// waves a recursion over targets of up to `max_target_len` labels needs (max_target_len + 1 pairs)
+static int pairs_waves(int max_target_len) {
+  const int pp = max_target_len + 1;
+  return pp <= 64 ? 1 : 1 + (pp - 64 + (64 - PAIRS_K) - 1) / (64 - PAIRS_K);
+}
+
 // grid (ceil(Tp / GRAD_FRAMES), N); one wave per frame.  Writes EVERY row of dlogits of its frames (zeros past the
 // sample's length and for infeasible samples).
 template <int CP>
@@ -605,34 +769,39 @@ __global__ void k_sum_small(const float* __restrict__ v, int n, float* __restric
 extern "C" {
 
 // `recursion` argument of ds2_ctc_loss_grad (kernel selection for A/B runs and tests; identical results in every setting):
-// 0 (default): the one-wave-per-recursion kernel where it wins -- <= 32 classes and targets of <= 63 labels (2 states per lane:
-//    253 vs 330 us on 32 clips of 751 frames; with 6 states per lane -- cfg3's 180 labels -- the single SIMD's VALU throughput loses
-//    to the four-wave kernel, 555 vs 414 us; profiles/r03g_ctc_ab.txt);  1: always the four-wave kernel;  2: the one-wave kernel up
-//    to 255 labels.  (Rounds 3-5: a process-wide ds2_ctc_set_variant.)
+// 0 (default): the pair-tile kernel (k_ctc_recursion_pairs) for targets of up to 783 labels, the four-wave kernel beyond;
+// 1: always the four-wave kernel (k_ctc_recursion / _big);  2: the one-wave kernel up to 255 labels (<= 32 classes), else four-wave;
+// 3: the choice of rounds 3-5 -- one wave up to 63 labels (253 vs 330 us on 32 clips of 751 frames), four waves beyond (with 6 states
+//    per lane -- cfg3's 180 labels -- the single SIMD's VALU throughput loses, 555 vs 414 us; profiles/r03g_ctc_ab.txt).
 constexpr int CTC_MAX_CLASSES = 8192;     // the gradient pass keeps one row of per-class sums per wave in LDS (4 x 32 KB at 8192)
 static int ctc_class_stride(int C) { return C <= 32 ? 32 : C <= 64 ? 64 : C <= 128 ? 128 : C <= 256 ? 256 : (C + 63) / 64 * 64; }
 
 long ds2_ctc_ws_floats(int Tp, int N, int C, int max_target_len) {
-  const long Lmax = 2L * max_target_len + 1;
-  return (long)N * Tp * ctc_class_stride(C) + 2L * N * Tp * Lmax + N;
+  const long LS = 2L * max_target_len + 2;       // row stride of the alpha / beta rows: 2 S + 1 states + one pad (see ds2_ctc_loss_grad)
+  return (long)N * Tp * ctc_class_stride(C) + 2L * N * Tp * LS + 2 + N;
 }
 
 int ds2_ctc_loss_grad(const float* logits, long ldl, const int* targets, const int* target_offsets, const int* input_lengths,
                       const int* target_lengths, int Tp, int N, int C, int blank, int max_target_len, float grad_scale,
                       float* nll, float* loss_sum, float* dlogits, long ldg, float* ws, int recursion, ds2_stream_t st_) {
   hipStream_t st = (hipStream_t)st_;
-  const int g_ctc_wave = recursion == 1 ? 0 : recursion == 2 ? 2 : 1;
+  const int g_ctc_wave = recursion == 1 ? 0 : recursion == 2 ? 2 : recursion == 3 ? 1 : 0;
+  const int pw = pairs_waves(max_target_len);
+  const bool pairs = recursion == 0 && pw <= PAIRS_MAX_WAVES;
   DS2_REQUIRE(Tp > 0 && N > 0 && C > 0 && C <= CTC_MAX_CLASSES && blank >= 0 && blank < C && max_target_len >= 0, DS2_ERR_ARG);
   DS2_REQUIRE(ldg >= C && ldl >= C, DS2_ERR_ARG);
   const int CP = ctc_class_stride(C);
-  const int Lmax = 2 * max_target_len + 1;
+  // Row stride of the alpha / beta scratch rows: the 2 S_max + 1 states and one pad, i.e. EVEN, and the beta rows start one float
+  // late -- the pair-tile recursion stores a (blank, label) pair with one aligned 8-byte store in both directions.  Every kernel below
+  // takes the stride where it says Lmax.
+  const int Lmax = 2 * max_target_len + 2;
   int dev = 0;
   (void)hipGetDevice(&dev);
   dev = dev >= 0 && dev < DS2_MAX_DEVICES ? dev : 0;
   float* ws_lp = ws;
   float* ws_alpha = ws + (long)N * Tp * CP;
-  float* ws_beta = ws_alpha + (long)N * Tp * Lmax;
-  float* ws_ll = ws_beta + (long)N * Tp * Lmax;
+  float* ws_beta = ws_alpha + (long)N * Tp * Lmax + 1;
+  float* ws_ll = ws_beta + (long)N * Tp * Lmax + 1;
   if (C > 256) {      // large label sets: no class rows in LDS (see k_ctc_recursion_big)
     const size_t shm_r = (size_t)Lmax * 12, shm_g = (size_t)GRAD_WAVES * CP * 4;
     DS2_REQUIRE(shm_r <= 160 * 1024 && shm_g <= 160 * 1024, DS2_ERR_ARG);
@@ -647,8 +816,12 @@ int ds2_ctc_loss_grad(const float* logits, long ldl, const int* targets, const i
     }
     hipLaunchKernelGGL(k_ctc_logsoftmax_big, dim3(ds2_cdiv((long)Tp * N, 4)), dim3(256), 0, st, logits, ldl, input_lengths, Tp, N, C, CP, ws_lp);
     DS2_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_ctc_recursion_big, dim3(N, 2), dim3(REC_THREADS), shm_r, st, targets, target_offsets, input_lengths, target_lengths,
-                       Tp, blank, Lmax, CP, nll, ws_lp, ws_alpha, ws_beta, ws_ll);
+    if (pairs)
+      hipLaunchKernelGGL(k_ctc_recursion_pairs<PAIRS_K>, dim3(N, 2), dim3(64 * pw), 0, st, targets, target_offsets, input_lengths, target_lengths,
+                         Tp, blank, Lmax, CP, nll, ws_lp, ws_alpha, ws_beta, ws_ll);
+    else
+      hipLaunchKernelGGL(k_ctc_recursion_big, dim3(N, 2), dim3(REC_THREADS), shm_r, st, targets, target_offsets, input_lengths, target_lengths,
+                         Tp, blank, Lmax, CP, nll, ws_lp, ws_alpha, ws_beta, ws_ll);
     DS2_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_ctc_gradient_big, dim3(ds2_cdiv(Tp, GRAD_FRAMES), N), dim3(GRAD_WAVES * 64), shm_g, st, targets, target_offsets,
                        input_lengths, target_lengths, Tp, N, C, blank, Lmax, CP, grad_scale, dlogits, ldg, ws_lp, ws_alpha, ws_beta, ws_ll);
@@ -669,7 +842,10 @@ int ds2_ctc_loss_grad(const float* logits, long ldl, const int* targets, const i
     hipLaunchKernelGGL(k_ctc_logsoftmax<CPT>, dim3(ds2_cdiv((long)Tp * N, 256)), dim3(256), 0, st, logits, ldl, input_lengths, Tp, \
                        N, C, ws_lp);                                                                                                \
     DS2_CHECK_LAUNCH();                                                                                                             \
-    if (CPT == 32 && ((g_ctc_wave == 1 && Lmax <= 128) || (g_ctc_wave == 2 && Lmax <= 512))) {                                                                                   \
+    if (pairs) {                                                                                                                    \
+      hipLaunchKernelGGL(k_ctc_recursion_pairs<PAIRS_K>, dim3(N, 2), dim3(64 * pw), 0, st, targets, target_offsets, input_lengths,  \
+                         target_lengths, Tp, blank, Lmax, CPT, nll, ws_lp, ws_alpha, ws_beta, ws_ll);                               \
+    } else if (CPT == 32 && ((g_ctc_wave == 1 && Lmax <= 128) || (g_ctc_wave == 2 && Lmax <= 512))) {                               \
       /* one wave per (sample, direction), 2 / 4 / 6 / 8 states per lane */                                                        \
       if (Lmax <= 128)                                                                                                              \
         hipLaunchKernelGGL(k_ctc_recursion_wave<2>, dim3(N, 2), dim3(64), 0, st, targets, target_offsets, input_lengths,            \

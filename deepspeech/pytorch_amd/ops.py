@@ -832,7 +832,7 @@ def greedy_decode(scores, sizes, blank):
     return toks, offs
 
 
-CTC_RECURSION = 0    # tests / A-B tools: 1 = always the four-wave recursion kernel, 2 = the one-wave kernel up to 255 labels
+CTC_RECURSION = 0    # tests / A-B tools: 0 = pair tiles (default), 1 = always the four-wave recursion kernel, 2 = the one-wave kernel up to 255 labels, 3 = rounds 3-5
 
 
 def ctc_loss_grad(logits, targets_i32, target_offsets, input_lengths, target_lengths, Tp, N, Cc, blank, max_target_len,

@@ -274,9 +274,9 @@ int ds2_softmax_rows(const float* logits, float* probs, long rows, int C, long l
  * infeasible sample contributes loss 0 and gradient 0.  Outputs: nll [N] f32 (per-sample), loss_sum [1] f32,
  * dlogits [Tp*N][ldg] f32 = grad_scale * d(loss_sum)/d(logits) (log_softmax backward fused; zero rows for t >= length;
  * columns >= C are zero-filled up to ldg).  ws: ds2_ctc_ws_floats(...) floats.  max_target_len: max over target_lengths.
- * recursion: which recursion kernel runs (identical results; for A/B runs and tests): 0 = the default choice (one wave per (sample,
- * direction) for <= 32 classes and targets of <= 63 labels, the four-wave kernel otherwise), 1 = always the four-wave kernel, 2 = the
- * one-wave kernel up to 255 labels. */
+ * recursion: which recursion kernel runs (bit-identical results; for A/B runs and tests): 0 = the default choice (the pair-tile
+ * kernel for targets of up to 783 labels, the four-wave kernel beyond), 1 = always the four-wave kernel, 2 = the one-wave kernel up to
+ * 255 labels (<= 32 classes), 3 = the choice of rounds 3-5 (one wave up to 63 labels, four waves beyond). */
 long ds2_ctc_ws_floats(int Tp, int N, int C, int max_target_len);
 int ds2_ctc_loss_grad(const float* logits, long ldl, const int* targets, const int* target_offsets, const int* input_lengths,
                       const int* target_lengths, int Tp, int N, int C, int blank, int max_target_len, float grad_scale,

@@ -794,29 +794,39 @@ def _ctc_case(N, Tp, lens, tlens, seed, Cc=29, scale=2.0):
     (3, 520, [520, 401, 77], [255, 190, 64]),       # 8 states per lane of the one-wave recursion (2S+1 = 511), 6 and 3 for the others
     (2, 530, [530, 530], [256, 3]),                 # 2S+1 = 513: beyond the one-wave kernel -> the four-wave kernel
     (5, 70, [70, 64, 33, 2, 1], [30, 31, 16, 1, 1]),  # lengths around the 8-step staging chunks; one- and two-frame clips
+    (4, 130, [130, 129, 121, 9], [63, 64, 57, 4]),    # pair tiles: 64 / 65 pairs = one wave exactly / the first pair of a second wave
+    (3, 300, [300, 290, 250], [111, 112, 48]),        # pair tiles: 112 pairs = two waves exactly (64 + 48 owned), 113 = a third
+    (2, 1700, [1700, 900], [783, 400]),               # pair tiles: 16 waves (the most), and 8
+    (2, 1700, [1700, 9], [784, 2]),                   # one label beyond the pair tiles: the four-wave kernel's strided form
 ])
-@pytest.mark.parametrize("recursion", [2, 1])
+@pytest.mark.parametrize("recursion", [0, 2, 1])
 def test_ctc_loss_and_grad(N, Tp, lens, tlens, recursion, monkeypatch):
-    monkeypatch.setattr(ops(), "CTC_RECURSION", recursion)   # 2: one wave per (sample, direction) up to 255 labels; 1: the four-wave kernel
+    # 0: pair tiles (the default); 2: one wave per (sample, direction) up to 255 labels; 1: the four-wave kernel
+    if max(tlens) > 600 and recursion == 2:
+        pytest.skip("same kernel as recursion = 1 at this size")
+    monkeypatch.setattr(ops(), "CTC_RECURSION", recursion)
     _ctc_check(N, Tp, lens, tlens)
 
 
-def test_ctc_recursion_kernels_agree_bit_for_bit():
-    """Same formulas, same order: the one-wave and the four-wave recursion give identical loss, per-sample nll and gradient."""
+@pytest.mark.parametrize("N,Tp,lens,tlens", [(6, 333, [333, 300, 251, 120, 64, 9], [150, 17, 99, 120, 1, 0]),
+                                             (3, 600, [600, 411, 600], [255, 200, 3])])
+def test_ctc_recursion_kernels_agree_bit_for_bit(N, Tp, lens, tlens):
+    """Same formulas, same order: the pair-tile, the one-wave and the four-wave recursion give identical loss, per-sample nll and
+    gradient."""
     from deepspeech.pytorch_amd import _lib
-    N, Tp, lens, tlens = 6, 333, [333, 300, 251, 120, 64, 9], [150, 17, 99, 120, 1, 0]
     logits, targets = _ctc_case(N, Tp, lens, tlens, seed=99)
     o = ops()
     lg = torch.zeros((Tp * N, 32), dtype=torch.float32, device=DEV)
     lg[:, :29] = cu(logits.reshape(Tp * N, 29))
     offs = np.concatenate([[0], np.cumsum(tlens)[:-1]]).astype(np.int32)
     outs = []
-    for recursion in (2, 1):
+    for recursion in (0, 2, 1, 3):
         outs.append(o.ctc_loss_grad(lg, torch.from_numpy(targets.astype(np.int32)).to(DEV), torch.from_numpy(offs).to(DEV),
                                     torch.from_numpy(np.asarray(lens, np.int32)).to(DEV),
                                     torch.from_numpy(np.asarray(tlens, np.int32)).to(DEV), Tp, N, 29, 0, int(max(tlens)), recursion=recursion))
-    for a, b in zip(outs[0], outs[1]):
-        assert torch.equal(a, b)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
 
 
 def _ctc_check(N, Tp, lens, tlens, Cc=29, blank=0):
@@ -850,9 +860,12 @@ def _ctc_check(N, Tp, lens, tlens, Cc=29, blank=0):
 @pytest.mark.parametrize("Cc,blank", [(257, 0), (300, 299), (1000, 0), (5000, 17)])
 @pytest.mark.parametrize("N,Tp,lens,tlens", [(3, 31, [31, 25, 19], [7, 6, 4]), (4, 40, [40, 39, 15, 11], [9, 9, 3, 21]),
                                              (2, 300, [300, 150], [140, 1]), (2, 9, [9, 5], [0, 2])])
-def test_ctc_loss_and_grad_large_label_sets(Cc, blank, N, Tp, lens, tlens):
+@pytest.mark.parametrize("recursion", [0, 1])
+def test_ctc_loss_and_grad_large_label_sets(Cc, blank, N, Tp, lens, tlens, recursion, monkeypatch):
     """More than 256 classes (the reference's labels file is unbounded, model.py:139,203; a Mandarin model has thousands): the class
-    rows are no longer staged in LDS, every state reads the log-probability of its own label (k_ctc_recursion_big)."""
+    rows are no longer staged in LDS, every state reads the log-probability of its own label (pair tiles; recursion = 1:
+    k_ctc_recursion_big)."""
+    monkeypatch.setattr(ops(), "CTC_RECURSION", recursion)
     _ctc_check(N, Tp, lens, tlens, Cc=Cc, blank=blank)
 
 

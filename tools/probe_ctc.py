@@ -2,6 +2,9 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from deepspeech.pytorch_amd import _lib
+if os.environ.get("DS2_LIB"):                   # A/B: another build of the library (tools/ab_variants.py --build-only ...)
+    _lib.LIB_PATH = os.environ["DS2_LIB"]
 from deepspeech.pytorch_amd import ops, synth
 
 if os.environ.get("DS2_CTC_RECURSION"):         # A/B: 1 = four-wave recursion kernel, 2 = one-wave kernel wherever it applies
