@@ -8,6 +8,7 @@
 #include <stdint.h>
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
@@ -204,6 +205,166 @@ __global__ void __launch_bounds__(256, 1) k_gemm9_nt(G9Args g) {
   }
 }
 
+__global__ void __launch_bounds__(256, 1) k_gemm9r_nt(G9Args g) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[131072];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  // XCD-aware tile id: the ids the dispatcher places on one XCD (id % 8) get a contiguous run of tiles
+  const int orig = blockIdx.x, xcd = orig & 7, loc = orig >> 3;
+  const int q8 = g.tiles >> 3, r8 = g.tiles & 7;
+  const int t_id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+  const int m0 = (t_id / g.tiles_n) * 256, n0 = (t_id % g.tiles_n) * 256;
+  const int nkt = g.K / 64;
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // DMA identity: one wave instruction moves 8 tile rows x 128 B; wave w owns rows w*8 .. w*8+7 of every 32-row band (8 bands)
+  uint32_t a_off[8], b_off[8];
+  {
+    const int rloc = wave * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((rloc >> 1) & 7);
+#pragma unroll
+    for (int rb = 0; rb < 8; ++rb) {
+      const int ar = min(m0 + rb * 32 + rloc, g.M - 1), br = min(n0 + rb * 32 + rloc, g.N - 1);
+      a_off[rb] = (uint32_t)(((long)ar * g.lda + chunk * 8) * 2);
+      b_off[rb] = (uint32_t)(((long)br * g.ldb + chunk * 8) * 2);
+    }
+  }
+  const unsigned char* a_base = (const unsigned char*)g.A;
+  const unsigned char* b_base = (const unsigned char*)g.B;
+  // register staging: the wave's 8 + 8 pieces of a K-tile (8 tile rows x 128 B each) travel global -> VGPR -> ds_write_b128, in the
+  // LDS image the DMA variant produces (piece rb of a 32-row band at band * 4096 + wave * 1024 + lane * 16)
+  u32x4 stg[16];
+  const uint32_t lds0w = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  const uint32_t wa = lds0w + wave * 1024 + lane * 16, wb = wa + 65536;
+#define G9R_LOAD(KT, X)                                                                                                   \
+  do {                                                                                                                    \
+    if ((X) < 8) stg[X] = *reinterpret_cast<const u32x4*>(a_base + (long)(KT) * 128 + (size_t)a_off[(X)&7]);              \
+    else stg[X] = *reinterpret_cast<const u32x4*>(b_base + (long)(KT) * 128 + (size_t)b_off[(X)&7]);                      \
+  } while (0)
+#define G9R_WRITE(BUF, X)                                                                                                 \
+  do {                                                                                                                    \
+    if ((X) < 8) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(wa), "v"(stg[X]), "i"((BUF) * 32768 + ((X)&7) * 4096) : "memory"); \
+    else asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(wb), "v"(stg[X]), "i"((BUF) * 32768 + ((X)&7) * 4096) : "memory");         \
+  } while (0)
+
+  // fragment read addresses: operand row (wave base + li), 16-byte chunk (2c + lq) ^ key of its 128-byte LDS row
+  const int li = lane & 31, lq = lane >> 5;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  uint32_t ra[4], rbk[4];
+  {
+    const int key = (li >> 1) & 7;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      ra[c] = lds0 + (wm * 128 + li) * 128 + (((2 * c + lq) ^ key) << 4);
+      rbk[c] = lds0 + 65536 + (wn * 128 + li) * 128 + (((2 * c + lq) ^ key) << 4);
+    }
+  }
+  uint4 fa[2][4], fb[2][4];
+#define G9_READ_ONE(S, BUF, C, X)                                                   \
+  do {                                                                              \
+    if ((X) < 4) G9_RD128(fa[S][(X)&3], ra[C], (BUF) * 32768 + ((X)&3) * 4096);     \
+    else G9_RD128(fb[S][(X)&3], rbk[C], (BUF) * 32768 + ((X)&3) * 4096);            \
+  } while (0)
+#define G9_MMA(S, I, J)                                                                                                            \
+  acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[S][J]), __builtin_bit_cast(bf16x8, fa[S][I]), \
+                                                      acc[I][J], 0, 0, 0)
+  // 16 MFMAs of fragment set S with the 8 reads of (set S ^ 1, buffer RBUF, k16-step RC) between them (DOREAD: 0 / 1)
+#ifndef G9_FRONT
+#define G9_FRONT 8      // reads issued one per MFMA from the start of the step (8: the first eight MFMAs carry them all)
+#endif
+#define G9_STEP(S, DOREAD, RBUF, RC)                              \
+  do {                                                            \
+    _Pragma("unroll") for (int x_ = 0; x_ < 16; ++x_) {           \
+      if (DOREAD && x_ < 8) G9_READ_ONE((S) ^ 1, RBUF, RC, x_);   \
+      G9_SB();                                                    \
+      G9_MMA(S, x_ >> 2, x_ & 3);                                 \
+      G9_SB();                                                    \
+    }                                                             \
+  } while (0)
+
+  // ---- prologue: K-tile 0 into LDS buffer 0, K-tile 1 staged in registers
+#pragma unroll
+  for (int x = 0; x < 16; ++x) G9R_LOAD(0, x);
+#pragma unroll
+  for (int x = 0; x < 16; ++x) G9R_WRITE(0, x);
+  if (nkt > 1) {
+#pragma unroll
+    for (int x = 0; x < 16; ++x) G9R_LOAD(1, x);
+  }
+  G9_WAIT_LGKM0();
+  G9_BARRIER();
+#pragma unroll
+  for (int x = 0; x < 8; ++x) G9_READ_ONE(0, 0, 0, x);
+  G9_WAIT_LGKM0();
+  G9_SB();
+
+  // One K-tile: 64 MFMAs in four steps of 16.  Steps 0-2 read the rest of BUF's fragments; step 2 also writes the staged K-tile
+  // KT + 1 into the other buffer (free since the barrier of the K-tile before); ONE barrier; step 3 reads K-tile KT + 1's first
+  // fragments and issues the global loads of K-tile KT + 2 into the staging registers (consumed a K-tile later, in step 2).
+#define G9R_KTILE(BUF, KT)                                                                      \
+  {                                                                                             \
+    const bool more2 = (KT) + 2 < nkt, more1 = (KT) + 1 < nkt;                                  \
+    G9_STEP(0, 1, BUF, 1);                                                                      \
+    G9_WAIT_LGKM0();                                                                            \
+    G9_SB();                                                                                    \
+    G9_STEP(1, 1, BUF, 2);                                                                      \
+    G9_WAIT_LGKM0();                                                                            \
+    G9_SB();                                                                                    \
+    _Pragma("unroll") for (int x_ = 0; x_ < 16; ++x_) {                                         \
+      if (x_ < 8) G9_READ_ONE(1, BUF, 3, x_);                                                   \
+      if (more1) G9R_WRITE((BUF) ^ 1, x_);                                                      \
+      G9_SB();                                                                                  \
+      G9_MMA(0, x_ >> 2, x_ & 3);                                                               \
+      G9_SB();                                                                                  \
+    }                                                                                           \
+    G9_WAIT_LGKM0();                                                                            \
+    G9_BARRIER();                                                                               \
+    _Pragma("unroll") for (int x_ = 0; x_ < 16; ++x_) {                                         \
+      if (more1 && x_ < 8) G9_READ_ONE(0, (BUF) ^ 1, 0, x_);                                    \
+      if (more2) G9R_LOAD((KT) + 2, x_);                                                        \
+      G9_SB();                                                                                  \
+      G9_MMA(1, x_ >> 2, x_ & 3);                                                               \
+      G9_SB();                                                                                  \
+    }                                                                                           \
+    G9_WAIT_LGKM0();                                                                            \
+    G9_SB();                                                                                    \
+  }
+  for (int kt = 0; kt < nkt; kt += 2) {
+    G9R_KTILE(0, kt)
+    G9R_KTILE(1, kt + 1)
+  }
+
+  // ---- epilogue (first version: straight from the registers; D rows = n, D columns = m: a lane holds 4 consecutive n of row m)
+  const float* bias = g.bias;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = m0 + wm * 128 + i * 32 + li;
+    if (row >= g.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = n0 + wn * 128 + j * 32 + 8 * q + 4 * lq;
+        if (col + 3 >= g.N) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] + (bias ? bias[col + e] : 0.f);
+        uint2 pk;
+        pk.x = pk_bf16(v[0], v[1]);
+        pk.y = pk_bf16(v[2], v[3]);
+        *reinterpret_cast<uint2*>(g.C + (long)row * g.ldc + col) = pk;
+      }
+  }
+}
+
 extern "C" int gemm9_nt(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long lda, long ldb, long ldc, void* st) {
   if (K % 128 != 0 || N % 4 != 0) return 1;
   G9Args g;
@@ -212,5 +373,16 @@ extern "C" int gemm9_nt(const void* A, const void* B, void* C, const float* bias
   g.tiles_n = (N + 255) / 256;
   g.tiles = g.tiles_n * ((M + 255) / 256);
   hipLaunchKernelGGL(k_gemm9_nt, dim3(g.tiles), dim3(256), 0, (hipStream_t)st, g);
+  return (int)hipGetLastError();
+}
+
+extern "C" int gemm9r_nt(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, long lda, long ldb, long ldc, void* st) {
+  if (K % 128 != 0 || N % 4 != 0) return 1;
+  G9Args g;
+  g.A = (const uint16_t*)A; g.B = (const uint16_t*)B; g.C = (uint16_t*)C; g.bias = bias; g.M = M; g.N = N; g.K = K;
+  g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.tiles_n = (N + 255) / 256;
+  g.tiles = g.tiles_n * ((M + 255) / 256);
+  hipLaunchKernelGGL(k_gemm9r_nt, dim3(g.tiles), dim3(256), 0, (hipStream_t)st, g);
   return (int)hipGetLastError();
 }

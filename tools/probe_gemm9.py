@@ -22,12 +22,13 @@ subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-
                        "-o", lib] + os.environ.get("G9_FLAGS", "").split())
 L = ctypes.CDLL(lib)
 L.gemm9_nt.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_long] * 3 + [ctypes.c_void_p]
+L.gemm9r_nt.argtypes = L.gemm9_nt.argtypes
 dev = "cuda"
 
 
-def g9(A, B, M, N, K, lda, ldb, bias=None):
+def g9(A, B, M, N, K, lda, ldb, bias=None, fn=None):
     C = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
-    rc = L.gemm9_nt(A.data_ptr(), B.data_ptr(), C.data_ptr(), bias.data_ptr() if bias is not None else None, M, N, K, lda, ldb, N,
+    rc = (fn or L.gemm9_nt)(A.data_ptr(), B.data_ptr(), C.data_ptr(), bias.data_ptr() if bias is not None else None, M, N, K, lda, ldb, N,
                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0, rc
     return C
@@ -51,10 +52,11 @@ for M, N, K in ((300, 520, 256), (1000, 256, 1024), (24032, 1024, 1024)):
     A = torch.randn(M, K, device=dev).to(torch.bfloat16)
     B = torch.randn(N, K, device=dev).to(torch.bfloat16)
     bias = torch.randn(N, device=dev)
-    C = g9(A, B, M, N, K, K, K, bias)
     ref = A.float() @ B.float().t() + bias
-    err = (C.float() - ref).abs().max().item() / ref.abs().max().item()
-    print("check M=%d N=%d K=%d: max rel err %.2e %s" % (M, N, K, err, "ok" if err < 8e-3 else "WRONG"), flush=True)
+    for name, fn in (("gemm9 (LDS-DMA)", L.gemm9_nt), ("gemm9r (register staging)", L.gemm9r_nt)):
+        C = g9(A, B, M, N, K, K, K, bias, fn=fn)
+        err = (C.float() - ref).abs().max().item() / ref.abs().max().item()
+        print("check %s M=%d N=%d K=%d: max rel err %.2e %s" % (name, M, N, K, err, "ok" if err < 8e-3 else "WRONG"), flush=True)
 
 shapes = [("i2h cfg3 K=1024 ld 1088", 24032, 6144, 1024, 1088), ("i2h cfg5a K=1280 ld 1344", 48064, 10240, 1280, 1344), ("dX cfg3 K=6144", 24032, 1024, 6144, 6144),
           ("square 8192", 8192, 8192, 8192, 8192), ("square 4096", 4096, 4096, 4096, 4096)]
@@ -63,10 +65,11 @@ for name, M, N, K, ld in shapes:
     B = torch.randn(N, ld, device=dev).to(torch.bfloat16)
     fl = 2.0 * M * N * K
     t9 = timeit(lambda: g9(A, B, M, N, K, ld, ld))
+    t9r = timeit(lambda: g9(A, B, M, N, K, ld, ld, fn=L.gemm9r_nt))
     t8 = timeit(lambda: ops.gemm8_nt(A, B, M=M, N=N, K=K, lda=ld, ldb=ld))
     Av, Bv = A[:, :K], B[:, :K]
     tv = timeit(lambda: torch.matmul(Av, Bv.t()))
-    c9, c8 = g9(A, B, M, N, K, ld, ld), ops.gemm8_nt(A, B, M=M, N=N, K=K, lda=ld, ldb=ld)
+    c9, c8 = g9(A, B, M, N, K, ld, ld, fn=L.gemm9r_nt), ops.gemm8_nt(A, B, M=M, N=N, K=K, lda=ld, ldb=ld)
     same = (c9.float() - c8.float()).abs().max().item()
-    print("%-28s gemm9 %.3f ms %5.0f TFLOP/s | gemm8 %.3f ms %5.0f | vendor library %.3f ms %5.0f | max |gemm9 - gemm8| %.3g" % (
-        name, t9, fl / t9 / 1e9, t8, fl / t8 / 1e9, tv, fl / tv / 1e9, same), flush=True)
+    print("%-28s gemm9 %.3f ms %5.0f TFLOP/s | gemm9r %.3f ms %5.0f | gemm8 %.3f ms %5.0f | vendor library %.3f ms %5.0f | max |gemm9r - gemm8| %.3g" % (
+        name, t9, fl / t9 / 1e9, t9r, fl / t9r / 1e9, t8, fl / t8 / 1e9, tv, fl / tv / 1e9, same), flush=True)
