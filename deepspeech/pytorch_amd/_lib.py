@@ -71,6 +71,7 @@ SIGNATURES = {
     "ds2_clip_coef": (_i, [_i, _vp, _vp, _f, _vp, _vp, _vp]),
     "ds2_opt_multi": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "ds2_opt_matrix": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _i, _vp, _vp]),
+    "ds2_opt_matrices": (_i, [_i, _i] + [_vp] * 13 + [_vp, _i, _vp, _vp]),
     "ds2_spect_frames": (_i, [_i]),
     "ds2_spect_ws_bytes": (_l, [_i, _i]),
     "ds2_spectrogram": (_i, [_vp, _l, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp]),

@@ -178,12 +178,12 @@ __global__ void __launch_bounds__(256) k_opt_matrix(float* __restrict__ p, const
 
 // Vectorised form for the un-permuted matrices (C % 4 == 0, Cout == C): a thread owns a 4-row x 4-column patch of the 64x64
 // tile -- 16-byte loads / stores of p, g, m, v, 8-byte stores of the bf16 copy, the same LDS image for the transpose.
-__global__ void __launch_bounds__(256) k_opt_matrix4(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                     float* __restrict__ v, int R, int C, uint16_t* __restrict__ dst, long ldd,
-                                                     uint16_t* __restrict__ dstT, long lddT, Hyper h) {
-  __shared__ uint32_t tileT[64 * 33];
+__device__ __forceinline__ void opt_matrix4_tile(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                 float* __restrict__ v, int R, int C, uint16_t* __restrict__ dst, long ldd,
+                                                 uint16_t* __restrict__ dstT, long lddT, const Hyper& h, int bx, int by,
+                                                 uint32_t* tileT) {
   const int tid = threadIdx.x, cx = tid & 15, ry = tid >> 4;         // 16 column quads x 16 row quads
-  const int c0 = blockIdx.x * 64 + cx * 4, r0 = blockIdx.y * 64 + ry * 4;
+  const int c0 = bx * 64 + cx * 4, r0 = by * 64 + ry * 4;
   const float cs = h.clip ? h.clip[1] : 1.f;
   float val[4][4];
 #pragma unroll
@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(256) k_opt_matrix4(float* __restrict__ p, cons
   }
   __syncthreads();
   const int col = tid >> 2, part = tid & 3;
-  const int jo = blockIdx.x * 64 + col, ro = blockIdx.y * 64 + part * 16;
+  const int jo = bx * 64 + col, ro = by * 64 + part * 16;
   if (jo >= C || ro >= R) return;
   uint32_t w[8];
 #pragma unroll
@@ -241,6 +241,38 @@ __global__ void __launch_bounds__(256) k_opt_matrix4(float* __restrict__ p, cons
   uint4* o = reinterpret_cast<uint4*>(dstT + (long)jo * lddT + ro);
   o[0] = make_uint4(w[0], w[1], w[2], w[3]);
   o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+__global__ void __launch_bounds__(256) k_opt_matrix4(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                     float* __restrict__ v, int R, int C, uint16_t* __restrict__ dst, long ldd,
+                                                     uint16_t* __restrict__ dstT, long lddT, Hyper h) {
+  __shared__ uint32_t tileT[64 * 33];
+  opt_matrix4_tile(p, g, m, v, R, C, dst, ldd, dstT, lddT, h, blockIdx.x, blockIdx.y, tileT);
+}
+
+// Round 6: ALL un-permuted weight matrices of a parameter group in ONE launch (cfg3: 18 launches of ~22 us -> one; every launch
+// boundary drained and refilled the memory pipeline of a purely HBM-bound pass).  Workgroup -> (matrix, 64 x 64 tile): the matrices
+// own consecutive id ranges, tiles row-major (column tile fastest: consecutive workgroups stream consecutive 256-byte row segments).
+constexpr int MAXM = 36;          // matrices per launch (the table is a kernel argument: 36 x 84 B + Hyper < 4 KB)
+struct MatTable {
+  float* p[MAXM];
+  const float* g[MAXM];
+  float* m[MAXM];
+  float* v[MAXM];
+  uint16_t* dst[MAXM];
+  uint16_t* dstT[MAXM];
+  long ldd[MAXM], lddT[MAXM];
+  int R[MAXM], C[MAXM];
+  int first_block[MAXM + 1];
+  int count;
+};
+__global__ void __launch_bounds__(256) k_opt_matrix4_multi(MatTable t, Hyper h) {
+  __shared__ uint32_t tileT[64 * 33];
+  const int b = blockIdx.x;
+  int i = 0;
+  while (i + 1 < t.count && b >= t.first_block[i + 1]) ++i;
+  const int local = b - t.first_block[i], tc = (t.C[i] + 63) / 64;
+  opt_matrix4_tile(t.p[i], t.g[i], t.m[i], t.v[i], t.R[i], t.C[i], t.dst[i], t.ldd[i], t.dstT[i], t.lddT[i], h, local % tc, local / tc, tileT);
 }
 
 // Permuted form (rnns.0 weight_ih: output column j = f*perm_c + c <- source column c*perm_f + f, zero columns [C, Cout)): tiles run
@@ -396,6 +428,57 @@ int ds2_opt_multi(int mode, int count, float* const* p, const float* const* g, f
   return 0;
 }
 
+static bool opt_matrix_vec_ok(int mode, const float* p, const float* g, const float* m, const float* v, int C, int perm_c, int Cout,
+                              const void* dst, long ldd) {
+  return perm_c == 0 && Cout == C && C % 4 == 0 && (dst == nullptr || ldd % 4 == 0) &&
+         (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)(mode == 0 ? v : p) | (uintptr_t)dst) & 15) == 0;
+}
+
+// `count` weight matrices of ONE parameter group (same hp / first): ds2_opt_matrix for each of them, with every matrix the
+// vectorised kernel takes (no column permutation, Cout == C, C % 4 == 0, 16-byte aligned) in one launch per MAXM of them.
+int ds2_opt_matrices(int mode, int count, float* const* p, const float* const* g, float* const* m, float* const* v, const int* R,
+                     const int* C, const int* perm_c, const int* perm_f, const int* Cout, void* const* dst, const long* ldd,
+                     void* const* dstT, const long* lddT, const float* hp, int first, const float* clip, ds2_stream_t st_) {
+  hipStream_t st = (hipStream_t)st_;
+  DS2_REQUIRE((mode == 0 || mode == 1) && count > 0 && p && g && m && R && C && perm_c && perm_f && Cout && dst && ldd && dstT && lddT && hp &&
+                  (mode == 1 || v), DS2_ERR_ARG);
+  const Hyper h = make_hyper(mode, hp, first, clip);
+  MatTable t{};
+  int blocks = 0;
+  auto flush = [&]() -> int {
+    if (t.count == 0) return 0;
+    t.first_block[t.count] = blocks;
+    hipLaunchKernelGGL(k_opt_matrix4_multi, dim3(blocks), dim3(256), 0, st, t, h);
+    DS2_CHECK_LAUNCH();
+    t.count = 0;
+    blocks = 0;
+    return 0;
+  };
+  for (int i = 0; i < count; ++i) {
+    float* vi = mode == 0 ? v[i] : nullptr;
+    DS2_REQUIRE(p[i] && g[i] && m[i] && (mode == 1 || vi), DS2_ERR_ARG);
+    DS2_REQUIRE(R[i] > 0 && C[i] > 0 && R[i] % 16 == 0 && Cout[i] >= C[i], DS2_ERR_ARG);
+    DS2_REQUIRE(perm_c[i] == 0 || perm_c[i] * perm_f[i] == C[i], DS2_ERR_ARG);
+    DS2_REQUIRE(dstT[i] == nullptr || (lddT[i] % 8 == 0 && (((uintptr_t)dstT[i]) & 15) == 0), DS2_ERR_ALIGN);
+    if (!opt_matrix_vec_ok(mode, p[i], g[i], m[i], vi, C[i], perm_c[i], Cout[i], dst[i], ldd[i])) {
+      const int rc = ds2_opt_matrix(mode, p[i], g[i], m[i], vi, R[i], C[i], perm_c[i], perm_f[i], Cout[i], dst[i], ldd[i], dstT[i], lddT[i], hp,
+                                    first, clip, st_);
+      if (rc != 0) return rc;
+      continue;
+    }
+    const int k = t.count++;
+    t.p[k] = p[i]; t.g[k] = g[i]; t.m[k] = m[i]; t.v[k] = vi; t.dst[k] = (uint16_t*)dst[i]; t.dstT[k] = (uint16_t*)dstT[i];
+    t.ldd[k] = ldd[i]; t.lddT[k] = lddT[i]; t.R[k] = R[i]; t.C[k] = C[i];
+    t.first_block[k] = blocks;
+    blocks += ds2_cdiv(C[i], 64) * ds2_cdiv(R[i], 64);
+    if (t.count == MAXM) {
+      const int rc = flush();
+      if (rc != 0) return rc;
+    }
+  }
+  return flush();
+}
+
 // One weight matrix p[R][C] (contiguous): update + bf16 layouts (see k_opt_matrix).  R % 16 == 0.
 int ds2_opt_matrix(int mode, float* p, const float* g, float* m, float* v, int R, int C, int perm_c, int perm_f, int Cout,
                    void* dst, long ldd, void* dstT, long lddT, const float* hp, int first, const float* clip, ds2_stream_t st_) {
@@ -405,8 +488,7 @@ int ds2_opt_matrix(int mode, float* p, const float* g, float* m, float* v, int R
   DS2_REQUIRE(perm_c == 0 || perm_c * perm_f == C, DS2_ERR_ARG);
   DS2_REQUIRE(dstT == nullptr || (lddT % 8 == 0 && (((uintptr_t)dstT) & 15) == 0), DS2_ERR_ALIGN);
   const Hyper h = make_hyper(mode, hp, first, clip);
-  const bool vec = perm_c == 0 && Cout == C && C % 4 == 0 && (dst == nullptr || ldd % 4 == 0) && (((uintptr_t)p | (uintptr_t)g |
-                    (uintptr_t)m | (uintptr_t)(mode == 0 ? v : p) | (uintptr_t)dst) & 15) == 0;
+  const bool vec = opt_matrix_vec_ok(mode, p, g, m, v, C, perm_c, Cout, dst, ldd);
   if (vec)
     hipLaunchKernelGGL(k_opt_matrix4, dim3(ds2_cdiv(C, 64), ds2_cdiv(R, 64)), dim3(256), 0, st, p, g, m, v, R, C, (uint16_t*)dst, ldd,
                        (uint16_t*)dstT, lddT, h);

@@ -7,8 +7,9 @@ ExponentialLR scheduler of reference model.py:292-296 and resume work unchanged)
   1. optionally the global-norm clip (``clip_grad_norm``: what Lightning's gradient_clip_val: 400 does through
      ``torch.nn.utils.clip_grad_norm_``, configs/an4.yaml:12) computed on the device, no host synchronisation;
   2. one multi-tensor launch for the small parameters (conv, BatchNorm, biases, head);
-  3. one launch per recurrent weight matrix that updates it AND writes the bf16 operand copy and transpose the next
-     forward / backward of the drop-in model needs (they land in the model's weight cache, stamped valid for the next step).
+  3. one launch for the recurrent weight matrices (round 6; the column-permuted ``rnns.0.weight_ih`` separately) that updates them
+     AND writes the bf16 operand copy and transpose the next forward / backward of the drop-in model needs (they land in the
+     model's weight cache, stamped valid for the next step).
 
 Arithmetic = torch's single-tensor AdamW / SGD-Nesterov in fp32 (tests/test_gpu_optim.py: <= a few ulp per step against
 torch.optim on the CPU).  There is no CPU path: CPU parameters raise."""
@@ -27,6 +28,10 @@ def _ptr_array(tensors):
 
 def _long_array(vals):
     return (C.c_long * len(vals))(*vals)
+
+
+def _int_array(vals):
+    return (C.c_int * len(vals))(*vals)
 
 
 def _float_array(vals):
@@ -104,6 +109,7 @@ class _FusedStep:
         m = self._model
         emit = m is not None and m.training and m.compute_dtype() == torch.bfloat16 and m._Hp == m.rnns[0].hidden_size
         small = {}
+        mats = {}
         touched = {}
         for (gi, p, _, s1, s2), g in zip(entries, grads):
             info = plan.get(id(p))
@@ -124,8 +130,13 @@ class _FusedStep:
                     dst, ldd, dstT, lddT = L["Whh"][d], Cc, L["WhhT"][d], GH
                 touched[li] = (L, D)
             pc, pf = perm if perm is not None else (0, 0)
-            call("ds2_opt_matrix", mode, ops.P(p), ops.P(g), ops.P(s1), ops.P(s2), GH, Cc, pc, pf, Io if kind == "ih" else Cc,
-                 ops.P(dst), ldd, ops.P(dstT), lddT, _float_array(hp_of_group[gi]), first_of_group[gi], ops.P(clip), ops.S())
+            mats.setdefault(gi, []).append((p, g, s1, s2, GH, Cc, pc, pf, Io if kind == "ih" else Cc, dst, ldd, dstT, lddT))
+        for gi, lst in mats.items():      # one launch per group for the matrices without a column permutation (ds2_opt_matrices)
+            col = list(zip(*lst))
+            call("ds2_opt_matrices", mode, len(lst), _ptr_array(col[0]), _ptr_array(col[1]), _ptr_array(col[2]), _ptr_array(col[3]),
+                 _int_array(col[4]), _int_array(col[5]), _int_array(col[6]), _int_array(col[7]), _int_array(col[8]), _ptr_array(col[9]),
+                 _long_array(col[10]), _ptr_array(col[11]), _long_array(col[12]), _float_array(hp_of_group[gi]), first_of_group[gi],
+                 ops.P(clip), ops.S())
         for gi, lst in small.items():
             n = _long_array([p.numel() for p, _, _, _ in lst])
             call("ds2_opt_multi", mode, len(lst), _ptr_array([x[0] for x in lst]), _ptr_array([x[1] for x in lst]),

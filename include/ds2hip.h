@@ -296,6 +296,11 @@ int ds2_opt_multi(int mode, int count, float* const* p, const float* const* g, f
                   const float* hp, int first, const float* clip, ds2_stream_t stream);
 int ds2_opt_matrix(int mode, float* p, const float* g, float* m, float* v, int R, int C, int perm_c, int perm_f, int Cout,
                    void* dst, long ldd, void* dstT, long lddT, const float* hp, int first, const float* clip, ds2_stream_t stream);
+/* ds2_opt_matrix for `count` matrices of ONE parameter group (arrays of the per-matrix arguments): every matrix without a column
+ * permutation (perm_c == 0, Cout == C, C % 4 == 0, 16-byte aligned) is updated in one launch per 36 of them, the others one by one. */
+int ds2_opt_matrices(int mode, int count, float* const* p, const float* const* g, float* const* m, float* const* v, const int* R,
+                     const int* C, const int* perm_c, const int* perm_f, const int* Cout, void* const* dst, const long* ldd,
+                     void* const* dstT, const long* lddT, const float* hp, int first, const float* clip, ds2_stream_t stream);
 
 /* ---- log-spectrogram front-end (SpectrogramParser.compute_spectrogram, loader/data_loader.py:73-94, + the padded batch layout
  * of _collate_fn, :247-270).  wav [N][ldw] f32 waveforms (utterance n = first nsamples[n] entries of row n; nsamples on the

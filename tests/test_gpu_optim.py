@@ -100,6 +100,47 @@ def test_opt_matrix_layouts_equal_the_cast_kernels():
         assert torch.equal(dst, d2) and torch.equal(dstT, d2T)
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_opt_matrices_equals_one_call_per_matrix(mode):
+    """ds2_opt_matrices (every un-permuted matrix of a group in one launch per 36, the permuted ones one by one) leaves the same
+    bits as ds2_opt_matrix matrix by matrix: parameters, both optimizer states, the bf16 copy and the bf16 transpose.  40 matrices of
+    mixed shapes (one launch is flushed in the middle), a column-permuted one and an odd-width one (C % 4 != 0) among them, some
+    without a copy, some without a transpose."""
+    import ctypes as C
+    from deepspeech.pytorch_amd import ops
+    from deepspeech.pytorch_amd._lib import call
+    rs = np.random.RandomState(40 + mode)
+    hp = (C.c_float * 7)(1 - 1e-3, 0.1, 0.999, 0.001, 0.0316, 1e-8, -0.015) if mode == 0 else (C.c_float * 7)(1e-3, 0.9, 0, 0, 1, 0, -0.02)
+    shapes = [(96, 1312, (32, 41), 1344), (48, 202, None, 202)] + [(16 * int(rs.randint(1, 9)), 4 * int(rs.randint(1, 70)), None, None) for _ in range(38)]
+    rs.shuffle(shapes)
+    sets = []
+    for k, (R, Cc, perm, Cout) in enumerate(shapes):
+        Cout = Cout or Cc
+        w, g = rs.standard_normal((R, Cc)).astype(np.float32), rs.standard_normal((R, Cc)).astype(np.float32)
+        m0, v0 = rs.standard_normal((R, Cc)).astype(np.float32) * 0.1, rs.random_sample((R, Cc)).astype(np.float32) * 0.01
+        a = [torch.from_numpy(x.copy()).to(DEV) for x in (w, g, m0, v0)]
+        b = [t.clone() for t in a]
+        lay = [None if k % 5 == 3 else torch.full((R, Cout), 7.0, dtype=torch.bfloat16, device=DEV),
+               None if k % 7 == 2 else torch.full((Cout, R), 7.0, dtype=torch.bfloat16, device=DEV)]
+        lay_b = [None if t is None else t.clone() for t in lay]
+        sets.append((R, Cc, perm if perm else (0, 0), Cout, a, b, lay, lay_b))
+    for R, Cc, (pc, pf), Cout, a, b, lay, lay_b in sets:
+        call("ds2_opt_matrix", mode, ops.P(b[0]), ops.P(b[1]), ops.P(b[2]), ops.P(b[3]), R, Cc, pc, pf, Cout, ops.P(lay_b[0]), Cout,
+             ops.P(lay_b[1]), R, hp, 0, ops.P(None), ops.S())
+    parr = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() if t is not None else 0 for t in ts])
+    iarr = lambda vs: (C.c_int * len(vs))(*vs)
+    larr = lambda vs: (C.c_long * len(vs))(*vs)
+    call("ds2_opt_matrices", mode, len(sets), parr([s_[4][0] for s_ in sets]), parr([s_[4][1] for s_ in sets]), parr([s_[4][2] for s_ in sets]),
+         parr([s_[4][3] for s_ in sets]), iarr([s_[0] for s_ in sets]), iarr([s_[1] for s_ in sets]), iarr([s_[2][0] for s_ in sets]),
+         iarr([s_[2][1] for s_ in sets]), iarr([s_[3] for s_ in sets]), parr([s_[6][0] for s_ in sets]), larr([s_[3] for s_ in sets]),
+         parr([s_[6][1] for s_ in sets]), larr([s_[0] for s_ in sets]), hp, 0, ops.P(None), ops.S())
+    for k, (R, Cc, _, Cout, a, b, lay, lay_b) in enumerate(sets):
+        for x, y in zip(a[:3] + ([a[3]] if mode == 0 else []), b[:3] + ([b[3]] if mode == 0 else [])):
+            assert torch.equal(x, y), (k, R, Cc)
+        for x, y in zip(lay, lay_b):
+            assert x is None or torch.equal(x, y), (k, R, Cc)
+
+
 def test_model_trains_identically_with_the_fused_optimizer():
     """Three training steps of the drop-in class (bf16 mode) with configure_optimizers()'s FusedAdamW (clip inside) against
     clip_grad_norm_ + torch.optim.AdamW: same loss trajectory; the bf16 weight layouts the optimizer leaves in the model's cache

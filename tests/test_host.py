@@ -35,7 +35,8 @@ def test_library_exports_every_declared_symbol(lib):
     assert lib.ds2_rnn_gates(0) == 3 and lib.ds2_rnn_gates(1) == 4 and lib.ds2_rnn_gates(2) == 1
     assert lib.ds2_rnn_state_bytes(2, 32, 1024) == 2 * 32 * 1024 * 24
     assert lib.ds2_norm_partials(10) == 2 and lib.ds2_norm_partials(10 ** 7) == 1024
-    assert lib.ds2_ctc_ws_floats(751, 32, 29, 180) == 32 * 751 * 32 + 2 * 32 * 751 * 361 + 32
+    # log-prob rows + alpha / beta rows of 2 S + 1 states and one pad float (an even stride: pair stores) + the beta shift + ll
+    assert lib.ds2_ctc_ws_floats(751, 32, 29, 180) == 32 * 751 * 32 + 2 * 32 * 751 * 362 + 2 + 32
     # conv2 forward (bf16 storage): fp32 partial sums of the even kernel rows, [N][41][T'][32]; none for fp32 storage
     assert lib.ds2_conv2_fwd_ws_bytes(1, 32, 161, 751) == 32 * 41 * 751 * 32 * 4 and lib.ds2_conv2_fwd_ws_bytes(0, 32, 161, 751) == 0 and lib.ds2_conv2_fwd_ws_bytes(1, 32, 81, 751) == 0
 
