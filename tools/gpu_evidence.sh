@@ -1,12 +1,15 @@
 #!/bin/bash
 # One GPU-box session that collects the round's evidence from ONE build: default bench line, the other configurations, stock
 # PyTorch-ROCm lines, rocprofv3 kernel stats per configuration, PMC passes (separate, kernel-trace only) for cfg3.
-#   gpurun --timeout 1500 -- 'bash tools/gpu_evidence.sh <tag>'        env: SKIP_STOCK=1, SKIP_PMC=1
+#   gpurun --timeout 1500 -- 'bash tools/gpu_evidence.sh <tag>'        env: SKIP_DEFAULT=1, SKIP_STOCK=1, SKIP_PMC=1, SKIP_STREAM=1
 tag=${1:-ev}
 out=gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
 here=$PWD
-timeout 300 python bench.py > $out/bench_default.json 2> $out/bench_default.err; echo "bench default rc=$?"; tail -c 600 $out/bench_default.json; echo
+if [ -z "$SKIP_DEFAULT" ]; then   # the default line includes the CPU leg (minutes): the end-of-round gate (tools/r06_gate.sh) runs the driver's command instead
+  timeout 300 python bench.py > $out/bench_default.json 2> $out/bench_default.err; echo "bench default rc=$?"; tail -c 600 $out/bench_default.json; echo
+fi
+timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-stock-baseline --no-other-configs > $out/bench_cfg3.json 2> $out/bench_cfg3.err; echo "bench cfg3 rc=$?"; grep -o '"ms_per_step": [0-9.]*' $out/bench_cfg3.json | head -1
 for cfg in cfg2 cfg5a cfg5b; do
   timeout 300 python bench.py --config $cfg --steps 10 --warmup 3 --no-cpu-baseline --no-stock-baseline > $out/bench_$cfg.json 2> $out/bench_$cfg.err; echo "bench $cfg rc=$?"
   grep -o '"ms_per_step": [0-9.]*' $out/bench_$cfg.json

@@ -56,7 +56,9 @@ def main():
         ("k_conv1_wgrad_mfma", "conv1 weight gradient (MFMA)", "mfma", conv1, peak, "TFLOP/s"),
         ("k_conv1_fwd<", "conv1 forward (VALU, fp32 storage)", "valu fp32", conv1, 157.3e12, "TFLOP/s"),
         ("k_conv1_wgrad<", "conv1 weight gradient (VALU, fp32 storage)", "valu fp32", conv1, 157.3e12, "TFLOP/s"),
-        ("k_opt_matrix4", "AdamW + bf16 layouts of a recurrent weight matrix (32 B per parameter)", "hbm", GH * H * 32.0, 8e12, "TB/s"),
+        ("k_opt_matrix4_multi", "AdamW + bf16 layouts of every un-permuted recurrent weight matrix, one launch (32 B per parameter)", "hbm",
+         D * GH * H * (2 * L - 1) * 32.0, 8e12, "TB/s"),
+        ("k_opt_matrix4(", "AdamW + bf16 layouts of a recurrent weight matrix (32 B per parameter)", "hbm", GH * H * 32.0, 8e12, "TB/s"),
         ("k_add2", "direction sum (2 reads + 1 write of [T'N][H])", "hbm", 3.0 * R * H * esz, 8e12, "TB/s"),
         ("k_bn_apply<bf16_t, false", "SequenceWise BatchNorm apply (read + write of [T'N][H])", "hbm", 2.0 * R * H * esz, 8e12, "TB/s"),
         ("k_bn_bwd_apply<bf16_t, false", "SequenceWise BatchNorm backward apply (2 reads + 1 write)", "hbm", 3.0 * R * H * esz, 8e12, "TB/s"),
