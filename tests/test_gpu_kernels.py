@@ -282,6 +282,26 @@ def test_conv1_fwd_and_wgrad(dtype, N, T, F0):
     assert relerr(np64(got), dw.reshape(32, 451).T) < 1e-4
 
 
+def test_conv1_fwd_persistent_blocks_equal_single_block_runs():
+    """The bf16 conv1 forward is a persistent kernel: a workgroup walks several (sample, frame block, row block) tiles through one
+    LDS patch.  A batch of 20 long clips is 1 080 tiles on 256 workgroups (4-5 tiles each); every sample run ALONE is 54 tiles (one
+    per workgroup).  Same arithmetic per tile, so the two must agree bit for bit (the kernel tests above are all single-tile)."""
+    rs = np.random.RandomState(77)
+    N, T = 20, 1501
+    x = torch.from_numpy(rs.standard_normal((N, 1, 161, T)).astype(np.float32)).to(DEV)
+    w1k = cu(rs.uniform(-0.05, 0.05, (451, 32)))
+    b = cu(rs.uniform(-0.1, 0.1, 32))
+    lens_in = np.array([T - 37 * i for i in range(N)])
+    lens = O.seq_lens(lens_in)
+    Tp = int(O.seq_lens(np.array([T]))[0])
+    o = ops()
+    full = o.conv1_fwd(x, w1k, b, torch.from_numpy(lens).to(DEV), Tp, torch.bfloat16)
+    for n in (0, 7, 19):
+        one = o.conv1_fwd(x[n:n + 1].contiguous(), w1k, b, torch.from_numpy(lens[n:n + 1]).to(DEV), Tp, torch.bfloat16)
+        assert torch.equal(full[n:n + 1], one), n
+    assert float(full.float().abs().sum()) > 0
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("N,Tp,F0", [(2, 19, 161), (3, 75, 161), (2, 300, 161),
                                      (2, 40, 81), (3, 21, 129), (1, 17, 257), (2, 15, 41)])   # F1 = 41 / 65 / 129 / 21 (odd and even)
