@@ -9,10 +9,13 @@
 //
 // Four launches on the caller's stream, split by what bounds each stage:
 //   k_ctc_logsoftmax  one thread per frame; bytes: logits once -> log-prob scratch [N][Tp][CP] (CP = 32 for <= 32 classes).
-//   k_ctc_recursion   grid (N, 2): the alpha and the beta recursion of a sample are independent workgroups of 4 waves.  T'
-//                     dependent steps, pure latency: the step is branch-free (operand addresses and transition masks are
-//                     fixed per thread before the loop), the frames' log-probs are staged in LDS a chunk ahead, and the
-//                     per-step barrier drains the LDS counter only -- the alpha/beta row stores stay in flight.
+//   k_ctc_recursion_pairs (round 6, the default)  grid (N, 2): the alpha and the beta recursion of a sample are independent
+//                     workgroups.  T' dependent steps, pure latency: the rows live in REGISTERS as (blank, label) state pairs on
+//                     overlapping wave tiles, one wave shift per step, halo exchange through LDS every 16 steps (see the kernel).
+//   k_ctc_recursion   (rounds 2-5; targets beyond the pair tiles, and `recursion` = 1) the same with the rows in LDS: 4 waves, the
+//                     step is branch-free (operand addresses and transition masks are fixed per thread before the loop), the
+//                     frames' log-probs are staged in LDS a chunk ahead, and the per-step barrier drains the LDS counter only --
+//                     the alpha/beta row stores stay in flight.
 //   k_ctc_gradient    frame-parallel, grid (T'/16, N) x one wave per frame: the alpha/beta rows (2 x 4 x T' x L bytes per
 //                     sample, beyond one XCD's L2 for long clips) stream back once at full-chip parallelism.
 //   k_sum_small       loss = sum of the per-sample nll.
@@ -244,7 +247,7 @@ __global__ void __launch_bounds__(REC_THREADS) k_ctc_recursion(const int* __rest
   }
 }
 
-// The same recursion with ONE WAVE per (sample, direction) -- the fast path for 32 classes and SHORT targets (see ds2_ctc_set_variant).
+// The same recursion with ONE WAVE per (sample, direction) -- the rounds 3-5 fast path for 32 classes and SHORT targets (`recursion` = 2 / 3 of ds2_ctc_loss_grad).
 // The states of the extended label sequence live in registers, NS per lane, blocked (lane l owns states l*NS .. l*NS + NS - 1); the
 // neighbours s-1 / s-2 (alpha) or s+1 / s+2 (beta) of a lane's first / last states come from the adjacent lane by a wave
 // shift.  No LDS round trip of the rows and no workgroup barrier per step (the 4-wave kernel above spends most of its 0.48 us per
