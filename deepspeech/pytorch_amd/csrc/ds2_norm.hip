@@ -22,6 +22,13 @@ struct RowMap {
   }
 };
 
+// The element arithmetic of the forward and backward passes, spelled with explicit fused operations: the forward apply, the backward
+// reduce and the backward apply must take the SAME Hardtanh decision for an element on a clamp boundary, whatever the compiler would
+// contract in each context.
+__device__ __forceinline__ float bn_affine(float x, float sc, float sh) { return __builtin_fmaf(x, sc, sh); }
+__device__ __forceinline__ bool hardtanh_open(float y) { return y > 0.f && y < 20.f; }
+__device__ __forceinline__ float bn_dx(float g, float xh, float sc, float k1, float k2) { return sc * __builtin_fmaf(-xh, k2, g - k1); }
+
 // ---------------------------------------------------------------------------------------------------------
 // column sums / sums of squares -> partial[blockIdx.y][C]
 // ---------------------------------------------------------------------------------------------------------
@@ -204,7 +211,7 @@ __global__ void __launch_bounds__(256) k_bn_apply(const T* __restrict__ X, T* __
       Vec16<T>::load(X + r * ldx + c0, v);
 #pragma unroll
       for (int i = 0; i < V; ++i) {
-        float y = v[i] * scale[c0 + i] + shift[c0 + i];
+        float y = bn_affine(v[i], scale[c0 + i], shift[c0 + i]);
         if (CONV) y = fminf(fmaxf(y, 0.f), 20.f);
         v[i] = y;
       }
@@ -255,8 +262,7 @@ __device__ __forceinline__ bool load_gated(const T* __restrict__ G, const T* __r
 #pragma unroll
   for (int i = 0; i < V; ++i) {
     if (CONV) {
-      float y = x[i] * scale[c0 + i] + shift[c0 + i];
-      if (!(y > 0.f && y < 20.f)) g[i] = 0.f;
+      if (!hardtanh_open(bn_affine(x[i], scale[c0 + i], shift[c0 + i]))) g[i] = 0.f;
     }
     xh[i] = (x[i] - mean[c0 + i]) * rstd[c0 + i];
   }
@@ -330,13 +336,93 @@ __global__ void __launch_bounds__(256)
     float g[V], xh[V], o[V];
     if (load_gated<T, CONV, SEQ_IN>(G, X, r, c0, C, ldg, ldx, scale, shift, mean, rstd, rm, lens, N, g, xh)) {
 #pragma unroll
-      for (int i = 0; i < V; ++i) o[i] = scale[c0 + i] * (g[i] - c1[c0 + i] - xh[i] * c2[c0 + i]);
+      for (int i = 0; i < V; ++i) o[i] = bn_dx(g[i], xh[i], scale[c0 + i], c1[c0 + i], c2[c0 + i]);
     } else {
       // masked position: the mask that follows the conv (model.py:61-68) zeroes this gradient
 #pragma unroll
       for (int i = 0; i < V; ++i) o[i] = 0.f;
     }
     Vec16<T>::store(DX + r * lddx + c0, o);
+  }
+}
+
+// Round 6: the same pass on the reductions' thread map -- a thread owns ONE 16-byte column chunk for the whole launch, so the six
+// per-channel vectors of its chunk (scale, shift, mean, rstd, c1, c2: 48 values in bf16 storage) are loaded once instead of once per
+// row (the grid-stride form above re-read them for every 16 bytes of payload: 3.1-3.9 TB/s on the conv tensors and at H = 1280), and
+// two rows are in flight per thread.  Same arithmetic per element: bit-identical output.
+template <typename T, bool CONV, bool SEQ_IN>
+__global__ void __launch_bounds__(NORM_RY* NORM_CX)
+    k_bn_bwd_apply_cols(const T* __restrict__ G, const T* __restrict__ X, T* __restrict__ DX, long R, int C, long ldg, long ldx,
+                        long lddx, const float* __restrict__ scale, const float* __restrict__ shift,
+                        const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ c1,
+                        const float* __restrict__ c2, RowMap rm, const int* __restrict__ lens, int N) {
+  constexpr int V = Vec16<T>::N;
+  const RedMap m(C / V);
+  if (!m.ok) return;
+  const int c0 = m.chunk * V;
+  float sc[V], sh[V], mu[V], rs[V], k1[V], k2[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    sc[i] = scale[c0 + i];
+    sh[i] = CONV ? shift[c0 + i] : 0.f;
+    mu[i] = mean[c0 + i];
+    rs[i] = rstd[c0 + i];
+    k1[i] = c1[c0 + i];
+    k2[i] = c2[c0 + i];
+  }
+  const long step = m.row_step();
+  auto addr = [&](long r, int& t, int& len, const T*& gp) {
+    int n = 0, f = 0;
+    t = 0;
+    if (CONV) {   // row -> (n, f, t) in 32-bit arithmetic (N*F*T' < 2^31: checked by the entry)
+      const unsigned ur = (unsigned)r, q = ur / (unsigned)rm.Tp;
+      t = (int)(ur - q * (unsigned)rm.Tp);
+      n = (int)(q / (unsigned)rm.F);
+      f = (int)(q - (unsigned)n * (unsigned)rm.F);
+    }
+    len = CONV ? lens[n] : 0;
+    gp = SEQ_IN ? G + ((long)t * N + n) * ldg + (long)f * C + c0 : G + r * ldg + c0;
+  };
+  auto finish = [&](long r, int t, int len, float (&x)[V], float (&g)[V]) {
+    float o[V];
+    if (CONV && t >= len) {      // masked position: the mask that follows the conv (model.py:61-68) zeroes this gradient
+#pragma unroll
+      for (int i = 0; i < V; ++i) o[i] = 0.f;
+    } else {
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        float gi = g[i];
+        if (CONV) {
+          if (!hardtanh_open(bn_affine(x[i], sc[i], sh[i]))) gi = 0.f;
+        }
+        const float xh = (x[i] - mu[i]) * rs[i];
+        o[i] = bn_dx(gi, xh, sc[i], k1[i], k2[i]);
+      }
+    }
+    Vec16<T>::store(DX + r * lddx + c0, o);
+  };
+  long r = m.first_row();
+  for (; r + step < R; r += 2 * step) {
+    int t0, t1, l0, l1;
+    const T *g0p, *g1p;
+    addr(r, t0, l0, g0p);
+    addr(r + step, t1, l1, g1p);
+    float x0[V], x1[V], g0[V], g1[V];
+    Vec16<T>::load(X + r * ldx + c0, x0);
+    Vec16<T>::load(X + (r + step) * ldx + c0, x1);
+    Vec16<T>::load(g0p, g0);
+    Vec16<T>::load(g1p, g1);
+    finish(r, t0, l0, x0, g0);
+    finish(r + step, t1, l1, x1, g1);
+  }
+  if (r < R) {
+    int t0, l0;
+    const T* g0p;
+    addr(r, t0, l0, g0p);
+    float x0[V], g0[V];
+    Vec16<T>::load(X + r * ldx + c0, x0);
+    Vec16<T>::load(g0p, g0);
+    finish(r, t0, l0, x0, g0);
   }
 }
 
@@ -461,10 +547,22 @@ int ds2_bn_bwd(int dtype, int mode, const void* G, const void* X, void* DX, long
 #define LAUNCH_RED(TT, CV, SI)                                                                                          \
   hipLaunchKernelGGL((k_bn_bwd_reduce<TT, CV, SI>), grd, blk, 0, st, (const TT*)G, (const TT*)X, R, C, ldg, ldx,          \
                      save_scale, save_shift, save_mean, save_rstd, rm, lens, N, ps, pq)
+  // apply pass: column chunks fixed per thread (k_bn_bwd_apply_cols); ~2048 workgroups in all
+  const int acb = ds2_cdiv(C / V, NORM_CX), arpx = NORM_CX / (C / V < NORM_CX ? C / V : NORM_CX);
+  long agy = ds2_cdiv(R, (long)NORM_RY * arpx * 2);
+  if (agy > 2048 / acb) agy = 2048 / acb;
+  if (agy < 1) agy = 1;
+  const dim3 agrd(acb, (unsigned)agy);
+#ifdef DS2_BN_APPLY_GRIDSTRIDE   /* A/B (tools/ab_variants.py): the grid-stride form of rounds 1-5 */
 #define LAUNCH_APP(TT, CV, SI)                                                                                          \
   hipLaunchKernelGGL((k_bn_bwd_apply<TT, CV, SI>), dim3(apply_grid(R*(C / V))), dim3(256), 0, st, (const TT*)G,           \
                      (const TT*)X, (TT*)DX, R, C, ldg, ldx, lddx, save_scale, save_shift, save_mean, save_rstd, c1, c2, \
                      rm, lens, N)
+#else
+#define LAUNCH_APP(TT, CV, SI)                                                                                          \
+  hipLaunchKernelGGL((k_bn_bwd_apply_cols<TT, CV, SI>), agrd, blk, 0, st, (const TT*)G, (const TT*)X, (TT*)DX, R, C, ldg, \
+                     ldx, lddx, save_scale, save_shift, save_mean, save_rstd, c1, c2, rm, lens, N)
+#endif
 #define BOTH(WHICH)                                        \
   if (dtype == DS2_F32) {                                  \
     if (mode == 0) WHICH(float, false, false);             \
