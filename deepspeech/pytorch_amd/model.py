@@ -456,7 +456,8 @@ def _rnn_layer_forward(mod, li, X, lens_dev, N, Tp, dtype, training, h0, c0, lpa
     if D == 2:
         out = ops.add2(hext[0, 1:Tp + 1].reshape(R, H), hext[1, 1:Tp + 1].reshape(R, H))
     else:
-        out = hext[0, 1:Tp + 1].reshape(R, H).clone()
+        out = hext[0, 1:Tp + 1].reshape(R, H)      # one direction: the layer's output IS the stored state sequence (a contiguous view;
+                                                   # rounds 1-5 cloned it: seven 123 MB copies per cfg5b step).  Nothing writes into it.
     return out, hn, cn, [X, Xh if has_bn else None, hext, Sv], (kind, H, D, G, I, has_bn, sv, Ht, layer.input_size)
 
 
