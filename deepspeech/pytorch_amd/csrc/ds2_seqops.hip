@@ -249,9 +249,36 @@ __device__ __forceinline__ LaCol la_column(int Tp, int N, int H) {
   return c;
 }
 
+// Round 6: the walk was latency-bound -- a frame's operand was loaded, converted and multiplied in the same step, behind a branch on
+// the segment end (one dependent L2 / HBM round trip per frame: 2.6 TB/s forward).  Now the RAW words of the operands of the next
+// LA_Q frames sit in a small register queue (loaded LA_Q steps ahead from clamped addresses, no branch; converted, masked and gated
+// when they are consumed), only the stores are guarded.  Same values, same summation order.
+#ifndef DS2_LA_Q
+#define DS2_LA_Q 4
+#endif
+constexpr int LA_Q = DS2_LA_Q;
+template <typename T> struct LaRaw;
+template <> struct LaRaw<bf16_t> {
+  typedef uint2 type;
+  static __device__ __forceinline__ uint2 load(const bf16_t* p) { return *reinterpret_cast<const uint2*>(p); }
+  static __device__ __forceinline__ void cvt(const uint2& v, float (&o)[4]) {
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+  }
+};
+template <> struct LaRaw<float> {
+  typedef float4 type;
+  static __device__ __forceinline__ float4 load(const float* p) { return *reinterpret_cast<const float4*>(p); }
+  static __device__ __forceinline__ void cvt(const float4& v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+};
+// row of frame t clamped into [0, Tp)
+__device__ __forceinline__ long la_row(int t, int Tp, long ts, long col) { return (long)min(max(t, 0), Tp - 1) * ts + col; }
+
 template <typename T, int CTX>
 __global__ void __launch_bounds__(256) k_lookahead_fwd_slide(const T* __restrict__ x, const float* __restrict__ w,
                                                               T* __restrict__ y, T* __restrict__ pre, int Tp, int N, int H) {
+  static_assert(CTX % LA_Q == 0, "queue slots are compile-time indices of the unrolled frame loop");
+  typedef LaRaw<T> Raw;
   const LaCol c = la_column<CTX>(Tp, N, H);
   if (!c.ok) return;
   float wk[CTX][4], xw[CTX][4];
@@ -262,26 +289,30 @@ __global__ void __launch_bounds__(256) k_lookahead_fwd_slide(const T* __restrict
   const long col = (long)c.n * H + c.h0, ts = (long)N * H;
 #pragma unroll
   for (int s = 0; s < CTX - 1; ++s) {                       // x[t0 .. t0+CTX-2] -> slots 0 .. CTX-2
-    la_load4(x + (long)min(c.t0 + s, Tp - 1) * ts + col, xw[s]);
+    la_load4(x + la_row(c.t0 + s, Tp, ts, col), xw[s]);
     if (c.t0 + s >= Tp)
 #pragma unroll
       for (int i = 0; i < 4; ++i) xw[s][i] = 0.f;
   }
+  typename Raw::type q[LA_Q];                               // x[t + CTX-1 + d], d < LA_Q, of the frame t about to be computed
+#pragma unroll
+  for (int d = 0; d < LA_Q; ++d) q[d] = Raw::load(x + la_row(c.t0 + CTX - 1 + d, Tp, ts, col));
   for (int tb = c.t0; tb < c.t1; tb += CTX) {
 #pragma unroll
     for (int j = 0; j < CTX; ++j) {
       const int t = tb + j;
+      const int tn = t + CTX - 1, slot = (j + CTX - 1) % CTX;
+      Raw::cvt(q[j % LA_Q], xw[slot]);
+      if (tn >= Tp)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xw[slot][i] = 0.f;
+      q[j % LA_Q] = Raw::load(x + la_row(tn + LA_Q, Tp, ts, col));
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < CTX; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = fmaf(wk[k][i], xw[(j + k) % CTX][i], acc[i]);
       if (t < c.t1) {
-        const int tn = t + CTX - 1, slot = (j + CTX - 1) % CTX;
-        la_load4(x + (long)min(tn, Tp - 1) * ts + col, xw[slot]);
-        if (tn >= Tp)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) xw[slot][i] = 0.f;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < CTX; ++k)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc[i] = fmaf(wk[k][i], xw[(j + k) % CTX][i], acc[i]);
         const long o = (long)t * ts + col;
         if (pre) la_store4(pre + o, acc);
 #pragma unroll
@@ -296,10 +327,21 @@ __global__ void __launch_bounds__(256) k_lookahead_fwd_slide(const T* __restrict
 template <typename T>
 __device__ __forceinline__ void la_load_g(const T* __restrict__ dy, const T* __restrict__ pre, int t, int Tp, long ts, long col,
                                           float (&g)[4]) {
-  const long o = (long)min(max(t, 0), Tp - 1) * ts + col;
+  const long o = la_row(t, Tp, ts, col);
   float p[4];
   la_load4(dy + o, g);
   la_load4(pre + o, p);
+  const bool in = t >= 0 && t < Tp;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) g[i] = (in && p[i] > 0.f && p[i] < 20.f) ? g[i] : 0.f;
+}
+// the same from queued raw words
+template <typename T>
+__device__ __forceinline__ void la_gate(const typename LaRaw<T>::type& rg, const typename LaRaw<T>::type& rp, int t, int Tp,
+                                        float (&g)[4]) {
+  float p[4];
+  LaRaw<T>::cvt(rg, g);
+  LaRaw<T>::cvt(rp, p);
   const bool in = t >= 0 && t < Tp;
 #pragma unroll
   for (int i = 0; i < 4; ++i) g[i] = (in && p[i] > 0.f && p[i] < 20.f) ? g[i] : 0.f;
@@ -309,6 +351,7 @@ template <typename T, int CTX>
 __global__ void __launch_bounds__(256) k_lookahead_bwd_x_slide(const T* __restrict__ dy, const T* __restrict__ pre,
                                                                 const float* __restrict__ w, T* __restrict__ dx, int Tp, int N,
                                                                 int H) {
+  typedef LaRaw<T> Raw;
   const LaCol c = la_column<CTX>(Tp, N, H);
   if (!c.ok) return;
   float wk[CTX][4], gw[CTX][4];
@@ -319,19 +362,25 @@ __global__ void __launch_bounds__(256) k_lookahead_bwd_x_slide(const T* __restri
   const long col = (long)c.n * H + c.h0, ts = (long)N * H;
 #pragma unroll
   for (int s = 1; s < CTX; ++s) la_load_g(dy, pre, c.t0 - CTX + s, Tp, ts, col, gw[s]);   // g[t0-CTX+1 .. t0-1] -> slots 1 .. CTX-1
+  typename Raw::type qg[LA_Q], qp[LA_Q];                    // dy / pre of frames t + d, d < LA_Q
+#pragma unroll
+  for (int d = 0; d < LA_Q; ++d) {
+    qg[d] = Raw::load(dy + la_row(c.t0 + d, Tp, ts, col));
+    qp[d] = Raw::load(pre + la_row(c.t0 + d, Tp, ts, col));
+  }
   for (int tb = c.t0; tb < c.t1; tb += CTX) {
 #pragma unroll
     for (int j = 0; j < CTX; ++j) {
       const int t = tb + j;
-      if (t < c.t1) {
-        la_load_g(dy, pre, t, Tp, ts, col, gw[j]);
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      la_gate<T>(qg[j % LA_Q], qp[j % LA_Q], t, Tp, gw[j]);
+      qg[j % LA_Q] = Raw::load(dy + la_row(t + LA_Q, Tp, ts, col));
+      qp[j % LA_Q] = Raw::load(pre + la_row(t + LA_Q, Tp, ts, col));
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < CTX; ++k)
+      for (int k = 0; k < CTX; ++k)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc[i] = fmaf(wk[k][i], gw[(j - k + CTX) % CTX][i], acc[i]);
-        la_store4(dx + (long)t * ts + col, acc);
-      }
+        for (int i = 0; i < 4; ++i) acc[i] = fmaf(wk[k][i], gw[(j - k + CTX) % CTX][i], acc[i]);
+      if (t < c.t1) la_store4(dx + (long)t * ts + col, acc);
     }
   }
 }
@@ -341,6 +390,7 @@ template <typename T, int CTX>
 __global__ void __launch_bounds__(256) k_lookahead_bwd_w_slide(const T* __restrict__ dy, const T* __restrict__ pre,
                                                                 const T* __restrict__ x, float* __restrict__ partial, int Tp,
                                                                 int N, int H) {
+  typedef LaRaw<T> Raw;
   const LaCol c = la_column<CTX>(Tp, N, H);
   if (!c.ok) return;
   float acc[CTX][4], gw[CTX][4];
@@ -351,19 +401,30 @@ __global__ void __launch_bounds__(256) k_lookahead_bwd_w_slide(const T* __restri
   const long col = (long)c.n * H + c.h0, ts = (long)N * H;
 #pragma unroll
   for (int s = 1; s < CTX; ++s) la_load_g(dy, pre, c.t0 - CTX + s, Tp, ts, col, gw[s]);
+  typename Raw::type qg[LA_Q], qp[LA_Q], qx[LA_Q];
+#pragma unroll
+  for (int d = 0; d < LA_Q; ++d) {
+    qg[d] = Raw::load(dy + la_row(c.t0 + d, Tp, ts, col));
+    qp[d] = Raw::load(pre + la_row(c.t0 + d, Tp, ts, col));
+    qx[d] = Raw::load(x + la_row(c.t0 + d, Tp, ts, col));
+  }
   for (int tb = c.t0; tb < c.t1; tb += CTX) {
 #pragma unroll
     for (int j = 0; j < CTX; ++j) {
       const int t = tb + j;
-      if (t < c.t1) {
-        float xv[4];
-        la_load_g(dy, pre, t, Tp, ts, col, gw[j]);
-        la_load4(x + (long)t * ts + col, xv);
+      float xv[4];
+      la_gate<T>(qg[j % LA_Q], qp[j % LA_Q], t, Tp, gw[j]);
+      Raw::cvt(qx[j % LA_Q], xv);
+      qg[j % LA_Q] = Raw::load(dy + la_row(t + LA_Q, Tp, ts, col));
+      qp[j % LA_Q] = Raw::load(pre + la_row(t + LA_Q, Tp, ts, col));
+      qx[j % LA_Q] = Raw::load(x + la_row(t + LA_Q, Tp, ts, col));
+      if (t >= c.t1)                                         // frames of the NEXT segment (or past the end) do not count here
 #pragma unroll
-        for (int k = 0; k < CTX; ++k)
+        for (int i = 0; i < 4; ++i) xv[i] = 0.f;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc[k][i] = fmaf(gw[(j - k + CTX) % CTX][i], xv[i], acc[k][i]);
-      }
+      for (int k = 0; k < CTX; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[k][i] = fmaf(gw[(j - k + CTX) % CTX][i], xv[i], acc[k][i]);
     }
   }
   float* dst = partial + ((long)(c.t0 / (LA_SEG_STEPS * CTX)) * N + c.n) * H * CTX + (long)c.h0 * CTX;
